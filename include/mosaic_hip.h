@@ -1,0 +1,180 @@
+/*
+ * mosaic_hip.h -- C ABI of the MI355X photomosaic best-fit engine.
+ *
+ * Drop-in boundary for ONE path of MorganGrundy/MosaicMagnifique: what
+ * CUDAPhotomosaicGenerator::generateBestFits() does on the device
+ * (src/Photomosaic/CUDA/CUDAPhotomosaicGenerator.cpp:40-368) and
+ * CPUPhotomosaicGenerator::generateBestFits() does on the host
+ * (src/Photomosaic/CPUPhotomosaicGenerator.cpp:33-113): for every valid grid
+ * cell, masked colour difference against every library image, plus the
+ * neighbour repeat penalty, argmin -> library index.
+ *
+ * The reference has no FFI layer; its seam is the C++ virtual class
+ * PhotomosaicGeneratorBase (src/Photomosaic/PhotomosaicGeneratorBase.h:32-112)
+ * and the kernel wrappers of CUDA/PhotomosaicGenerator.cuh:6-43.  A reference
+ * maintainer binds this header from a ~100-line HIPPhotomosaicGenerator
+ * subclass; the Qt/OpenCV host, Grid/CellShape/ImageLibrary
+ * plumbing and the padded best-fit grid layout stay as they are.
+ *
+ * Plain C: pointers + sizes, no C++/torch types.  All input pointers are HOST
+ * memory unless a parameter says "device".  Every entry point returns an
+ * mm_status; no exception crosses the boundary.  One call at a time per
+ * engine; engines are independent (one per GPU / host thread).
+ */
+#ifndef MOSAIC_HIP_H
+#define MOSAIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_ABI_VERSION 1
+
+/* Return codes.  The reference returns bool and reports through a modal
+ * CUDAErrMessageBox that separates "expected" errors (out of memory, bad
+ * device) from unexpected ones (CUDA/CUDAUtility.h:32-62); the categories
+ * below carry the same split, the text is in mm_last_error(). */
+typedef enum mm_status {
+    MM_OK = 0,
+    MM_CANCELLED = 1,        /* cancel flag seen: generateBestFits() returns false */
+    MM_INVALID_ARGUMENT = 2, /* ColourDifference::getFunction throws std::invalid_argument (ColourDifference.cpp:23) */
+    MM_OUT_OF_MEMORY = 3,    /* "expected": pre-flight check of CUDAPhotomosaicGenerator.cpp:398-430 */
+    MM_DEVICE_ERROR = 4,     /* "unexpected": any other HIP error, with name + file:line */
+    MM_NOT_READY = 5         /* library / masks / target not staged yet */
+} mm_status;
+
+/* Colour difference selector = ColourDifference::Type
+ * (src/Photomosaic/ColourDifference.h:13-19). */
+enum { MM_RGB_EUCLIDEAN = 0, MM_CIE76 = 1, MM_CIEDE2000 = 2 };
+
+/* GridUtility::PAD_GRID (src/Grid/GridUtility.h:33). */
+#define MM_PAD_GRID 2
+
+typedef struct mm_engine mm_engine;
+
+/* One valid grid cell, as the host computes it per cell today:
+ *  x, y              top-left of GridUtility::getRectAt (Grid/GridUtility.cpp:86-115),
+ *                    target-pixel coordinates, may be negative / past the edge;
+ *  row_min..col_max  the detail-space local bound returned by getCellAt
+ *                    (PhotomosaicGeneratorBase.cpp:319-326), half open, in the
+ *                    order of the CUDA path's targetArea[4]
+ *                    (CUDAPhotomosaicGenerator.cpp:193-196);
+ *  mask_id           flipH + 2*flipV, the index CUDAPhotomosaicGenerator.cpp:208 uses;
+ *  grid_x, grid_y    padded grid position (x + PAD_GRID, y + PAD_GRID).
+ * Cells must be passed in the reference's raster order (y outer, x inner):
+ * the repeat penalty depends on it. */
+typedef struct mm_cell {
+    int32_t x, y;
+    int32_t row_min, row_max, col_min, col_max;
+    int32_t mask_id;
+    int32_t grid_x, grid_y;
+} mm_cell;
+
+/* Per-call device timings (HIP events on the engine's stream), milliseconds.
+ * Phase names follow the reference's TimingLogger ids
+ * (CUDAPhotomosaicGenerator.cpp: cudaMemcpy, DiffReduce, Repeats, FindLowest). */
+typedef struct mm_timing {
+    double stage_ms;      /* H2D of cell records + cell gather ("cudaMemcpy") */
+    double score_ms;      /* fused difference + reduction kernels ("DiffReduce") */
+    double select_ms;     /* per-cell candidate selection (top-K) */
+    double resolve_ms;    /* repeat penalty + argmin + exact tie-break ("Repeats"+"FindLowest") */
+    double total_ms;      /* first launch to results on the host */
+    int64_t score_launches;   /* launches of the dominant score kernel */
+    int64_t pair_evals;       /* colour differences evaluated by it (active pixels x candidates) */
+    int64_t exact_rescored;   /* candidates re-summed in reference order to break a near-tie */
+} mm_timing;
+
+/* Progress: called on the calling thread between device batches with
+ * monotone values up to the number of cells (the reference emits one
+ * progress(int) per cell, CPUPhotomosaicGenerator.cpp:87-88).  cancel is
+ * polled at the same points (PhotomosaicGeneratorBase::cancel, :217-220). */
+typedef void (*mm_progress_cb)(int cells_done, void *user);
+
+/* ---- lifetime ---------------------------------------------------------- */
+
+int mm_abi_version(void);
+/* Number of visible HIP devices (MainWindow.cpp:162-214 enumerates them). */
+mm_status mm_device_count(int *count);
+/* CUDAPhotomosaicGenerator(const int device), CUDA/CUDAPhotomosaicGenerator.h:31. */
+mm_status mm_create(int device, mm_engine **out);
+void mm_destroy(mm_engine *e);
+/* Text of the last failure on this engine (e == NULL: last mm_create failure):
+ * "<what>: <hipErrorName> (<code>) at <file>:<line>", the shape of
+ * createCUDAErrStr (CUDA/CUDAUtility.h:27-30). */
+const char *mm_last_error(const mm_engine *e);
+
+/* ---- staging (once; replaces the per-generate cudaMalloc + H2D of
+ * CUDAPhotomosaicGenerator.cpp:113-149,372-510) -------------------------- */
+
+/* Library after preprocessLibraryImages (PhotomosaicGeneratorBase.cpp:255-290):
+ * n_images square images, f32 HWC [n][size][size][3], BGR in [0,255] for
+ * RGB_EUCLIDEAN or Lab for CIE76/CIEDE2000.  Copied; the caller may free. */
+mm_status mm_set_library(mm_engine *e, const float *images, int n_images, int size);
+/* The 4 detail-cell masks, u8 [4][size][size], order (flipH,flipV) =
+ * (0,0),(1,0),(0,1),(1,1) (CUDAPhotomosaicGenerator.cpp:122-134); != 0 = active. */
+mm_status mm_set_masks(mm_engine *e, const uint8_t *masks, int size);
+/* Main image after preprocessMainImage (PhotomosaicGeneratorBase.cpp:223-252),
+ * f32 HWC [rows][cols][3].  Cells are gathered from it on the device. */
+mm_status mm_set_target(mm_engine *e, const float *image, int rows, int cols);
+
+/* ---- the hot path ------------------------------------------------------ */
+
+/* generateBestFits() for one size step.
+ *  best_fit_out   [grid_h*grid_w] row-major padded grid, the layout of the CUDA
+ *                 path's bestFit[] (cellPosition = grid_y*grid_w + grid_x);
+ *                 entries not named by `cells` hold the sentinel n_images
+ *                 (CUDAPhotomosaicGenerator.cpp:140-149,286,320);
+ *  best_score_out optional [grid_h*grid_w], bestVariant per cell (NaN elsewhere).
+ * Returns MM_CANCELLED if *cancel became non-zero. */
+mm_status mm_generate(mm_engine *e, const mm_cell *cells, int n_cells,
+                      int grid_w, int grid_h, int diff_type,
+                      int repeat_range, int repeat_addition,
+                      int64_t *best_fit_out, double *best_score_out,
+                      mm_progress_cb progress, void *progress_user,
+                      volatile int *cancel);
+
+/* Split form for the cell-sharded multi-GPU run: each rank scores its own
+ * contiguous block of cells, the per-cell candidate lists are all-gathered,
+ * every rank then resolves the whole grid identically.
+ * mm_candidates_per_cell: how many (index, score) candidates per cell the
+ * resolve needs: the window of calculateRepeats (CPUPhotomosaicGenerator.cpp:
+ * 185-225) holds at most R(2R+1)+R neighbours, so the winner is among the
+ * R(2R+1)+R+1 lowest base scores; +1 runner-up for the near-tie check. */
+int mm_candidates_per_cell(int n_images, int repeat_range, int repeat_addition);
+/* cand_index_out [n_cells][k] int32, cand_score_out [n_cells][k] f64: the k
+ * lowest base scores per cell ascending by (score, index).  Host pointers, or
+ * device pointers if outputs_on_device != 0 (results complete on return). */
+mm_status mm_score_cells(mm_engine *e, const mm_cell *cells, int n_cells,
+                         int diff_type, int k,
+                         int32_t *cand_index_out, double *cand_score_out,
+                         int outputs_on_device,
+                         mm_progress_cb progress, void *progress_user,
+                         volatile int *cancel);
+/* cells = ALL valid cells of the grid in raster order with their candidate lists. */
+mm_status mm_resolve(mm_engine *e, const mm_cell *cells, int n_cells,
+                     int grid_w, int grid_h, int diff_type,
+                     int repeat_range, int repeat_addition, int k,
+                     const int32_t *cand_index, const double *cand_score,
+                     int inputs_on_device,
+                     int64_t *best_fit_out, double *best_score_out);
+
+/* Timings of the last mm_generate / mm_score_cells (+ mm_resolve) on e. */
+mm_status mm_get_timing(const mm_engine *e, mm_timing *out);
+
+/* ---- per-pair colour difference ---------------------------------------- */
+
+/* n pairs of f32 triplets -> fp64 differences on the device: the counterpart
+ * of ColourDifference::getCUDAFunction applied to a flat image
+ * (ColourDifference.cpp:164-172; exercised by test/tst_ColourDifference.h:233-466).
+ * first = main-image pixel, second = library pixel. */
+mm_status mm_colour_diff_batch(mm_engine *e, int diff_type,
+                               const float *first, const float *second,
+                               size_t n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOSAIC_HIP_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of ``libmosaic_hip.so`` (include/mosaic_hip.h).
+
+There is no CPU fallback: if the library is missing or cannot be loaded this
+module raises, and every product path above it fails with it.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+from . import _build
+
+c_int_p = ctypes.POINTER(ctypes.c_int)
+
+
+class MMCell(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("x", "y", "row_min", "row_max", "col_min", "col_max", "mask_id", "grid_x", "grid_y")]
+
+
+class MMTiming(ctypes.Structure):
+    _fields_ = [("stage_ms", ctypes.c_double), ("score_ms", ctypes.c_double),
+                ("select_ms", ctypes.c_double), ("resolve_ms", ctypes.c_double),
+                ("total_ms", ctypes.c_double), ("score_launches", ctypes.c_int64),
+                ("pair_evals", ctypes.c_int64), ("exact_rescored", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+PROGRESS_CB = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)
+
+MM_OK, MM_CANCELLED, MM_INVALID_ARGUMENT, MM_OUT_OF_MEMORY, MM_DEVICE_ERROR, MM_NOT_READY = range(6)
+STATUS_NAMES = ("MM_OK", "MM_CANCELLED", "MM_INVALID_ARGUMENT", "MM_OUT_OF_MEMORY",
+                "MM_DEVICE_ERROR", "MM_NOT_READY")
+
+# Every symbol include/mosaic_hip.h declares: (restype, argtypes).
+_VP = ctypes.c_void_p
+SIGNATURES = {
+    "mm_abi_version": (ctypes.c_int, []),
+    "mm_device_count": (ctypes.c_int, [c_int_p]),
+    "mm_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_VP)]),
+    "mm_destroy": (None, [_VP]),
+    "mm_last_error": (ctypes.c_char_p, [_VP]),
+    "mm_set_library": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
+    "mm_set_masks": (ctypes.c_int, [_VP, _VP, ctypes.c_int]),
+    "mm_set_target": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
+    "mm_generate": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, _VP, _VP, _VP, _VP, _VP]),
+    "mm_candidates_per_cell": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mm_score_cells": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP,
+                                      ctypes.c_int, _VP, _VP, _VP]),
+    "mm_resolve": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP, ctypes.c_int, _VP, _VP]),
+    "mm_get_timing": (ctypes.c_int, [_VP, ctypes.POINTER(MMTiming)]),
+    "mm_colour_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Load (once) and type the C ABI.  Raises if the HIP engine is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "HIP engine %s is not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % path)
+    # One HIP runtime per process: torch ships its own libamdhip64 (same SONAME
+    # as /opt/rocm's).  Importing torch first makes the loader hand this library
+    # the runtime torch already mapped, so device pointers / streams are shared
+    # with torch.distributed (RCCL) in the multi-GPU path.
+    if "torch" not in sys.modules and not os.environ.get("MOSAIC_HIP_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.mm_abi_version() != 1:
+        raise RuntimeError("libmosaic_hip.so ABI version %d != 1" % lib.mm_abi_version())
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def as_cells(records):
+    """numpy structured records (grid.CELL_DTYPE) -> contiguous buffer matching mm_cell."""
+    rec = np.ascontiguousarray(records)
+    assert rec.dtype.itemsize == ctypes.sizeof(MMCell), (rec.dtype.itemsize, ctypes.sizeof(MMCell))
+    return rec

@@ -1,0 +1,610 @@
+// engine.hip -- host orchestration + C ABI of the best-fit engine (include/mosaic_hip.h).
+//
+// Replaces the device half of CUDAPhotomosaicGenerator::generateBestFits
+// (src/Photomosaic/CUDA/CUDAPhotomosaicGenerator.cpp:40-368).  What is NOT
+// reproduced from it, on purpose: per-generate cudaMalloc of everything
+// (:372-510), one H2D per cell (:180-185), an L*P*8-byte memset per cell
+// (:213), >= 2 launches + 1 D2D per (cell, library image) (:234-250), the
+// serial <<<1,1>>> repeat / lowest kernels.  Here the library, masks and target
+// are staged once, cells are gathered on the device, one launch scores a whole
+// batch of cells against the whole library, and the raster-order dependency of
+// the repeat penalty is confined to a small resolve pass over K candidates.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct mm_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    std::string err;
+
+    // staged inputs
+    DevBuf lib;      int n_lib = 0, lib_size = 0;
+    DevBuf masks;    int mask_size = 0;
+    DevBuf target;   int rows = 0, cols = 0;
+
+    // per-call workspaces (grown on demand, kept)
+    DevBuf recs, cells, cmask, scores, cand_i, cand_s, grid, best, counter;
+
+    mm_timing timing{};
+};
+
+namespace {
+
+void set_err(mm_engine* e, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf; else g_create_error = buf;
+}
+
+// The shape of createCUDAErrStr (CUDA/CUDAUtility.h:27-30) + the expected /
+// unexpected split of CUDAErrMessageBox (:32-62).
+mm_status hip_fail(mm_engine* e, hipError_t code, const char* what, const char* file, int line)
+{
+    set_err(e, "%s: %s (%d) at %s:%d", what, hipGetErrorName(code), (int)code, file, line);
+    (void)hipGetLastError();
+    return code == hipErrorOutOfMemory ? MM_OUT_OF_MEMORY : MM_DEVICE_ERROR;
+}
+
+#define HIP_TRY(e, call, what)                                                   \
+    do {                                                                          \
+        hipError_t hip_try_code_ = (call);                                        \
+        if (hip_try_code_ != hipSuccess)                                          \
+            return hip_fail((e), hip_try_code_, (what), __FILE__, __LINE__);      \
+    } while (0)
+
+mm_status ensure(mm_engine* e, DevBuf& b, size_t bytes, const char* what)
+{
+    if (b.bytes >= bytes && b.p) return MM_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(e, hipMalloc(&b.p, bytes), what);
+    b.bytes = bytes;
+    return MM_OK;
+}
+
+void release(DevBuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+inline bool known_type(int t) { return t == MM_RGB_EUCLIDEAN || t == MM_CIE76 || t == MM_CIEDE2000; }
+
+mm_status check_ready(mm_engine* e)
+{
+    if (!e->lib.p || !e->masks.p || !e->target.p) {
+        set_err(e, "library, masks and target must be staged before generating");
+        return MM_NOT_READY;
+    }
+    if (e->lib_size != e->mask_size) {
+        set_err(e, "library image size %d != mask size %d (detail cell size must match, "
+                   "PhotomosaicGeneratorBase.cpp:262-271)", e->lib_size, e->mask_size);
+        return MM_INVALID_ARGUMENT;
+    }
+    return MM_OK;
+}
+
+mm_status check_cells(mm_engine* e, const mm_cell* cells, int n, int grid_w, int grid_h)
+{
+    const int size = e->lib_size;
+    for (int i = 0; i < n; ++i) {
+        const mm_cell& c = cells[i];
+        const bool ok =
+            c.row_min >= 0 && c.row_min < c.row_max && c.row_max <= size &&
+            c.col_min >= 0 && c.col_min < c.col_max && c.col_max <= size &&
+            c.mask_id >= 0 && c.mask_id < 4 &&
+            (long long)c.y + c.row_min >= 0 && (long long)c.y + c.row_max <= e->rows &&
+            (long long)c.x + c.col_min >= 0 && (long long)c.x + c.col_max <= e->cols &&
+            (grid_w <= 0 || (c.grid_x >= 0 && c.grid_x < grid_w && c.grid_y >= 0 && c.grid_y < grid_h));
+        if (!ok) {
+            set_err(e, "cell %d: bound [%d,%d)x[%d,%d) at (%d,%d), mask %d, grid (%d,%d) does not fit "
+                       "a %dx%d cell on a %dx%d image / %dx%d grid", i, c.row_min, c.row_max,
+                    c.col_min, c.col_max, c.x, c.y, c.mask_id, c.grid_x, c.grid_y, size, size,
+                    e->cols, e->rows, grid_w, grid_h);
+            return MM_INVALID_ARGUMENT;
+        }
+    }
+    return MM_OK;
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+template <typename F>
+mm_status by_type(int diff_type, F&& f)
+{
+    if (diff_type == MM_CIEDE2000) return f(std::integral_constant<int, mm::CIEDE2000>{});
+    return f(std::integral_constant<int, mm::RGB_EUCLIDEAN>{});   // CIE76 == Euclid on Lab
+}
+
+// Scores `n` cells (records already on the device at recs_dev) in batches and
+// leaves the K lowest candidates per cell in cand_i_dev / cand_s_dev.
+mm_status score_cells_device(mm_engine* e, const mm_cell* recs_dev, int n, int diff_type, int K,
+                             int32_t* cand_i_dev, double* cand_s_dev,
+                             mm_progress_cb progress, void* user, volatile int* cancel)
+{
+    const int L = e->n_lib, size = e->lib_size, P = size * size, ppad = round_up(P, 256);
+    // Batch so that scores + gathered cells stay within a fixed budget.
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(e, hipMemGetInfo(&free_b, &total_b), "Failed to query device memory");
+    const size_t per_cell = (size_t)L * sizeof(double) + (size_t)ppad * 13;
+    size_t budget = std::min<size_t>(free_b / 2 + e->scores.bytes + e->cells.bytes + e->cmask.bytes,
+                                     (size_t)6 << 30);
+    if (budget < per_cell) {
+        set_err(e, "Not enough device memory: one cell needs %zu bytes of workspace, %zu free",
+                per_cell, free_b);
+        return MM_OUT_OF_MEMORY;
+    }
+    const int batch = (int)std::min<size_t>((size_t)n, std::min<size_t>(budget / per_cell, 32768));
+    mm_status st;
+    if ((st = ensure(e, e->cells, (size_t)batch * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
+        (st = ensure(e, e->cmask, (size_t)batch * ppad, "Failed to allocate cell masks")) ||
+        (st = ensure(e, e->scores, (size_t)batch * L * sizeof(double), "Failed to allocate variants")))
+        return st;
+
+    const int cand_per_block = 16;
+    const int cell_group = 512;
+    float stage_ms = 0.f, score_ms = 0.f, select_ms = 0.f;
+    for (int done = 0; done < n; done += batch) {
+        if (cancel && *cancel) return MM_CANCELLED;
+        const int b = std::min(batch, n - done);
+        HIP_TRY(e, hipEventRecord(e->ev[0], e->stream), "event");
+        mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
+            recs_dev + done, (const float*)e->target.p, e->cols, (const uint8_t*)e->masks.p,
+            (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad);
+        HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
+        HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
+
+        const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
+        const long long blocks = (long long)b * n_tiles;
+        if (blocks > 0x7fffffffLL) { set_err(e, "score grid too large"); return MM_INVALID_ARGUMENT; }
+        st = by_type(diff_type, [&](auto T) {
+            mm::score_kernel<decltype(T)::value><<<dim3((unsigned)blocks), mm::kBlock, 0, e->stream>>>(
+                (const float*)e->cells.p, (const uint8_t*)e->cmask.p, (const float*)e->lib.p,
+                (double*)e->scores.p, b, L, ppad, cand_per_block, cell_group);
+            return MM_OK;
+        });
+        HIP_TRY(e, hipGetLastError(), "Error during colour difference / add reduction kernel");
+        HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
+
+        mm::select_kernel<<<b, mm::kBlock, 0, e->stream>>>(
+            (const double*)e->scores.p, L, K, cand_i_dev + (size_t)done * K, cand_s_dev + (size_t)done * K);
+        HIP_TRY(e, hipGetLastError(), "Error during candidate selection kernel");
+        HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
+        HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+        stage_ms += elapsed(e->ev[0], e->ev[1]);
+        score_ms += elapsed(e->ev[1], e->ev[2]);
+        select_ms += elapsed(e->ev[2], e->ev[3]);
+        e->timing.score_launches += 1;
+        if (progress) progress(done + b, user);
+    }
+    e->timing.stage_ms += stage_ms;
+    e->timing.score_ms += score_ms;
+    e->timing.select_ms += select_ms;
+    return MM_OK;
+}
+
+mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_w, int grid_h,
+                         int diff_type, int range, int addition, int K,
+                         const int32_t* cand_i_dev, const double* cand_s_dev,
+                         int64_t* best_fit_out, double* best_score_out)
+{
+    const size_t cells_total = (size_t)grid_w * grid_h;
+    mm_status st;
+    if ((st = ensure(e, e->grid, cells_total * sizeof(long long), "Failed to allocate best fits")) ||
+        (st = ensure(e, e->best, cells_total * sizeof(double), "Failed to allocate best scores")) ||
+        (st = ensure(e, e->counter, sizeof(unsigned long long), "Failed to allocate counter")))
+        return st;
+
+    // Set best fits to max value (CUDAPhotomosaicGenerator.cpp:140-149), scores to NaN.
+    std::vector<long long> init(cells_total, (long long)e->n_lib);
+    std::vector<double> nan_init(cells_total, std::numeric_limits<double>::quiet_NaN());
+    HIP_TRY(e, hipMemcpyAsync(e->grid.p, init.data(), cells_total * sizeof(long long), hipMemcpyHostToDevice, e->stream),
+            "Failed to copy max best fit from host to device");
+    HIP_TRY(e, hipMemcpyAsync(e->best.p, nan_init.data(), cells_total * sizeof(double), hipMemcpyHostToDevice, e->stream),
+            "Failed to reset lowest variant");
+    HIP_TRY(e, hipMemsetAsync(e->counter.p, 0, sizeof(unsigned long long), e->stream), "Failed to clear counter");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");   // host vectors go out of scope below
+
+    const int size = e->lib_size, P = size * size, ppad = round_up(P, 256);
+    mm::ResolveArgs a{};
+    a.recs = recs_dev; a.n_cells = n; a.grid_w = grid_w; a.grid_h = grid_h; a.L = e->n_lib;
+    a.repeat_range = range; a.repeat_addition = addition; a.K = K;
+    a.cand_index = cand_i_dev; a.cand_score = cand_s_dev;
+    a.grid = (long long*)e->grid.p; a.best_score = (double*)e->best.p;
+    a.target = (const float*)e->target.p; a.rows = e->rows; a.cols = e->cols;
+    a.masks = (const uint8_t*)e->masks.p; a.lib = (const float*)e->lib.p;
+    a.size = size; a.P = P; a.ppad = ppad;
+    a.tie_band = 1e-9;
+    a.exact_count = (unsigned long long*)e->counter.p;
+
+    const int sequential = (range > 0 && addition != 0) ? 1 : 0;
+    const int blocks = sequential ? 1 : std::max(1, std::min(n, 2048));
+    HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
+    if (n > 0) {
+        st = by_type(diff_type, [&](auto T) {
+            mm::resolve_kernel<decltype(T)::value><<<blocks, mm::kBlock, 0, e->stream>>>(a, sequential);
+            return MM_OK;
+        });
+        HIP_TRY(e, hipGetLastError(), "Error during calculate repeats / find lowest kernel");
+    }
+    HIP_TRY(e, hipEventRecord(e->ev[5], e->stream), "event");
+
+    // Copy best fit to host (CUDAPhotomosaicGenerator.cpp:305-306).
+    static_assert(sizeof(long long) == sizeof(int64_t), "grid entries are 64-bit");
+    HIP_TRY(e, hipMemcpyAsync(best_fit_out, e->grid.p, cells_total * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream),
+            "Error copying best fits to host");
+    if (best_score_out)
+        HIP_TRY(e, hipMemcpyAsync(best_score_out, e->best.p, cells_total * sizeof(double), hipMemcpyDeviceToHost, e->stream),
+                "Error copying best scores to host");
+    unsigned long long exact = 0;
+    HIP_TRY(e, hipMemcpyAsync(&exact, e->counter.p, sizeof exact, hipMemcpyDeviceToHost, e->stream), "counter");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    e->timing.resolve_ms += elapsed(e->ev[4], e->ev[5]);
+    e->timing.exact_rescored += (int64_t)exact;
+    return MM_OK;
+}
+
+int64_t count_pair_evals(const mm_engine* e, const mm_cell* cells, int n)
+{
+    // Upper bound used for reporting: bound area per cell x candidates (the mask
+    // thins it further; bench.py computes the exact active-pixel figure itself).
+    int64_t px = 0;
+    for (int i = 0; i < n; ++i)
+        px += (int64_t)(cells[i].row_max - cells[i].row_min) * (cells[i].col_max - cells[i].col_min);
+    return px * e->n_lib;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+
+extern "C" {
+
+int mm_abi_version(void) { return MM_ABI_VERSION; }
+
+mm_status mm_device_count(int* count)
+{
+    if (!count) return MM_INVALID_ARGUMENT;
+    *count = 0;
+    hipError_t code = hipGetDeviceCount(count);
+    if (code != hipSuccess) {
+        *count = 0;
+        return hip_fail(nullptr, code, "Failed to count devices", __FILE__, __LINE__);
+    }
+    return MM_OK;
+}
+
+mm_status mm_create(int device, mm_engine** out)
+{
+    if (!out) return MM_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    hipError_t code = hipGetDeviceCount(&count);
+    if (code != hipSuccess) return hip_fail(nullptr, code, "Failed to count devices", __FILE__, __LINE__);
+    if (device < 0 || device >= count) {
+        set_err(nullptr, "Invalid device %d (%d visible)", device, count);
+        return MM_INVALID_ARGUMENT;
+    }
+    mm_engine* e = new (std::nothrow) mm_engine();
+    if (!e) { set_err(nullptr, "out of host memory"); return MM_OUT_OF_MEMORY; }
+    e->device = device;
+    code = hipSetDevice(device);
+    if (code == hipSuccess) code = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    for (int i = 0; code == hipSuccess && i < 8; ++i) code = hipEventCreate(&e->ev[i]);
+    if (code != hipSuccess) {
+        mm_status st = hip_fail(nullptr, code, "Failed to initialise device", __FILE__, __LINE__);
+        mm_destroy(e);
+        return st;
+    }
+    *out = e;
+    return MM_OK;
+}
+
+void mm_destroy(mm_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (DevBuf* b : { &e->lib, &e->masks, &e->target, &e->recs, &e->cells, &e->cmask, &e->scores,
+                       &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter })
+        release(*b);
+    for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char* mm_last_error(const mm_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+mm_status mm_set_library(mm_engine* e, const float* images, int n_images, int size)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!images || n_images <= 0 || size <= 0 || size > 4096) {
+        set_err(e, "mm_set_library: need n_images > 0 and 0 < size <= 4096 (got %d, %d)", n_images, size);
+        return MM_INVALID_ARGUMENT;
+    }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    const int P = size * size, ppad = round_up(P, 256);
+    const size_t planar_bytes = (size_t)n_images * 3 * ppad * sizeof(float);
+    mm_status st = ensure(e, e->lib, planar_bytes, "Failed to allocate library images");
+    if (st) return st;
+    HIP_TRY(e, hipMemsetAsync(e->lib.p, 0, planar_bytes, e->stream), "Failed to clear library images");
+
+    // H2D in chunks through a bounded staging buffer, transposed to planes on the device.
+    const int chunk = std::max(1, (int)std::min<size_t>((size_t)n_images, ((size_t)256 << 20) / ((size_t)P * 12)));
+    DevBuf stage;
+    st = ensure(e, stage, (size_t)chunk * P * 3 * sizeof(float), "Failed to allocate library staging buffer");
+    if (st) return st;
+    for (int i0 = 0; i0 < n_images; i0 += chunk) {
+        const int c = std::min(chunk, n_images - i0);
+        hipError_t code = hipMemcpyAsync(stage.p, images + (size_t)i0 * P * 3, (size_t)c * P * 3 * sizeof(float),
+                                         hipMemcpyHostToDevice, e->stream);
+        if (code == hipSuccess) {
+            const int blocks = (int)std::min<size_t>(((size_t)c * P + mm::kBlock - 1) / mm::kBlock, 16384);
+            mm::hwc_to_planar_kernel<<<blocks, mm::kBlock, 0, e->stream>>>(
+                (const float*)stage.p, (float*)e->lib.p + (size_t)i0 * 3 * ppad, c, P, ppad);
+            code = hipGetLastError();
+        }
+        if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
+        if (code != hipSuccess) {
+            release(stage);
+            return hip_fail(e, code, "Failed to copy library image to device", __FILE__, __LINE__);
+        }
+    }
+    release(stage);
+    e->n_lib = n_images;
+    e->lib_size = size;
+    return MM_OK;
+}
+
+mm_status mm_set_masks(mm_engine* e, const uint8_t* masks, int size)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!masks || size <= 0 || size > 4096) {
+        set_err(e, "mm_set_masks: need 0 < size <= 4096 (got %d)", size);
+        return MM_INVALID_ARGUMENT;
+    }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    const int P = size * size, ppad = round_up(P, 256);
+    std::vector<uint8_t> padded((size_t)4 * ppad, 0);
+    for (int m = 0; m < 4; ++m) memcpy(padded.data() + (size_t)m * ppad, masks + (size_t)m * P, (size_t)P);
+    mm_status st = ensure(e, e->masks, padded.size(), "Failed to allocate cell masks");
+    if (st) return st;
+    HIP_TRY(e, hipMemcpy(e->masks.p, padded.data(), padded.size(), hipMemcpyHostToDevice),
+            "Failed to copy cell mask to device");
+    e->mask_size = size;
+    return MM_OK;
+}
+
+mm_status mm_set_target(mm_engine* e, const float* image, int rows, int cols)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!image || rows <= 0 || cols <= 0) {
+        set_err(e, "mm_set_target: need rows, cols > 0 (got %d, %d)", rows, cols);
+        return MM_INVALID_ARGUMENT;
+    }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    const size_t bytes = (size_t)rows * cols * 3 * sizeof(float);
+    mm_status st = ensure(e, e->target, bytes, "Failed to allocate main image");
+    if (st) return st;
+    HIP_TRY(e, hipMemcpy(e->target.p, image, bytes, hipMemcpyHostToDevice), "Failed to copy main image to device");
+    e->rows = rows;
+    e->cols = cols;
+    return MM_OK;
+}
+
+int mm_candidates_per_cell(int n_images, int repeat_range, int repeat_addition)
+{
+    if (n_images <= 0) return 0;
+    long long k = 2;     // winner + runner-up (near-tie check)
+    if (repeat_range > 0 && repeat_addition > 0) {
+        // At most R(2R+1)+R neighbours can be penalised; a positive addition can
+        // only push candidates back, so the winner is among the R(2R+1)+R+1 lowest.
+        const long long r = repeat_range;
+        k = r * (2 * r + 1) + r + 2;
+    } else if (repeat_range > 0 && repeat_addition < 0) {
+        k = n_images;    // a negative "penalty" can promote any candidate
+    }
+    return (int)std::min<long long>(k, n_images);
+}
+
+mm_status mm_score_cells(mm_engine* e, const mm_cell* cells, int n_cells, int diff_type, int k,
+                         int32_t* cand_index_out, double* cand_score_out, int outputs_on_device,
+                         mm_progress_cb progress, void* progress_user, volatile int* cancel)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!known_type(diff_type)) { set_err(e, "No function for given type %d", diff_type); return MM_INVALID_ARGUMENT; }
+    if (n_cells < 0 || (n_cells > 0 && !cells) || k <= 0 || !cand_index_out || !cand_score_out) {
+        set_err(e, "mm_score_cells: bad arguments");
+        return MM_INVALID_ARGUMENT;
+    }
+    mm_status st = check_ready(e);
+    if (st) return st;
+    if ((st = check_cells(e, cells, n_cells, 0, 0))) return st;
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    e->timing = mm_timing{};
+    if (n_cells == 0) return MM_OK;
+
+    HIP_TRY(e, hipEventRecord(e->ev[6], e->stream), "event");
+    if ((st = ensure(e, e->recs, (size_t)n_cells * sizeof(mm_cell), "Failed to allocate cell records"))) return st;
+    HIP_TRY(e, hipMemcpyAsync(e->recs.p, cells, (size_t)n_cells * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
+            "Failed to copy cell records to device");
+    int32_t* ci = cand_index_out;
+    double* cs = cand_score_out;
+    if (!outputs_on_device) {
+        if ((st = ensure(e, e->cand_i, (size_t)n_cells * k * sizeof(int32_t), "Failed to allocate candidates")) ||
+            (st = ensure(e, e->cand_s, (size_t)n_cells * k * sizeof(double), "Failed to allocate candidates")))
+            return st;
+        ci = (int32_t*)e->cand_i.p;
+        cs = (double*)e->cand_s.p;
+    }
+    st = score_cells_device(e, (const mm_cell*)e->recs.p, n_cells, diff_type, k, ci, cs, progress, progress_user, cancel);
+    if (st) return st;
+    if (!outputs_on_device) {
+        HIP_TRY(e, hipMemcpyAsync(cand_index_out, ci, (size_t)n_cells * k * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream),
+                "Error copying candidates to host");
+        HIP_TRY(e, hipMemcpyAsync(cand_score_out, cs, (size_t)n_cells * k * sizeof(double), hipMemcpyDeviceToHost, e->stream),
+                "Error copying candidates to host");
+    }
+    HIP_TRY(e, hipEventRecord(e->ev[7], e->stream), "event");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
+    e->timing.pair_evals = count_pair_evals(e, cells, n_cells);
+    return MM_OK;
+}
+
+mm_status mm_resolve(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w, int grid_h, int diff_type,
+                     int repeat_range, int repeat_addition, int k,
+                     const int32_t* cand_index, const double* cand_score, int inputs_on_device,
+                     int64_t* best_fit_out, double* best_score_out)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!known_type(diff_type)) { set_err(e, "No function for given type %d", diff_type); return MM_INVALID_ARGUMENT; }
+    if (n_cells < 0 || (n_cells > 0 && (!cells || !cand_index || !cand_score)) || k <= 0 || grid_w <= 0 ||
+        grid_h <= 0 || !best_fit_out || repeat_range < 0) {
+        set_err(e, "mm_resolve: bad arguments");
+        return MM_INVALID_ARGUMENT;
+    }
+    mm_status st = check_ready(e);
+    if (st) return st;
+    if ((st = check_cells(e, cells, n_cells, grid_w, grid_h))) return st;
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    if ((st = ensure(e, e->recs, (size_t)std::max(n_cells, 1) * sizeof(mm_cell), "Failed to allocate cell records"))) return st;
+    HIP_TRY(e, hipMemcpyAsync(e->recs.p, cells, (size_t)n_cells * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
+            "Failed to copy cell records to device");
+    const int32_t* ci = cand_index;
+    const double* cs = cand_score;
+    if (!inputs_on_device && n_cells > 0) {
+        if ((st = ensure(e, e->cand_i, (size_t)n_cells * k * sizeof(int32_t), "Failed to allocate candidates")) ||
+            (st = ensure(e, e->cand_s, (size_t)n_cells * k * sizeof(double), "Failed to allocate candidates")))
+            return st;
+        HIP_TRY(e, hipMemcpyAsync(e->cand_i.p, cand_index, (size_t)n_cells * k * sizeof(int32_t), hipMemcpyHostToDevice, e->stream),
+                "Failed to copy candidates to device");
+        HIP_TRY(e, hipMemcpyAsync(e->cand_s.p, cand_score, (size_t)n_cells * k * sizeof(double), hipMemcpyHostToDevice, e->stream),
+                "Failed to copy candidates to device");
+        ci = (const int32_t*)e->cand_i.p;
+        cs = (const double*)e->cand_s.p;
+    }
+    return resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
+                          repeat_addition, k, ci, cs, best_fit_out, best_score_out);
+}
+
+mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w, int grid_h, int diff_type,
+                      int repeat_range, int repeat_addition, int64_t* best_fit_out, double* best_score_out,
+                      mm_progress_cb progress, void* progress_user, volatile int* cancel)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!known_type(diff_type)) { set_err(e, "No function for given type %d", diff_type); return MM_INVALID_ARGUMENT; }
+    if (n_cells < 0 || (n_cells > 0 && !cells) || grid_w <= 0 || grid_h <= 0 || !best_fit_out || repeat_range < 0) {
+        set_err(e, "mm_generate: bad arguments");
+        return MM_INVALID_ARGUMENT;
+    }
+    mm_status st = check_ready(e);
+    if (st) return st;
+    if ((st = check_cells(e, cells, n_cells, grid_w, grid_h))) return st;
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    e->timing = mm_timing{};
+
+    const int K = std::max(1, mm_candidates_per_cell(e->n_lib, repeat_range, repeat_addition));
+    HIP_TRY(e, hipEventRecord(e->ev[6], e->stream), "event");
+    if ((st = ensure(e, e->recs, (size_t)std::max(n_cells, 1) * sizeof(mm_cell), "Failed to allocate cell records")) ||
+        (st = ensure(e, e->cand_i, (size_t)std::max(n_cells, 1) * K * sizeof(int32_t), "Failed to allocate candidates")) ||
+        (st = ensure(e, e->cand_s, (size_t)std::max(n_cells, 1) * K * sizeof(double), "Failed to allocate candidates")))
+        return st;
+    HIP_TRY(e, hipMemcpyAsync(e->recs.p, cells, (size_t)n_cells * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
+            "Failed to copy cell records to device");
+    if (n_cells > 0) {
+        st = score_cells_device(e, (const mm_cell*)e->recs.p, n_cells, diff_type, K, (int32_t*)e->cand_i.p,
+                                (double*)e->cand_s.p, progress, progress_user, cancel);
+        if (st) return st;
+    }
+    if (cancel && *cancel) return MM_CANCELLED;
+    st = resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
+                        repeat_addition, K, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p,
+                        best_fit_out, best_score_out);
+    if (st) return st;
+    HIP_TRY(e, hipEventRecord(e->ev[7], e->stream), "event");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
+    e->timing.pair_evals = count_pair_evals(e, cells, n_cells);
+    return MM_OK;
+}
+
+mm_status mm_get_timing(const mm_engine* e, mm_timing* out)
+{
+    if (!e || !out) return MM_INVALID_ARGUMENT;
+    *out = e->timing;
+    return MM_OK;
+}
+
+mm_status mm_colour_diff_batch(mm_engine* e, int diff_type, const float* first, const float* second,
+                               size_t n, double* out)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!known_type(diff_type)) { set_err(e, "No function for given type %d", diff_type); return MM_INVALID_ARGUMENT; }
+    if (n == 0) return MM_OK;
+    if (!first || !second || !out) { set_err(e, "mm_colour_diff_batch: null pointer"); return MM_INVALID_ARGUMENT; }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    DevBuf a, b, o;
+    mm_status st;
+    if ((st = ensure(e, a, n * 3 * sizeof(float), "Failed to allocate pairs")) ||
+        (st = ensure(e, b, n * 3 * sizeof(float), "Failed to allocate pairs")) ||
+        (st = ensure(e, o, n * sizeof(double), "Failed to allocate differences"))) {
+        release(a); release(b); release(o);
+        return st;
+    }
+    hipError_t code = hipMemcpyAsync(a.p, first, n * 3 * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    if (code == hipSuccess) code = hipMemcpyAsync(b.p, second, n * 3 * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    if (code == hipSuccess) {
+        const int blocks = (int)std::min<size_t>((n + mm::kBlock - 1) / mm::kBlock, 8192);
+        by_type(diff_type, [&](auto T) {
+            mm::pair_diff_kernel<decltype(T)::value><<<blocks, mm::kBlock, 0, e->stream>>>(
+                (const float*)a.p, (const float*)b.p, n, (double*)o.p);
+            return MM_OK;
+        });
+        code = hipGetLastError();
+    }
+    if (code == hipSuccess) code = hipMemcpyAsync(out, o.p, n * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
+    release(a); release(b); release(o);
+    if (code != hipSuccess) return hip_fail(e, code, "Error during colour difference kernel", __FILE__, __LINE__);
+    return MM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,408 @@
+// kernels.hpp -- device kernels of the best-fit engine (gfx950 / CDNA4, wave64).
+//
+// Data layout in HBM (DESIGN.md "Layout"):
+//   library   f32 planar  [L][3][ppad]      ppad = P rounded up to 256, pad = 0
+//   masks     u8          [4][ppad]         pad = 0
+//   target    f32 HWC     [rows][cols][3]   as handed over by the host
+//   cells     f32 planar  [B][3][ppad]      gathered per batch, zero outside the image
+//   cmask     u8          [B][ppad]         mask variant AND local bound, per cell
+//   scores    f64         [B][L]            base score of every (cell, candidate)
+//   cand_*    i32/f64     [N][K]            K lowest (score, index) per cell, ascending
+//   grid      i64         [gridH][gridW]    chosen index, sentinel L elsewhere
+//
+// No MFMA anywhere: the per-pair term is a sqrt / transcendental of the pair,
+// not a bilinear form, so the work is VALU + a reduction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mosaic_hip.h"
+#include "colour_diff.hpp"
+
+namespace mm {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kWave = 64;
+constexpr double kInf = __builtin_huge_val();
+
+// ---------------------------------------------------------------------------
+// wave / block reductions
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+struct ScoreIdx { double s; int i; };
+
+// Lexicographic (score, index) order: the lowest index wins a tie, which is what
+// the reference's ascending scan with strict < does (CPUPhotomosaicGenerator.cpp:165).
+__device__ __forceinline__ bool lex_less(double s, int i, double t, int j)
+{
+    return s < t || (s == t && i < j);
+}
+
+__device__ __forceinline__ ScoreIdx wave_min(ScoreIdx v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double s = __shfl_xor(v.s, off, kWave);
+        const int i = __shfl_xor(v.i, off, kWave);
+        if (lex_less(s, i, v.s, v.i)) { v.s = s; v.i = i; }
+    }
+    return v;
+}
+
+// Block-wide lexicographic min; every thread gets the result.  `sh` = 4 slots.
+__device__ __forceinline__ ScoreIdx block_min(ScoreIdx v, ScoreIdx* sh)
+{
+    v = wave_min(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();                       // sh may still be read from a previous call
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    ScoreIdx r = sh[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; ++w)
+        if (lex_less(sh[w].s, sh[w].i, r.s, r.i)) r = sh[w];
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// staging kernels
+// ---------------------------------------------------------------------------
+
+// HWC [n][P][3] -> planar [n][3][ppad] (pad region pre-zeroed by the caller).
+__global__ void __launch_bounds__(kBlock)
+hwc_to_planar_kernel(const float* __restrict__ hwc, float* __restrict__ planar,
+                     int n_images, int P, int ppad)
+{
+    const size_t total = (size_t)n_images * P;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * kBlock) {
+        const size_t img = t / P;
+        const int p = (int)(t - img * P);
+        const float* src = hwc + t * 3;
+        float* dst = planar + img * 3 * (size_t)ppad + p;
+        dst[0] = src[0];
+        dst[ppad] = src[1];
+        dst[2 * (size_t)ppad] = src[2];
+    }
+}
+
+// getCellAt on the device (PhotomosaicGeneratorBase.cpp:293-329, detail 1):
+// the visible part of the target under the cell rect, zero elsewhere, as planes;
+// and the per-cell active mask = mask variant AND local bound (the CUDA path's
+// imageDifferenceEdge target_area test, CUDA/PhotomosaicGenerator.cu:53-72).
+__global__ void __launch_bounds__(kBlock)
+gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ target,
+                    int cols, const uint8_t* __restrict__ masks,
+                    float* __restrict__ cells, uint8_t* __restrict__ cmask,
+                    int size, int P, int ppad)
+{
+    const mm_cell rec = recs[blockIdx.y];
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= ppad) return;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    uint8_t m = 0;
+    if (p < P) {
+        const int row = p / size, col = p - row * size;
+        if (row >= rec.row_min && row < rec.row_max && col >= rec.col_min && col < rec.col_max) {
+            const float* src = target + ((size_t)(rec.y + row) * cols + (rec.x + col)) * 3;
+            v0 = src[0]; v1 = src[1]; v2 = src[2];
+            m = masks[(size_t)rec.mask_id * ppad + p] != 0;
+        }
+    }
+    float* dst = cells + (size_t)blockIdx.y * 3 * ppad + p;
+    dst[0] = v0;
+    dst[ppad] = v1;
+    dst[2 * (size_t)ppad] = v2;
+    cmask[(size_t)blockIdx.y * ppad + p] = m;
+}
+
+// ---------------------------------------------------------------------------
+// score kernel (the dominant kernel): base score of every (cell, candidate)
+// ---------------------------------------------------------------------------
+//
+// One wave owns one (cell, candidate) pair at a time and walks the whole cell:
+// lane k takes float4 pixel groups k, k+64, ... of each colour plane (1 KiB
+// coalesced per wave-instruction), accumulates the masked colour difference in
+// fp64 in a register, and the 64 partial sums are combined with xor-shuffles.
+// The 4 waves of a workgroup take 4 candidates against the same cell.
+//
+// Work decode (1-D grid): cells vary fastest inside a group of `cell_group`
+// cells, then candidate tiles, then cell groups -- so the workgroups resident
+// at one time share a few candidate tiles (library reuse in L2) rather than
+// streaming the whole library once per cell.
+template <int TYPE>
+__global__ void __launch_bounds__(kBlock)
+score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
+             const float* __restrict__ lib, double* __restrict__ scores,
+             int n_cells, int L, int ppad, int cand_per_block, int cell_group)
+{
+    const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
+    const long long bid = blockIdx.x;
+    const long long per_group = (long long)cell_group * n_tiles;
+    const int group = (int)(bid / per_group);
+    const long long rem = bid - (long long)group * per_group;
+    const int cells_here = min(cell_group, n_cells - group * cell_group);
+    const int tile = (int)(rem / cells_here);
+    const int cell = group * cell_group + (int)(rem - (long long)tile * cells_here);
+    if (tile >= n_tiles || cell >= n_cells) return;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int groups = ppad / (4 * kWave);            // float4 groups per lane
+    const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
+    const float4* c1 = c0 + ppad / 4;
+    const float4* c2 = c1 + ppad / 4;
+    const uint32_t* mk = reinterpret_cast<const uint32_t*>(cmask + (size_t)cell * ppad);
+
+    const int l_end = min((tile + 1) * cand_per_block, L);
+    for (int l = tile * cand_per_block + wave; l < l_end; l += kBlock / kWave) {
+        const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
+        const float4* b1 = b0 + ppad / 4;
+        const float4* b2 = b1 + ppad / 4;
+        double acc = 0.0;
+        for (int j = 0; j < groups; ++j) {
+            const int q = lane + kWave * j;
+            const uint32_t m = mk[q];
+            if (m == 0) continue;
+            const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
+            const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
+            if (m & 0x000000ffu) acc += colour_diff<TYPE>(Px{p0.x, p1.x, p2.x}, Px{q0.x, q1.x, q2.x});
+            if (m & 0x0000ff00u) acc += colour_diff<TYPE>(Px{p0.y, p1.y, p2.y}, Px{q0.y, q1.y, q2.y});
+            if (m & 0x00ff0000u) acc += colour_diff<TYPE>(Px{p0.z, p1.z, p2.z}, Px{q0.z, q1.z, q2.z});
+            if (m & 0xff000000u) acc += colour_diff<TYPE>(Px{p0.w, p1.w, p2.w}, Px{q0.w, q1.w, q2.w});
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) scores[(size_t)cell * L + l] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// candidate selection: the K lowest (score, index) of each cell's row
+// ---------------------------------------------------------------------------
+//
+// One workgroup per cell, K rounds; round r takes the lexicographic minimum of
+// the entries strictly above round r-1's pick, so nothing is mutated and the
+// row is re-read from L2 (40-80 KB).  Slots past the row length get index -1.
+__global__ void __launch_bounds__(kBlock)
+select_kernel(const double* __restrict__ scores, int L, int K,
+              int32_t* __restrict__ cand_index, double* __restrict__ cand_score)
+{
+    __shared__ ScoreIdx sh[kBlock / kWave];
+    const double* row = scores + (size_t)blockIdx.x * L;
+    double prev_s = -kInf;
+    int prev_i = -1;
+    for (int r = 0; r < K; ++r) {
+        ScoreIdx best{kInf, 0x7fffffff};
+        for (int l = threadIdx.x; l < L; l += kBlock) {
+            const double s = row[l];
+            if (lex_less(prev_s, prev_i, s, l) && lex_less(s, l, best.s, best.i)) { best.s = s; best.i = l; }
+        }
+        best = block_min(best, sh);
+        const bool none = best.i == 0x7fffffff;
+        if (threadIdx.x == 0) {
+            cand_index[(size_t)blockIdx.x * K + r] = none ? -1 : best.i;
+            cand_score[(size_t)blockIdx.x * K + r] = none ? kInf : best.s;
+        }
+        if (none) {          // row exhausted (K > L, or NaN / +inf tail): fill the rest
+            for (int t = r + 1 + threadIdx.x; t < K; t += kBlock) {
+                cand_index[(size_t)blockIdx.x * K + t] = -1;
+                cand_score[(size_t)blockIdx.x * K + t] = kInf;
+            }
+            break;
+        }
+        prev_s = best.s;
+        prev_i = best.i;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// resolve: repeat penalty + argmin + exact tie-break, in the reference's order
+// ---------------------------------------------------------------------------
+
+struct ResolveArgs {
+    const mm_cell* recs;
+    int n_cells;
+    int grid_w, grid_h;
+    int L;
+    int repeat_range, repeat_addition;
+    int K;
+    const int32_t* cand_index;
+    const double* cand_score;
+    long long* grid;            // [grid_h*grid_w], pre-filled with the sentinel L
+    double* best_score;         // [grid_h*grid_w], pre-filled with NaN
+    // pixel data for the exact tie-break
+    const float* target; int rows, cols;
+    const uint8_t* masks;
+    const float* lib;
+    int size, P, ppad;
+    double tie_band;            // relative gap under which two totals count as a near-tie
+    unsigned long long* exact_count;
+};
+
+// Repeat value of library image `cand` at padded cell (px, py):
+// CPUPhotomosaicGenerator::calculateRepeats (CPUPhotomosaicGenerator.cpp:185-225)
+// -- rows clamp(py-R,0,H)..py-1 over columns clamp(px-R,0,W)..clamp(px+R,0,W-1),
+// then the same row's columns startX..px-1; untouched cells hold the sentinel
+// and never match (the CUDA path's `bestFit[n] < L` test, PhotomosaicGenerator.cu:137).
+__device__ __forceinline__ int repeat_value(const ResolveArgs& a, int px, int py, int cand)
+{
+    const int R = a.repeat_range;
+    const int sy = min(max(py - R, 0), a.grid_h);
+    const int sx = min(max(px - R, 0), a.grid_w);
+    const int ex = min(max(px + R, 0), a.grid_w - 1);
+    int rep = 0;
+    for (int ry = sy; ry < py; ++ry)
+        for (int rx = sx; rx <= ex; ++rx)
+            if (a.grid[(size_t)ry * a.grid_w + rx] == cand) rep += a.repeat_addition;
+    for (int rx = sx; rx < px; ++rx)
+        if (a.grid[(size_t)py * a.grid_w + rx] == cand) rep += a.repeat_addition;
+    return rep;
+}
+
+constexpr int kExactChunk = 2048;   // pixels per LDS chunk of the sequential re-sum
+
+// The reference's own summation for ONE (cell, candidate): start from the repeat
+// value as int -> double, add the active pixels' differences one by one in
+// row-major order (CPUPhotomosaicGenerator.cpp:143-161).  All threads evaluate
+// the per-pixel terms; thread 0 adds them in order.  Returns the total to every
+// thread.
+template <int TYPE>
+__device__ double exact_total(const ResolveArgs& a, const mm_cell& rec, int cand, int rep,
+                              double* buf, double* bcast)
+{
+    double running = (double)rep;
+    const float* l0 = a.lib + (size_t)cand * 3 * a.ppad;
+    const uint8_t* mk = a.masks + (size_t)rec.mask_id * a.ppad;
+    for (int base = 0; base < a.P; base += kExactChunk) {
+        const int n = min(kExactChunk, a.P - base);
+        for (int t = threadIdx.x; t < n; t += kBlock) {
+            const int p = base + t;
+            const int row = p / a.size, col = p - row * a.size;
+            double term = -1.0;                               // marker: not active
+            if (mk[p] != 0 && row >= rec.row_min && row < rec.row_max &&
+                col >= rec.col_min && col < rec.col_max) {
+                const float* src = a.target + ((size_t)(rec.y + row) * a.cols + (rec.x + col)) * 3;
+                term = colour_diff<TYPE>(Px{src[0], src[1], src[2]},
+                                         Px{l0[p], l0[a.ppad + p], l0[2 * (size_t)a.ppad + p]});
+            }
+            buf[t] = term;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int t = 0; t < n; ++t)
+                if (buf[t] != -1.0) running += buf[t];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *bcast = running;
+    __syncthreads();
+    running = *bcast;
+    __syncthreads();
+    return running;
+}
+
+// sequential != 0: ONE workgroup walks the cells in raster order (each cell's
+// penalty reads the cells chosen before it).  sequential == 0 (no repeats):
+// workgroups take cells independently.
+template <int TYPE>
+__global__ void __launch_bounds__(kBlock)
+resolve_kernel(ResolveArgs a, int sequential)
+{
+    __shared__ ScoreIdx sh[kBlock / kWave];
+    __shared__ double buf[kExactChunk];
+    __shared__ double bcast;
+
+    const int first = sequential ? 0 : blockIdx.x;
+    const int stride = sequential ? 1 : gridDim.x;
+    for (int c = first; c < a.n_cells; c += stride) {
+        const mm_cell rec = a.recs[c];
+        const int32_t* ci = a.cand_index + (size_t)c * a.K;
+        const double* cs = a.cand_score + (size_t)c * a.K;
+        const bool penalise = a.repeat_range > 0 && a.repeat_addition != 0;
+
+        // pass 1: lowest (total, index) over the cell's candidates
+        ScoreIdx best{kInf, 0x7fffffff};
+        for (int k = threadIdx.x; k < a.K; k += kBlock) {
+            const int cand = ci[k];
+            if (cand < 0) continue;
+            const int rep = penalise ? repeat_value(a, rec.grid_x, rec.grid_y, cand) : 0;
+            const double total = (double)rep + cs[k];
+            if (lex_less(total, cand, best.s, best.i)) { best.s = total; best.i = cand; }
+        }
+        best = block_min(best, sh);
+
+        long long chosen = a.L;                // sentinel: "Failed to find a best fit" (:173-177)
+        double chosen_total = best.s;
+        if (best.i != 0x7fffffff) {
+            chosen = best.i;
+            // pass 2: how many candidates sit within the near-tie band of the minimum?
+            const double thr = best.s + fabs(best.s) * a.tie_band;
+            int near = 0;
+            for (int k = threadIdx.x; k < a.K; k += kBlock) {
+                const int cand = ci[k];
+                if (cand < 0) continue;
+                const int rep = penalise ? repeat_value(a, rec.grid_x, rec.grid_y, cand) : 0;
+                if ((double)rep + cs[k] <= thr) ++near;
+            }
+            const int many_in_one = __syncthreads_or(near > 1);
+            const int holders = __syncthreads_count(near > 0);
+            if (many_in_one || holders > 1) {
+                // Re-sum every contender in the reference's order, ascending index,
+                // strict < : exactly the CPU scan restricted to the contenders.
+                double ex_best = kInf;
+                int ex_idx = -1;
+                int prev = -1;
+                for (;;) {
+                    int nxt = 0x7fffffff;                // lowest contender index above prev
+                    for (int k = threadIdx.x; k < a.K; k += kBlock) {
+                        const int cand = ci[k];
+                        if (cand <= prev || cand >= nxt) continue;
+                        const int rep = penalise ? repeat_value(a, rec.grid_x, rec.grid_y, cand) : 0;
+                        if ((double)rep + cs[k] <= thr) nxt = cand;
+                    }
+                    ScoreIdx key{(double)nxt, nxt};      // block-min on the index alone
+                    key = block_min(key, sh);
+                    if (key.i == 0x7fffffff) break;
+                    const int nxt_rep = penalise ? repeat_value(a, rec.grid_x, rec.grid_y, key.i) : 0;
+                    const double ex = exact_total<TYPE>(a, rec, key.i, nxt_rep, buf, &bcast);
+                    if (threadIdx.x == 0) atomicAdd(a.exact_count, 1ull);
+                    if (ex < ex_best) { ex_best = ex; ex_idx = key.i; }
+                    prev = key.i;
+                }
+                if (ex_idx >= 0) { chosen = ex_idx; chosen_total = ex_best; }
+            }
+        }
+
+        const size_t pos = (size_t)rec.grid_y * a.grid_w + rec.grid_x;
+        if (threadIdx.x == 0) {
+            a.grid[pos] = chosen;
+            a.best_score[pos] = chosen_total;
+        }
+        __syncthreads();          // workgroup-scope release/acquire: the next cell reads grid[]
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-pair batch (KATs, differential tests)
+// ---------------------------------------------------------------------------
+
+template <int TYPE>
+__global__ void __launch_bounds__(kBlock)
+pair_diff_kernel(const float* __restrict__ first, const float* __restrict__ second,
+                 size_t n, double* __restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * kBlock) {
+        const float* p = first + 3 * i;
+        const float* q = second + 3 * i;
+        out[i] = colour_diff<TYPE>(Px{p[0], p[1], p[2]}, Px{q[0], q[1], q[2]});
+    }
+}
+
+}  // namespace mm

@@ -1,0 +1,159 @@
+"""Numpy-facing wrapper of the C ABI (one engine = one GPU).
+
+Nothing is computed here: every method marshals numpy arrays into the entry
+points of include/mosaic_hip.h and turns a non-zero ``mm_status`` into
+``EngineError``.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .grid import CELL_DTYPE
+
+
+class EngineError(RuntimeError):
+    def __init__(self, status, message):
+        self.status = status
+        name = _lib.STATUS_NAMES[status] if 0 <= status < len(_lib.STATUS_NAMES) else str(status)
+        super().__init__("%s: %s" % (name, message))
+
+
+class Cancelled(EngineError):
+    pass
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    st = _lib.load().mm_device_count(ctypes.byref(n))
+    if st != _lib.MM_OK:
+        raise EngineError(st, (_lib.load().mm_last_error(None) or b"").decode())
+    return n.value
+
+
+class Engine:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        st = self._lib.mm_create(int(device), ctypes.byref(self._h))
+        if st != _lib.MM_OK:
+            raise EngineError(st, (self._lib.mm_last_error(None) or b"").decode())
+        self.device = int(device)
+        self.n_library = 0
+        self.size = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, st):
+        if st == _lib.MM_OK:
+            return
+        msg = (self._lib.mm_last_error(self._h) or b"").decode()
+        raise (Cancelled if st == _lib.MM_CANCELLED else EngineError)(st, msg)
+
+    # -- staging -------------------------------------------------------------
+    def set_library(self, images):
+        """f32 ``[n][size][size][3]`` (after preprocessLibraryImages)."""
+        a = np.ascontiguousarray(images, dtype=np.float32)
+        if a.ndim != 4 or a.shape[1] != a.shape[2] or a.shape[3] != 3:
+            raise ValueError("library must be [n][size][size][3]")
+        self._check(self._lib.mm_set_library(self._h, _lib.ptr(a), a.shape[0], a.shape[1]))
+        self.n_library, self.size = a.shape[0], a.shape[1]
+
+    def set_masks(self, masks):
+        """u8 ``[4][size][size]`` in the order flipH + 2*flipV."""
+        a = np.ascontiguousarray(masks, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[0] != 4 or a.shape[1] != a.shape[2]:
+            raise ValueError("masks must be [4][size][size]")
+        self._check(self._lib.mm_set_masks(self._h, _lib.ptr(a), a.shape[1]))
+
+    def set_target(self, image):
+        """f32 ``[rows][cols][3]`` (after preprocessMainImage)."""
+        a = np.ascontiguousarray(image, dtype=np.float32)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("target must be [rows][cols][3]")
+        self._check(self._lib.mm_set_target(self._h, _lib.ptr(a), a.shape[0], a.shape[1]))
+
+    # -- hot path ------------------------------------------------------------
+    def _callbacks(self, progress, cancel):
+        cb = _lib.PROGRESS_CB(lambda done, _u: progress(done)) if progress else None
+        flag = cancel if cancel is not None else None      # ctypes.c_int owned by the caller
+        return cb, (ctypes.byref(flag) if flag is not None else None)
+
+    def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0,
+                 want_scores=True, progress=None, cancel=None):
+        """mm_generate -> (best_fit int64 [grid_h][grid_w] with sentinel n_library,
+        best_score f64 [grid_h][grid_w] or None)."""
+        rec = _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
+        best = np.empty((grid_h, grid_w), dtype=np.int64)
+        score = np.empty((grid_h, grid_w), dtype=np.float64) if want_scores else None
+        cb, cflag = self._callbacks(progress, cancel)
+        self._check(self._lib.mm_generate(
+            self._h, _lib.ptr(rec), len(rec), grid_w, grid_h, int(diff_type),
+            int(repeat_range), int(repeat_addition), _lib.ptr(best), _lib.ptr(score),
+            ctypes.cast(cb, ctypes.c_void_p) if cb else None, None, cflag))
+        return best, score
+
+    def candidates_per_cell(self, repeat_range, repeat_addition):
+        return self._lib.mm_candidates_per_cell(self.n_library, int(repeat_range), int(repeat_addition))
+
+    def score_cells(self, cells, diff_type, k, out_index=None, out_score=None, on_device=False,
+                    progress=None, cancel=None):
+        """mm_score_cells.  Host mode returns (index int32 [n][k], score f64 [n][k]);
+        device mode writes to the given raw device addresses (ints)."""
+        rec = _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
+        cb, cflag = self._callbacks(progress, cancel)
+        if on_device:
+            pi, ps = ctypes.c_void_p(int(out_index)), ctypes.c_void_p(int(out_score))
+            idx = sc = None
+        else:
+            idx = np.empty((len(rec), k), dtype=np.int32)
+            sc = np.empty((len(rec), k), dtype=np.float64)
+            pi, ps = _lib.ptr(idx), _lib.ptr(sc)
+        self._check(self._lib.mm_score_cells(
+            self._h, _lib.ptr(rec), len(rec), int(diff_type), int(k), pi, ps, 1 if on_device else 0,
+            ctypes.cast(cb, ctypes.c_void_p) if cb else None, None, cflag))
+        return idx, sc
+
+    def resolve(self, cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, k,
+                cand_index, cand_score, on_device=False, want_scores=True):
+        """mm_resolve over ALL cells of the grid with their gathered candidate lists."""
+        rec = _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
+        best = np.empty((grid_h, grid_w), dtype=np.int64)
+        score = np.empty((grid_h, grid_w), dtype=np.float64) if want_scores else None
+        if on_device:
+            pi, ps = ctypes.c_void_p(int(cand_index)), ctypes.c_void_p(int(cand_score))
+        else:
+            ci = np.ascontiguousarray(cand_index, dtype=np.int32)
+            cs = np.ascontiguousarray(cand_score, dtype=np.float64)
+            pi, ps = _lib.ptr(ci), _lib.ptr(cs)
+        self._check(self._lib.mm_resolve(
+            self._h, _lib.ptr(rec), len(rec), grid_w, grid_h, int(diff_type), int(repeat_range),
+            int(repeat_addition), int(k), pi, ps, 1 if on_device else 0, _lib.ptr(best), _lib.ptr(score)))
+        return best, score
+
+    def timing(self):
+        t = _lib.MMTiming()
+        self._check(self._lib.mm_get_timing(self._h, ctypes.byref(t)))
+        return t.as_dict()
+
+    def colour_diff_batch(self, diff_type, first, second):
+        """n pairs of f32 triplets -> f64 differences (first = main pixel, second = library pixel)."""
+        a = np.ascontiguousarray(first, dtype=np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(second, dtype=np.float32).reshape(-1, 3)
+        if a.shape != b.shape:
+            raise ValueError("pair arrays differ in shape")
+        out = np.empty(a.shape[0], dtype=np.float64)
+        self._check(self._lib.mm_colour_diff_batch(self._h, int(diff_type), _lib.ptr(a), _lib.ptr(b),
+                                                   a.shape[0], _lib.ptr(out)))
+        return out

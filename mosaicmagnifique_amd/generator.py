@@ -1,0 +1,170 @@
+"""``HIPPhotomosaicGenerator``: the reference's generator interface over the HIP engine.
+
+Same names, argument meaning and error behaviour as ``PhotomosaicGeneratorBase``
+(src/Photomosaic/PhotomosaicGeneratorBase.h:36-81) and its device back-end
+``CUDAPhotomosaicGenerator(device)`` (CUDA/CUDAPhotomosaicGenerator.h:31), so a
+test written against the reference reads the same here.  ``cv::Mat`` becomes a
+numpy array, ``MosaicBestFit`` a list (one entry per size step) of int64 arrays
+over the padded grid with ``grid.NULLOPT`` for ``std::nullopt``.
+
+All arithmetic of the hot path happens behind the C ABI; this class only does
+what the reference's host does around it: colour conversion of the inputs,
+marshalling, and writing the result back where the grid state ``has_value()``
+(CUDAPhotomosaicGenerator.cpp:310-324).
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from . import colourdifference as ColourDifference
+from . import grid as GridUtility
+from . import synth
+from .cellshape import CellGroup
+from .engine import Cancelled, Engine, EngineError
+
+log = logging.getLogger("mosaicmagnifique_amd")
+
+
+class HIPPhotomosaicGenerator:
+    def __init__(self, device=0):
+        self.m_engine = Engine(device)
+        self.m_img = None
+        self.m_lib = None
+        self.m_colourDiffType = ColourDifference.Type.RGB_EUCLIDEAN
+        self.m_cells = CellGroup()
+        self.m_bestFits = []
+        self.m_repeatRange = 0
+        self.m_repeatAddition = 0
+        self.m_progress = 0
+        self.m_wasCanceled = ctypes.c_int(0)
+        self.m_bestScores = []
+        self._progress_listeners = []
+        self._staged = None          # what is resident on the device: (lib id, img id, type, mask id)
+        self.lastError = ""
+
+    # -- setters (PhotomosaicGeneratorBase.cpp:44-93) -------------------------
+    def setMainImage(self, img):
+        """u8 BGR ``[rows][cols][3]`` (converted like preprocessMainImage) or an
+        already preprocessed f32 array."""
+        self.m_img = np.asarray(img)
+
+    def setLibrary(self, lib):
+        """Sequence / array of square u8 BGR images at the cell size, or f32 preprocessed."""
+        self.m_lib = np.asarray(lib)
+
+    def setColourDifference(self, t):
+        t = ColourDifference.Type(t)
+        if t == ColourDifference.Type.MAX:
+            raise ValueError("No function for given type")     # ColourDifference.cpp:23
+        self.m_colourDiffType = t
+
+    def setColourScheme(self, t=0):
+        if int(t) != 0:
+            raise NotImplementedError("colour-scheme variants are outside the hot-path scope (SURVEY 8f N3)")
+
+    def setCellGroup(self, cellGroup):
+        self.m_cells = cellGroup
+
+    def getCellGroup(self):
+        return self.m_cells
+
+    def setGridState(self, gridState):
+        self.m_bestFits = [np.array(s, dtype=np.int64) for s in gridState]
+
+    def setRepeat(self, repeatRange=0, repeatAddition=0):
+        self.m_repeatRange = int(repeatRange)
+        self.m_repeatAddition = int(repeatAddition)
+
+    # -- progress / cancel ---------------------------------------------------
+    def connectProgress(self, fn):
+        """The ``progress(int)`` signal."""
+        self._progress_listeners.append(fn)
+
+    def getMaxProgress(self):
+        """PhotomosaicGeneratorBase::getMaxProgress (:210-214)."""
+        s = len(self.m_bestFits)
+        return int(4 ** (s - 1)) * s * self.m_bestFits[0].shape[1] * self.m_bestFits[0].shape[0]
+
+    def cancel(self):
+        self.m_wasCanceled.value = 1
+
+    # -- preprocessing (PhotomosaicGeneratorBase.cpp:223-290) -----------------
+    def preprocessMainImage(self):
+        if self.m_img.dtype == np.uint8:
+            return synth.preprocess(self.m_img, self.m_colourDiffType)
+        return np.ascontiguousarray(self.m_img, dtype=np.float32)
+
+    def preprocessLibraryImages(self):
+        if self.m_cells.getDetail() != 1:
+            raise NotImplementedError("detail != 100 %: library resize stays on the OpenCV host")
+        if self.m_lib.dtype == np.uint8:
+            return synth.preprocess(self.m_lib, self.m_colourDiffType)
+        return np.ascontiguousarray(self.m_lib, dtype=np.float32)
+
+    # -- the hot path --------------------------------------------------------
+    def generateBestFits(self):
+        """Returns True if successful, False on cancel or device error (the
+        reference's bool contract, CUDAPhotomosaicGenerator.cpp:367); the error
+        text is in ``lastError`` (the reference shows it in a message box)."""
+        try:
+            return self._generate()
+        except Cancelled:
+            log.info("Photomosaic generation cancelled.")
+            return False
+        except EngineError as err:
+            self.lastError = str(err)
+            log.critical(self.lastError)
+            return False
+
+    def _generate(self):
+        if len(self.m_bestFits) != 1:
+            raise NotImplementedError("size steps > 0 are outside the hot-path scope (SURVEY 8f N3)")
+        detailShape = self.m_cells.getCell(0, True)
+        key = (id(self.m_lib), id(self.m_img), self.m_colourDiffType, id(detailShape))
+        if key != self._staged:
+            main = self.preprocessMainImage()
+            lib = self.preprocessLibraryImages()
+            self.m_engine.set_library(lib)
+            self.m_engine.set_masks(detailShape.masks4())
+            self.m_engine.set_target(main)
+            self._staged = key
+            self._rows, self._cols = main.shape[0], main.shape[1]
+
+        self.m_progress = 0
+        step = self.m_bestFits[0]
+        cells = GridUtility.cell_records(self.m_cells, step, self._rows, self._cols)
+        # Invalid cells still tick the progress bar in the reference; emit the
+        # total once the device batches are through.
+        def on_progress(done):
+            self.m_progress = done
+            for fn in self._progress_listeners:
+                fn(done)
+
+        best, score = self.m_engine.generate(
+            cells, step.shape[1], step.shape[0], int(self.m_colourDiffType),
+            self.m_repeatRange, self.m_repeatAddition, want_scores=True,
+            progress=on_progress if self._progress_listeners else None, cancel=self.m_wasCanceled)
+
+        # Write back only where the grid state has a value (CUDAPhotomosaicGenerator.cpp:310-324).
+        valid = step >= 0
+        out = step.copy()
+        out[valid] = best[valid]
+        # "Failed to find a best fit... The cell will be removed" (CPUPhotomosaicGenerator.cpp:173-177)
+        out[valid & (best >= self.m_engine.n_library)] = GridUtility.NULLOPT
+        self.m_bestFits = [out]
+        self.m_bestScores = [score]
+        for fn in self._progress_listeners:
+            fn(self.getMaxProgress())
+        return True
+
+    def getBestFits(self):
+        return [s.copy() for s in self.m_bestFits]
+
+    def getBestScores(self):
+        """bestVariant per cell (NaN where the grid has no value); not in the
+        reference interface, used by the parity tests."""
+        return [s.copy() for s in self.m_bestScores]
+
+    def timing(self):
+        return self.m_engine.timing()

@@ -1,0 +1,112 @@
+/*
+ * oracle.h -- CPU restatement of the MosaicMagnifique photomosaic best-fit path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker the HIP engine is compared
+ * against; nothing under mosaicmagnifique_amd/ may include, link or call it.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * Parity pin: the colour-difference functions are checked against every
+ * known-answer vector the reference's own tests hold for this path
+ * (test/tst_ColourDifference.h:26-35 RGB, :49-56 CIE76, :73-108 the 34
+ * Sharma-2005 CIEDE2000 pairs) -- tests/golden/colour_diff_kats.json.  The
+ * reference has no absolute pin for chosen indices (its generator tests are
+ * differential only), so the generator part of this
+ * oracle is pinned by restating CPUPhotomosaicGenerator.cpp line by line and
+ * by the semantic pins in test/tst_CUDAKernel.h (repeat window, strict-<
+ * lowest scan).  The reference itself cannot be built in this image (needs
+ * OpenCV + Qt headers, neither installed), so there is no oracle/_ref.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference checkout's src/).
+ */
+#ifndef MM_ORACLE_H
+#define MM_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ColourDifference::Type, Photomosaic/ColourDifference.h:13-19 */
+enum { ORC_RGB_EUCLIDEAN = 0, ORC_CIE76 = 1, ORC_CIEDE2000 = 2 };
+
+/* GridUtility::PAD_GRID, Grid/GridUtility.h:33 */
+#define ORC_PAD_GRID 2
+
+/* Geometry half of CellShape (CellShape/CellShape.h:25-113): everything the
+ * grid code reads except the mask pixels. */
+typedef struct orc_shape {
+    int32_t size;              /* getSize(): mask rows (square) */
+    int32_t row_spacing, col_spacing;
+    int32_t alt_row_spacing, alt_col_spacing;
+    int32_t alt_row_offset, alt_col_offset;
+    int32_t alt_col_flip_h, alt_col_flip_v;
+    int32_t alt_row_flip_h, alt_row_flip_v;
+} orc_shape;
+
+typedef struct orc_rect { int32_t x, y, w, h; } orc_rect; /* cv::Rect */
+
+/* ---- colour difference (Photomosaic/ColourDifference.cpp) ---- */
+double orc_rgb_euclidean(const double first[3], const double second[3]);
+double orc_ciede2000(const double first[3], const double second[3]);
+/* getFunction() dispatch; returns NaN for an unknown type (the reference throws). */
+double orc_colour_diff(int type, const double first[3], const double second[3]);
+/* n pairs of f32 triplets, promoted to double exactly as Vec3f -> Vec3d does. */
+void orc_colour_diff_batch(int type, const float *first, const float *second,
+                           size_t n, double *out);
+
+/* ---- geometry (Grid/GridUtility.cpp) ---- */
+void orc_grid_size(const orc_shape *s, int img_w, int img_h, int pad,
+                   int *grid_w, int *grid_h);
+orc_rect orc_rect_at(const orc_shape *s, int x, int y);
+void orc_flip_state_at(const orc_shape *s, int x, int y, int *flip_h, int *flip_v);
+
+/* Grid state for sizeSteps == 0 (Grid/GridGenerator.cpp:29-110,113-140,191-192):
+ * state[gy*grid_w+gx] = 0 where the cell rect meets the image (optional(0)),
+ * -1 where it does not (nullopt). */
+void orc_grid_state(const orc_shape *s, int img_w, int img_h,
+                    int grid_w, int grid_h, int64_t *state);
+
+/* PhotomosaicGeneratorBase::getCellAt at detail == 1
+ * (Photomosaic/PhotomosaicGeneratorBase.cpp:293-329).  img is HWC f32 with 3
+ * channels; cell_out (size*size*3) is zero filled then receives the visible
+ * part.  Returns the local bound. */
+orc_rect orc_cell_at(const orc_shape *s, int x, int y, const float *img,
+                     int rows, int cols, float *cell_out);
+
+/* CPUPhotomosaicGenerator::calculateRepeats (CPUPhotomosaicGenerator.cpp:185-225).
+ * grid is the padded state (-1 = nullopt).  px,py are padded coordinates.
+ * Writes up to cap (library index, repeat value) pairs, returns how many. */
+int orc_repeats(const int64_t *grid, int grid_w, int grid_h, int px, int py,
+                int range, int addition, int64_t *keys, int *vals, int cap);
+
+/* CPUPhotomosaicGenerator::findCellBestFit (CPUPhotomosaicGenerator.cpp:117-181),
+ * one main-image variant.  cell/lib images are HWC f32, mask is u8 size*size.
+ * early_exit != 0 keeps the reference's `variant < bestVariant` loop guards;
+ * 0 sums every active pixel (same argmin, since every term is >= 0).
+ * Returns the chosen library index or -1; *best_out gets bestVariant. */
+int64_t orc_find_cell_best_fit(int type, const float *cell, orc_rect bounds,
+                               const uint8_t *mask, int size,
+                               const float *lib, int64_t n_lib,
+                               const int64_t *rep_keys, const int *rep_vals, int n_rep,
+                               int early_exit, double *best_out);
+
+/* CPUPhotomosaicGenerator::generateBestFits (CPUPhotomosaicGenerator.cpp:33-113)
+ * for one size step, detail 1, colour scheme NONE.  masks = 4 masks of
+ * size*size in the order (flipH,flipV) = (0,0),(1,0),(0,1),(1,1).
+ * grid: in = state from orc_grid_state, out = best fits (-1 stays -1).
+ * scores (may be NULL): bestVariant per padded cell (NaN where not computed).
+ * max_cells < 0: all cells; otherwise stop after that many valid cells in
+ * raster order (bounded CPU-baseline sample).  Returns cells processed. */
+int orc_generate_best_fits(const orc_shape *s, const float *img, int rows, int cols,
+                           const float *lib, int64_t n_lib, const uint8_t *masks,
+                           int type, int repeat_range, int repeat_addition,
+                           int grid_w, int grid_h, int64_t *grid, double *scores,
+                           int max_cells, int early_exit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
