@@ -85,6 +85,7 @@ typedef struct mm_timing {
     int64_t score_launches;   /* launches of the dominant score kernel */
     int64_t pair_evals;       /* colour differences evaluated by it (active pixels x candidates) */
     int64_t exact_rescored;   /* candidates re-summed in reference order to break a near-tie */
+    int64_t dense_rows;       /* cells whose candidate list overflowed (whole row recomputed) */
 } mm_timing;
 
 /* Progress: called on the calling thread between device batches with
@@ -145,7 +146,10 @@ mm_status mm_generate(mm_engine *e, const mm_cell *cells, int n_cells,
  * R(2R+1)+R+1 lowest base scores; +1 runner-up for the near-tie check. */
 int mm_candidates_per_cell(int n_images, int repeat_range, int repeat_addition);
 /* cand_index_out [n_cells][k] int32, cand_score_out [n_cells][k] f64: the k
- * lowest base scores per cell ascending by (score, index).  Host pointers, or
+ * lowest base scores per cell ascending by (score, index); index -1 = no such
+ * candidate.  A LAST index <= -2 encodes -(index + 2) and marks a list that was
+ * cut through a cluster of near-tied scores: mm_resolve then recomputes that
+ * cell's whole row, so the lists can be all-gathered as they are.  Host pointers, or
  * device pointers if outputs_on_device != 0 (results complete on return). */
 mm_status mm_score_cells(mm_engine *e, const mm_cell *cells, int n_cells,
                          int diff_type, int k,

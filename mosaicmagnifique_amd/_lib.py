@@ -23,7 +23,8 @@ class MMTiming(ctypes.Structure):
     _fields_ = [("stage_ms", ctypes.c_double), ("score_ms", ctypes.c_double),
                 ("select_ms", ctypes.c_double), ("resolve_ms", ctypes.c_double),
                 ("total_ms", ctypes.c_double), ("score_launches", ctypes.c_int64),
-                ("pair_evals", ctypes.c_int64), ("exact_rescored", ctypes.c_int64)]
+                ("pair_evals", ctypes.c_int64), ("exact_rescored", ctypes.c_int64),
+                ("dense_rows", ctypes.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -46,7 +46,7 @@ struct mm_engine {
     DevBuf target;   int rows = 0, cols = 0;
 
     // per-call workspaces (grown on demand, kept)
-    DevBuf recs, cells, cmask, scores, cand_i, cand_s, grid, best, counter;
+    DevBuf recs, cells, cmask, scores, cand_i, cand_s, grid, best, counter, scratch;
 
     mm_timing timing{};
 };
@@ -95,6 +95,11 @@ void release(DevBuf& b)
     b.p = nullptr;
     b.bytes = 0;
 }
+
+// Relative gap under which two fp64 totals count as a near-tie and are re-summed in
+// the reference's order.  The parallel-order sums differ from the sequential ones
+// by <= ~P * 2^-53 (~5e-13 at P = 4096); 1e-9 leaves three orders of margin.
+constexpr double kTieBand = 1e-9;
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -202,7 +207,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* recs_dev, int n, int d
         HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
 
         mm::select_kernel<<<b, mm::kBlock, 0, e->stream>>>(
-            (const double*)e->scores.p, L, K, cand_i_dev + (size_t)done * K, cand_s_dev + (size_t)done * K);
+            (const double*)e->scores.p, L, K, kTieBand, cand_i_dev + (size_t)done * K, cand_s_dev + (size_t)done * K);
         HIP_TRY(e, hipGetLastError(), "Error during candidate selection kernel");
         HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
         HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
@@ -227,7 +232,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
     mm_status st;
     if ((st = ensure(e, e->grid, cells_total * sizeof(long long), "Failed to allocate best fits")) ||
         (st = ensure(e, e->best, cells_total * sizeof(double), "Failed to allocate best scores")) ||
-        (st = ensure(e, e->counter, sizeof(unsigned long long), "Failed to allocate counter")))
+        (st = ensure(e, e->counter, 2 * sizeof(unsigned long long), "Failed to allocate counter")))
         return st;
 
     // Set best fits to max value (CUDAPhotomosaicGenerator.cpp:140-149), scores to NaN.
@@ -237,7 +242,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
             "Failed to copy max best fit from host to device");
     HIP_TRY(e, hipMemcpyAsync(e->best.p, nan_init.data(), cells_total * sizeof(double), hipMemcpyHostToDevice, e->stream),
             "Failed to reset lowest variant");
-    HIP_TRY(e, hipMemsetAsync(e->counter.p, 0, sizeof(unsigned long long), e->stream), "Failed to clear counter");
+    HIP_TRY(e, hipMemsetAsync(e->counter.p, 0, 2 * sizeof(unsigned long long), e->stream), "Failed to clear counter");
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");   // host vectors go out of scope below
 
     const int size = e->lib_size, P = size * size, ppad = round_up(P, 256);
@@ -249,11 +254,15 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
     a.target = (const float*)e->target.p; a.rows = e->rows; a.cols = e->cols;
     a.masks = (const uint8_t*)e->masks.p; a.lib = (const float*)e->lib.p;
     a.size = size; a.P = P; a.ppad = ppad;
-    a.tie_band = 1e-9;
+    a.tie_band = kTieBand;
     a.exact_count = (unsigned long long*)e->counter.p;
+    a.dense_count = a.exact_count + 1;
 
     const int sequential = (range > 0 && addition != 0) ? 1 : 0;
-    const int blocks = sequential ? 1 : std::max(1, std::min(n, 2048));
+    const int blocks = sequential ? 1 : std::max(1, std::min(n, 1024));
+    if ((st = ensure(e, e->scratch, (size_t)blocks * e->n_lib * sizeof(double), "Failed to allocate row scratch")))
+        return st;
+    a.scratch = (double*)e->scratch.p;
     HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
     if (n > 0) {
         st = by_type(diff_type, [&](auto T) {
@@ -271,11 +280,12 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
     if (best_score_out)
         HIP_TRY(e, hipMemcpyAsync(best_score_out, e->best.p, cells_total * sizeof(double), hipMemcpyDeviceToHost, e->stream),
                 "Error copying best scores to host");
-    unsigned long long exact = 0;
-    HIP_TRY(e, hipMemcpyAsync(&exact, e->counter.p, sizeof exact, hipMemcpyDeviceToHost, e->stream), "counter");
+    unsigned long long exact[2] = {0, 0};
+    HIP_TRY(e, hipMemcpyAsync(exact, e->counter.p, sizeof exact, hipMemcpyDeviceToHost, e->stream), "counter");
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
     e->timing.resolve_ms += elapsed(e->ev[4], e->ev[5]);
-    e->timing.exact_rescored += (int64_t)exact;
+    e->timing.exact_rescored += (int64_t)exact[0];
+    e->timing.dense_rows += (int64_t)exact[1];
     return MM_OK;
 }
 
@@ -343,7 +353,7 @@ void mm_destroy(mm_engine* e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf* b : { &e->lib, &e->masks, &e->target, &e->recs, &e->cells, &e->cmask, &e->scores,
-                       &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter })
+                       &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter, &e->scratch })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);

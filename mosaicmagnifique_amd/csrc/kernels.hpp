@@ -190,15 +190,21 @@ score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
 // One workgroup per cell, K rounds; round r takes the lexicographic minimum of
 // the entries strictly above round r-1's pick, so nothing is mutated and the
 // row is re-read from L2 (40-80 KB).  Slots past the row length get index -1.
+//
+// Overflow mark: the resolve breaks near-ties by re-summing ALL candidates within
+// `tie_band` of the minimum in the reference's order.  If the first candidate
+// left OUT of the list is within the band of the last one kept, the list cuts
+// through such a cluster; the last index is then stored as -(index + 2) and the
+// resolve recomputes that cell's whole row instead of trusting the list.
 __global__ void __launch_bounds__(kBlock)
-select_kernel(const double* __restrict__ scores, int L, int K,
+select_kernel(const double* __restrict__ scores, int L, int K, double tie_band,
               int32_t* __restrict__ cand_index, double* __restrict__ cand_score)
 {
     __shared__ ScoreIdx sh[kBlock / kWave];
     const double* row = scores + (size_t)blockIdx.x * L;
     double prev_s = -kInf;
     int prev_i = -1;
-    for (int r = 0; r < K; ++r) {
+    for (int r = 0; r <= K; ++r) {
         ScoreIdx best{kInf, 0x7fffffff};
         for (int l = threadIdx.x; l < L; l += kBlock) {
             const double s = row[l];
@@ -206,6 +212,11 @@ select_kernel(const double* __restrict__ scores, int L, int K,
         }
         best = block_min(best, sh);
         const bool none = best.i == 0x7fffffff;
+        if (r == K) {        // one past the list: does it belong to the last entry's cluster?
+            if (!none && threadIdx.x == 0 && best.s <= prev_s + fabs(prev_s) * (4.0 * tie_band))
+                cand_index[(size_t)blockIdx.x * K + K - 1] = -(prev_i + 2);
+            break;
+        }
         if (threadIdx.x == 0) {
             cand_index[(size_t)blockIdx.x * K + r] = none ? -1 : best.i;
             cand_score[(size_t)blockIdx.x * K + r] = none ? kInf : best.s;
@@ -244,6 +255,8 @@ struct ResolveArgs {
     int size, P, ppad;
     double tie_band;            // relative gap under which two totals count as a near-tie
     unsigned long long* exact_count;
+    double* scratch;            // [gridDim.x][L]: full score row of a cell whose list overflowed
+    unsigned long long* dense_count;
 };
 
 // Repeat value of library image `cand` at padded cell (px, py):
@@ -307,6 +320,33 @@ __device__ double exact_total(const ResolveArgs& a, const mm_cell& rec, int cand
     return running;
 }
 
+// Base score of EVERY library image for one cell, by one workgroup (slow path:
+// only for cells whose candidate list was cut through a near-tie cluster).
+template <int TYPE>
+__device__ void dense_row(const ResolveArgs& a, const mm_cell& rec, double* row, double* sh4)
+{
+    const uint8_t* mk = a.masks + (size_t)rec.mask_id * a.ppad;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int l = 0; l < a.L; ++l) {
+        const float* l0 = a.lib + (size_t)l * 3 * a.ppad;
+        double acc = 0.0;
+        for (int p = threadIdx.x; p < a.P; p += kBlock) {
+            const int r = p / a.size, c = p - r * a.size;
+            if (mk[p] != 0 && r >= rec.row_min && r < rec.row_max && c >= rec.col_min && c < rec.col_max) {
+                const float* src = a.target + ((size_t)(rec.y + r) * a.cols + (rec.x + c)) * 3;
+                acc += colour_diff<TYPE>(Px{src[0], src[1], src[2]},
+                                         Px{l0[p], l0[a.ppad + p], l0[2 * (size_t)a.ppad + p]});
+            }
+        }
+        acc = wave_sum(acc);
+        __syncthreads();
+        if (lane == 0) sh4[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) row[l] = ((sh4[0] + sh4[1]) + sh4[2]) + sh4[3];
+    }
+    __syncthreads();
+}
+
 // sequential != 0: ONE workgroup walks the cells in raster order (each cell's
 // penalty reads the cells chosen before it).  sequential == 0 (no repeats):
 // workgroups take cells independently.
@@ -317,6 +357,7 @@ resolve_kernel(ResolveArgs a, int sequential)
     __shared__ ScoreIdx sh[kBlock / kWave];
     __shared__ double buf[kExactChunk];
     __shared__ double bcast;
+    __shared__ double sh4[kBlock / kWave];
 
     const int first = sequential ? 0 : blockIdx.x;
     const int stride = sequential ? 1 : gridDim.x;
@@ -324,12 +365,22 @@ resolve_kernel(ResolveArgs a, int sequential)
         const mm_cell rec = a.recs[c];
         const int32_t* ci = a.cand_index + (size_t)c * a.K;
         const double* cs = a.cand_score + (size_t)c * a.K;
+        int K = a.K;
         const bool penalise = a.repeat_range > 0 && a.repeat_addition != 0;
+        if (ci[K - 1] <= -2) {             // overflow mark: take the whole row instead
+            double* row = a.scratch + (size_t)blockIdx.x * a.L;
+            dense_row<TYPE>(a, rec, row, sh4);
+            if (threadIdx.x == 0) atomicAdd(a.dense_count, 1ull);
+            ci = nullptr;
+            cs = row;
+            K = a.L;
+        }
+        auto cand_at = [&](int k) { return ci ? ci[k] : k; };
 
         // pass 1: lowest (total, index) over the cell's candidates
         ScoreIdx best{kInf, 0x7fffffff};
-        for (int k = threadIdx.x; k < a.K; k += kBlock) {
-            const int cand = ci[k];
+        for (int k = threadIdx.x; k < K; k += kBlock) {
+            const int cand = cand_at(k);
             if (cand < 0) continue;
             const int rep = penalise ? repeat_value(a, rec.grid_x, rec.grid_y, cand) : 0;
             const double total = (double)rep + cs[k];
@@ -344,8 +395,8 @@ resolve_kernel(ResolveArgs a, int sequential)
             // pass 2: how many candidates sit within the near-tie band of the minimum?
             const double thr = best.s + fabs(best.s) * a.tie_band;
             int near = 0;
-            for (int k = threadIdx.x; k < a.K; k += kBlock) {
-                const int cand = ci[k];
+            for (int k = threadIdx.x; k < K; k += kBlock) {
+                const int cand = cand_at(k);
                 if (cand < 0) continue;
                 const int rep = penalise ? repeat_value(a, rec.grid_x, rec.grid_y, cand) : 0;
                 if ((double)rep + cs[k] <= thr) ++near;
@@ -360,8 +411,8 @@ resolve_kernel(ResolveArgs a, int sequential)
                 int prev = -1;
                 for (;;) {
                     int nxt = 0x7fffffff;                // lowest contender index above prev
-                    for (int k = threadIdx.x; k < a.K; k += kBlock) {
-                        const int cand = ci[k];
+                    for (int k = threadIdx.x; k < K; k += kBlock) {
+                        const int cand = cand_at(k);
                         if (cand <= prev || cand >= nxt) continue;
                         const int rep = penalise ? repeat_value(a, rec.grid_x, rec.grid_y, cand) : 0;
                         if ((double)rep + cs[k] <= thr) nxt = cand;

@@ -1,0 +1,100 @@
+"""Cell-sharded multi-GPU run: one process per GPU, ``torch.distributed`` (backend
+``nccl`` = RCCL over xGMI on the GPU box, ``gloo`` on CPU for the tests).
+
+The reference has no multi-GPU code (one ``CUDAPhotomosaicGenerator(device)``,
+CUDA/CUDAPhotomosaicGenerator.h:31).  The split is new and follows the data
+dependencies of the path: base scores of different cells are independent, so
+valid cells (raster order) are cut into ``world`` contiguous blocks; library,
+masks and target are replicated (<= ~1.1 GB even for config E, trivial against
+288 GB of HBM).  The only exchange is ONE all-gather of the per-cell candidate
+lists (K x 12 bytes per cell: a few KB to a few MB), after which every rank runs
+the same deterministic resolve, so all ranks end with the identical best-fit grid.
+The payload is latency-bound, far below the size where the 7 x ~153 GB/s xGMI
+links matter: a single collective on one stream, no bucketing, no overlap games.
+"""
+import numpy as np
+
+
+def shard_range(n_cells, world, rank):
+    """Contiguous block [lo, hi) of the raster-ordered cells owned by ``rank``;
+    blocks are ceil(n/world) long (the last ones may be short or empty)."""
+    per = -(-n_cells // world) if n_cells else 0
+    lo = min(rank * per, n_cells)
+    return lo, min(lo + per, n_cells)
+
+
+def padded_len(n_cells, world):
+    return -(-n_cells // world) if n_cells else 0
+
+
+def allgather_candidates(idx_local, score_local, n_cells, world, group=None):
+    """All-gather of the shards' candidate lists.
+
+    idx_local  int32  [per][k]   (torch tensor, rows past the shard's own count are padding)
+    score_local f64   [per][k]
+    Returns (idx [n_cells][k], score [n_cells][k]) identical on every rank.
+    Works on CUDA tensors (nccl/RCCL) and CPU tensors (gloo).
+    """
+    import torch
+    import torch.distributed as dist
+    per, k = idx_local.shape
+    assert per == padded_len(n_cells, world) and score_local.shape == (per, k)
+    idx_all = torch.empty((world * per, k), dtype=idx_local.dtype, device=idx_local.device)
+    score_all = torch.empty((world * per, k), dtype=score_local.dtype, device=score_local.device)
+    if world == 1:
+        idx_all.copy_(idx_local)
+        score_all.copy_(score_local)
+    else:
+        dist.all_gather_into_tensor(idx_all, idx_local.contiguous(), group=group)
+        dist.all_gather_into_tensor(score_all, score_local.contiguous(), group=group)
+    # shards are contiguous blocks of `per`, so trimming the tail removes exactly the padding
+    return idx_all[:n_cells], score_all[:n_cells]
+
+
+class ShardedBestFit:
+    """generateBestFits over ``world`` GPUs (this process drives GPU ``local_rank``).
+
+    engine: an Engine with library / masks / target already staged (replicated).
+    """
+
+    def __init__(self, engine, rank, world, group=None):
+        self.engine, self.rank, self.world, self.group = engine, rank, world, group
+        self._bufs = None
+
+    def _buffers(self, per, k):
+        import torch
+        key = (per, k)
+        if self._bufs is None or self._bufs[0] != key:
+            dev = torch.device("cuda", self.engine.device)
+            self._bufs = (key,
+                          torch.full((max(per, 1), k), -1, dtype=torch.int32, device=dev),
+                          torch.full((max(per, 1), k), float("inf"), dtype=torch.float64, device=dev))
+        return self._bufs[1], self._bufs[2]
+
+    def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0):
+        """cells: ALL valid cells in raster order (every rank passes the same array).
+        Returns (best_fit, best_score) as Engine.generate does, identical on all ranks."""
+        import torch
+        n = len(cells)
+        k = self.engine.candidates_per_cell(repeat_range, repeat_addition)
+        per = padded_len(n, self.world)
+        lo, hi = shard_range(n, self.world, self.rank)
+        idx, score = self._buffers(per, k)
+        if hi - lo < per:                       # short last shard: keep the padding rows inert
+            idx[hi - lo:] = -1
+            score[hi - lo:] = float("inf")
+        if hi > lo:
+            self.engine.score_cells(cells[lo:hi], diff_type, k, out_index=idx.data_ptr(),
+                                    out_score=score.data_ptr(), on_device=True)
+        idx_all, score_all = allgather_candidates(idx[:per], score[:per], n, self.world, self.group)
+        torch.cuda.synchronize(idx.device)      # the engine runs on its own stream
+        return self.engine.resolve(cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, k,
+                                   idx_all.data_ptr(), score_all.data_ptr(), on_device=True)
+
+
+def merge_on_host(shards, n_cells):
+    """Host-side equivalent of the all-gather for already-copied numpy shards
+    (list of (idx, score) in rank order); used by tests."""
+    idx = np.concatenate([s[0] for s in shards])[:n_cells]
+    score = np.concatenate([s[1] for s in shards])[:n_cells]
+    return idx, score

@@ -42,13 +42,17 @@ def library_u8(n_images, size, seed=SEED_LIBRARY, first=0):
     [-32, 32]: distinct, low-variance patches, so candidate scores spread
     realistically and accidental exact ties do not happen.
     """
-    i = np.arange(first, first + n_images, dtype=np.uint32)[:, None, None, None]
-    y = np.arange(size, dtype=np.uint32)[None, :, None, None]
-    x = np.arange(size, dtype=np.uint32)[None, None, :, None]
-    c = np.arange(3, dtype=np.uint32)[None, None, None, :]
-    base = (mix(seed, i, c, 0xFFFF, 0xFFFF) % _U(256)).astype(np.int32)
-    noise = (mix(seed, i, y, x, c) % _U(65)).astype(np.int32) - 32
-    return np.clip(base + noise, 0, 255).astype(np.uint8)
+    i = np.arange(first, first + n_images, dtype=np.uint32)
+    c = np.arange(3, dtype=np.uint32)
+    base = (mix(seed, i[:, None], c[None, :], 0xFFFF) % _U(256)).astype(np.int16)
+    pix = np.arange(size * size, dtype=np.uint32)
+    h = mix(seed, i[:, None], pix[None, :])                       # one hash per pixel ...
+    out = np.empty((n_images, size * size, 3), dtype=np.uint8)
+    with np.errstate(over="ignore"):
+        for ch in range(3):                                       # ... three channels from it
+            noise = (_fmix32(h + _U(0x27D4EB2F) * _U(ch + 1)) % _U(65)).astype(np.int16) - 32
+            out[:, :, ch] = np.clip(base[:, ch:ch + 1] + noise, 0, 255)
+    return out.reshape(n_images, size, size, 3)
 
 
 def target_u8(rows, cols, lattice=64, seed=SEED_TARGET):
@@ -66,17 +70,37 @@ def target_u8(rows, cols, lattice=64, seed=SEED_TARGET):
     x0 = np.floor(xx).astype(np.int64)
     fy = (yy - y0)[:, None, None]
     fx = (xx - x0)[None, :, None]
-    top = nodes[y0][:, x0] * (1 - fx) + nodes[y0][:, x0 + 1] * fx
-    bot = nodes[y0 + 1][:, x0] * (1 - fx) + nodes[y0 + 1][:, x0 + 1] * fx
-    smooth = top * (1 - fy) + bot * fy
-
-    y = np.arange(rows, dtype=np.uint32)[:, None, None]
-    x = np.arange(cols, dtype=np.uint32)[None, :, None]
-    noise = (mix(seed, y, x, c, 0x5A5A) % _U(33)).astype(np.float64) - 16
-    return np.clip(np.rint(smooth + noise), 0, 255).astype(np.uint8)
+    fx2 = (xx - x0)[None, :, None]
+    along_x = nodes[:, x0] * (1 - fx2) + nodes[:, x0 + 1] * fx2      # [ly][cols][3], separable blend
+    del fx
+    out = np.empty((rows, cols, 3), dtype=np.uint8)
+    band = max(1, (1 << 22) // max(cols, 1))
+    for r0 in range(0, rows, band):
+        r1 = min(rows, r0 + band)
+        f = fy[r0:r1]
+        smooth = along_x[y0[r0:r1]] * (1 - f) + along_x[y0[r0:r1] + 1] * f
+        y = np.arange(r0, r1, dtype=np.uint32)[:, None]
+        x = np.arange(cols, dtype=np.uint32)[None, :]
+        h = mix(seed, y, x, 0x5A5A)
+        with np.errstate(over="ignore"):
+            for ch in range(3):
+                noise = (_fmix32(h + _U(0x27D4EB2F) * _U(ch + 1)) % _U(33)).astype(np.float64) - 16
+                out[r0:r1, :, ch] = np.clip(np.rint(smooth[:, :, ch] + noise), 0, 255)
+    return out
 
 
 def bgr_u8_to_lab_f32(img):
+    """Chunked driver of _lab_block (keeps the float64 temporaries cache-sized)."""
+    img = np.asarray(img)
+    flat = img.reshape(-1, 3)
+    out = np.empty(flat.shape, dtype=np.float32)
+    step = 1 << 20
+    for i in range(0, flat.shape[0], step):
+        out[i:i + step] = _lab_block(flat[i:i + step])
+    return out.reshape(img.shape)
+
+
+def _lab_block(img):
     """u8 BGR -> f32 CIELab (L in [0,100], a,b about [-127,127]); sRGB, D65.
 
     The reference does this with OpenCV (``convertTo(CV_32F, 1/255)`` then
@@ -86,8 +110,9 @@ def bgr_u8_to_lab_f32(img):
     engine are fed the same f32 Lab arrays.  Plain float64 formulae, rounded
     to f32 once at the end.
     """
-    v = img.astype(np.float64) / 255.0
-    lin = np.where(v > 0.04045, ((v + 0.055) / 1.055) ** 2.4, v / 12.92)
+    lut = np.arange(256, dtype=np.float64) / 255.0
+    lut = np.where(lut > 0.04045, ((lut + 0.055) / 1.055) ** 2.4, lut / 12.92)
+    lin = lut[img]                                                # sRGB decode of u8 via table
     b, g, r = lin[..., 0], lin[..., 1], lin[..., 2]
     x = (0.412453 * r + 0.357580 * g + 0.180423 * b) / 0.950456
     y = 0.212671 * r + 0.715160 * g + 0.072169 * b
