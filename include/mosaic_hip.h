@@ -86,6 +86,9 @@ typedef struct mm_timing {
     int64_t pair_evals;       /* colour differences evaluated by it (active pixels x candidates) */
     int64_t exact_rescored;   /* candidates re-summed in reference order to break a near-tie */
     int64_t dense_rows;       /* cells whose candidate list overflowed (whole row recomputed) */
+    double rescore_ms;        /* fp64 re-score of the filter's contenders (+ fp64-only re-runs) */
+    int64_t dense_cells;      /* cells the fp32 filter could not vouch for: re-run fp64-only */
+    int64_t edge_pairs;       /* pixel pairs on the CIEDE2000 hue discontinuity patched in fp64 */
 } mm_timing;
 
 /* Progress: called on the calling thread between device batches with
@@ -165,6 +168,11 @@ mm_status mm_resolve(mm_engine *e, const mm_cell *cells, int n_cells,
                      int inputs_on_device,
                      int64_t *best_fit_out, double *best_score_out);
 
+/* Engine options.  "filter" (default 1): two-tier scoring -- an fp32 filter pass over
+ * every (cell, candidate), then the fp64 reference-form score of each cell's
+ * contenders only; 0 scores everything in fp64.  Results are identical either way. */
+mm_status mm_set_option(mm_engine *e, const char *name, int value);
+
 /* Timings of the last mm_generate / mm_score_cells (+ mm_resolve) on e. */
 mm_status mm_get_timing(const mm_engine *e, mm_timing *out);
 
@@ -177,6 +185,13 @@ mm_status mm_get_timing(const mm_engine *e, mm_timing *out);
 mm_status mm_colour_diff_batch(mm_engine *e, int diff_type,
                                const float *first, const float *second,
                                size_t n, double *out);
+
+/* Diagnostics: the fp32 FILTER form of the same difference (tier 1 of the two-tier
+ * scoring).  It never decides a result; this entry exists so that its
+ * error against mm_colour_diff_batch can be measured (tests/test_gpu_filter.py). */
+mm_status mm_filter_diff_batch(mm_engine *e, int diff_type,
+                               const float *first, const float *second,
+                               size_t n, float *out);
 
 #ifdef __cplusplus
 }

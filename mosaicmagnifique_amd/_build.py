@@ -10,15 +10,18 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmosaic_hip.so")
-SOURCES = [os.path.join(CSRC, "engine.hip")]
-HEADERS = [os.path.join(CSRC, "kernels.hpp"), os.path.join(CSRC, "colour_diff.hpp"),
-           os.path.join(HERE, "..", "include", "mosaic_hip.h")]
+# Two translation units with different floating-point rules:
+#  engine.hip  -ffp-contract=off : the fp64 arbiter kernels must not fuse a*b+c -- the
+#              reference's CPU path is an SSE2 build and summation / rounding order is
+#              part of the parity contract (csrc/colour_diff.hpp);
+#  filter.hip  default contraction: the fp32 filter pass wants fused multiply-adds.
+UNITS = [("engine.hip", ["-ffp-contract=off"]), ("filter.hip", ["-ffp-contract=fast"])]
+SOURCES = [os.path.join(CSRC, name) for name, _ in UNITS]
+HEADERS = [os.path.join(CSRC, h) for h in ("kernels.hpp", "colour_diff.hpp", "colour_diff_fast.hpp",
+                                           "launch.hpp")] + \
+          [os.path.join(HERE, "..", "include", "mosaic_hip.h")]
 
-# -ffp-contract=off: the arbiter kernels must not fuse a*b+c -- the reference's
-# CPU path is an SSE2 build and summation / rounding order is part of the
-# parity contract (csrc/colour_diff.hpp).
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-ffp-contract=off", "-Wall", "-Wextra"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
 
 
 def hipcc():
@@ -39,14 +42,22 @@ def build(force=False, verbose=False):
     """Compile the engine if the library is missing or older than its sources."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB + ".tmp"] + SOURCES
+    objs = []
+    for name, extra in UNITS:
+        obj = os.path.join(CSRC, name + ".o")
+        _run([hipcc()] + HIPCC_FLAGS + extra + ["-c", os.path.join(CSRC, name), "-o", obj], verbose)
+        objs.append(obj)
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs, verbose)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n%s\n%s" % (res.stdout, res.stderr))
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
 
 
 if __name__ == "__main__":

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "launch.hpp"
 
 namespace {
 
@@ -37,7 +38,7 @@ struct DevBuf {
 struct mm_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[12] = {};
     std::string err;
 
     // staged inputs
@@ -47,6 +48,9 @@ struct mm_engine {
 
     // per-call workspaces (grown on demand, kept)
     DevBuf recs, cells, cmask, scores, cand_i, cand_s, grid, best, counter, scratch;
+    // two-tier scoring workspaces
+    DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s;
+    int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
 
     mm_timing timing{};
 };
@@ -156,17 +160,62 @@ mm_status by_type(int diff_type, F&& f)
     return f(std::integral_constant<int, mm::RGB_EUCLIDEAN>{});   // CIE76 == Euclid on Lab
 }
 
-// Scores `n` cells (records already on the device at recs_dev) in batches and
-// leaves the K lowest candidates per cell in cand_i_dev / cand_s_dev.
-mm_status score_cells_device(mm_engine* e, const mm_cell* recs_dev, int n, int diff_type, int K,
-                             int32_t* cand_i_dev, double* cand_s_dev,
+// Error bounds of the fp32 filter forms (colour_diff_fast.hpp), per pixel pair and
+// for the fp32 accumulation of one lane's share of a cell.  Measured on 2e8 random
+// and adversarial pairs (tests/tools_filter_accuracy.py, tests/test_gpu_filter.py):
+// CIEDE2000 max |fp32 - fp64| = 2.5e-4; the bound used is 4x that.  Euclid: three
+// roundings of a value <= 442.
+mm::FilterBand filter_band(int diff_type, int ppad)
+{
+    mm::FilterBand b;
+    b.px_abs = diff_type == MM_CIEDE2000 ? 1e-3f : 5e-4f;
+    b.rel = 2e-5f + 1.2e-7f * (float)(ppad / 64);
+    return b;
+}
+
+// fp64-only scoring of `b` cells whose records are at recs_dev: gather, score every
+// (cell, candidate), keep the K lowest.  Results to ci / cs ([b][K]).
+mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_type, int K,
+                      int32_t* ci, double* cs, hipEvent_t after_gather, hipEvent_t after_score)
+{
+    const int L = e->n_lib, size = e->lib_size, P = size * size, ppad = round_up(P, 256);
+    const int cand_per_block = 16, cell_group = 512;
+    mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
+        recs_dev, (const float*)e->target.p, e->cols, (const uint8_t*)e->masks.p,
+        (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad);
+    HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
+    if (after_gather) HIP_TRY(e, hipEventRecord(after_gather, e->stream), "event");
+    const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
+    const long long blocks = (long long)b * n_tiles;
+    if (blocks > 0x7fffffffLL) { set_err(e, "score grid too large"); return MM_INVALID_ARGUMENT; }
+    by_type(diff_type, [&](auto T) {
+        mm::score_kernel<decltype(T)::value><<<dim3((unsigned)blocks), mm::kBlock, 0, e->stream>>>(
+            (const float*)e->cells.p, (const uint8_t*)e->cmask.p, (const float*)e->lib.p,
+            (double*)e->scores.p, b, L, ppad, cand_per_block, cell_group);
+        return MM_OK;
+    });
+    HIP_TRY(e, hipGetLastError(), "Error during colour difference / add reduction kernel");
+    if (after_score) HIP_TRY(e, hipEventRecord(after_score, e->stream), "event");
+    mm::select_kernel<<<b, mm::kBlock, 0, e->stream>>>((const double*)e->scores.p, L, K, kTieBand, ci, cs);
+    HIP_TRY(e, hipGetLastError(), "Error during candidate selection kernel");
+    return MM_OK;
+}
+
+// Scores `n` cells in batches and leaves the K lowest candidates per cell in
+// cand_i_dev / cand_s_dev.  cells_host = the same records on the host (needed to
+// re-run flagged cells through the fp64-only path).
+mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_cell* recs_dev, int n,
+                             int diff_type, int K, int32_t* cand_i_dev, double* cand_s_dev,
                              mm_progress_cb progress, void* user, volatile int* cancel)
 {
     const int L = e->n_lib, size = e->lib_size, P = size * size, ppad = round_up(P, 256);
+    const bool two_tier = e->use_filter != 0 && K < L;
+    const int Kc = two_tier ? std::min(L, round_up(K + 32, 4)) : 0;
+
     // Batch so that scores + gathered cells stay within a fixed budget.
     size_t free_b = 0, total_b = 0;
     HIP_TRY(e, hipMemGetInfo(&free_b, &total_b), "Failed to query device memory");
-    const size_t per_cell = (size_t)L * sizeof(double) + (size_t)ppad * 13;
+    const size_t per_cell = (size_t)L * sizeof(double) + (size_t)ppad * 13 + (size_t)Kc * 16 + 1;
     size_t budget = std::min<size_t>(free_b / 2 + e->scores.bytes + e->cells.bytes + e->cmask.bytes,
                                      (size_t)6 << 30);
     if (budget < per_cell) {
@@ -180,46 +229,122 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* recs_dev, int n, int d
         (st = ensure(e, e->cmask, (size_t)batch * ppad, "Failed to allocate cell masks")) ||
         (st = ensure(e, e->scores, (size_t)batch * L * sizeof(double), "Failed to allocate variants")))
         return st;
+    unsigned int edge_cap = 0;
+    if (two_tier) {
+        const double pairs = (double)batch * L * P;
+        edge_cap = (unsigned int)std::min<double>(64e6, std::max<double>(1e6, pairs / 2000.0));
+        if ((st = ensure(e, e->cont_i, (size_t)batch * Kc * sizeof(int32_t), "Failed to allocate contenders")) ||
+            (st = ensure(e, e->cont_f, (size_t)batch * Kc * sizeof(float), "Failed to allocate contenders")) ||
+            (st = ensure(e, e->cont_s, (size_t)batch * Kc * sizeof(double), "Failed to allocate contenders")) ||
+            (st = ensure(e, e->flags, (size_t)batch, "Failed to allocate cell flags")) ||
+            (st = ensure(e, e->edge_count, sizeof(unsigned int), "Failed to allocate edge counter")) ||
+            (st = ensure(e, e->edges, (size_t)edge_cap * sizeof(mm::EdgeEntry), "Failed to allocate edge list")))
+            return st;
+    }
+    const mm::FilterBand band = filter_band(diff_type, ppad);
+    const int ftype = diff_type == MM_CIEDE2000 ? mm::CIEDE2000 : mm::RGB_EUCLIDEAN;
 
-    const int cand_per_block = 16;
-    const int cell_group = 512;
-    float stage_ms = 0.f, score_ms = 0.f, select_ms = 0.f;
+    std::vector<uint8_t> flags_host;
+    std::vector<mm_cell> dense_cells;
+    std::vector<int> dense_slots;
     for (int done = 0; done < n; done += batch) {
         if (cancel && *cancel) return MM_CANCELLED;
         const int b = std::min(batch, n - done);
+        int32_t* ci = cand_i_dev + (size_t)done * K;
+        double* cs = cand_s_dev + (size_t)done * K;
         HIP_TRY(e, hipEventRecord(e->ev[0], e->stream), "event");
+        if (!two_tier) {
+            if ((st = dense_batch(e, recs_dev + done, b, diff_type, K, ci, cs, e->ev[1], e->ev[2]))) return st;
+            HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
+            HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+            e->timing.stage_ms += elapsed(e->ev[0], e->ev[1]);
+            e->timing.score_ms += elapsed(e->ev[1], e->ev[2]);
+            e->timing.select_ms += elapsed(e->ev[2], e->ev[3]);
+            e->timing.score_launches += 1;
+            if (progress) progress(done + b, user);
+            continue;
+        }
+
         mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
             recs_dev + done, (const float*)e->target.p, e->cols, (const uint8_t*)e->masks.p,
             (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad);
         HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
         HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
 
-        const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
-        const long long blocks = (long long)b * n_tiles;
-        if (blocks > 0x7fffffffLL) { set_err(e, "score grid too large"); return MM_INVALID_ARGUMENT; }
-        st = by_type(diff_type, [&](auto T) {
-            mm::score_kernel<decltype(T)::value><<<dim3((unsigned)blocks), mm::kBlock, 0, e->stream>>>(
-                (const float*)e->cells.p, (const uint8_t*)e->cmask.p, (const float*)e->lib.p,
-                (double*)e->scores.p, b, L, ppad, cand_per_block, cell_group);
-            return MM_OK;
-        });
-        HIP_TRY(e, hipGetLastError(), "Error during colour difference / add reduction kernel");
+        // tier 1: fp32 filter score of every (cell, candidate)
+        HIP_TRY(e, mm::launch_filter(ftype, (const float*)e->cells.p, (const uint8_t*)e->cmask.p,
+                                     (const float*)e->lib.p, (float*)e->scores.p, b, L, ppad,
+                                     (mm::EdgeEntry*)e->edges.p, (unsigned int*)e->edge_count.p, edge_cap,
+                                     e->stream),
+                "Error during filter colour difference kernel");
         HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
 
-        mm::select_kernel<<<b, mm::kBlock, 0, e->stream>>>(
-            (const double*)e->scores.p, L, K, kTieBand, cand_i_dev + (size_t)done * K, cand_s_dev + (size_t)done * K);
-        HIP_TRY(e, hipGetLastError(), "Error during candidate selection kernel");
+        mm::contenders_kernel<<<b, mm::kBlock, 0, e->stream>>>(
+            (const float*)e->scores.p, (const uint8_t*)e->cmask.p, L, ppad, K, Kc, band,
+            (int32_t*)e->cont_i.p, (float*)e->cont_f.p, (uint8_t*)e->flags.p);
+        HIP_TRY(e, hipGetLastError(), "Error during contender selection kernel");
         HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
+
+        // tier 2: fp64 reference-form score of the contenders only
+        const long long waves = (long long)b * Kc;
+        by_type(diff_type, [&](auto T) {
+            mm::rescore_kernel<decltype(T)::value><<<(unsigned)((waves + 3) / 4), mm::kBlock, 0, e->stream>>>(
+                (const float*)e->cells.p, (const uint8_t*)e->cmask.p, (const float*)e->lib.p,
+                (const int32_t*)e->cont_i.p, (double*)e->cont_s.p, b, Kc, ppad);
+            return MM_OK;
+        });
+        HIP_TRY(e, hipGetLastError(), "Error during contender re-score kernel");
+        HIP_TRY(e, hipEventRecord(e->ev[8], e->stream), "event");
+
+        mm::rerank_kernel<<<b, mm::kBlock, 0, e->stream>>>(
+            (const int32_t*)e->cont_i.p, (const float*)e->cont_f.p, (const double*)e->cont_s.p,
+            (const uint8_t*)e->cmask.p, Kc, K, ppad, band, kTieBand, ci, cs, (uint8_t*)e->flags.p);
+        HIP_TRY(e, hipGetLastError(), "Error during re-rank kernel");
+        HIP_TRY(e, hipEventRecord(e->ev[9], e->stream), "event");
+
+        flags_host.resize((size_t)b);
+        unsigned int edge_n = 0;
+        HIP_TRY(e, hipMemcpyAsync(flags_host.data(), e->flags.p, (size_t)b, hipMemcpyDeviceToHost, e->stream), "flags");
+        HIP_TRY(e, hipMemcpyAsync(&edge_n, e->edge_count.p, sizeof edge_n, hipMemcpyDeviceToHost, e->stream), "edge count");
         HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
-        stage_ms += elapsed(e->ev[0], e->ev[1]);
-        score_ms += elapsed(e->ev[1], e->ev[2]);
-        select_ms += elapsed(e->ev[2], e->ev[3]);
+        e->timing.stage_ms += elapsed(e->ev[0], e->ev[1]);
+        e->timing.score_ms += elapsed(e->ev[1], e->ev[2]);
+        e->timing.select_ms += elapsed(e->ev[2], e->ev[3]) + elapsed(e->ev[8], e->ev[9]);
+        e->timing.rescore_ms += elapsed(e->ev[3], e->ev[8]);
         e->timing.score_launches += 1;
+        e->timing.edge_pairs += edge_n;
+
+        // cells the filter could not vouch for go through the fp64-only path
+        dense_cells.clear();
+        dense_slots.clear();
+        const bool all_dense = edge_n > edge_cap;        // discontinuity log overflowed
+        for (int i = 0; i < b; ++i)
+            if (all_dense || flags_host[(size_t)i]) { dense_cells.push_back(cells_host[done + i]); dense_slots.push_back(done + i); }
+        if (!dense_cells.empty()) {
+            const int nd = (int)dense_cells.size();
+            if ((st = ensure(e, e->dense_recs, (size_t)nd * sizeof(mm_cell), "Failed to allocate cell records")) ||
+                (st = ensure(e, e->dense_i, (size_t)nd * K * sizeof(int32_t), "Failed to allocate candidates")) ||
+                (st = ensure(e, e->dense_s, (size_t)nd * K * sizeof(double), "Failed to allocate candidates")))
+                return st;
+            HIP_TRY(e, hipMemcpyAsync(e->dense_recs.p, dense_cells.data(), (size_t)nd * sizeof(mm_cell),
+                                      hipMemcpyHostToDevice, e->stream), "Failed to copy cell records to device");
+            HIP_TRY(e, hipEventRecord(e->ev[10], e->stream), "event");
+            if ((st = dense_batch(e, (const mm_cell*)e->dense_recs.p, nd, diff_type, K, (int32_t*)e->dense_i.p,
+                                  (double*)e->dense_s.p, nullptr, nullptr)))
+                return st;
+            for (int i = 0; i < nd; ++i) {
+                HIP_TRY(e, hipMemcpyAsync(cand_i_dev + (size_t)dense_slots[(size_t)i] * K, (int32_t*)e->dense_i.p + (size_t)i * K,
+                                          (size_t)K * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream), "scatter");
+                HIP_TRY(e, hipMemcpyAsync(cand_s_dev + (size_t)dense_slots[(size_t)i] * K, (double*)e->dense_s.p + (size_t)i * K,
+                                          (size_t)K * sizeof(double), hipMemcpyDeviceToDevice, e->stream), "scatter");
+            }
+            HIP_TRY(e, hipEventRecord(e->ev[11], e->stream), "event");
+            HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+            e->timing.rescore_ms += elapsed(e->ev[10], e->ev[11]);
+            e->timing.dense_cells += nd;
+        }
         if (progress) progress(done + b, user);
     }
-    e->timing.stage_ms += stage_ms;
-    e->timing.score_ms += score_ms;
-    e->timing.select_ms += select_ms;
     return MM_OK;
 }
 
@@ -337,7 +462,7 @@ mm_status mm_create(int device, mm_engine** out)
     e->device = device;
     code = hipSetDevice(device);
     if (code == hipSuccess) code = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    for (int i = 0; code == hipSuccess && i < 8; ++i) code = hipEventCreate(&e->ev[i]);
+    for (int i = 0; code == hipSuccess && i < 12; ++i) code = hipEventCreate(&e->ev[i]);
     if (code != hipSuccess) {
         mm_status st = hip_fail(nullptr, code, "Failed to initialise device", __FILE__, __LINE__);
         mm_destroy(e);
@@ -353,7 +478,9 @@ void mm_destroy(mm_engine* e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf* b : { &e->lib, &e->masks, &e->target, &e->recs, &e->cells, &e->cmask, &e->scores,
-                       &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter, &e->scratch })
+                       &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter, &e->scratch,
+                       &e->cont_i, &e->cont_f, &e->cont_s, &e->flags, &e->edges, &e->edge_count,
+                       &e->dense_recs, &e->dense_i, &e->dense_s })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -484,7 +611,7 @@ mm_status mm_score_cells(mm_engine* e, const mm_cell* cells, int n_cells, int di
         ci = (int32_t*)e->cand_i.p;
         cs = (double*)e->cand_s.p;
     }
-    st = score_cells_device(e, (const mm_cell*)e->recs.p, n_cells, diff_type, k, ci, cs, progress, progress_user, cancel);
+    st = score_cells_device(e, cells, (const mm_cell*)e->recs.p, n_cells, diff_type, k, ci, cs, progress, progress_user, cancel);
     if (st) return st;
     if (!outputs_on_device) {
         HIP_TRY(e, hipMemcpyAsync(cand_index_out, ci, (size_t)n_cells * k * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream),
@@ -560,7 +687,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     HIP_TRY(e, hipMemcpyAsync(e->recs.p, cells, (size_t)n_cells * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
             "Failed to copy cell records to device");
     if (n_cells > 0) {
-        st = score_cells_device(e, (const mm_cell*)e->recs.p, n_cells, diff_type, K, (int32_t*)e->cand_i.p,
+        st = score_cells_device(e, cells, (const mm_cell*)e->recs.p, n_cells, diff_type, K, (int32_t*)e->cand_i.p,
                                 (double*)e->cand_s.p, progress, progress_user, cancel);
         if (st) return st;
     }
@@ -574,6 +701,14 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
     e->timing.pair_evals = count_pair_evals(e, cells, n_cells);
     return MM_OK;
+}
+
+mm_status mm_set_option(mm_engine* e, const char* name, int value)
+{
+    if (!e || !name) return MM_INVALID_ARGUMENT;
+    if (strcmp(name, "filter") == 0) { e->use_filter = value != 0; return MM_OK; }
+    set_err(e, "mm_set_option: unknown option '%s'", name);
+    return MM_INVALID_ARGUMENT;
 }
 
 mm_status mm_get_timing(const mm_engine* e, mm_timing* out)
@@ -614,6 +749,34 @@ mm_status mm_colour_diff_batch(mm_engine* e, int diff_type, const float* first, 
     if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
     release(a); release(b); release(o);
     if (code != hipSuccess) return hip_fail(e, code, "Error during colour difference kernel", __FILE__, __LINE__);
+    return MM_OK;
+}
+
+mm_status mm_filter_diff_batch(mm_engine* e, int diff_type, const float* first, const float* second,
+                               size_t n, float* out)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!known_type(diff_type)) { set_err(e, "No function for given type %d", diff_type); return MM_INVALID_ARGUMENT; }
+    if (n == 0) return MM_OK;
+    if (!first || !second || !out) { set_err(e, "mm_filter_diff_batch: null pointer"); return MM_INVALID_ARGUMENT; }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    DevBuf a, b, o;
+    mm_status st;
+    if ((st = ensure(e, a, n * 3 * sizeof(float), "Failed to allocate pairs")) ||
+        (st = ensure(e, b, n * 3 * sizeof(float), "Failed to allocate pairs")) ||
+        (st = ensure(e, o, n * sizeof(float), "Failed to allocate differences"))) {
+        release(a); release(b); release(o);
+        return st;
+    }
+    hipError_t code = hipMemcpyAsync(a.p, first, n * 3 * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    if (code == hipSuccess) code = hipMemcpyAsync(b.p, second, n * 3 * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    if (code == hipSuccess)
+        code = mm::launch_pair_fast(diff_type == MM_CIEDE2000 ? mm::CIEDE2000 : mm::RGB_EUCLIDEAN,
+                                    (const float*)a.p, (const float*)b.p, n, (float*)o.p, 1, e->stream);
+    if (code == hipSuccess) code = hipMemcpyAsync(out, o.p, n * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+    if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
+    release(a); release(b); release(o);
+    if (code != hipSuccess) return hip_fail(e, code, "Error during filter difference kernel", __FILE__, __LINE__);
     return MM_OK;
 }
 

@@ -234,6 +234,182 @@ select_kernel(const double* __restrict__ scores, int L, int K, double tie_band,
 }
 
 // ---------------------------------------------------------------------------
+// two-tier scoring: contenders from the fp32 filter scores, fp64 re-score, re-rank
+// ---------------------------------------------------------------------------
+
+struct FilterBand {
+    float px_abs;      // bound on the fp32 form's error per pixel pair
+    float rel;         // bound on the relative error of the fp32 accumulation
+};
+
+// Contenders of one cell: every candidate whose filter score is within the error
+// band of the K-th lowest filter score.  If |filter - true| <= err for all
+// candidates, the K lowest TRUE scores are all among {filter <= v_K + 2 err}:
+// the K candidates with the lowest filter scores have true scores <= v_K + err, so
+// the K-th lowest true score is <= v_K + err, and anything truly that low has a
+// filter score <= v_K + 2 err.  One workgroup per cell.
+//   cont_index [cell][Kc]   candidate ids, -1 padded (unordered)
+//   cont_filter[cell][Kc]   their filter scores (for the canary in rerank_kernel)
+//   flags[cell]             bit 0: more than Kc contenders (cell needs the dense fp64 path)
+__global__ void __launch_bounds__(kBlock)
+contenders_kernel(const float* __restrict__ fscores, const uint8_t* __restrict__ cmask,
+                  int L, int ppad, int K, int Kc, FilterBand band,
+                  int32_t* __restrict__ cont_index, float* __restrict__ cont_filter,
+                  uint8_t* __restrict__ flags)
+{
+    __shared__ ScoreIdx sh[kBlock / kWave];
+    __shared__ int n_cont;
+    __shared__ int n_active;
+    const float* row = fscores + (size_t)blockIdx.x * L;
+    if (threadIdx.x == 0) { n_cont = 0; n_active = 0; }
+    __syncthreads();
+
+    // active pixels of the cell (scales the absolute part of the band)
+    int act = 0;
+    const uint32_t* mk = reinterpret_cast<const uint32_t*>(cmask + (size_t)blockIdx.x * ppad);
+    for (int q = threadIdx.x; q < ppad / 4; q += kBlock) act += __popc(mk[q] & 0x01010101u);
+    atomicAdd(&n_active, act);
+
+    // K-th lowest filter score (ties by index), K rounds as in select_kernel
+    double prev_s = -kInf;
+    int prev_i = -1;
+    for (int r = 0; r < K; ++r) {
+        ScoreIdx best{kInf, 0x7fffffff};
+        for (int l = threadIdx.x; l < L; l += kBlock) {
+            const double s = (double)row[l];
+            if (lex_less(prev_s, prev_i, s, l) && lex_less(s, l, best.s, best.i)) { best.s = s; best.i = l; }
+        }
+        best = block_min(best, sh);
+        if (best.i == 0x7fffffff) break;       // fewer than K finite scores: keep the last one found
+        prev_s = best.s;
+        prev_i = best.i;
+    }
+    __syncthreads();
+    const double err = (double)n_active * band.px_abs + fabs(prev_s) * band.rel;
+    const double thr = (prev_i < 0) ? kInf : prev_s + 2.0 * err;
+
+    int32_t* ci = cont_index + (size_t)blockIdx.x * Kc;
+    float* cf = cont_filter + (size_t)blockIdx.x * Kc;
+    for (int l = threadIdx.x; l < L; l += kBlock) {
+        const float s = row[l];
+        if ((double)s <= thr) {
+            const int slot = atomicAdd(&n_cont, 1);
+            if (slot < Kc) { ci[slot] = l; cf[slot] = s; }
+        }
+    }
+    __syncthreads();
+    const int n = n_cont;
+    for (int t = n + threadIdx.x; t < Kc; t += kBlock) { ci[t] = -1; cf[t] = 0.0f; }
+    if (threadIdx.x == 0) flags[blockIdx.x] = n > Kc ? 1 : 0;
+}
+
+// fp64 reference-form score of every contender: one wave per (cell, slot), same
+// lane / pixel assignment and summation order as score_kernel.
+template <int TYPE>
+__global__ void __launch_bounds__(kBlock)
+rescore_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
+               const float* __restrict__ lib, const int32_t* __restrict__ cont_index,
+               double* __restrict__ cont_score, int n_cells, int Kc, int ppad)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * (kBlock / kWave) + wave;
+    const int cell = (int)(w / Kc);
+    if (cell >= n_cells) return;
+    const int l = cont_index[w];
+    if (l < 0) { if (lane == 0) cont_score[w] = kInf; return; }
+
+    const int groups = ppad / (4 * kWave);
+    const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
+    const float4* c1 = c0 + ppad / 4;
+    const float4* c2 = c1 + ppad / 4;
+    const uint32_t* mk = reinterpret_cast<const uint32_t*>(cmask + (size_t)cell * ppad);
+    const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
+    const float4* b1 = b0 + ppad / 4;
+    const float4* b2 = b1 + ppad / 4;
+    double acc = 0.0;
+    for (int j = 0; j < groups; ++j) {
+        const int q = lane + kWave * j;
+        const uint32_t m = mk[q];
+        if (m == 0) continue;
+        const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
+        const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
+        if (m & 0x000000ffu) acc += colour_diff<TYPE>(Px{p0.x, p1.x, p2.x}, Px{q0.x, q1.x, q2.x});
+        if (m & 0x0000ff00u) acc += colour_diff<TYPE>(Px{p0.y, p1.y, p2.y}, Px{q0.y, q1.y, q2.y});
+        if (m & 0x00ff0000u) acc += colour_diff<TYPE>(Px{p0.z, p1.z, p2.z}, Px{q0.z, q1.z, q2.z});
+        if (m & 0xff000000u) acc += colour_diff<TYPE>(Px{p0.w, p1.w, p2.w}, Px{q0.w, q1.w, q2.w});
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) cont_score[w] = acc;
+}
+
+// Re-rank: the K lowest (fp64 score, index) among a cell's contenders, in the
+// format select_kernel produces (overflow mark included).  Also the canary: if any
+// contender's filter score is further from its fp64 score than a quarter of the
+// band the filter was trusted with, the cell is flagged for the dense fp64 path
+// (bit 1) instead of being believed.  One wave per cell would do; a workgroup keeps
+// the reduction helpers shared.
+__global__ void __launch_bounds__(kBlock)
+rerank_kernel(const int32_t* __restrict__ cont_index, const float* __restrict__ cont_filter,
+              const double* __restrict__ cont_score, const uint8_t* __restrict__ cmask,
+              int Kc, int K, int ppad, FilterBand band, double tie_band,
+              int32_t* __restrict__ cand_index, double* __restrict__ cand_score,
+              uint8_t* __restrict__ flags)
+{
+    __shared__ ScoreIdx sh[kBlock / kWave];
+    __shared__ int n_active;
+    const int32_t* ci = cont_index + (size_t)blockIdx.x * Kc;
+    const float* cf = cont_filter + (size_t)blockIdx.x * Kc;
+    const double* cs = cont_score + (size_t)blockIdx.x * Kc;
+    if (threadIdx.x == 0) n_active = 0;
+    __syncthreads();
+    int act = 0;
+    const uint32_t* mk = reinterpret_cast<const uint32_t*>(cmask + (size_t)blockIdx.x * ppad);
+    for (int q = threadIdx.x; q < ppad / 4; q += kBlock) act += __popc(mk[q] & 0x01010101u);
+    atomicAdd(&n_active, act);
+    __syncthreads();
+
+    int bad = 0;
+    for (int t = threadIdx.x; t < Kc; t += kBlock) {
+        if (ci[t] < 0) continue;
+        const double err = (double)n_active * band.px_abs + fabs(cs[t]) * band.rel;
+        if (!(fabs((double)cf[t] - cs[t]) <= 0.25 * err)) bad = 1;     // also catches NaN
+    }
+    if (__syncthreads_or(bad) && threadIdx.x == 0) flags[blockIdx.x] |= 2;
+
+    double prev_s = -kInf;
+    int prev_i = -1;
+    for (int r = 0; r <= K; ++r) {
+        ScoreIdx best{kInf, 0x7fffffff};
+        for (int t = threadIdx.x; t < Kc; t += kBlock) {
+            const int l = ci[t];
+            if (l < 0) continue;
+            const double s = cs[t];
+            if (lex_less(prev_s, prev_i, s, l) && lex_less(s, l, best.s, best.i)) { best.s = s; best.i = l; }
+        }
+        best = block_min(best, sh);
+        const bool none = best.i == 0x7fffffff;
+        if (r == K) {
+            if (!none && threadIdx.x == 0 && best.s <= prev_s + fabs(prev_s) * (4.0 * tie_band))
+                cand_index[(size_t)blockIdx.x * K + K - 1] = -(prev_i + 2);
+            break;
+        }
+        if (threadIdx.x == 0) {
+            cand_index[(size_t)blockIdx.x * K + r] = none ? -1 : best.i;
+            cand_score[(size_t)blockIdx.x * K + r] = none ? kInf : best.s;
+        }
+        if (none) {
+            for (int t = r + 1 + threadIdx.x; t < K; t += kBlock) {
+                cand_index[(size_t)blockIdx.x * K + t] = -1;
+                cand_score[(size_t)blockIdx.x * K + t] = kInf;
+            }
+            break;
+        }
+        prev_s = best.s;
+        prev_i = best.i;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // resolve: repeat penalty + argmin + exact tie-break, in the reference's order
 // ---------------------------------------------------------------------------
 

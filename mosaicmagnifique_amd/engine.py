@@ -142,6 +142,10 @@ class Engine:
             int(repeat_addition), int(k), pi, ps, 1 if on_device else 0, _lib.ptr(best), _lib.ptr(score)))
         return best, score
 
+    def set_option(self, name, value):
+        """mm_set_option: "filter" 1 (default, two-tier fp32 filter + fp64 re-score) or 0 (fp64 only)."""
+        self._check(self._lib.mm_set_option(self._h, name.encode(), int(value)))
+
     def timing(self):
         t = _lib.MMTiming()
         self._check(self._lib.mm_get_timing(self._h, ctypes.byref(t)))
@@ -155,5 +159,14 @@ class Engine:
             raise ValueError("pair arrays differ in shape")
         out = np.empty(a.shape[0], dtype=np.float64)
         self._check(self._lib.mm_colour_diff_batch(self._h, int(diff_type), _lib.ptr(a), _lib.ptr(b),
+                                                   a.shape[0], _lib.ptr(out)))
+        return out
+
+    def filter_diff_batch(self, diff_type, first, second):
+        """The fp32 filter form of the difference (diagnostics; never decides a result)."""
+        a = np.ascontiguousarray(first, dtype=np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(second, dtype=np.float32).reshape(-1, 3)
+        out = np.empty(a.shape[0], dtype=np.float32)
+        self._check(self._lib.mm_filter_diff_batch(self._h, int(diff_type), _lib.ptr(a), _lib.ptr(b),
                                                    a.shape[0], _lib.ptr(out)))
         return out

@@ -26,9 +26,10 @@ SHAPES = {
 REL_TOL = {0: 1e-12, 1: 1e-12, 2: 1e-4}
 
 
-def generate(shape, img, lib, t, rep=(0, 0), device=0):
+def generate(shape, img, lib, t, rep=(0, 0), device=0, use_filter=1):
     group = cases.group_of(shape)
     gen = HIPPhotomosaicGenerator(device)
+    gen.m_engine.set_option("filter", use_filter)
     gen.setMainImage(img)
     gen.setLibrary(lib)
     gen.setColourDifference(t)
@@ -39,8 +40,8 @@ def generate(shape, img, lib, t, rep=(0, 0), device=0):
     return gen
 
 
-def compare(oracle, shape, img, lib, t, rep=(0, 0)):
-    gen = generate(shape, img, lib, t, rep)
+def compare(oracle, shape, img, lib, t, rep=(0, 0), use_filter=1):
+    gen = generate(shape, img, lib, t, rep, use_filter=use_filter)
     got, score = gen.getBestFits()[0], gen.getBestScores()[0]
     want, want_score, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), *rep)
     assert got.shape == want.shape
@@ -54,10 +55,11 @@ def compare(oracle, shape, img, lib, t, rep=(0, 0)):
     return gen
 
 
+@pytest.mark.parametrize("use_filter", [1, 0], ids=["two_tier", "fp64_only"])
 @pytest.mark.parametrize("rep", [(0, 0), (2, 300), (20, 10000)], ids=["norepeat", "repeat2", "repeat20"])
 @pytest.mark.parametrize("shape_name", SHAPES)
 @pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIE76, Type.CIEDE2000])
-def test_compare_matrix(oracle, t, shape_name, rep):
+def test_compare_matrix(oracle, t, shape_name, rep, use_filter):
     """COMPARE_{RGB_EUCLIDEAN,CIE76,CIEDE2000} x {square, Hexagon, flipped/offset}
     x {no repeats, repeats, the reference's (20, 10000) repeats case}.  Ragged image
     sizes so the last row / column of cells (and the x=-1 / y=-1 cells of offset
@@ -67,7 +69,9 @@ def test_compare_matrix(oracle, t, shape_name, rep):
     rows, cols = 5 * size + size // 3, 6 * size + size // 2
     n_lib = 64 if size >= 64 else 150
     img, lib = cases.inputs(rows, cols, size, n_lib, t, lattice=2 * size)
-    compare(oracle, shape, img, lib, t, rep)
+    gen = compare(oracle, shape, img, lib, t, rep, use_filter)
+    tm = gen.timing()
+    assert (tm["rescore_ms"] > 0) == bool(use_filter and gen.m_engine.candidates_per_cell(*rep) < n_lib)
 
 
 @pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIEDE2000])
