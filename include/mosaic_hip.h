@@ -89,6 +89,7 @@ typedef struct mm_timing {
     double rescore_ms;        /* fp64 re-score of the filter's contenders (+ fp64-only re-runs) */
     int64_t dense_cells;      /* cells the fp32 filter could not vouch for: re-run fp64-only */
     int64_t edge_pairs;       /* pixel pairs on the CIEDE2000 hue discontinuity patched in fp64 */
+    double seed_ms;           /* seeds + pruning limits ahead of the filter pass */
 } mm_timing;
 
 /* Progress: called on the calling thread between device batches with
@@ -170,7 +171,9 @@ mm_status mm_resolve(mm_engine *e, const mm_cell *cells, int n_cells,
 
 /* Engine options.  "filter" (default 1): two-tier scoring -- an fp32 filter pass over
  * every (cell, candidate), then the fp64 reference-form score of each cell's
- * contenders only; 0 scores everything in fp64.  Results are identical either way. */
+ * contenders only; 0 scores everything in fp64.  "prune" (default 1): the filter pass
+ * abandons a candidate once its running sum passes a per-cell upper bound (the device
+ * form of the reference's early exit).  Results are identical whatever the options. */
 mm_status mm_set_option(mm_engine *e, const char *name, int value);
 
 /* Timings of the last mm_generate / mm_score_cells (+ mm_resolve) on e. */

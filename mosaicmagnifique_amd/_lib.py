@@ -25,7 +25,8 @@ class MMTiming(ctypes.Structure):
                 ("total_ms", ctypes.c_double), ("score_launches", ctypes.c_int64),
                 ("pair_evals", ctypes.c_int64), ("exact_rescored", ctypes.c_int64),
                 ("dense_rows", ctypes.c_int64), ("rescore_ms", ctypes.c_double),
-                ("dense_cells", ctypes.c_int64), ("edge_pairs", ctypes.c_int64)]
+                ("dense_cells", ctypes.c_int64), ("edge_pairs", ctypes.c_int64),
+                ("seed_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

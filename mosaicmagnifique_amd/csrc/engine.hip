@@ -50,7 +50,9 @@ struct mm_engine {
     DevBuf recs, cells, cmask, scores, cand_i, cand_s, grid, best, counter, scratch;
     // two-tier scoring workspaces
     DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s;
+    DevBuf lib_means, seeds, seed_score, limits;
     int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
+    int use_prune = 1;           // mm_set_option("prune", 0): filter pass without early exit
 
     mm_timing timing{};
 };
@@ -243,6 +245,15 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     }
     const mm::FilterBand band = filter_band(diff_type, ppad);
     const int ftype = diff_type == MM_CIEDE2000 ? mm::CIEDE2000 : mm::RGB_EUCLIDEAN;
+    // Early exit needs seeds: K <= M <= 256 of them, and the L proxy distances in LDS.
+    const int M = std::min(L, std::min(256, round_up(K + 22, 4)));
+    const bool prune = two_tier && e->use_prune != 0 && K <= M && (size_t)L * sizeof(float) <= 150 * 1024;
+    if (prune) {
+        if ((st = ensure(e, e->seeds, (size_t)batch * M * sizeof(int32_t), "Failed to allocate seeds")) ||
+            (st = ensure(e, e->seed_score, (size_t)batch * M * sizeof(float), "Failed to allocate seeds")) ||
+            (st = ensure(e, e->limits, (size_t)batch * sizeof(float), "Failed to allocate pruning limits")))
+            return st;
+    }
 
     std::vector<uint8_t> flags_host;
     std::vector<mm_cell> dense_cells;
@@ -271,11 +282,19 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
         HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
 
-        // tier 1: fp32 filter score of every (cell, candidate)
+        // tier 1: fp32 filter score of every (cell, candidate), with early exit against a
+        // per-cell limit obtained from a few proxy-chosen seeds
+        if (prune)
+            HIP_TRY(e, mm::launch_prune_limits(ftype, (const float*)e->cells.p, (const uint8_t*)e->cmask.p,
+                                               (const float*)e->lib.p, (const float*)e->lib_means.p, b, L, ppad,
+                                               M, K, band.px_abs, band.rel, (int32_t*)e->seeds.p,
+                                               (float*)e->seed_score.p, (float*)e->limits.p, e->stream),
+                    "Error during seed / pruning limit kernels");
+        HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
         HIP_TRY(e, mm::launch_filter(ftype, (const float*)e->cells.p, (const uint8_t*)e->cmask.p,
                                      (const float*)e->lib.p, (float*)e->scores.p, b, L, ppad,
                                      (mm::EdgeEntry*)e->edges.p, (unsigned int*)e->edge_count.p, edge_cap,
-                                     e->stream),
+                                     prune ? (const float*)e->limits.p : nullptr, e->stream),
                 "Error during filter colour difference kernel");
         HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
 
@@ -308,7 +327,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         HIP_TRY(e, hipMemcpyAsync(&edge_n, e->edge_count.p, sizeof edge_n, hipMemcpyDeviceToHost, e->stream), "edge count");
         HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
         e->timing.stage_ms += elapsed(e->ev[0], e->ev[1]);
-        e->timing.score_ms += elapsed(e->ev[1], e->ev[2]);
+        e->timing.seed_ms += elapsed(e->ev[1], e->ev[4]);
+        e->timing.score_ms += elapsed(e->ev[4], e->ev[2]);
         e->timing.select_ms += elapsed(e->ev[2], e->ev[3]) + elapsed(e->ev[8], e->ev[9]);
         e->timing.rescore_ms += elapsed(e->ev[3], e->ev[8]);
         e->timing.score_launches += 1;
@@ -480,7 +500,8 @@ void mm_destroy(mm_engine* e)
     for (DevBuf* b : { &e->lib, &e->masks, &e->target, &e->recs, &e->cells, &e->cmask, &e->scores,
                        &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter, &e->scratch,
                        &e->cont_i, &e->cont_f, &e->cont_s, &e->flags, &e->edges, &e->edge_count,
-                       &e->dense_recs, &e->dense_i, &e->dense_s })
+                       &e->dense_recs, &e->dense_i, &e->dense_s, &e->lib_means, &e->seeds,
+                       &e->seed_score, &e->limits })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -525,6 +546,11 @@ mm_status mm_set_library(mm_engine* e, const float* images, int n_images, int si
         }
     }
     release(stage);
+    if ((st = ensure(e, e->lib_means, (size_t)n_images * 3 * sizeof(float), "Failed to allocate library means")))
+        return st;
+    HIP_TRY(e, mm::launch_image_means((const float*)e->lib.p, (float*)e->lib_means.p, n_images, P, ppad, e->stream),
+            "Error during library mean kernel");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
     e->n_lib = n_images;
     e->lib_size = size;
     return MM_OK;
@@ -707,6 +733,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
 {
     if (!e || !name) return MM_INVALID_ARGUMENT;
     if (strcmp(name, "filter") == 0) { e->use_filter = value != 0; return MM_OK; }
+    if (strcmp(name, "prune") == 0) { e->use_prune = value != 0; return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);
     return MM_INVALID_ARGUMENT;
 }

@@ -47,7 +47,7 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
               const float* __restrict__ lib, float* __restrict__ scores,
               int n_cells, int L, int ppad, int cand_per_block, int cell_group,
               EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
-              unsigned int edge_cap)
+              unsigned int edge_cap, const float* __restrict__ prune_above, int check_every)
 {
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long bid = blockIdx.x;
@@ -66,13 +66,22 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
     const float4* c2 = c1 + ppad / 4;
     const uint32_t* mk = reinterpret_cast<const uint32_t*>(cmask + (size_t)cell * ppad);
 
+    // Early exit, the device form of the reference's `variant < bestVariant` loop guards
+    // (CPUPhotomosaicGenerator.cpp:149,153): every term is >= 0, so once the running
+    // sum of a candidate exceeds `limit` -- an upper bound on the score a contender of
+    // this cell can have (prune_kernel) -- the candidate cannot be one and gets +inf.
+    // The test is wave-uniform: one wave owns the whole candidate.
+    const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
+
     const int l_end = min((tile + 1) * cand_per_block, L);
     for (int l = tile * cand_per_block + wave; l < l_end; l += kBlock / kWave) {
         const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
         const float4* b1 = b0 + ppad / 4;
         const float4* b2 = b1 + ppad / 4;
         float acc = 0.0f;
+        bool pruned = false;
         for (int j = 0; j < groups; ++j) {
+            if (j != 0 && j % check_every == 0 && wave_sum_f(acc) > limit) { pruned = true; break; }
             const int q = lane + kWave * j;
             const uint32_t m = mk[q];
             if (m == 0) continue;
@@ -98,7 +107,176 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
             }
         }
         acc = wave_sum_f(acc);
-        if (lane == 0) scores[(size_t)cell * L + l] = acc;
+        if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
+    }
+}
+
+// One pair for the seed scores: fp32 form, with the fp64 form taken inline on the
+// hue discontinuity (the seeds are few, the divergence is irrelevant there).
+template <int TYPE>
+__device__ __forceinline__ float pair_seed(const PxF& p, const PxF& q)
+{
+    bool edge;
+    float v = pair_fast<TYPE>(p, q, &edge);
+    if constexpr (TYPE == CIEDE2000)
+        if (edge) v = (float)ciede2000(Px{p.c0, p.c1, p.c2}, Px{q.c0, q.c1, q.c2});
+    return v;
+}
+
+// fp32 filter score of LISTED candidates (the seeds whose scores bound the pruning
+// limit): one wave per (cell, slot), no early exit; same values as filter_kernel +
+// edge_fix_kernel produce, up to fp32 summation order.
+template <int TYPE>
+__global__ void __launch_bounds__(kBlock)
+seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
+                  const float* __restrict__ lib, const int32_t* __restrict__ seeds,
+                  float* __restrict__ seed_score, int n_cells, int M, int ppad)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * (kBlock / kWave) + wave;
+    const int cell = (int)(w / M);
+    if (cell >= n_cells) return;
+    const int l = seeds[w];
+    if (l < 0) { if (lane == 0) seed_score[w] = __builtin_huge_valf(); return; }
+    const int groups = ppad / (4 * kWave);
+    const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
+    const float4* c1 = c0 + ppad / 4;
+    const float4* c2 = c1 + ppad / 4;
+    const uint32_t* mk = reinterpret_cast<const uint32_t*>(cmask + (size_t)cell * ppad);
+    const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
+    const float4* b1 = b0 + ppad / 4;
+    const float4* b2 = b1 + ppad / 4;
+    float acc = 0.0f;
+    for (int j = 0; j < groups; ++j) {
+        const int q = lane + kWave * j;
+        const uint32_t m = mk[q];
+        if (m == 0) continue;
+        const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
+        const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
+        const float v0 = pair_seed<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x});
+        const float v1 = pair_seed<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y});
+        const float v2 = pair_seed<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z});
+        const float v3 = pair_seed<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w});
+        acc += ((m & 0x000000ffu) ? v0 : 0.0f) + ((m & 0x0000ff00u) ? v1 : 0.0f)
+             + ((m & 0x00ff0000u) ? v2 : 0.0f) + ((m & 0xff000000u) ? v3 : 0.0f);
+    }
+    acc = wave_sum_f(acc);
+    if (lane == 0) seed_score[w] = acc;
+}
+
+// Mean colour of every library image (over all pixels), f32 [L][3]: a proxy used only
+// to pick which candidates to score first.
+__global__ void __launch_bounds__(kBlock)
+image_means_kernel(const float* __restrict__ planar, float* __restrict__ means, int P, int ppad)
+{
+    __shared__ float sh[3][kBlock / kWave];
+    const float* img = planar + (size_t)blockIdx.x * 3 * ppad;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int p = threadIdx.x; p < P; p += kBlock) { s0 += img[p]; s1 += img[ppad + p]; s2 += img[2 * (size_t)ppad + p]; }
+    s0 = wave_sum_f(s0); s1 = wave_sum_f(s1); s2 = wave_sum_f(s2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh[0][wave] = s0; sh[1][wave] = s1; sh[2][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = 0.f;
+        for (int w = 0; w < kBlock / kWave; ++w) t += sh[threadIdx.x][w];
+        means[(size_t)blockIdx.x * 3 + threadIdx.x] = t / (float)P;
+    }
+}
+
+// Seeds of one cell: the M library images whose mean colour is closest (same fp32
+// difference form) to the cell's mean colour over its active pixels.  One workgroup
+// per cell, M rounds of a block-wide arg-min over L proxy distances kept in LDS.
+template <int TYPE>
+__global__ void __launch_bounds__(kBlock)
+seed_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
+            const float* __restrict__ lib_means, int L, int ppad, int M,
+            int32_t* __restrict__ seeds)
+{
+    extern __shared__ float proxy[];                 // [L]
+    __shared__ float red[4][kBlock / kWave];
+    __shared__ float best_v[kBlock / kWave];
+    __shared__ int best_i[kBlock / kWave];
+    const float* c = cells + (size_t)blockIdx.x * 3 * ppad;
+    const uint8_t* mk = cmask + (size_t)blockIdx.x * ppad;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, n = 0.f;
+    for (int p = threadIdx.x; p < ppad; p += kBlock)
+        if (mk[p]) { s0 += c[p]; s1 += c[ppad + p]; s2 += c[2 * (size_t)ppad + p]; n += 1.f; }
+    s0 = wave_sum_f(s0); s1 = wave_sum_f(s1); s2 = wave_sum_f(s2); n = wave_sum_f(n);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; red[3][wave] = n; }
+    __syncthreads();
+    float t[4];
+    for (int k = 0; k < 4; ++k) { t[k] = 0.f; for (int w = 0; w < kBlock / kWave; ++w) t[k] += red[k][w]; }
+    const float inv = 1.0f / fmaxf(t[3], 1.0f);
+    const PxF mean{t[0] * inv, t[1] * inv, t[2] * inv};
+    for (int l = threadIdx.x; l < L; l += kBlock) {
+        bool e;
+        proxy[l] = pair_fast<TYPE>(mean, PxF{lib_means[3 * l], lib_means[3 * l + 1], lib_means[3 * l + 2]}, &e);
+    }
+    __syncthreads();
+    for (int r = 0; r < M; ++r) {
+        float v = __builtin_huge_valf();
+        int i = 0x7fffffff;
+        for (int l = threadIdx.x; l < L; l += kBlock) {
+            const float d = proxy[l];
+            if (d < v) { v = d; i = l; }                       // lowest index first within a thread
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off, kWave);
+            const int oi = __shfl_xor(i, off, kWave);
+            if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+        }
+        if (lane == 0) { best_v[wave] = v; best_i[wave] = i; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kBlock / kWave; ++w)
+                if (best_v[w] < v || (best_v[w] == v && best_i[w] < i)) { v = best_v[w]; i = best_i[w]; }
+            seeds[(size_t)blockIdx.x * M + r] = (i == 0x7fffffff) ? -1 : i;
+            if (i != 0x7fffffff) proxy[i] = __builtin_huge_valf();       // taken
+        }
+        __syncthreads();
+    }
+}
+
+// Pruning limit of one cell from its seeds' filter scores: the K-th lowest seed score
+// is an upper bound on the cell's K-th lowest filter score v_K, so nothing scoring
+// above  it + 2*err  can be a contender (contenders_kernel keeps filter <= v_K + 2 err).
+// One wave per cell, M <= 256 seeds.
+__global__ void __launch_bounds__(kWave)
+prune_limit_kernel(const float* __restrict__ seed_score, const uint8_t* __restrict__ cmask,
+                   int M, int K, int ppad, float px_abs, float rel, float* __restrict__ limit)
+{
+    const int lane = threadIdx.x;
+    const float* sc = seed_score + (size_t)blockIdx.x * M;
+    int act = 0;
+    const uint32_t* mk = reinterpret_cast<const uint32_t*>(cmask + (size_t)blockIdx.x * ppad);
+    for (int q = lane; q < ppad / 4; q += kWave) act += __popc(mk[q] & 0x01010101u);
+    for (int off = 32; off > 0; off >>= 1) act += __shfl_xor(act, off, kWave);
+
+    float v[4];                                   // this lane's seeds (M <= 256)
+    for (int k = 0; k < 4; ++k) v[k] = (lane + kWave * k < M) ? sc[lane + kWave * k] : __builtin_huge_valf();
+    float kth = __builtin_huge_valf();
+    for (int r = 0; r < K; ++r) {                 // K rounds: pop the minimum
+        float m = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+        float w = m;
+        for (int off = 32; off > 0; off >>= 1) w = fminf(w, __shfl_xor(w, off, kWave));
+        kth = w;
+        // remove ONE instance of the minimum: the lowest lane holding it
+        const unsigned long long holders = __ballot(m == w);
+        if (holders == 0) break;                  // all +inf
+        if (lane == __ffsll((long long)holders) - 1) {
+            if (v[0] == w) v[0] = __builtin_huge_valf();
+            else if (v[1] == w) v[1] = __builtin_huge_valf();
+            else if (v[2] == w) v[2] = __builtin_huge_valf();
+            else v[3] = __builtin_huge_valf();
+        }
+    }
+    if (lane == 0) {
+        const float err = (float)act * px_abs + fabsf(kth) * rel;
+        // the seed sums and the filter's running sums are fp32 sums in different orders:
+        // a further relative 1e-4 keeps the comparison on the safe side
+        limit[blockIdx.x] = (kth + 2.0f * err) * 1.0001f + 1e-3f;
     }
 }
 
@@ -144,23 +322,56 @@ pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ seco
 hipError_t launch_filter(int type, const float* cells, const uint8_t* cmask, const float* lib,
                          float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
-                         hipStream_t stream)
+                         const float* prune_above, hipStream_t stream)
 {
     const int cand_per_block = 16, cell_group = 512;
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long blocks = (long long)n_cells * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    const int groups = ppad / 256;
+    const int check_every = groups >= 16 ? groups / 8 : (groups >= 4 ? 2 : 1);
     hipError_t code = hipMemsetAsync(edge_count, 0, sizeof(unsigned int), stream);
     if (code != hipSuccess) return code;
     if (type == CIEDE2000) {
         filter_kernel<CIEDE2000><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
-            cells, cmask, lib, scores, n_cells, L, ppad, cand_per_block, cell_group, edges, edge_count, edge_cap);
+            cells, cmask, lib, scores, n_cells, L, ppad, cand_per_block, cell_group, edges, edge_count, edge_cap,
+            prune_above, check_every);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(cells, lib, scores, L, ppad, edges, edge_count, edge_cap);
     } else {
         filter_kernel<RGB_EUCLIDEAN><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
-            cells, cmask, lib, scores, n_cells, L, ppad, cand_per_block, cell_group, edges, edge_count, edge_cap);
+            cells, cmask, lib, scores, n_cells, L, ppad, cand_per_block, cell_group, edges, edge_count, edge_cap,
+            prune_above, check_every);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_image_means(const float* planar, float* means, int n_images, int P, int ppad, hipStream_t stream)
+{
+    image_means_kernel<<<n_images, kBlock, 0, stream>>>(planar, means, P, ppad);
+    return hipGetLastError();
+}
+
+hipError_t launch_prune_limits(int type, const float* cells, const uint8_t* cmask, const float* lib,
+                               const float* lib_means, int n_cells, int L, int ppad, int M, int K,
+                               float px_abs, float rel, int32_t* seeds, float* seed_score, float* limit,
+                               hipStream_t stream)
+{
+    if (M > 256 || M < K || (size_t)L * sizeof(float) > 150 * 1024) return hipErrorInvalidValue;
+    const size_t lds = (size_t)L * sizeof(float);
+    const long long waves = (long long)n_cells * M;
+    if (type == CIEDE2000) {
+        seed_kernel<CIEDE2000><<<n_cells, kBlock, lds, stream>>>(cells, cmask, lib_means, L, ppad, M, seeds);
+        seed_score_kernel<CIEDE2000><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(
+            cells, cmask, lib, seeds, seed_score, n_cells, M, ppad);
+    } else {
+        seed_kernel<RGB_EUCLIDEAN><<<n_cells, kBlock, lds, stream>>>(cells, cmask, lib_means, L, ppad, M, seeds);
+        seed_score_kernel<RGB_EUCLIDEAN><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(
+            cells, cmask, lib, seeds, seed_score, n_cells, M, ppad);
+    }
+    hipError_t code = hipGetLastError();
+    if (code != hipSuccess) return code;
+    prune_limit_kernel<<<n_cells, kWave, 0, stream>>>(seed_score, cmask, M, K, ppad, px_abs, rel, limit);
     return hipGetLastError();
 }
 

@@ -14,11 +14,26 @@ struct EdgeEntry { int cell, cand, pixel; };
 // Tier-1 filter scores f32 [n_cells][L] (see filter.hip).  Pairs on the discontinuity
 // are logged to `edges` (capacity edge_cap, count in *edge_count, which may exceed
 // the capacity: the caller must then not trust the scores) and patched with the
-// fp64 form by a follow-up kernel on the same stream.
+// fp64 form by a follow-up kernel on the same stream.  prune_above (may be null):
+// per-cell limit above which a candidate is abandoned and scored +inf.
 hipError_t launch_filter(int type, const float* cells, const uint8_t* cmask, const float* lib,
                          float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
-                         hipStream_t stream);
+                         const float* prune_above, hipStream_t stream);
+
+// Mean colour per library image, f32 [n][3] (a proxy for choosing seeds; never a score).
+hipError_t launch_image_means(const float* planar, float* means, int n_images, int P, int ppad,
+                              hipStream_t stream);
+
+// Per-cell pruning limit for launch_filter: M seeds per cell picked by mean-colour
+// proximity are scored in full; the K-th lowest of them bounds the cell's K-th lowest
+// score from above, so a candidate whose running sum passes limit[cell] cannot be a
+// contender.  seeds [n][M] i32, seed_score [n][M] f32, limit [n] f32 are workspaces /
+// outputs.  Requires K <= M <= 256 and L floats to fit LDS (L <= 38400).
+hipError_t launch_prune_limits(int type, const float* cells, const uint8_t* cmask, const float* lib,
+                               const float* lib_means, int n_cells, int L, int ppad, int M, int K,
+                               float px_abs, float rel, int32_t* seeds, float* seed_score, float* limit,
+                               hipStream_t stream);
 
 // fp32 filter form of the per-pair difference (accuracy harness).  flag_edges != 0
 // writes -1 for pairs the filter hands to the fp64 form.

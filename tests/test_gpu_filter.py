@@ -68,8 +68,12 @@ def run_both(oracle, engine, shape, img, lib, t, rep=(0, 0)):
     cells = G.cell_records(group, state, img.shape[0], img.shape[1])
     engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
     engine.set_option("filter", 1)
+    engine.set_option("prune", 0)
+    bestn, scoren = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    engine.set_option("prune", 1)
     best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
     tm = engine.timing()
+    assert np.array_equal(best, bestn) and np.array_equal(score[state >= 0], scoren[state >= 0])
     engine.set_option("filter", 0)
     best0, score0 = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
     engine.set_option("filter", 1)
