@@ -132,9 +132,15 @@ def main():
     from mosaicmagnifique_amd.engine import Engine
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MOSAIC_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL init, device-side
+    # candidate lists, all-gather, resolve from device memory) even with one rank.
+    use_dist = world > 1 or os.environ.get("MOSAIC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     w = build_workload(args.config, world)
@@ -146,7 +152,7 @@ def main():
     stage_s = time.perf_counter() - t_stage
 
     cells, gw, gh, t, rep = w["cells"], w["grid_w"], w["grid_h"], w["t"], w["rep"]
-    sharded = ShardedBestFit(engine, rank, world) if world > 1 else None
+    sharded = ShardedBestFit(engine, rank, world) if use_dist else None
 
     def step():
         if sharded is not None:
@@ -154,7 +160,7 @@ def main():
         return engine.generate(cells, gw, gh, t, *rep)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,8 +183,7 @@ def main():
         elapsed = float(el.item())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     n_cells = len(cells)
@@ -224,6 +229,7 @@ def main():
         },
         "stage_once_s": stage_s,
         "exact_rescored_per_step": exact / max(args.steps, 1),
+        "last_step_device_ms": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
     }
 
     if world == 1 and not args.no_cpu:
@@ -240,7 +246,7 @@ def main():
         out["parity_on_cpu_sample"] = {"indices_equal": bool(same), "max_rel_score_err": rel}
         out["speedup_vs_cpu"] = value / (done / dt)
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -41,7 +41,7 @@ def allgather_candidates(idx_local, score_local, n_cells, world, group=None):
     assert per == padded_len(n_cells, world) and score_local.shape == (per, k)
     idx_all = torch.empty((world * per, k), dtype=idx_local.dtype, device=idx_local.device)
     score_all = torch.empty((world * per, k), dtype=score_local.dtype, device=score_local.device)
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         idx_all.copy_(idx_local)
         score_all.copy_(score_local)
     else:

@@ -1,0 +1,61 @@
+// Test driver for the C++ host mirror: reads a scenario written by pytest, runs
+// HIPPhotomosaicGenerator the way the reference's generator tests drive theirs
+// (test/tst_CUDAGenerator.h:163-212), writes the best-fit grid.
+//   scenario.bin: int32 header {rows, cols, size, L, type, range, addition, 6 spacings/offsets, 4 flips}
+//                 then f32 image, f32 library, u8 mask (size*size)
+//   result.bin:   int32 gridH, gridW, then int64 grid (-1 = nullopt)
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../mosaicmagnifique_amd/csrc/host/HIPPhotomosaicGenerator.h"
+
+int main(int argc, char** argv)
+{
+    if (argc != 3) return 2;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    int32_t h[17];
+    if (fread(h, sizeof h, 1, f) != 1) return 2;
+    const int rows = h[0], cols = h[1], size = h[2], L = h[3];
+    Image img{rows, cols, std::vector<float>((size_t)rows * cols * 3)};
+    if (fread(img.data.data(), sizeof(float), img.data.size(), f) != img.data.size()) return 2;
+    std::vector<Image> lib((size_t)L, Image{size, size, std::vector<float>((size_t)size * size * 3)});
+    for (auto& im : lib)
+        if (fread(im.data.data(), sizeof(float), im.data.size(), f) != im.data.size()) return 2;
+    std::vector<uint8_t> mask((size_t)size * size);
+    if (fread(mask.data(), 1, mask.size(), f) != mask.size()) return 2;
+    fclose(f);
+
+    CellShape shape(size, mask);
+    shape.rowSpacing = h[7]; shape.colSpacing = h[8]; shape.alternateRowSpacing = h[9]; shape.alternateColSpacing = h[10];
+    shape.alternateRowOffset = h[11]; shape.alternateColOffset = h[12];
+    shape.alternateColFlipHorizontal = h[13]; shape.alternateColFlipVertical = h[14];
+    shape.alternateRowFlipHorizontal = h[15]; shape.alternateRowFlipVertical = h[16];
+    CellGroup group;
+    group.setCellShape(shape);
+
+    HIPPhotomosaicGenerator generator(0);
+    generator.setMainImage(img);
+    generator.setLibrary(lib);
+    generator.setColourDifference(static_cast<ColourDifference::Type>(h[4]));
+    generator.setCellGroup(group);
+    generator.setGridState(GridUtility::getGridState(group, rows, cols));
+    generator.setRepeat(h[5], h[6]);
+    int last = -1, monotone = 1;
+    generator.progress = [&](int v) { if (v < last) monotone = 0; last = v; };
+    if (!generator.generateBestFits()) { fprintf(stderr, "generateBestFits failed: %s\n", generator.lastError().c_str()); return 1; }
+    if (!monotone || last != generator.getMaxProgress()) { fprintf(stderr, "progress not monotone / incomplete\n"); return 1; }
+
+    const auto grid = generator.getBestFits().at(0);
+    FILE* o = fopen(argv[2], "wb");
+    const int32_t dims[2] = {(int32_t)grid.size(), (int32_t)grid.at(0).size()};
+    fwrite(dims, sizeof dims, 1, o);
+    for (const auto& row : grid)
+        for (const auto& cell : row) {
+            const int64_t v = cell.has_value() ? (int64_t)cell.value() : -1;
+            fwrite(&v, sizeof v, 1, o);
+        }
+    fclose(o);
+    return 0;
+}

@@ -258,3 +258,22 @@ def test_empty_cell_list(engine):
     engine.set_target(np.zeros((8, 8, 3), np.float32))
     best, score = engine.generate(np.zeros(0, dtype=G.CELL_DTYPE), 4, 3, 0)
     assert (best == 3).all() and np.isnan(score).all()
+
+
+def test_sharded_device_path_world1(oracle, engine):
+    """ShardedBestFit with one rank: candidate lists written straight into torch CUDA
+    tensors (mm_score_cells outputs_on_device), resolve reading device memory -- the
+    multi-GPU step minus the collective (which the gloo test covers)."""
+    import torch
+    from mosaicmagnifique_amd.dist import ShardedBestFit
+    shape = cases.hexagon_shape()
+    group = cases.group_of(shape)
+    t, rep = Type.CIEDE2000, (2, 250)
+    img, lib = cases.inputs(260, 300, 64, 70, t)
+    state = G.getGridState(group, 260, 300)[0]
+    cells = G.cell_records(group, state, 260, 300)
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    whole, whole_score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    best, score = ShardedBestFit(engine, 0, 1).generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    assert np.array_equal(best, whole) and np.array_equal(score[state >= 0], whole_score[state >= 0])
+    assert torch.cuda.is_available()
