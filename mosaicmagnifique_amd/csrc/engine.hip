@@ -50,7 +50,9 @@ struct mm_engine {
     DevBuf recs, cells, cmask, scores, cand_i, cand_s, grid, best, counter, scratch;
     // two-tier scoring workspaces
     DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s;
-    DevBuf lib_means, seeds, seed_score, limits;
+    DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
+    int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
+    int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
     int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
     int use_prune = 1;           // mm_set_option("prune", 0): filter pass without early exit
 
@@ -404,12 +406,72 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
     a.dense_count = a.exact_count + 1;
 
     const int sequential = (range > 0 && addition != 0) ? 1 : 0;
-    const int blocks = sequential ? 1 : std::max(1, std::min(n, 1024));
-    if ((st = ensure(e, e->scratch, (size_t)blocks * e->n_lib * sizeof(double), "Failed to allocate row scratch")))
-        return st;
-    a.scratch = (double*)e->scratch.p;
+    const size_t ring_bytes = sequential ? (size_t)(range + 1) * grid_w * sizeof(int) : 0;
+    const bool wave_form = e->use_wave_resolve != 0 && ring_bytes <= 120 * 1024;
     HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
-    if (n > 0) {
+    if (n > 0 && wave_form) {
+        // marked cells (list cut through a near-tie cluster): full rows, computed in parallel
+        if ((st = ensure(e, e->row_slot, (size_t)n * sizeof(int) + sizeof(int), "Failed to allocate row slots"))) return st;
+        int* slot = (int*)e->row_slot.p;
+        int* mark_count = slot + n;
+        HIP_TRY(e, hipMemsetAsync(mark_count, 0, sizeof(int), e->stream), "Failed to clear counter");
+        mm::mark_scan_kernel<<<std::min((n + mm::kBlock - 1) / mm::kBlock, 256), mm::kBlock, 0, e->stream>>>(
+            cand_i_dev, n, K, slot, mark_count);
+        HIP_TRY(e, hipGetLastError(), "Error during mark scan kernel");
+        int marked = 0;
+        HIP_TRY(e, hipMemcpyAsync(&marked, mark_count, sizeof(int), hipMemcpyDeviceToHost, e->stream), "mark count");
+        HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+        a.row_slot = marked > 0 ? slot : nullptr;      // no marks: skip the per-cell lookup
+        if (marked > 0) {
+            if ((st = ensure(e, e->dense_rows_buf, (size_t)marked * e->n_lib * sizeof(double), "Failed to allocate score rows")))
+                return st;
+            a.dense_rows = (const double*)e->dense_rows_buf.p;
+            by_type(diff_type, [&](auto T) {
+                mm::dense_rows_kernel<decltype(T)::value><<<n, mm::kBlock, 0, e->stream>>>(a, (double*)e->dense_rows_buf.p);
+                return MM_OK;
+            });
+            HIP_TRY(e, hipGetLastError(), "Error during dense rows kernel");
+        }
+        // whole grid + progress counters + per-wave exact buffers in LDS?
+        const size_t rows_lds = (((size_t)grid_w * grid_h + grid_h + 2) & ~(size_t)1) * sizeof(int) +
+                                (size_t)mm::kRowWaves * mm::kRowExactChunk * sizeof(double);
+        if (sequential && e->use_row_pipeline != 0 && rows_lds <= 158 * 1024) {
+            if ((st = ensure(e, e->row_index, ((size_t)2 * grid_h + 1) * sizeof(int), "Failed to allocate row index")))
+                return st;
+            int* row_first = (int*)e->row_index.p;
+            int* row_count = row_first + grid_h;
+            int* stuck = row_count + grid_h;
+            HIP_TRY(e, hipMemsetAsync(row_first, 0, ((size_t)2 * grid_h + 1) * sizeof(int), e->stream), "Failed to clear row index");
+            mm::row_index_kernel<<<std::min((n + mm::kBlock - 1) / mm::kBlock, 256), mm::kBlock, 0, e->stream>>>(
+                recs_dev, n, row_first, row_count);
+            HIP_TRY(e, hipGetLastError(), "Error during row index kernel");
+            st = by_type(diff_type, [&](auto T) {
+                auto kern = mm::resolve_rows_kernel<decltype(T)::value>;
+                hipError_t code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds);
+                if (code != hipSuccess) return hip_fail(e, code, "Failed to raise the LDS limit", __FILE__, __LINE__);
+                kern<<<1, mm::kRowWaves * mm::kWave, rows_lds, e->stream>>>(a, row_first, row_count, stuck);
+                return MM_OK;
+            });
+            if (st) return st;
+            HIP_TRY(e, hipGetLastError(), "Error during calculate repeats / find lowest kernel");
+            int stuck_host = 0;
+            HIP_TRY(e, hipMemcpyAsync(&stuck_host, stuck, sizeof(int), hipMemcpyDeviceToHost, e->stream), "stuck flag");
+            HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+            if (stuck_host) { set_err(e, "row-pipelined resolve made no progress (internal error)"); return MM_DEVICE_ERROR; }
+        } else {
+            const int blocks = sequential ? 1 : std::max(1, std::min(n, 8192));
+            by_type(diff_type, [&](auto T) {
+                mm::resolve_wave_kernel<decltype(T)::value><<<blocks, mm::kWave, ring_bytes, e->stream>>>(a, sequential);
+                return MM_OK;
+            });
+            HIP_TRY(e, hipGetLastError(), "Error during calculate repeats / find lowest kernel");
+        }
+    } else if (n > 0) {
+        const int blocks = sequential ? 1 : std::max(1, std::min(n, 1024));
+        if ((st = ensure(e, e->scratch, (size_t)blocks * e->n_lib * sizeof(double), "Failed to allocate row scratch")))
+            return st;
+        a.scratch = (double*)e->scratch.p;
         st = by_type(diff_type, [&](auto T) {
             mm::resolve_kernel<decltype(T)::value><<<blocks, mm::kBlock, 0, e->stream>>>(a, sequential);
             return MM_OK;
@@ -501,7 +563,7 @@ void mm_destroy(mm_engine* e)
                        &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter, &e->scratch,
                        &e->cont_i, &e->cont_f, &e->cont_s, &e->flags, &e->edges, &e->edge_count,
                        &e->dense_recs, &e->dense_i, &e->dense_s, &e->lib_means, &e->seeds,
-                       &e->seed_score, &e->limits })
+                       &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -734,6 +796,8 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (!e || !name) return MM_INVALID_ARGUMENT;
     if (strcmp(name, "filter") == 0) { e->use_filter = value != 0; return MM_OK; }
     if (strcmp(name, "prune") == 0) { e->use_prune = value != 0; return MM_OK; }
+    if (strcmp(name, "wave_resolve") == 0) { e->use_wave_resolve = value != 0; return MM_OK; }
+    if (strcmp(name, "row_pipeline") == 0) { e->use_row_pipeline = value != 0; return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);
     return MM_INVALID_ARGUMENT;
 }

@@ -433,6 +433,9 @@ struct ResolveArgs {
     unsigned long long* exact_count;
     double* scratch;            // [gridDim.x][L]: full score row of a cell whose list overflowed
     unsigned long long* dense_count;
+    // wave resolve: rows precomputed by dense_rows_kernel for the marked cells
+    const int* row_slot;        // [n_cells] slot in `rows`, -1 = list is complete
+    const double* dense_rows;   // [marked][L]
 };
 
 // Repeat value of library image `cand` at padded cell (px, py):
@@ -471,7 +474,7 @@ __device__ double exact_total(const ResolveArgs& a, const mm_cell& rec, int cand
     const uint8_t* mk = a.masks + (size_t)rec.mask_id * a.ppad;
     for (int base = 0; base < a.P; base += kExactChunk) {
         const int n = min(kExactChunk, a.P - base);
-        for (int t = threadIdx.x; t < n; t += kBlock) {
+        for (int t = threadIdx.x; t < n; t += (int)blockDim.x) {
             const int p = base + t;
             const int row = p / a.size, col = p - row * a.size;
             double term = -1.0;                               // marker: not active
@@ -612,6 +615,397 @@ resolve_kernel(ResolveArgs a, int sequential)
             a.best_score[pos] = chosen_total;
         }
         __syncthreads();          // workgroup-scope release/acquire: the next cell reads grid[]
+    }
+}
+
+// ---------------------------------------------------------------------------
+// resolve, wave form: one wave per cell chain, no workgroup barriers on the hot path
+// ---------------------------------------------------------------------------
+
+// Which cells carry the overflow mark, and a dense slot number for each of them.
+__global__ void __launch_bounds__(kBlock)
+mark_scan_kernel(const int32_t* __restrict__ cand_index, int n_cells, int K,
+                 int* __restrict__ row_slot, int* __restrict__ count)
+{
+    for (int c = blockIdx.x * kBlock + threadIdx.x; c < n_cells; c += gridDim.x * kBlock)
+        row_slot[c] = (cand_index[(size_t)c * K + K - 1] <= -2) ? atomicAdd(count, 1) : -1;
+}
+
+// Full fp64 score rows of the marked cells, one workgroup per cell (parallel: base
+// scores do not depend on the repeat penalty, so this never sits on the serial chain).
+template <int TYPE>
+__global__ void __launch_bounds__(kBlock)
+dense_rows_kernel(ResolveArgs a, double* __restrict__ rows)
+{
+    __shared__ double sh4[kBlock / kWave];
+    const int slot = a.row_slot[blockIdx.x];
+    if (slot < 0) return;
+    dense_row<TYPE>(a, a.recs[blockIdx.x], rows + (size_t)slot * a.L, sh4);
+    if (threadIdx.x == 0) atomicAdd(a.dense_count, 1ull);
+}
+
+// sequential != 0: ONE wave walks the cells in raster order; the chosen indices of the
+// last R+1 grid rows live in an LDS ring (the only state calculateRepeats reads,
+// CPUPhotomosaicGenerator.cpp:189-224).  Lane k holds candidate k; the <= R(2R+1)+R
+// neighbour picks are fetched once into lanes and matched against every lane's
+// candidate with v_readlane broadcasts; a wave-wide (total, index) arg-min and a ballot
+// for the near-tie test finish the cell.  The next cell's record and candidates are
+// loaded while the current one is processed.  sequential == 0: waves take cells
+// independently (no penalty, no ring).
+template <int TYPE>
+__global__ void __launch_bounds__(kWave)
+resolve_wave_kernel(ResolveArgs a, int sequential)
+{
+    extern __shared__ int ring[];              // [(R+1)][grid_w], sequential mode only
+    __shared__ double buf[kExactChunk];
+    __shared__ double bcast;
+    const int lane = threadIdx.x;
+    const bool penalise = sequential && a.repeat_range > 0 && a.repeat_addition != 0;
+    const int R = a.repeat_range, ring_rows = R + 1, gw = a.grid_w;
+    const int sentinel = a.L;
+    if (penalise) {
+        for (int i = lane; i < ring_rows * gw; i += kWave) ring[i] = sentinel;
+        __syncthreads();
+    }
+    int cur_row = -1;
+
+    const int first = sequential ? 0 : blockIdx.x;
+    const int stride = sequential ? 1 : gridDim.x;
+    if (first >= a.n_cells) return;
+
+    // software pipeline: (rec, my candidate) of the cell about to be processed
+    mm_cell rec = a.recs[first];
+    int my_ci = lane < a.K ? a.cand_index[(size_t)first * a.K + lane] : -1;
+    double my_cs = lane < a.K ? a.cand_score[(size_t)first * a.K + lane] : kInf;
+
+    for (int c = first; c < a.n_cells; c += stride) {
+        const int nc = c + stride;
+        mm_cell nrec = rec;
+        int nci = -1;
+        double ncs = kInf;
+        if (nc < a.n_cells) {                   // prefetch the next cell
+            nrec = a.recs[nc];
+            if (lane < a.K) { nci = a.cand_index[(size_t)nc * a.K + lane]; ncs = a.cand_score[(size_t)nc * a.K + lane]; }
+        }
+
+        const int px = rec.grid_x, py = rec.grid_y;
+        int n_above = 0, wrow = 0, sx = 0, sy = 0, nn = 0;
+        if (penalise) {
+            if (py != cur_row) {                // entering a grid row: recycle the ring rows it needs
+                for (int r = max(cur_row + 1, py - R); r <= py; ++r)
+                    for (int x = lane; x < gw; x += kWave) ring[(r % ring_rows) * gw + x] = sentinel;
+                cur_row = py;
+                __syncthreads();
+            }
+            sy = min(max(py - R, 0), a.grid_h);
+            sx = min(max(px - R, 0), gw);
+            const int ex = min(max(px + R, 0), gw - 1);
+            wrow = ex - sx + 1;
+            n_above = (py - sy) * wrow;
+            nn = n_above + (px - sx);
+        }
+
+        // dense row instead of the list?
+        const int slot = a.row_slot ? a.row_slot[c] : -1;
+        const bool dense = slot >= 0;
+        const int K = dense ? a.L : a.K;
+        const double* row = dense ? a.dense_rows + (size_t)slot * a.L : nullptr;
+
+        // candidate of this lane in chunk `base`, with its total
+        auto eval = [&](int base, int& cand, double& total, int& rep_out) {
+            const int k = base + lane;
+            double s;
+            if (dense) { cand = k < K ? k : -1; s = k < K ? row[k] : kInf; }
+            else if (base == 0) { cand = my_ci; s = my_cs; }
+            else { cand = k < K ? a.cand_index[(size_t)c * a.K + k] : -1; s = k < K ? a.cand_score[(size_t)c * a.K + k] : kInf; }
+            int rep = 0;
+            for (int t0 = 0; t0 < nn; t0 += kWave) {        // neighbours, 64 at a time
+                const int t = t0 + lane;
+                int nbv = sentinel;
+                if (t < nn) {
+                    int ry, rx;
+                    if (t < n_above) { const int q = t / wrow; ry = sy + q; rx = sx + (t - q * wrow); }
+                    else { ry = py; rx = sx + (t - n_above); }
+                    nbv = ring[(ry % ring_rows) * gw + rx];
+                }
+                const int cnt = min(kWave, nn - t0);
+                for (int j = 0; j < cnt; ++j)
+                    rep += (__builtin_amdgcn_readlane(nbv, j) == cand) ? a.repeat_addition : 0;
+            }
+            rep_out = rep;
+            total = (double)rep + s;
+        };
+
+        // pass 1: lowest (total, index)
+        ScoreIdx best{kInf, 0x7fffffff};
+        int c0 = -1, r0 = 0;
+        double t0v = kInf;
+        for (int base = 0; base < K; base += kWave) {
+            int cand, rep; double total;
+            eval(base, cand, total, rep);
+            if (base == 0) { c0 = cand; t0v = total; r0 = rep; }
+            if (cand >= 0 && lex_less(total, cand, best.s, best.i)) { best.s = total; best.i = cand; }
+        }
+        best = wave_min(best);
+
+        long long chosen = a.L;                 // sentinel: "Failed to find a best fit" (:173-177)
+        double chosen_total = best.s;
+        if (best.i != 0x7fffffff) {
+            chosen = best.i;
+            const double thr = best.s + fabs(best.s) * a.tie_band;
+            int near = 0;
+            for (int base = 0; base < K; base += kWave) {
+                int cand, rep; double total;
+                if (base == 0) { cand = c0; total = t0v; } else eval(base, cand, total, rep);
+                near += __popcll(__ballot(cand >= 0 && total <= thr));
+            }
+            if (near > 1) {
+                // Re-sum every contender in the reference's order, ascending index, strict <
+                double ex_best = kInf;
+                int ex_idx = -1, prev = -1;
+                for (;;) {
+                    int key_i = 0x7fffffff, key_rep = 0;     // lowest contender index above prev, with its repeat value
+                    for (int base = 0; base < K; base += kWave) {
+                        int cand, rep; double total;
+                        if (base == 0) { cand = c0; total = t0v; rep = r0; } else eval(base, cand, total, rep);
+                        if (cand > prev && total <= thr && cand < key_i) { key_i = cand; key_rep = rep; }
+                    }
+                    const ScoreIdx win = wave_min(ScoreIdx{(double)key_i, key_i});
+                    if (win.i == 0x7fffffff) break;
+                    // the lane holding `win.i` knows its repeat value
+                    const unsigned long long who = __ballot(key_i == win.i);
+                    const int win_rep = __shfl(key_rep, __ffsll((long long)who) - 1, kWave);
+                    const double ex = exact_total<TYPE>(a, rec, win.i, win_rep, buf, &bcast);
+                    if (lane == 0) atomicAdd(a.exact_count, 1ull);
+                    if (ex < ex_best) { ex_best = ex; ex_idx = win.i; }
+                    prev = win.i;
+                }
+                if (ex_idx >= 0) { chosen = ex_idx; chosen_total = ex_best; }
+            }
+        }
+
+        if (lane == 0) {
+            const size_t pos = (size_t)py * gw + px;
+            a.grid[pos] = chosen;
+            a.best_score[pos] = chosen_total;
+            if (penalise) ring[(py % ring_rows) * gw + px] = (int)chosen;
+        }
+        if (penalise) __syncthreads();          // single wave: orders the LDS write before the next reads
+
+        rec = nrec;
+        my_ci = nci;
+        my_cs = ncs;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// resolve, row-pipelined form: the raster-order dependency as a wavefront
+// ---------------------------------------------------------------------------
+//
+// calculateRepeats at (x, y) reads rows y-R..y-1 over columns x-R..x+R and row y to
+// the left (CPUPhotomosaicGenerator.cpp:189-224).  So row y may work on column x as
+// soon as row y-1 has finished column x+R: up to grid_w/(R+1) rows can be in flight.
+// One workgroup, one wave per row in flight; the whole padded grid of chosen indices
+// and one progress counter per row live in LDS.  progress[y] = p means every cell of
+// row y with grid_x < p is final.  A wave spins (bounded, with s_sleep) on the row
+// above; rows are taken in increasing order, so the wait graph is acyclic.
+
+constexpr int kRowWaves = 8;
+constexpr int kRowExactChunk = 128;      // doubles of per-wave LDS for the exact re-sum
+
+// First cell and cell count of every grid row (cells are in raster order).
+__global__ void __launch_bounds__(kBlock)
+row_index_kernel(const mm_cell* __restrict__ recs, int n_cells, int* __restrict__ row_first,
+                 int* __restrict__ row_count)
+{
+    for (int c = blockIdx.x * kBlock + threadIdx.x; c < n_cells; c += gridDim.x * kBlock) {
+        const int y = recs[c].grid_y;
+        if (c == 0 || recs[c - 1].grid_y != y) row_first[y] = c;
+        atomicAdd(&row_count[y], 1);
+    }
+}
+
+// exact_total for ONE wave (no workgroup barrier): same arithmetic, same order.
+template <int TYPE>
+__device__ double exact_total_wave(const ResolveArgs& a, const mm_cell& rec, int cand, int rep, double* wbuf)
+{
+    const int lane = threadIdx.x & 63;
+    double running = (double)rep;
+    const float* l0 = a.lib + (size_t)cand * 3 * a.ppad;
+    const uint8_t* mk = a.masks + (size_t)rec.mask_id * a.ppad;
+    for (int base = 0; base < a.P; base += kRowExactChunk) {
+        const int n = min(kRowExactChunk, a.P - base);
+        for (int t = lane; t < n; t += kWave) {
+            const int p = base + t;
+            const int row = p / a.size, col = p - row * a.size;
+            double term = -1.0;
+            if (mk[p] != 0 && row >= rec.row_min && row < rec.row_max &&
+                col >= rec.col_min && col < rec.col_max) {
+                const float* src = a.target + ((size_t)(rec.y + row) * a.cols + (rec.x + col)) * 3;
+                term = colour_diff<TYPE>(Px{src[0], src[1], src[2]},
+                                         Px{l0[p], l0[a.ppad + p], l0[2 * (size_t)a.ppad + p]});
+            }
+            wbuf[t] = term;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0)
+            for (int t = 0; t < n; ++t)
+                if (wbuf[t] != -1.0) running += wbuf[t];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return __shfl(running, 0, kWave);
+}
+
+template <int TYPE>
+__global__ void __launch_bounds__(kRowWaves * kWave)
+resolve_rows_kernel(ResolveArgs a, const int* __restrict__ row_first, const int* __restrict__ row_count,
+                    int* __restrict__ stuck)
+{
+    extern __shared__ int lds[];
+    const int gw = a.grid_w, gh = a.grid_h;
+    int* lgrid = lds;                                  // [gh][gw] chosen index, sentinel L
+    volatile int* progress = lds + (size_t)gw * gh;    // [gh]
+    volatile int* abort_flag = progress + gh;          // set once if a wait times out
+    double* exact_buf = reinterpret_cast<double*>(lds + (((size_t)gw * gh + gh + 2) & ~(size_t)1));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* wbuf = exact_buf + (size_t)wave * kRowExactChunk;
+    const int R = a.repeat_range, sentinel = a.L;
+
+    for (int i = threadIdx.x; i < gw * gh; i += blockDim.x) lgrid[i] = sentinel;
+    for (int y = threadIdx.x; y < gh; y += blockDim.x) progress[y] = row_count[y] == 0 ? gw : 0;
+    if (threadIdx.x == 0) *abort_flag = 0;
+    __syncthreads();                                   // the only workgroup barrier
+
+    for (int py = wave; py < gh; py += kRowWaves) {
+        const int n_row = row_count[py];
+        if (n_row == 0) continue;
+        const int c_first = row_first[py];
+        mm_cell rec = a.recs[c_first];
+        int my_ci = lane < a.K ? a.cand_index[(size_t)c_first * a.K + lane] : -1;
+        double my_cs = lane < a.K ? a.cand_score[(size_t)c_first * a.K + lane] : kInf;
+
+        for (int i = 0; i < n_row; ++i) {
+            const int c = c_first + i;
+            mm_cell nrec = rec;
+            int nci = -1;
+            double ncs = kInf;
+            if (i + 1 < n_row) {                       // prefetch the row's next cell
+                nrec = a.recs[c + 1];
+                if (lane < a.K) { nci = a.cand_index[(size_t)(c + 1) * a.K + lane]; ncs = a.cand_score[(size_t)(c + 1) * a.K + lane]; }
+            }
+            const int px = rec.grid_x;
+            const int sy = min(max(py - R, 0), gh);
+            const int sx = min(max(px - R, 0), gw);
+            const int ex = min(max(px + R, 0), gw - 1);
+            const int wrow = ex - sx + 1;
+            const int n_above = (py - sy) * wrow;
+            const int nn = n_above + (px - sx);
+
+            // Wait until every row of the window has cleared columns <= ex.  (Each row is
+            // checked: with ragged rows -- offset cell shapes -- "row y-1 is past ex" does
+            // not imply the rows above it are.)  The spin is bounded; a timeout raises
+            // `stuck` and releases every wave, so the kernel always drains.
+            for (int ry = sy; ry < py; ++ry) {
+                int spins = 0;
+                while (progress[ry] < ex + 1 && *abort_flag == 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1 << 22)) { *abort_flag = 1; if (lane == 0) atomicExch(stuck, 1); }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+            const int slot = a.row_slot ? a.row_slot[c] : -1;
+            const bool dense = slot >= 0;
+            const int K = dense ? a.L : a.K;
+            const double* row = dense ? a.dense_rows + (size_t)slot * a.L : nullptr;
+
+            auto eval = [&](int base, int& cand, double& total, int& rep_out) {
+                const int k = base + lane;
+                double s;
+                if (dense) { cand = k < K ? k : -1; s = k < K ? row[k] : kInf; }
+                else if (base == 0) { cand = my_ci; s = my_cs; }
+                else { cand = k < K ? a.cand_index[(size_t)c * a.K + k] : -1; s = k < K ? a.cand_score[(size_t)c * a.K + k] : kInf; }
+                int rep = 0;
+                for (int t0 = 0; t0 < nn; t0 += kWave) {
+                    const int t = t0 + lane;
+                    int nbv = sentinel;
+                    if (t < nn) {
+                        int ry, rx;
+                        if (t < n_above) { const int q = t / wrow; ry = sy + q; rx = sx + (t - q * wrow); }
+                        else { ry = py; rx = sx + (t - n_above); }
+                        nbv = lgrid[ry * gw + rx];
+                    }
+                    const int cnt = min(kWave, nn - t0);
+                    for (int j = 0; j < cnt; ++j)
+                        rep += (__builtin_amdgcn_readlane(nbv, j) == cand) ? a.repeat_addition : 0;
+                }
+                rep_out = rep;
+                total = (double)rep + s;
+            };
+
+            ScoreIdx best{kInf, 0x7fffffff};
+            int c0 = -1, r0 = 0;
+            double t0v = kInf;
+            for (int base = 0; base < K; base += kWave) {
+                int cand, rep; double total;
+                eval(base, cand, total, rep);
+                if (base == 0) { c0 = cand; t0v = total; r0 = rep; }
+                if (cand >= 0 && lex_less(total, cand, best.s, best.i)) { best.s = total; best.i = cand; }
+            }
+            best = wave_min(best);
+
+            long long chosen = a.L;
+            double chosen_total = best.s;
+            if (best.i != 0x7fffffff) {
+                chosen = best.i;
+                const double thr = best.s + fabs(best.s) * a.tie_band;
+                int near = 0;
+                for (int base = 0; base < K; base += kWave) {
+                    int cand, rep; double total;
+                    if (base == 0) { cand = c0; total = t0v; } else eval(base, cand, total, rep);
+                    near += __popcll(__ballot(cand >= 0 && total <= thr));
+                }
+                if (near > 1) {
+                    double ex_best = kInf;
+                    int ex_idx = -1, prev = -1;
+                    for (;;) {
+                        int key_i = 0x7fffffff, key_rep = 0;
+                        for (int base = 0; base < K; base += kWave) {
+                            int cand, rep; double total;
+                            if (base == 0) { cand = c0; total = t0v; rep = r0; } else eval(base, cand, total, rep);
+                            if (cand > prev && total <= thr && cand < key_i) { key_i = cand; key_rep = rep; }
+                        }
+                        const ScoreIdx win = wave_min(ScoreIdx{(double)key_i, key_i});
+                        if (win.i == 0x7fffffff) break;
+                        const unsigned long long who = __ballot(key_i == win.i);
+                        const int win_rep = __shfl(key_rep, __ffsll((long long)who) - 1, kWave);
+                        const double ex = exact_total_wave<TYPE>(a, rec, win.i, win_rep, wbuf);
+                        if (lane == 0) atomicAdd(a.exact_count, 1ull);
+                        if (ex < ex_best) { ex_best = ex; ex_idx = win.i; }
+                        prev = win.i;
+                    }
+                    if (ex_idx >= 0) { chosen = ex_idx; chosen_total = ex_best; }
+                }
+            }
+
+            if (lane == 0) {
+                const size_t pos = (size_t)py * gw + px;
+                a.grid[pos] = chosen;
+                a.best_score[pos] = chosen_total;
+                lgrid[pos] = (int)chosen;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                // cells between this one and the row's next valid cell are not in the grid: final too
+                progress[py] = (i + 1 < n_row) ? nrec.grid_x : gw;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");    // our own next read of lgrid[py][px]
+
+            rec = nrec;
+            my_ci = nci;
+            my_cs = ncs;
+        }
     }
 }
 

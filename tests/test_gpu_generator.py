@@ -26,10 +26,15 @@ SHAPES = {
 REL_TOL = {0: 1e-12, 1: 1e-12, 2: 1e-4}
 
 
-def generate(shape, img, lib, t, rep=(0, 0), device=0, use_filter=1):
+RESOLVE_MODES = {"rows": (1, 1), "wave": (1, 0), "workgroup": (0, 0)}     # (wave_resolve, row_pipeline)
+
+
+def generate(shape, img, lib, t, rep=(0, 0), device=0, use_filter=1, wave_resolve="rows"):
     group = cases.group_of(shape)
     gen = HIPPhotomosaicGenerator(device)
     gen.m_engine.set_option("filter", use_filter)
+    gen.m_engine.set_option("wave_resolve", RESOLVE_MODES[wave_resolve][0])
+    gen.m_engine.set_option("row_pipeline", RESOLVE_MODES[wave_resolve][1])
     gen.setMainImage(img)
     gen.setLibrary(lib)
     gen.setColourDifference(t)
@@ -40,8 +45,8 @@ def generate(shape, img, lib, t, rep=(0, 0), device=0, use_filter=1):
     return gen
 
 
-def compare(oracle, shape, img, lib, t, rep=(0, 0), use_filter=1):
-    gen = generate(shape, img, lib, t, rep, use_filter=use_filter)
+def compare(oracle, shape, img, lib, t, rep=(0, 0), use_filter=1, wave_resolve="rows"):
+    gen = generate(shape, img, lib, t, rep, use_filter=use_filter, wave_resolve=wave_resolve)
     got, score = gen.getBestFits()[0], gen.getBestScores()[0]
     want, want_score, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), *rep)
     assert got.shape == want.shape
@@ -74,20 +79,23 @@ def test_compare_matrix(oracle, t, shape_name, rep, use_filter):
     assert (tm["rescore_ms"] > 0) == bool(use_filter and gen.m_engine.candidates_per_cell(*rep) < n_lib)
 
 
+@pytest.mark.parametrize("wave_resolve", list(RESOLVE_MODES))
 @pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIEDE2000])
-def test_duplicate_library_images_lowest_index_wins(oracle, t):
+def test_duplicate_library_images_lowest_index_wins(oracle, t, wave_resolve):
     shape = cases.square_shape(16)
     img, lib = cases.inputs(96, 96, 16, 60, t)
     first = generate(shape, img, lib, t).getBestFits()[0]
     winners = np.unique(first[first >= 0])
     dups = [((int(w) + 31) % 60, int(w)) for w in winners[:6]]
     img, lib = cases.inputs(96, 96, 16, 60, t, duplicates=dups)
-    compare(oracle, shape, img, lib, t)
-    compare(oracle, shape, img, lib, t, rep=(1, 40))
+    compare(oracle, shape, img, lib, t, wave_resolve=wave_resolve)
+    compare(oracle, shape, img, lib, t, rep=(1, 40), wave_resolve=wave_resolve)
+    compare(oracle, shape, img, lib, t, rep=(9, 7), wave_resolve=wave_resolve)     # window > 64 neighbours
 
 
+@pytest.mark.parametrize("wave_resolve", list(RESOLVE_MODES))
 @pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIE76])
-def test_near_tie_is_broken_in_reference_summation_order(oracle, t):
+def test_near_tie_is_broken_in_reference_summation_order(oracle, t, wave_resolve):
     """Flat target + two library images that are pixel PERMUTATIONS of each other:
     the same multiset of per-pixel terms, so the two sums agree to ~1e-16 relative and
     only the reference's sequential order decides.  Forces the exact re-sum path."""
@@ -103,12 +111,12 @@ def test_near_tie_is_broken_in_reference_summation_order(oracle, t):
     for k, idx in enumerate((7, 3, 29)):
         perm = rng.permutation(size * size)
         lib[idx] = patch.reshape(-1, 3)[perm].reshape(size, size, 3) if k else patch
-    gen = compare(oracle, shape, img, lib, t)
+    gen = compare(oracle, shape, img, lib, t, wave_resolve=wave_resolve)
     tm = gen.timing()
     # 3 near-tied candidates but a 2-entry list: the list is marked as overflowing and
     # the cell's whole row is recomputed before the exact re-sum
     assert tm["exact_rescored"] >= 3 and tm["dense_rows"] > 0
-    gen = compare(oracle, shape, img, lib, t, rep=(1, 1))
+    gen = compare(oracle, shape, img, lib, t, rep=(1, 1), wave_resolve=wave_resolve)
     assert gen.timing()["exact_rescored"] > 0 and gen.timing()["dense_rows"] == 0
 
 
@@ -277,3 +285,14 @@ def test_sharded_device_path_world1(oracle, engine):
     best, score = ShardedBestFit(engine, 0, 1).generate(cells, state.shape[1], state.shape[0], int(t), *rep)
     assert np.array_equal(best, whole) and np.array_equal(score[state >= 0], whole_score[state >= 0])
     assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("wave_resolve", list(RESOLVE_MODES))
+def test_resolve_forms_on_ragged_rows(oracle, wave_resolve):
+    """Hexagon rows are offset and ragged (x = -1 cells exist on some rows only) and the
+    repeat window spans several rows: the row-pipelined resolve must wait on every row
+    of the window, not just the one above."""
+    shape = cases.hexagon_shape()
+    img, lib = cases.inputs(500, 430, 64, 30, Type.RGB_EUCLIDEAN, lattice=500)
+    compare(oracle, shape, img, lib, Type.RGB_EUCLIDEAN, rep=(3, 2000), wave_resolve=wave_resolve)
+    compare(oracle, shape, img, lib, Type.RGB_EUCLIDEAN, rep=(1, 100000), wave_resolve=wave_resolve)
