@@ -573,16 +573,18 @@ resolve_kernel(ResolveArgs a, int sequential)
             chosen = best.i;
             // pass 2: how many candidates sit within the near-tie band of the minimum?
             const double thr = best.s + fabs(best.s) * a.tie_band;
-            int near = 0;
+            int near = 0, nonzero = 0;
             for (int k = threadIdx.x; k < K; k += kBlock) {
                 const int cand = cand_at(k);
                 if (cand < 0) continue;
                 const int rep = penalise ? repeat_value(a, rec.grid_x, rec.grid_y, cand) : 0;
-                if ((double)rep + cs[k] <= thr) ++near;
+                if ((double)rep + cs[k] <= thr) { ++near; nonzero |= cs[k] != 0.0; }
             }
             const int many_in_one = __syncthreads_or(near > 1);
             const int holders = __syncthreads_count(near > 0);
-            if (many_in_one || holders > 1) {
+            // base score exactly 0 => reference-order total is exactly (double)repeat: no re-sum
+            const int any_nonzero = __syncthreads_or(nonzero);
+            if ((many_in_one || holders > 1) && any_nonzero) {
                 // Re-sum every contender in the reference's order, ascending index,
                 // strict < : exactly the CPU scan restricted to the contenders.
                 double ex_best = kInf;
@@ -600,8 +602,13 @@ resolve_kernel(ResolveArgs a, int sequential)
                     key = block_min(key, sh);
                     if (key.i == 0x7fffffff) break;
                     const int nxt_rep = penalise ? repeat_value(a, rec.grid_x, rec.grid_y, key.i) : 0;
-                    const double ex = exact_total<TYPE>(a, rec, key.i, nxt_rep, buf, &bcast);
-                    if (threadIdx.x == 0) atomicAdd(a.exact_count, 1ull);
+                    // base score of the winner index (whichever thread holds it tells the block)
+                    int zero_here = 0;
+                    for (int k = threadIdx.x; k < K; k += kBlock)
+                        if (cand_at(k) == key.i && cs[k] == 0.0) zero_here = 1;
+                    const bool is_zero = __syncthreads_or(zero_here) != 0;
+                    const double ex = is_zero ? (double)nxt_rep : exact_total<TYPE>(a, rec, key.i, nxt_rep, buf, &bcast);
+                    if (threadIdx.x == 0 && !is_zero) atomicAdd(a.exact_count, 1ull);
                     if (ex < ex_best) { ex_best = ex; ex_idx = key.i; }
                     prev = key.i;
                 }
@@ -712,7 +719,7 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
         const double* row = dense ? a.dense_rows + (size_t)slot * a.L : nullptr;
 
         // candidate of this lane in chunk `base`, with its total
-        auto eval = [&](int base, int& cand, double& total, int& rep_out) {
+        auto eval = [&](int base, int& cand, double& total, int& rep_out, double& base_out) {
             const int k = base + lane;
             double s;
             if (dense) { cand = k < K ? k : -1; s = k < K ? row[k] : kInf; }
@@ -733,17 +740,18 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
                     rep += (__builtin_amdgcn_readlane(nbv, j) == cand) ? a.repeat_addition : 0;
             }
             rep_out = rep;
+            base_out = s;
             total = (double)rep + s;
         };
 
         // pass 1: lowest (total, index)
         ScoreIdx best{kInf, 0x7fffffff};
         int c0 = -1, r0 = 0;
-        double t0v = kInf;
+        double t0v = kInf, s0 = kInf;
         for (int base = 0; base < K; base += kWave) {
-            int cand, rep; double total;
-            eval(base, cand, total, rep);
-            if (base == 0) { c0 = cand; t0v = total; r0 = rep; }
+            int cand, rep; double total, sb;
+            eval(base, cand, total, rep, sb);
+            if (base == 0) { c0 = cand; t0v = total; r0 = rep; s0 = sb; }
             if (cand >= 0 && lex_less(total, cand, best.s, best.i)) { best.s = total; best.i = cand; }
         }
         best = wave_min(best);
@@ -753,30 +761,36 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
         if (best.i != 0x7fffffff) {
             chosen = best.i;
             const double thr = best.s + fabs(best.s) * a.tie_band;
-            int near = 0;
+            // A contender whose base score is exactly 0 (no active pixel, or every pixel
+            // identical) has the reference-order total (double)repeat + 0 exactly: nothing
+            // to re-sum.  Only contenders with a non-zero base need the exact pass.
+            int near = 0, nonzero = 0;
             for (int base = 0; base < K; base += kWave) {
-                int cand, rep; double total;
-                if (base == 0) { cand = c0; total = t0v; } else eval(base, cand, total, rep);
+                int cand, rep; double total, sb;
+                if (base == 0) { cand = c0; total = t0v; sb = s0; } else eval(base, cand, total, rep, sb);
                 near += __popcll(__ballot(cand >= 0 && total <= thr));
+                nonzero += __popcll(__ballot(cand >= 0 && total <= thr && sb != 0.0));
             }
-            if (near > 1) {
+            if (near > 1 && nonzero > 0) {
                 // Re-sum every contender in the reference's order, ascending index, strict <
                 double ex_best = kInf;
                 int ex_idx = -1, prev = -1;
                 for (;;) {
-                    int key_i = 0x7fffffff, key_rep = 0;     // lowest contender index above prev, with its repeat value
+                    int key_i = 0x7fffffff, key_rep = 0, key_zero = 0;   // lowest contender index above prev
                     for (int base = 0; base < K; base += kWave) {
-                        int cand, rep; double total;
-                        if (base == 0) { cand = c0; total = t0v; rep = r0; } else eval(base, cand, total, rep);
-                        if (cand > prev && total <= thr && cand < key_i) { key_i = cand; key_rep = rep; }
+                        int cand, rep; double total, sb;
+                        if (base == 0) { cand = c0; total = t0v; rep = r0; sb = s0; } else eval(base, cand, total, rep, sb);
+                        if (cand > prev && total <= thr && cand < key_i) { key_i = cand; key_rep = rep; key_zero = sb == 0.0; }
                     }
                     const ScoreIdx win = wave_min(ScoreIdx{(double)key_i, key_i});
                     if (win.i == 0x7fffffff) break;
                     // the lane holding `win.i` knows its repeat value
                     const unsigned long long who = __ballot(key_i == win.i);
-                    const int win_rep = __shfl(key_rep, __ffsll((long long)who) - 1, kWave);
-                    const double ex = exact_total<TYPE>(a, rec, win.i, win_rep, buf, &bcast);
-                    if (lane == 0) atomicAdd(a.exact_count, 1ull);
+                    const int src = __ffsll((long long)who) - 1;
+                    const int win_rep = __shfl(key_rep, src, kWave);
+                    const bool win_zero = __shfl(key_zero, src, kWave) != 0;
+                    const double ex = win_zero ? (double)win_rep : exact_total<TYPE>(a, rec, win.i, win_rep, buf, &bcast);
+                    if (lane == 0 && !win_zero) atomicAdd(a.exact_count, 1ull);
                     if (ex < ex_best) { ex_best = ex; ex_idx = win.i; }
                     prev = win.i;
                 }
@@ -922,7 +936,7 @@ resolve_rows_kernel(ResolveArgs a, const int* __restrict__ row_first, const int*
             const int K = dense ? a.L : a.K;
             const double* row = dense ? a.dense_rows + (size_t)slot * a.L : nullptr;
 
-            auto eval = [&](int base, int& cand, double& total, int& rep_out) {
+            auto eval = [&](int base, int& cand, double& total, int& rep_out, double& base_out) {
                 const int k = base + lane;
                 double s;
                 if (dense) { cand = k < K ? k : -1; s = k < K ? row[k] : kInf; }
@@ -943,16 +957,17 @@ resolve_rows_kernel(ResolveArgs a, const int* __restrict__ row_first, const int*
                         rep += (__builtin_amdgcn_readlane(nbv, j) == cand) ? a.repeat_addition : 0;
                 }
                 rep_out = rep;
+                base_out = s;
                 total = (double)rep + s;
             };
 
             ScoreIdx best{kInf, 0x7fffffff};
             int c0 = -1, r0 = 0;
-            double t0v = kInf;
+            double t0v = kInf, s0 = kInf;
             for (int base = 0; base < K; base += kWave) {
-                int cand, rep; double total;
-                eval(base, cand, total, rep);
-                if (base == 0) { c0 = cand; t0v = total; r0 = rep; }
+                int cand, rep; double total, sb;
+                eval(base, cand, total, rep, sb);
+                if (base == 0) { c0 = cand; t0v = total; r0 = rep; s0 = sb; }
                 if (cand >= 0 && lex_less(total, cand, best.s, best.i)) { best.s = total; best.i = cand; }
             }
             best = wave_min(best);
@@ -962,28 +977,34 @@ resolve_rows_kernel(ResolveArgs a, const int* __restrict__ row_first, const int*
             if (best.i != 0x7fffffff) {
                 chosen = best.i;
                 const double thr = best.s + fabs(best.s) * a.tie_band;
-                int near = 0;
+                // A contender whose base score is exactly 0 (no active pixel, or every pixel
+                // identical) has the reference-order total (double)repeat + 0 exactly: nothing
+                // to re-sum.  Only contenders with a non-zero base need the exact pass.
+                int near = 0, nonzero = 0;
                 for (int base = 0; base < K; base += kWave) {
-                    int cand, rep; double total;
-                    if (base == 0) { cand = c0; total = t0v; } else eval(base, cand, total, rep);
+                    int cand, rep; double total, sb;
+                    if (base == 0) { cand = c0; total = t0v; sb = s0; } else eval(base, cand, total, rep, sb);
                     near += __popcll(__ballot(cand >= 0 && total <= thr));
+                    nonzero += __popcll(__ballot(cand >= 0 && total <= thr && sb != 0.0));
                 }
-                if (near > 1) {
+                if (near > 1 && nonzero > 0) {
                     double ex_best = kInf;
                     int ex_idx = -1, prev = -1;
                     for (;;) {
-                        int key_i = 0x7fffffff, key_rep = 0;
+                        int key_i = 0x7fffffff, key_rep = 0, key_zero = 0;
                         for (int base = 0; base < K; base += kWave) {
-                            int cand, rep; double total;
-                            if (base == 0) { cand = c0; total = t0v; rep = r0; } else eval(base, cand, total, rep);
-                            if (cand > prev && total <= thr && cand < key_i) { key_i = cand; key_rep = rep; }
+                            int cand, rep; double total, sb;
+                            if (base == 0) { cand = c0; total = t0v; rep = r0; sb = s0; } else eval(base, cand, total, rep, sb);
+                            if (cand > prev && total <= thr && cand < key_i) { key_i = cand; key_rep = rep; key_zero = sb == 0.0; }
                         }
                         const ScoreIdx win = wave_min(ScoreIdx{(double)key_i, key_i});
                         if (win.i == 0x7fffffff) break;
                         const unsigned long long who = __ballot(key_i == win.i);
-                        const int win_rep = __shfl(key_rep, __ffsll((long long)who) - 1, kWave);
-                        const double ex = exact_total_wave<TYPE>(a, rec, win.i, win_rep, wbuf);
-                        if (lane == 0) atomicAdd(a.exact_count, 1ull);
+                        const int src = __ffsll((long long)who) - 1;
+                        const int win_rep = __shfl(key_rep, src, kWave);
+                        const bool win_zero = __shfl(key_zero, src, kWave) != 0;
+                        const double ex = win_zero ? (double)win_rep : exact_total_wave<TYPE>(a, rec, win.i, win_rep, wbuf);
+                        if (lane == 0 && !win_zero) atomicAdd(a.exact_count, 1ull);
                         if (ex < ex_best) { ex_best = ex; ex_idx = win.i; }
                         prev = win.i;
                     }

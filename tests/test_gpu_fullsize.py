@@ -66,6 +66,9 @@ def test_config_c_ciede2000_2048_hexagon_l1000(oracle, engine):
     valid = state >= 0
     assert (best[valid] < L).all()
     prefix_parity(oracle, shape, img, lib, t, (0, 0), best, score, 12, 1e-4)
+    # clipped border cells whose visible part misses the mask have NO active pixel: every
+    # candidate scores exactly 0 and index 0 wins without any reference-order re-sum
+    assert engine.timing()["exact_rescored"] == 0
     # interior (unclipped) and clipped cells both present in the prefix? check one clipped cell explicitly
     clipped = cells[(cells["row_max"] - cells["row_min"] < 64) | (cells["col_max"] - cells["col_min"] < 64)]
     assert len(clipped) > 100
