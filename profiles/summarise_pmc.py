@@ -14,7 +14,6 @@ import json
 import os
 import sys
 
-DOMINANT = ("filter_kernel", "score_kernel")
 
 
 def per_kernel(path):
@@ -29,11 +28,13 @@ def per_kernel(path):
 def main():
     config, fetch_csv, write_csv = sys.argv[1:4]
     fetch, write = per_kernel(fetch_csv), per_kernel(write_csv)
-    name = next(k for k in fetch if any(d in k for d in DOMINANT))
+    import re
+    name = next((k for k in fetch if re.search(r"\bfilter_kernel<", k)), None) or \
+        next(k for k in fetch if re.search(r"mm::score_kernel<", k))
     fn, fv = fetch[name]
     wn, wv = write[name]
     entry = {
-        "kernel": name.split("(")[0].split("::")[-1].strip(),
+        "kernel": re.search(r"(\w+_kernel)<", name).group(1),
         "launches": fn,
         "FETCH_SIZE_KiB_per_launch": fv / fn,
         "WRITE_SIZE_KiB_per_launch": wv / wn,
