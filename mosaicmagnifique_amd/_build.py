@@ -14,8 +14,11 @@ LIB = os.path.join(HERE, "libmosaic_hip.so")
 #  engine.hip  -ffp-contract=off : the fp64 arbiter kernels must not fuse a*b+c -- the
 #              reference's CPU path is an SSE2 build and summation / rounding order is
 #              part of the parity contract (csrc/colour_diff.hpp);
-#  filter.hip  default contraction: the fp32 filter pass wants fused multiply-adds.
-UNITS = [("engine.hip", ["-ffp-contract=off"]), ("filter.hip", ["-ffp-contract=fast"])]
+#  filter.hip  default contraction: the fp32 filter pass wants fused multiply-adds;
+#              -fno-slp-vectorize: on gfx950 a v_pk_*_f32 costs two issue slots, so SLP
+#              packing buys nothing and adds register-pairing moves (10 % of the kernel).
+UNITS = [("engine.hip", ["-ffp-contract=off"]),
+         ("filter.hip", ["-ffp-contract=fast", "-fno-slp-vectorize"])]
 SOURCES = [os.path.join(CSRC, name) for name, _ in UNITS]
 HEADERS = [os.path.join(CSRC, h) for h in ("kernels.hpp", "colour_diff.hpp", "colour_diff_fast.hpp",
                                            "launch.hpp")] + \

@@ -14,13 +14,12 @@
 //     the mean hue direction (cos, sin)(h1 + dh/2) -- exactly the reference's
 //     mean-hue case analysis (:107-122), which is "h1 plus half the wrapped
 //     difference" in all three branches;
-//   * T's four cosines (:124-127) come from (cos h, sin h) by multiple-angle
-//     recurrences (12 FMAs);
-//   * the only inverse trig left is the angle between the mean hue and 275 deg for
-//     the rotation term (:132-133): tangent-half-angle + an odd polynomial, needed
-//     only to ~1e-5 rad;
+//   * T (:124-127) and the rotation term's sin(2 d_theta) (:132-133,:145) depend on the
+//     mean hue angle alone: one interpolated lookup in a 2048-entry LDS table indexed
+//     by the "diamond angle" of the mean-hue vector (no inverse trig, one v_rcp_f32);
+//   * the per-pixel chroma sqrt(a^2+b^2) is read from precomputed planes;
 //   * sqrt(x/(x+k)) = x * rsq(x*(x+k)); divisions are v_rcp_f32.
-// About 12 quarter-rate ops + ~110 full-rate ops per pixel pair, against ~900 fp64
+// About 13 quarter-rate ops + ~100 full-rate ops per pixel pair, against ~900 fp64
 // instructions for the reference form.
 //
 // The formula is DISCONTINUOUS where the two hues are opposite (|dh| = 180 deg: the
@@ -55,13 +54,24 @@ __device__ __forceinline__ float sqrt_ratio7(float x)
     return z * frsq(fmaxf(z * (z + 1.0f), 1e-36f));
 }
 
+// Hue table: T (ColourDifference.cpp:124-127) and sin(2*d_theta) (:132-133,:145) depend
+// on the mean hue angle ALONE, so both are tabulated over the circle and interpolated
+// linearly.  The index is the "diamond angle" of the mean-hue unit vector (hc, hs):
+//   t = 2 - copysign(1 + hc / (|hc| + |hs|), hs)   in [0, 4),  monotone in the angle,
+// which needs one v_rcp_f32 and no inverse trig.  Entry i holds {T, dT, G, dG} at
+// t_i = 4 i / kHueLutSize with d* the difference to entry i+1 (kHueLutSize + 1 entries;
+// the last repeats the first).  Built in fp64 on the host (engine.hip build_hue_lut).
+// Interpolation error at 2048 entries: < 2e-5 on T, < 2e-5 on G.
+constexpr int kHueLutSize = 2048;
+
 // Returns the fp32 estimate; *needs_exact is set when the pair sits on the
 // opposite-hue discontinuity and the caller must use the fp64 form instead.
-__device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, bool* needs_exact)
+// c1, c2: chroma sqrt(a^2 + b^2) of p and q, precomputed per pixel (stored planes).
+// lut: the hue table in LDS.
+__device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, float c1, float c2,
+                                                const float4* __restrict__ lut, bool* needs_exact)
 {
-    // chroma, G, a', C' (:48-59)
-    const float c1 = fsqrt(fmaf(p.c1, p.c1, p.c2 * p.c2));
-    const float c2 = fsqrt(fmaf(q.c1, q.c1, q.c2 * q.c2));
+    // G, a', C' (:50-59)
     const float one_g = 1.5f - 0.5f * sqrt_ratio7(0.5f * (c1 + c2));     // 1 + G
     const float a1 = one_g * p.c1, a2 = one_g * q.c1;
     const float m1 = fmaf(a1, a1, p.c2 * p.c2), m2 = fmaf(a2, a2, q.c2 * q.c2);
@@ -90,49 +100,19 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, bool
     const float d_c = c2p - c1p;
     const float d_h = 2.0f * fsqrt(c1p * c2p) * sh;         // :102
 
-    // mean hue direction (:104-122) and T (:124-127)
+    // mean hue direction (:104-122) -> table index -> T and sin(2 d_theta)
     const float hc = fmaf(u1x, ch, -(u1y * sh));
     const float hs = fmaf(u1y, ch, u1x * sh);
-    const float hc2 = fmaf(2.0f * hc, hc, -1.0f), hs2 = 2.0f * hs * hc;
-    const float hc3 = fmaf(hc2, hc, -(hs2 * hs)), hs3 = fmaf(hs2, hc, hc2 * hs);
-    const float hc4 = fmaf(2.0f * hc2, hc2, -1.0f), hs4 = 2.0f * hs2 * hc2;
-    // cos(h-30) = .8660254 c + .5 s ; cos(3h+6) = .9945219 c3 - .1045285 s3 ; cos(4h-63) = .4539905 c4 + .8910065 s4
-    const float t = 1.0f - 0.17f * fmaf(0.8660254f, hc, 0.5f * hs) + 0.24f * hc2
-                  + 0.32f * fmaf(0.9945219f, hc3, -0.1045285f * hs3)
-                  - 0.20f * fmaf(0.4539905f, hc4, 0.8910065f * hs4);
-
-    // rotation term (:132-145): d = angle(h_bar) - 275 deg, wrapped; the reference's
-    // h_bar lies in [0, 360) and is NOT wrapped around 275, which only matters for
-    // d in (85, 180] deg where its exponent is below exp(-51): zero there.
-    // cos275 = .08715574, sin275 = -.9961947
-    const float cr = fmaf(hc, 0.08715574f, hs * -0.9961947f);
-    const float sr = fmaf(hs, 0.08715574f, hc * 0.9961947f);
-    float r_t = 0.0f;
-    {
-        // tangent half-angle: d = 2 atan(sr / (1 + cr)); beyond |d| > ~93 deg the
-        // Gaussian is < 1e-6 and is dropped (cr < -0.052)
-        const float th = sr * frcp(fmaxf(1.0f + cr, 0.9f));
-        const float w = th * th;
-        // atan(th), |th| <= 1.06: odd polynomial fitted for max error 5.4e-7 rad in fp32
-        float at = fmaf(w, 0.00543570053f, -0.0292898156f);
-        at = fmaf(at, w, 0.0744650885f);
-        at = fmaf(at, w, -0.129404366f);
-        at = fmaf(at, w, 0.197280779f);
-        at = fmaf(at, w, -0.333082348f);
-        at = fmaf(at, w, 0.999993205f) * th;
-        const float d = at + at;                             // radians
-        const float zz = d * (1.0f / 0.43633231f);          // d / 25 deg
-        // exp(-z^2) = exp2(-z^2 * log2 e)
-        float g = fexp2(zz * zz * -1.44269504f);
-        g = (cr < -0.052f || d > 1.4835299f) ? 0.0f : g;
-        const float x = 1.04719755f * g;                    // 2 * d_theta, in [0, 60 deg]
-        const float x2 = x * x;
-        const float s2 = x * fmaf(x2, fmaf(x2, fmaf(x2, -1.984127e-4f, 8.3333333e-3f), -0.16666667f), 1.0f);
-        const float cpb = 0.5f * (c1p + c2p);
-        r_t = -s2 * 2.0f * sqrt_ratio7(cpb);
-    }
+    const float qd = hc * frcp(fmaxf(fabsf(hc) + fabsf(hs), 1e-20f));
+    const float x = (2.0f - copysignf(1.0f + qd, hs)) * (float)(kHueLutSize / 4);
+    const int idx = min(max((int)x, 0), kHueLutSize - 1);      // x >= 0: truncation = floor
+    const float fr = x - (float)idx;                            // x == N (angle 2 pi) -> entry N-1, fr = 1
+    const float4 en = lut[idx];
+    const float t = fmaf(fr, en.y, en.x);
+    const float s2 = fmaf(fr, en.w, en.z);
 
     const float cpb = 0.5f * (c1p + c2p);
+    const float r_t = -s2 * 2.0f * sqrt_ratio7(cpb);        // :136,:145
     const float lb = 0.5f * (p.c0 + q.c0) - 50.0f;
     const float l2 = lb * lb;
     const float s_l = fmaf(0.015f * l2, frsq(20.0f + l2), 1.0f);
@@ -140,8 +120,10 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, bool
     const float s_h = fmaf(0.015f * cpb, t, 1.0f);
 
     const float t_l = d_l * frcp(s_l), t_c = d_c * frcp(s_c), t_h = d_h * frcp(s_h);
-    const float x = fmaf(t_l, t_l, fmaf(t_c, t_c, fmaf(t_h, t_h, r_t * t_c * t_h)));
-    return fsqrt(fmaxf(x, 0.0f));
+    const float xx = fmaf(t_l, t_l, fmaf(t_c, t_c, fmaf(t_h, t_h, r_t * t_c * t_h)));
+    return fsqrt(fmaxf(xx, 0.0f));
 }
+
+__device__ __forceinline__ float chroma_of(float a, float b) { return fsqrt(fmaf(a, a, b * b)); }
 
 }  // namespace mm

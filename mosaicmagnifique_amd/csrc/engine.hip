@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "colour_diff_fast.hpp"
 #include "launch.hpp"
 
 namespace {
@@ -51,6 +52,7 @@ struct mm_engine {
     // two-tier scoring workspaces
     DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s;
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
+    DevBuf lib_chroma, cell_chroma, hue_lut;
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
     int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
@@ -164,16 +166,63 @@ mm_status by_type(int diff_type, F&& f)
     return f(std::integral_constant<int, mm::RGB_EUCLIDEAN>{});   // CIE76 == Euclid on Lab
 }
 
-// Error bounds of the fp32 filter forms (colour_diff_fast.hpp), per pixel pair and
-// for the fp32 accumulation of one lane's share of a cell.  Measured on 2e8 random
-// and adversarial pairs (tests/tools_filter_accuracy.py, tests/test_gpu_filter.py):
-// CIEDE2000 max |fp32 - fp64| = 2.5e-4; the bound used is 4x that.  Euclid: three
-// roundings of a value <= 442.
+// The hue table of colour_diff_fast.hpp, in fp64 from the reference formulas: entry i is the
+// mean hue whose diamond angle is t_i = 4 i / N; {T, dT, G, dG} with G = sin(2 d_theta),
+// d_theta = rad(30) exp(-((h - rad(275)) / rad(25))^2) and h in [0, 2 pi) NOT wrapped around
+// 275 degrees (ColourDifference.cpp:124-133,145).
+std::vector<float> build_hue_lut()
+{
+    constexpr int N = mm::kHueLutSize;
+    constexpr double pi = 3.14159265358979323846;
+    auto rad = [&](double d) { return d * pi / 180.0; };
+    std::vector<double> T(N + 1), G(N + 1);
+    for (int i = 0; i <= N; ++i) {
+        const double t = 4.0 * (i % N) / N;
+        // invert t = 2 - copysign(1 + q, hs), q = hc / (|hc| + |hs|)
+        const bool upper = t <= 2.0;
+        const double q = upper ? 1.0 - t : t - 3.0;
+        const double hc = q, hs = (upper ? 1.0 : -1.0) * (1.0 - std::fabs(q));
+        double h = std::atan2(hs, hc);
+        if (h < 0.0) h += 2.0 * pi;
+        T[i] = 1.0 - 0.17 * std::cos(h - rad(30.0)) + 0.24 * std::cos(2.0 * h) +
+               0.32 * std::cos(3.0 * h + rad(6.0)) - 0.20 * std::cos(4.0 * h - rad(63.0));
+        const double z = (h - rad(275.0)) / rad(25.0);
+        G[i] = std::sin(2.0 * rad(30.0) * std::exp(-z * z));
+    }
+    std::vector<float> lut((size_t)(N + 1) * 4);
+    for (int i = 0; i <= N; ++i) {
+        const int j = std::min(i + 1, N);
+        lut[(size_t)4 * i + 0] = (float)T[i];
+        lut[(size_t)4 * i + 1] = (float)(T[j] - T[i]);
+        lut[(size_t)4 * i + 2] = (float)G[i];
+        lut[(size_t)4 * i + 3] = (float)(G[j] - G[i]);
+    }
+    return lut;
+}
+
+mm_status ensure_hue_lut(mm_engine* e)
+{
+    if (e->hue_lut.p) return MM_OK;
+    const std::vector<float> lut = build_hue_lut();
+    mm_status st = ensure(e, e->hue_lut, lut.size() * sizeof(float), "Failed to allocate hue table");
+    if (st) return st;
+    HIP_TRY(e, hipMemcpy(e->hue_lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice),
+            "Failed to copy hue table to device");
+    return MM_OK;
+}
+
+// Error bounds of the fp32 filter forms (colour_diff_fast.hpp) against the fp64 forms,
+// per pixel pair:  |fp32 - fp64| <= px_abs + px_rel * value, plus the fp32 accumulation of
+// one lane's share of a cell (relative, grows with the pixels per lane).
+// Measured on 2e8 random and adversarial pairs (tests/tools_filter_accuracy.py,
+// tests/test_gpu_filter.py): CIEDE2000 max |err| = 2.5e-4 + 1.8e-5 * value (the relative part
+// is the linear interpolation of the hue table); the bound trusted here is 4x the absolute
+// and 3x the relative part.  Euclid: three roundings of a value <= 442.
 mm::FilterBand filter_band(int diff_type, int ppad)
 {
     mm::FilterBand b;
     b.px_abs = diff_type == MM_CIEDE2000 ? 1e-3f : 5e-4f;
-    b.rel = 2e-5f + 1.2e-7f * (float)(ppad / 64);
+    b.rel = (diff_type == MM_CIEDE2000 ? 6e-5f : 0.0f) + 2e-5f + 1.2e-7f * (float)(ppad / 64);
     return b;
 }
 
@@ -219,7 +268,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     // Batch so that scores + gathered cells stay within a fixed budget.
     size_t free_b = 0, total_b = 0;
     HIP_TRY(e, hipMemGetInfo(&free_b, &total_b), "Failed to query device memory");
-    const size_t per_cell = (size_t)L * sizeof(double) + (size_t)ppad * 13 + (size_t)Kc * 16 + 1;
+    const size_t per_cell = (size_t)L * sizeof(double) + (size_t)ppad * 17 + (size_t)Kc * 16 + 1;
     size_t budget = std::min<size_t>(free_b / 2 + e->scores.bytes + e->cells.bytes + e->cmask.bytes,
                                      (size_t)6 << 30);
     if (budget < per_cell) {
@@ -247,9 +296,18 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     }
     const mm::FilterBand band = filter_band(diff_type, ppad);
     const int ftype = diff_type == MM_CIEDE2000 ? mm::CIEDE2000 : mm::RGB_EUCLIDEAN;
+    if (two_tier) {
+        if ((st = ensure_hue_lut(e)) ||
+            (st = ensure(e, e->cell_chroma, (size_t)batch * ppad * sizeof(float), "Failed to allocate cell chroma planes")))
+            return st;
+    }
+    mm::FilterInputs fin{};
+    fin.cells = (const float*)e->cells.p; fin.cmask = (const uint8_t*)e->cmask.p;
+    fin.cell_chroma = (const float*)e->cell_chroma.p; fin.lib = (const float*)e->lib.p;
+    fin.lib_chroma = (const float*)e->lib_chroma.p; fin.hue_lut = (const float4*)e->hue_lut.p;
     // Early exit needs seeds: K <= M <= 256 of them, and the L proxy distances in LDS.
     const int M = std::min(L, std::min(256, round_up(K + 22, 4)));
-    const bool prune = two_tier && e->use_prune != 0 && K <= M && (size_t)L * sizeof(float) <= 150 * 1024;
+    const bool prune = two_tier && e->use_prune != 0 && K <= M && (size_t)L * sizeof(float) <= 100 * 1024;
     if (prune) {
         if ((st = ensure(e, e->seeds, (size_t)batch * M * sizeof(int32_t), "Failed to allocate seeds")) ||
             (st = ensure(e, e->seed_score, (size_t)batch * M * sizeof(float), "Failed to allocate seeds")) ||
@@ -282,19 +340,20 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             recs_dev + done, (const float*)e->target.p, e->cols, (const uint8_t*)e->masks.p,
             (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad);
         HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
+        if (diff_type == MM_CIEDE2000)
+            HIP_TRY(e, mm::launch_chroma_planes((const float*)e->cells.p, (float*)e->cell_chroma.p, (size_t)b, ppad, e->stream),
+                    "Error during cell chroma kernel");
         HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
 
         // tier 1: fp32 filter score of every (cell, candidate), with early exit against a
         // per-cell limit obtained from a few proxy-chosen seeds
         if (prune)
-            HIP_TRY(e, mm::launch_prune_limits(ftype, (const float*)e->cells.p, (const uint8_t*)e->cmask.p,
-                                               (const float*)e->lib.p, (const float*)e->lib_means.p, b, L, ppad,
+            HIP_TRY(e, mm::launch_prune_limits(ftype, fin, (const float*)e->lib_means.p, b, L, ppad,
                                                M, K, band.px_abs, band.rel, (int32_t*)e->seeds.p,
                                                (float*)e->seed_score.p, (float*)e->limits.p, e->stream),
                     "Error during seed / pruning limit kernels");
         HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
-        HIP_TRY(e, mm::launch_filter(ftype, (const float*)e->cells.p, (const uint8_t*)e->cmask.p,
-                                     (const float*)e->lib.p, (float*)e->scores.p, b, L, ppad,
+        HIP_TRY(e, mm::launch_filter(ftype, fin, (float*)e->scores.p, b, L, ppad,
                                      (mm::EdgeEntry*)e->edges.p, (unsigned int*)e->edge_count.p, edge_cap,
                                      prune ? (const float*)e->limits.p : nullptr, e->stream),
                 "Error during filter colour difference kernel");
@@ -563,7 +622,8 @@ void mm_destroy(mm_engine* e)
                        &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter, &e->scratch,
                        &e->cont_i, &e->cont_f, &e->cont_s, &e->flags, &e->edges, &e->edge_count,
                        &e->dense_recs, &e->dense_i, &e->dense_s, &e->lib_means, &e->seeds,
-                       &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index })
+                       &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
+                       &e->hue_lut })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -612,6 +672,10 @@ mm_status mm_set_library(mm_engine* e, const float* images, int n_images, int si
         return st;
     HIP_TRY(e, mm::launch_image_means((const float*)e->lib.p, (float*)e->lib_means.p, n_images, P, ppad, e->stream),
             "Error during library mean kernel");
+    if ((st = ensure(e, e->lib_chroma, (size_t)n_images * ppad * sizeof(float), "Failed to allocate library chroma planes")))
+        return st;
+    HIP_TRY(e, mm::launch_chroma_planes((const float*)e->lib.p, (float*)e->lib_chroma.p, (size_t)n_images, ppad, e->stream),
+            "Error during library chroma kernel");
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
     e->n_lib = n_images;
     e->lib_size = size;
@@ -859,11 +923,13 @@ mm_status mm_filter_diff_batch(mm_engine* e, int diff_type, const float* first, 
         release(a); release(b); release(o);
         return st;
     }
+    if ((st = ensure_hue_lut(e))) { release(a); release(b); release(o); return st; }
     hipError_t code = hipMemcpyAsync(a.p, first, n * 3 * sizeof(float), hipMemcpyHostToDevice, e->stream);
     if (code == hipSuccess) code = hipMemcpyAsync(b.p, second, n * 3 * sizeof(float), hipMemcpyHostToDevice, e->stream);
     if (code == hipSuccess)
         code = mm::launch_pair_fast(diff_type == MM_CIEDE2000 ? mm::CIEDE2000 : mm::RGB_EUCLIDEAN,
-                                    (const float*)a.p, (const float*)b.p, n, (float*)o.p, 1, e->stream);
+                                    (const float*)a.p, (const float*)b.p, n, (float*)o.p, 1,
+                                    (const float4*)e->hue_lut.p, e->stream);
     if (code == hipSuccess) code = hipMemcpyAsync(out, o.p, n * sizeof(float), hipMemcpyDeviceToHost, e->stream);
     if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
     release(a); release(b); release(o);

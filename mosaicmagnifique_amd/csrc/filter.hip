@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "colour_diff.hpp"
 #include "colour_diff_fast.hpp"
 #include "launch.hpp"
@@ -26,16 +28,25 @@ __device__ __forceinline__ float wave_sum_f(float v)
 
 // One pair through the fp32 form.  For CIEDE2000 `edge` reports a pair on the
 // opposite-hue discontinuity (colour_diff_fast.hpp): the filter kernel logs it and
-// edge_fix_kernel later replaces its fp32 term by the fp64 one.
+// edge_fix_kernel later replaces its fp32 term by the fp64 one.  cp, cq = chroma of
+// p and q (read from the precomputed planes), lut = the hue table in LDS.
 template <int TYPE>
-__device__ __forceinline__ float pair_fast(const PxF& p, const PxF& q, bool* edge)
+__device__ __forceinline__ float pair_fast(const PxF& p, const PxF& q, float cp, float cq,
+                                           const float4* lut, bool* edge)
 {
     if constexpr (TYPE == CIEDE2000) {
-        return ciede2000_fast(p, q, edge);
+        return ciede2000_fast(p, q, cp, cq, lut, edge);
     } else {
         *edge = false;
         return euclidean_fast(p, q);
     }
+}
+
+// The hue table, global -> LDS, by the whole workgroup.
+__device__ __forceinline__ void load_hue_lut(float4* lds, const float4* __restrict__ global)
+{
+    for (int i = threadIdx.x; i <= kHueLutSize; i += blockDim.x) lds[i] = global[i];
+    __syncthreads();
 }
 
 // Same work decomposition as score_kernel (kernels.hpp): one wave per
@@ -44,11 +55,15 @@ __device__ __forceinline__ float pair_fast(const PxF& p, const PxF& q, bool* edg
 template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
 filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
-              const float* __restrict__ lib, float* __restrict__ scores,
+              const float* __restrict__ cell_chroma, const float* __restrict__ lib,
+              const float* __restrict__ lib_chroma, float* __restrict__ scores,
               int n_cells, int L, int ppad, int cand_per_block, int cell_group,
               EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
-              unsigned int edge_cap, const float* __restrict__ prune_above, int check_every)
+              unsigned int edge_cap, const float* __restrict__ prune_above, int check_every,
+              const float4* __restrict__ hue_lut)
 {
+    __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
+    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long bid = blockIdx.x;
     const long long per_group = (long long)cell_group * n_tiles;
@@ -65,6 +80,7 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
     const float4* c1 = c0 + ppad / 4;
     const float4* c2 = c1 + ppad / 4;
     const uint32_t* mk = reinterpret_cast<const uint32_t*>(cmask + (size_t)cell * ppad);
+    const float4* cc = reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
 
     // Early exit, the device form of the reference's `variant < bestVariant` loop guards
     // (CPUPhotomosaicGenerator.cpp:149,153): every term is >= 0, so once the running
@@ -78,6 +94,7 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
         const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
         const float4* b1 = b0 + ppad / 4;
         const float4* b2 = b1 + ppad / 4;
+        const float4* bc = reinterpret_cast<const float4*>(lib_chroma + (size_t)l * ppad);
         float acc = 0.0f;
         bool pruned = false;
         for (int j = 0; j < groups; ++j) {
@@ -87,11 +104,13 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
             if (m == 0) continue;
             const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
             const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
+            float4 pc{0.f, 0.f, 0.f, 0.f}, qc{0.f, 0.f, 0.f, 0.f};
+            if constexpr (TYPE == CIEDE2000) { pc = cc[q]; qc = bc[q]; }
             bool e0, e1, e2, e3;
-            const float v0 = pair_fast<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, &e0);
-            const float v1 = pair_fast<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, &e1);
-            const float v2 = pair_fast<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, &e2);
-            const float v3 = pair_fast<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, &e3);
+            const float v0 = pair_fast<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
+            const float v1 = pair_fast<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
+            const float v2 = pair_fast<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
+            const float v3 = pair_fast<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
             acc += ((m & 0x000000ffu) ? v0 : 0.0f) + ((m & 0x0000ff00u) ? v1 : 0.0f)
                  + ((m & 0x00ff0000u) ? v2 : 0.0f) + ((m & 0xff000000u) ? v3 : 0.0f);
             if constexpr (TYPE == CIEDE2000) {
@@ -114,10 +133,10 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
 // One pair for the seed scores: fp32 form, with the fp64 form taken inline on the
 // hue discontinuity (the seeds are few, the divergence is irrelevant there).
 template <int TYPE>
-__device__ __forceinline__ float pair_seed(const PxF& p, const PxF& q)
+__device__ __forceinline__ float pair_seed(const PxF& p, const PxF& q, float cp, float cq, const float4* lut)
 {
     bool edge;
-    float v = pair_fast<TYPE>(p, q, &edge);
+    float v = pair_fast<TYPE>(p, q, cp, cq, lut, &edge);
     if constexpr (TYPE == CIEDE2000)
         if (edge) v = (float)ciede2000(Px{p.c0, p.c1, p.c2}, Px{q.c0, q.c1, q.c2});
     return v;
@@ -129,9 +148,13 @@ __device__ __forceinline__ float pair_seed(const PxF& p, const PxF& q)
 template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
 seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
-                  const float* __restrict__ lib, const int32_t* __restrict__ seeds,
-                  float* __restrict__ seed_score, int n_cells, int M, int ppad)
+                  const float* __restrict__ cell_chroma, const float* __restrict__ lib,
+                  const float* __restrict__ lib_chroma, const int32_t* __restrict__ seeds,
+                  float* __restrict__ seed_score, int n_cells, int M, int ppad,
+                  const float4* __restrict__ hue_lut)
 {
+    __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
+    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long w = (long long)blockIdx.x * (kBlock / kWave) + wave;
     const int cell = (int)(w / M);
@@ -146,6 +169,8 @@ seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
     const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
     const float4* b1 = b0 + ppad / 4;
     const float4* b2 = b1 + ppad / 4;
+    const float4* cc = reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
+    const float4* bc = reinterpret_cast<const float4*>(lib_chroma + (size_t)l * ppad);
     float acc = 0.0f;
     for (int j = 0; j < groups; ++j) {
         const int q = lane + kWave * j;
@@ -153,15 +178,32 @@ seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
         if (m == 0) continue;
         const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
         const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
-        const float v0 = pair_seed<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x});
-        const float v1 = pair_seed<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y});
-        const float v2 = pair_seed<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z});
-        const float v3 = pair_seed<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w});
+        float4 pc{0.f, 0.f, 0.f, 0.f}, qc{0.f, 0.f, 0.f, 0.f};
+        if constexpr (TYPE == CIEDE2000) { pc = cc[q]; qc = bc[q]; }
+        const float v0 = pair_seed<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut);
+        const float v1 = pair_seed<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut);
+        const float v2 = pair_seed<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut);
+        const float v3 = pair_seed<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut);
         acc += ((m & 0x000000ffu) ? v0 : 0.0f) + ((m & 0x0000ff00u) ? v1 : 0.0f)
              + ((m & 0x00ff0000u) ? v2 : 0.0f) + ((m & 0xff000000u) ? v3 : 0.0f);
     }
     acc = wave_sum_f(acc);
     if (lane == 0) seed_score[w] = acc;
+}
+
+// Chroma sqrt(a^2 + b^2) of every pixel of n planar images: [n][3][ppad] -> [n][ppad].
+__global__ void __launch_bounds__(kBlock)
+chroma_planes_kernel(const float* __restrict__ planar, float* __restrict__ chroma, size_t n_images, int ppad)
+{
+    const size_t total = n_images * (size_t)(ppad / 4);
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const size_t img = t / (size_t)(ppad / 4);
+        const size_t q = t - img * (size_t)(ppad / 4);
+        const float4* base = reinterpret_cast<const float4*>(planar + img * 3 * (size_t)ppad);
+        const float4 a = base[ppad / 4 + q], b = base[2 * (size_t)(ppad / 4) + q];
+        reinterpret_cast<float4*>(chroma + img * (size_t)ppad)[q] =
+            float4{chroma_of(a.x, b.x), chroma_of(a.y, b.y), chroma_of(a.z, b.z), chroma_of(a.w, b.w)};
+    }
 }
 
 // Mean colour of every library image (over all pixels), f32 [L][3]: a proxy used only
@@ -191,9 +233,11 @@ template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
 seed_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
             const float* __restrict__ lib_means, int L, int ppad, int M,
-            int32_t* __restrict__ seeds)
+            int32_t* __restrict__ seeds, const float4* __restrict__ hue_lut)
 {
     extern __shared__ float proxy[];                 // [L]
+    __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
+    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     __shared__ float red[4][kBlock / kWave];
     __shared__ float best_v[kBlock / kWave];
     __shared__ int best_i[kBlock / kWave];
@@ -210,9 +254,11 @@ seed_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
     for (int k = 0; k < 4; ++k) { t[k] = 0.f; for (int w = 0; w < kBlock / kWave; ++w) t[k] += red[k][w]; }
     const float inv = 1.0f / fmaxf(t[3], 1.0f);
     const PxF mean{t[0] * inv, t[1] * inv, t[2] * inv};
+    const float mean_c = chroma_of(mean.c1, mean.c2);
     for (int l = threadIdx.x; l < L; l += kBlock) {
         bool e;
-        proxy[l] = pair_fast<TYPE>(mean, PxF{lib_means[3 * l], lib_means[3 * l + 1], lib_means[3 * l + 2]}, &e);
+        const PxF lm{lib_means[3 * l], lib_means[3 * l + 1], lib_means[3 * l + 2]};
+        proxy[l] = pair_fast<TYPE>(mean, lm, mean_c, chroma_of(lm.c1, lm.c2), lut, &e);
     }
     __syncthreads();
     for (int r = 0; r < M; ++r) {
@@ -283,11 +329,14 @@ prune_limit_kernel(const float* __restrict__ seed_score, const uint8_t* __restri
 // Replaces the fp32 term of every logged discontinuity pair by the fp64
 // reference-form value: scores[cell][cand] += (float)(exact - fast).
 __global__ void __launch_bounds__(kBlock)
-edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ lib,
+edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ cell_chroma,
+                const float* __restrict__ lib, const float* __restrict__ lib_chroma,
                 float* __restrict__ scores, int L, int ppad,
                 const EdgeEntry* __restrict__ edges, const unsigned int* __restrict__ edge_count,
-                unsigned int edge_cap)
+                unsigned int edge_cap, const float4* __restrict__ hue_lut)
 {
+    __shared__ float4 lut[kHueLutSize + 1];
+    load_hue_lut(lut, hue_lut);
     const unsigned int n = min(*edge_count, edge_cap);
     for (unsigned int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const EdgeEntry en = edges[i];
@@ -295,7 +344,8 @@ edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ lib,
         const float* b = lib + (size_t)en.cand * 3 * ppad + en.pixel;
         const PxF p{c[0], c[ppad], c[2 * (size_t)ppad]}, q{b[0], b[ppad], b[2 * (size_t)ppad]};
         bool edge;
-        const float fast = ciede2000_fast(p, q, &edge);
+        const float fast = ciede2000_fast(p, q, cell_chroma[(size_t)en.cell * ppad + en.pixel],
+                                          lib_chroma[(size_t)en.cand * ppad + en.pixel], lut, &edge);
         const double exact = ciede2000(Px{p.c0, p.c1, p.c2}, Px{q.c0, q.c1, q.c2});
         atomicAdd(&scores[(size_t)en.cell * L + en.cand], (float)(exact - (double)fast));
     }
@@ -304,14 +354,17 @@ edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ lib,
 template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
 pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ second,
-                 size_t n, float* __restrict__ out, int flag_edges)
+                 size_t n, float* __restrict__ out, int flag_edges, const float4* __restrict__ hue_lut)
 {
+    __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
+    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
          i += (size_t)gridDim.x * kBlock) {
         const float* p = first + 3 * i;
         const float* q = second + 3 * i;
         bool edge;
-        float v = pair_fast<TYPE>(PxF{p[0], p[1], p[2]}, PxF{q[0], q[1], q[2]}, &edge);
+        float v = pair_fast<TYPE>(PxF{p[0], p[1], p[2]}, PxF{q[0], q[1], q[2]}, chroma_of(p[1], p[2]),
+                                  chroma_of(q[1], q[2]), lut, &edge);
         if (edge && flag_edges) v = -1.0f;      // diagnostics: show where the fp64 form takes over
         out[i] = v;
     }
@@ -319,8 +372,7 @@ pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ seco
 
 }  // namespace
 
-hipError_t launch_filter(int type, const float* cells, const uint8_t* cmask, const float* lib,
-                         float* scores, int n_cells, int L, int ppad,
+hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream)
 {
@@ -329,20 +381,30 @@ hipError_t launch_filter(int type, const float* cells, const uint8_t* cmask, con
     const long long blocks = (long long)n_cells * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const int groups = ppad / 256;
-    const int check_every = groups >= 16 ? groups / 8 : (groups >= 4 ? 2 : 1);
+    const int check_every = groups > 16 ? groups / 16 : 1;
     hipError_t code = hipMemsetAsync(edge_count, 0, sizeof(unsigned int), stream);
     if (code != hipSuccess) return code;
     if (type == CIEDE2000) {
         filter_kernel<CIEDE2000><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
-            cells, cmask, lib, scores, n_cells, L, ppad, cand_per_block, cell_group, edges, edge_count, edge_cap,
-            prune_above, check_every);
+            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
+            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut);
         if ((code = hipGetLastError()) != hipSuccess) return code;
-        edge_fix_kernel<<<1024, kBlock, 0, stream>>>(cells, lib, scores, L, ppad, edges, edge_count, edge_cap);
+        edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
+                                                     edges, edge_count, edge_cap, in.hue_lut);
     } else {
         filter_kernel<RGB_EUCLIDEAN><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
-            cells, cmask, lib, scores, n_cells, L, ppad, cand_per_block, cell_group, edges, edge_count, edge_cap,
-            prune_above, check_every);
+            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
+            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_chroma_planes(const float* planar, float* chroma, size_t n_images, int ppad, hipStream_t stream)
+{
+    const size_t total = n_images * (size_t)(ppad / 4);
+    const unsigned blocks = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 65536);
+    if (blocks == 0) return hipSuccess;
+    chroma_planes_kernel<<<blocks, kBlock, 0, stream>>>(planar, chroma, n_images, ppad);
     return hipGetLastError();
 }
 
@@ -352,37 +414,36 @@ hipError_t launch_image_means(const float* planar, float* means, int n_images, i
     return hipGetLastError();
 }
 
-hipError_t launch_prune_limits(int type, const float* cells, const uint8_t* cmask, const float* lib,
-                               const float* lib_means, int n_cells, int L, int ppad, int M, int K,
-                               float px_abs, float rel, int32_t* seeds, float* seed_score, float* limit,
-                               hipStream_t stream)
+hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* lib_means, int n_cells, int L,
+                               int ppad, int M, int K, float px_abs, float rel, int32_t* seeds,
+                               float* seed_score, float* limit, hipStream_t stream)
 {
-    if (M > 256 || M < K || (size_t)L * sizeof(float) > 150 * 1024) return hipErrorInvalidValue;
+    if (M > 256 || M < K || (size_t)L * sizeof(float) > 100 * 1024) return hipErrorInvalidValue;
     const size_t lds = (size_t)L * sizeof(float);
     const long long waves = (long long)n_cells * M;
     if (type == CIEDE2000) {
-        seed_kernel<CIEDE2000><<<n_cells, kBlock, lds, stream>>>(cells, cmask, lib_means, L, ppad, M, seeds);
+        seed_kernel<CIEDE2000><<<n_cells, kBlock, lds, stream>>>(in.cells, in.cmask, lib_means, L, ppad, M, seeds, in.hue_lut);
         seed_score_kernel<CIEDE2000><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(
-            cells, cmask, lib, seeds, seed_score, n_cells, M, ppad);
+            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut);
     } else {
-        seed_kernel<RGB_EUCLIDEAN><<<n_cells, kBlock, lds, stream>>>(cells, cmask, lib_means, L, ppad, M, seeds);
+        seed_kernel<RGB_EUCLIDEAN><<<n_cells, kBlock, lds, stream>>>(in.cells, in.cmask, lib_means, L, ppad, M, seeds, in.hue_lut);
         seed_score_kernel<RGB_EUCLIDEAN><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(
-            cells, cmask, lib, seeds, seed_score, n_cells, M, ppad);
+            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut);
     }
     hipError_t code = hipGetLastError();
     if (code != hipSuccess) return code;
-    prune_limit_kernel<<<n_cells, kWave, 0, stream>>>(seed_score, cmask, M, K, ppad, px_abs, rel, limit);
+    prune_limit_kernel<<<n_cells, kWave, 0, stream>>>(seed_score, in.cmask, M, K, ppad, px_abs, rel, limit);
     return hipGetLastError();
 }
 
 hipError_t launch_pair_fast(int type, const float* first, const float* second, size_t n,
-                            float* out, int flag_edges, hipStream_t stream)
+                            float* out, int flag_edges, const float4* hue_lut, hipStream_t stream)
 {
     const int blocks = (int)((n + kBlock - 1) / kBlock < 8192 ? (n + kBlock - 1) / kBlock : 8192);
     if (type == CIEDE2000)
-        pair_fast_kernel<CIEDE2000><<<blocks, kBlock, 0, stream>>>(first, second, n, out, flag_edges);
+        pair_fast_kernel<CIEDE2000><<<blocks, kBlock, 0, stream>>>(first, second, n, out, flag_edges, hue_lut);
     else
-        pair_fast_kernel<RGB_EUCLIDEAN><<<blocks, kBlock, 0, stream>>>(first, second, n, out, flag_edges);
+        pair_fast_kernel<RGB_EUCLIDEAN><<<blocks, kBlock, 0, stream>>>(first, second, n, out, flag_edges, hue_lut);
     return hipGetLastError();
 }
 

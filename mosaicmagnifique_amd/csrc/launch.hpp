@@ -11,15 +11,27 @@ namespace mm {
 // A pixel pair the fp32 CIEDE2000 form must not judge (opposite-hue discontinuity).
 struct EdgeEntry { int cell, cand, pixel; };
 
+// Device inputs of the fp32 filter kernels.
+struct FilterInputs {
+    const float* cells;         // f32 planar [B][3][ppad]
+    const uint8_t* cmask;       // u8 [B][ppad]
+    const float* cell_chroma;   // f32 [B][ppad]  sqrt(a^2+b^2) per cell pixel (CIEDE2000 only)
+    const float* lib;           // f32 planar [L][3][ppad]
+    const float* lib_chroma;    // f32 [L][ppad]
+    const float4* hue_lut;      // [kHueLutSize + 1] {T, dT, sin(2 d_theta), d}  (colour_diff_fast.hpp)
+};
+
 // Tier-1 filter scores f32 [n_cells][L] (see filter.hip).  Pairs on the discontinuity
 // are logged to `edges` (capacity edge_cap, count in *edge_count, which may exceed
 // the capacity: the caller must then not trust the scores) and patched with the
 // fp64 form by a follow-up kernel on the same stream.  prune_above (may be null):
 // per-cell limit above which a candidate is abandoned and scored +inf.
-hipError_t launch_filter(int type, const float* cells, const uint8_t* cmask, const float* lib,
-                         float* scores, int n_cells, int L, int ppad,
+hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream);
+
+// Chroma planes of n planar images: [n][3][ppad] -> [n][ppad].
+hipError_t launch_chroma_planes(const float* planar, float* chroma, size_t n_images, int ppad, hipStream_t stream);
 
 // Mean colour per library image, f32 [n][3] (a proxy for choosing seeds; never a score).
 hipError_t launch_image_means(const float* planar, float* means, int n_images, int P, int ppad,
@@ -29,15 +41,14 @@ hipError_t launch_image_means(const float* planar, float* means, int n_images, i
 // proximity are scored in full; the K-th lowest of them bounds the cell's K-th lowest
 // score from above, so a candidate whose running sum passes limit[cell] cannot be a
 // contender.  seeds [n][M] i32, seed_score [n][M] f32, limit [n] f32 are workspaces /
-// outputs.  Requires K <= M <= 256 and L floats to fit LDS (L <= 38400).
-hipError_t launch_prune_limits(int type, const float* cells, const uint8_t* cmask, const float* lib,
-                               const float* lib_means, int n_cells, int L, int ppad, int M, int K,
-                               float px_abs, float rel, int32_t* seeds, float* seed_score, float* limit,
-                               hipStream_t stream);
+// outputs.  Requires K <= M <= 256 and L floats to fit LDS beside the hue table (L <= 25600).
+hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* lib_means, int n_cells, int L,
+                               int ppad, int M, int K, float px_abs, float rel, int32_t* seeds,
+                               float* seed_score, float* limit, hipStream_t stream);
 
 // fp32 filter form of the per-pair difference (accuracy harness).  flag_edges != 0
 // writes -1 for pairs the filter hands to the fp64 form.
 hipError_t launch_pair_fast(int type, const float* first, const float* second, size_t n,
-                            float* out, int flag_edges, hipStream_t stream);
+                            float* out, int flag_edges, const float4* hue_lut, hipStream_t stream);
 
 }  // namespace mm

@@ -1,6 +1,6 @@
 """Tier 1 of the two-tier scoring: the fp32 filter form never decides a result, but its
 error against the fp64 form must stay inside the band the engine trusts it with
-(engine.hip filter_band: 1e-3 per CIEDE2000 pixel pair, 5e-4 per Euclid pair), and
+(engine.hip filter_band: 1e-3 + 6e-5 * value per CIEDE2000 pixel pair, 5e-4 per Euclid pair), and
 every escape hatch (discontinuity log, contender overflow, canary) must hand the
 cell to the fp64-only path with the result unchanged."""
 import numpy as np
@@ -43,7 +43,10 @@ def test_ciede2000_filter_error_is_inside_the_band(engine):
         fast = engine.filter_diff_batch(2, a, b).astype(np.float64)
         handed_over = fast < 0                     # pairs the filter gives to the fp64 form
         err = np.abs(fast - exact)[~handed_over]
-        assert err.max() <= 5e-4, (name, err.max())        # band trusts 1e-3
+        # the engine trusts 1e-3 + 6e-5 * value per pixel pair (engine.hip filter_band);
+        # hold the measured error to half of that
+        slack = err - (5e-4 + 3e-5 * exact[~handed_over])
+        assert slack.max() <= 0, (name, err.max())
         if name.startswith("opposite"):
             assert handed_over.any()
         else:
