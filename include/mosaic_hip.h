@@ -90,6 +90,7 @@ typedef struct mm_timing {
     int64_t dense_cells;      /* cells the fp32 filter could not vouch for: re-run fp64-only */
     int64_t edge_pairs;       /* pixel pairs on the CIEDE2000 hue discontinuity patched in fp64 */
     double seed_ms;           /* seeds + pruning limits ahead of the filter pass */
+    double build_ms;          /* mm_build_photomosaic: owner map + compose kernels */
 } mm_timing;
 
 /* Progress: called on the calling thread between device batches with
@@ -168,6 +169,20 @@ mm_status mm_resolve(mm_engine *e, const mm_cell *cells, int n_cells,
                      const int32_t *cand_index, const double *cand_score,
                      int inputs_on_device,
                      int64_t *best_fit_out, double *best_score_out);
+
+/* ---- composing the result -------------------------------- */
+
+/* The library as setLibrary() received it: u8 BGR [n][size][size][3], n and order as
+ * in mm_set_library.  Needed only by mm_build_photomosaic. */
+mm_status mm_set_library_bgr(mm_engine *e, const uint8_t *images, int n_images, int size);
+/* PhotomosaicGeneratorBase::buildPhotomosaic (PhotomosaicGeneratorBase.cpp:110-207) for one
+ * size step: BGRA canvas of `background`, every cell with a value painted in raster order
+ * through its flipped mask (later cells win where shapes overlap), library alpha 255.
+ *  best_fit     [grid_h*grid_w] as mm_generate wrote it (entries < 0 or >= n_images: no value)
+ *  mosaic_out   u8 BGRA [rows][cols][4] (host) */
+mm_status mm_build_photomosaic(mm_engine *e, const mm_cell *cells, int n_cells, int grid_w, int grid_h,
+                               const int64_t *best_fit, const uint8_t background[4], int rows, int cols,
+                               uint8_t *mosaic_out);
 
 /* Engine options.  "filter" (default 1): two-tier scoring -- an fp32 filter pass over
  * every (cell, candidate), then the fp64 reference-form score of each cell's

@@ -26,7 +26,7 @@ class MMTiming(ctypes.Structure):
                 ("pair_evals", ctypes.c_int64), ("exact_rescored", ctypes.c_int64),
                 ("dense_rows", ctypes.c_int64), ("rescore_ms", ctypes.c_double),
                 ("dense_cells", ctypes.c_int64), ("edge_pairs", ctypes.c_int64),
-                ("seed_ms", ctypes.c_double)]
+                ("seed_ms", ctypes.c_double), ("build_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -56,6 +56,9 @@ SIGNATURES = {
                                       ctypes.c_int, _VP, _VP, _VP]),
     "mm_resolve": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP, ctypes.c_int, _VP, _VP]),
+    "mm_set_library_bgr": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
+    "mm_build_photomosaic": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP,
+                                            ctypes.c_int, ctypes.c_int, _VP]),
     "mm_set_option": (ctypes.c_int, [_VP, ctypes.c_char_p, ctypes.c_int]),
     "mm_get_timing": (ctypes.c_int, [_VP, ctypes.POINTER(MMTiming)]),
     "mm_colour_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),

@@ -53,6 +53,7 @@ struct mm_engine {
     DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s;
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut;
+    DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
     int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
@@ -623,7 +624,7 @@ void mm_destroy(mm_engine* e)
                        &e->cont_i, &e->cont_f, &e->cont_s, &e->flags, &e->edges, &e->edge_count,
                        &e->dense_recs, &e->dense_i, &e->dense_s, &e->lib_means, &e->seeds,
                        &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
-                       &e->hue_lut })
+                       &e->hue_lut, &e->lib_bgr, &e->owner, &e->mosaic })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -852,6 +853,90 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
     e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
     e->timing.pair_evals = count_pair_evals(e, cells, n_cells);
+    return MM_OK;
+}
+
+mm_status mm_set_library_bgr(mm_engine* e, const uint8_t* images, int n_images, int size)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!images || n_images <= 0 || size <= 0 || size > 4096) {
+        set_err(e, "mm_set_library_bgr: need n_images > 0 and 0 < size <= 4096 (got %d, %d)", n_images, size);
+        return MM_INVALID_ARGUMENT;
+    }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    const size_t bytes = (size_t)n_images * size * size * 3;
+    mm_status st = ensure(e, e->lib_bgr, bytes, "Failed to allocate library images");
+    if (st) return st;
+    HIP_TRY(e, hipMemcpy(e->lib_bgr.p, images, bytes, hipMemcpyHostToDevice), "Failed to copy library image to device");
+    e->n_lib_bgr = n_images;
+    e->lib_bgr_size = size;
+    return MM_OK;
+}
+
+mm_status mm_build_photomosaic(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w, int grid_h,
+                               const int64_t* best_fit, const uint8_t background[4], int rows, int cols,
+                               uint8_t* mosaic_out)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (n_cells < 0 || (n_cells > 0 && !cells) || grid_w <= 0 || grid_h <= 0 || !best_fit || !background ||
+        rows <= 0 || cols <= 0 || !mosaic_out) {
+        set_err(e, "mm_build_photomosaic: bad arguments");
+        return MM_INVALID_ARGUMENT;
+    }
+    if (!e->lib_bgr.p || !e->masks.p) {
+        set_err(e, "u8 library (mm_set_library_bgr) and masks must be staged before building the photomosaic");
+        return MM_NOT_READY;
+    }
+    if (e->lib_bgr_size != e->mask_size) {
+        set_err(e, "library image size %d != mask size %d", e->lib_bgr_size, e->mask_size);
+        return MM_INVALID_ARGUMENT;
+    }
+    const int size = e->lib_bgr_size, P = size * size, ppad = round_up(P, 256);
+    for (int i = 0; i < n_cells; ++i) {
+        const mm_cell& c = cells[i];
+        const bool ok = c.row_min >= 0 && c.row_min < c.row_max && c.row_max <= size && c.col_min >= 0 &&
+                        c.col_min < c.col_max && c.col_max <= size && c.mask_id >= 0 && c.mask_id < 4 &&
+                        (long long)c.y + c.row_min >= 0 && (long long)c.y + c.row_max <= rows &&
+                        (long long)c.x + c.col_min >= 0 && (long long)c.x + c.col_max <= cols &&
+                        c.grid_x >= 0 && c.grid_x < grid_w && c.grid_y >= 0 && c.grid_y < grid_h;
+        if (!ok) { set_err(e, "mm_build_photomosaic: cell %d does not fit the %dx%d image / %dx%d grid", i, cols, rows, grid_w, grid_h); return MM_INVALID_ARGUMENT; }
+    }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    const size_t n_pixels = (size_t)rows * cols, grid_cells = (size_t)grid_w * grid_h;
+    mm_status st;
+    if ((st = ensure(e, e->recs, (size_t)std::max(n_cells, 1) * sizeof(mm_cell), "Failed to allocate cell records")) ||
+        (st = ensure(e, e->grid, grid_cells * sizeof(long long), "Failed to allocate best fits")) ||
+        (st = ensure(e, e->owner, n_pixels * sizeof(unsigned int), "Failed to allocate owner map")) ||
+        (st = ensure(e, e->mosaic, n_pixels * sizeof(uint32_t), "Failed to allocate photomosaic")))
+        return st;
+    HIP_TRY(e, hipEventRecord(e->ev[6], e->stream), "event");
+    HIP_TRY(e, hipMemcpyAsync(e->recs.p, cells, (size_t)n_cells * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
+            "Failed to copy cell records to device");
+    HIP_TRY(e, hipMemcpyAsync(e->grid.p, best_fit, grid_cells * sizeof(long long), hipMemcpyHostToDevice, e->stream),
+            "Failed to copy best fits to device");
+    HIP_TRY(e, hipMemsetAsync(e->owner.p, 0, n_pixels * sizeof(unsigned int), e->stream), "Failed to clear owner map");
+    HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
+    if (n_cells > 0) {
+        mm::mosaic_owner_kernel<<<dim3((P + mm::kBlock - 1) / mm::kBlock, n_cells), mm::kBlock, 0, e->stream>>>(
+            (const mm_cell*)e->recs.p, (const long long*)e->grid.p, grid_w, e->n_lib_bgr, (const uint8_t*)e->masks.p,
+            size, P, ppad, cols, (unsigned int*)e->owner.p);
+        HIP_TRY(e, hipGetLastError(), "Error during photomosaic owner kernel");
+    }
+    const uint32_t bg = (uint32_t)background[0] | ((uint32_t)background[1] << 8) | ((uint32_t)background[2] << 16) |
+                        ((uint32_t)background[3] << 24);
+    const unsigned blocks = (unsigned)std::min<size_t>((n_pixels + mm::kBlock - 1) / mm::kBlock, 16384);
+    mm::mosaic_compose_kernel<<<blocks, mm::kBlock, 0, e->stream>>>(
+        (const unsigned int*)e->owner.p, (const mm_cell*)e->recs.p, (const long long*)e->grid.p, grid_w,
+        (const uint8_t*)e->lib_bgr.p, size, cols, n_pixels, bg, (uint32_t*)e->mosaic.p);
+    HIP_TRY(e, hipGetLastError(), "Error during photomosaic compose kernel");
+    HIP_TRY(e, hipEventRecord(e->ev[5], e->stream), "event");
+    HIP_TRY(e, hipMemcpyAsync(mosaic_out, e->mosaic.p, n_pixels * 4, hipMemcpyDeviceToHost, e->stream),
+            "Error copying photomosaic to host");
+    HIP_TRY(e, hipEventRecord(e->ev[7], e->stream), "event");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    e->timing = mm_timing{};
+    e->timing.build_ms = elapsed(e->ev[4], e->ev[5]);
+    e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
     return MM_OK;
 }
 

@@ -119,6 +119,69 @@ mm_timing HIPPhotomosaicGenerator::timing() const
     return t;
 }
 
+// One record per valid cell, raster order (CPUPhotomosaicGenerator.cpp:63-77); the bound
+// is getCellAt's at detail 1 (PhotomosaicGeneratorBase.cpp:299-326).
+std::vector<mm_cell> HIPPhotomosaicGenerator::cellRecords(bool onlyWithValue) const
+{
+    const CellShape& normal = m_cells.getCell(0);
+    const CellShape& detail = m_cells.getCell(0, true);
+    const int size = detail.getSize();
+    const GridUtility::StepBestFit& grid = m_bestFits[0];
+    const int gridH = (int)grid.size(), gridW = (int)grid.at(0).size();
+    std::vector<mm_cell> cells;
+    for (int y = -GridUtility::PAD_GRID; y < gridH - GridUtility::PAD_GRID; ++y)
+        for (int x = -GridUtility::PAD_GRID; x < gridW - GridUtility::PAD_GRID; ++x) {
+            if (onlyWithValue && !grid[(size_t)(y + GridUtility::PAD_GRID)][(size_t)(x + GridUtility::PAD_GRID)].has_value()) continue;
+            const GridUtility::Rect r = GridUtility::getRectAt(normal, x, y);
+            const int y0 = std::clamp(r.y, 0, m_img.rows), y1 = std::clamp(r.y + r.height, 0, m_img.rows);
+            const int x0 = std::clamp(r.x, 0, m_img.cols), x1 = std::clamp(r.x + r.width, 0, m_img.cols);
+            if (y0 == y1 || x0 == x1) continue;                  // rect misses the image (never has a value)
+            const double d = m_cells.getDetail();
+            int bx = std::min(size - 1, (int)((x0 - r.x) * d)), by = std::min(size - 1, (int)((y0 - r.y) * d));
+            int bw = std::max(1, (int)((x1 - x0) * d)), bh = std::max(1, (int)((y1 - y0) * d));
+            bw = std::min(size - bx, bw);
+            bh = std::min(size - by, bh);
+            const GridUtility::FlipState f = GridUtility::getFlipStateAt(detail, x, y);
+            cells.push_back(mm_cell{ r.x, r.y, by, by + bh, bx, bx + bw, (f.horizontal ? 1 : 0) + (f.vertical ? 2 : 0),
+                                     x + GridUtility::PAD_GRID, y + GridUtility::PAD_GRID });
+        }
+    return cells;
+}
+
+std::vector<uint8_t> HIPPhotomosaicGenerator::buildPhotomosaic(const uint8_t backgroundColour[4])
+{
+    m_lastError.clear();
+    if (m_bestFits.size() != 1 || m_libBgr.empty()) { m_lastError = "buildPhotomosaic needs one size step and the u8 library"; return {}; }
+    const CellShape& normal = m_cells.getCell(0);
+    const int size = normal.getSize();
+    mm_status st;
+    if (m_staleBgr) {
+        std::vector<uint8_t> flat;
+        flat.reserve(m_libBgr.size() * (size_t)size * size * 3);
+        for (const auto& im : m_libBgr) {
+            if (im.size() != (size_t)size * size * 3) { m_lastError = "library image size != cell size"; return {}; }
+            flat.insert(flat.end(), im.begin(), im.end());
+        }
+        std::vector<uint8_t> masks;
+        for (int id = 0; id < 4; ++id) { const auto& m = normal.getCellMask(id & 1, id & 2); masks.insert(masks.end(), m.begin(), m.end()); }
+        if ((st = mm_set_library_bgr(m_engine, flat.data(), (int)m_libBgr.size(), size)) != MM_OK ||
+            (st = mm_set_masks(m_engine, masks.data(), size)) != MM_OK) { m_lastError = mm_last_error(m_engine); return {}; }
+        m_staleBgr = false;
+    }
+    const GridUtility::StepBestFit& grid = m_bestFits[0];
+    const int gridH = (int)grid.size(), gridW = (int)grid.at(0).size();
+    std::vector<int64_t> fits((size_t)gridW * gridH, -1);
+    for (int gy = 0; gy < gridH; ++gy)
+        for (int gx = 0; gx < gridW; ++gx)
+            if (grid[(size_t)gy][(size_t)gx].has_value()) fits[(size_t)gy * gridW + gx] = (int64_t)grid[(size_t)gy][(size_t)gx].value();
+    const std::vector<mm_cell> cells = cellRecords(true);
+    std::vector<uint8_t> mosaic((size_t)m_img.rows * m_img.cols * 4);
+    st = mm_build_photomosaic(m_engine, cells.data(), (int)cells.size(), gridW, gridH, fits.data(), backgroundColour,
+                              m_img.rows, m_img.cols, mosaic.data());
+    if (st != MM_OK) { m_lastError = mm_last_error(m_engine); return {}; }
+    return mosaic;
+}
+
 static void onProgress(int done, void* user)
 {
     auto* self = static_cast<HIPPhotomosaicGenerator*>(user);
@@ -156,26 +219,9 @@ bool HIPPhotomosaicGenerator::generateBestFits()
         m_staleInputs = false;
     }
 
-    // One record per valid cell, raster order (CPUPhotomosaicGenerator.cpp:63-77); the bound
-    // is getCellAt's at detail 1 (PhotomosaicGeneratorBase.cpp:299-326).
     GridUtility::StepBestFit& grid = m_bestFits[0];
     const int gridH = (int)grid.size(), gridW = (int)grid.at(0).size();
-    std::vector<mm_cell> cells;
-    for (int y = -GridUtility::PAD_GRID; y < gridH - GridUtility::PAD_GRID; ++y)
-        for (int x = -GridUtility::PAD_GRID; x < gridW - GridUtility::PAD_GRID; ++x) {
-            if (!grid[(size_t)(y + GridUtility::PAD_GRID)][(size_t)(x + GridUtility::PAD_GRID)].has_value()) continue;
-            const GridUtility::Rect r = GridUtility::getRectAt(normal, x, y);
-            const int y0 = std::clamp(r.y, 0, m_img.rows), y1 = std::clamp(r.y + r.height, 0, m_img.rows);
-            const int x0 = std::clamp(r.x, 0, m_img.cols), x1 = std::clamp(r.x + r.width, 0, m_img.cols);
-            const double d = m_cells.getDetail();
-            int bx = std::min(size - 1, (int)((x0 - r.x) * d)), by = std::min(size - 1, (int)((y0 - r.y) * d));
-            int bw = std::max(1, (int)((x1 - x0) * d)), bh = std::max(1, (int)((y1 - y0) * d));
-            bw = std::min(size - bx, bw);
-            bh = std::min(size - by, bh);
-            const GridUtility::FlipState f = GridUtility::getFlipStateAt(detail, x, y);
-            cells.push_back(mm_cell{ r.x, r.y, by, by + bh, bx, bx + bw, (f.horizontal ? 1 : 0) + (f.vertical ? 2 : 0),
-                                     x + GridUtility::PAD_GRID, y + GridUtility::PAD_GRID });
-        }
+    const std::vector<mm_cell> cells = cellRecords(true);
 
     std::vector<int64_t> bestFit((size_t)gridW * gridH);
     const mm_status st = mm_generate(m_engine, cells.data(), (int)cells.size(), gridW, gridH, (int)m_colourDiffType,

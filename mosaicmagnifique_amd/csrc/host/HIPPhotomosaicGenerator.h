@@ -91,6 +91,9 @@ public:
 
     void setMainImage(const Image& img);
     void setLibrary(const std::vector<Image>& lib);
+    // The library as u8 BGR (what the reference's setLibrary receives before preprocessing);
+    // only buildPhotomosaic needs it.
+    void setLibraryBGR(const std::vector<std::vector<uint8_t>>& libBgr) { m_libBgr = libBgr; m_staleBgr = true; }
     void setColourDifference(ColourDifference::Type type);      // throws std::invalid_argument on MAX
     void setCellGroup(const CellGroup& cellGroup);
     const CellGroup& getCellGroup() const { return m_cells; }
@@ -100,6 +103,9 @@ public:
     // Returns true if successful; false on cancel or device error (lastError()).
     bool generateBestFits();
     GridUtility::MosaicBestFit getBestFits() const { return m_bestFits; }
+    // PhotomosaicGeneratorBase::buildPhotomosaic (PhotomosaicGeneratorBase.cpp:110-207) on the
+    // device: BGRA u8 [rows][cols][4]; empty on error (lastError()).
+    std::vector<uint8_t> buildPhotomosaic(const uint8_t backgroundColour[4]);
     int getMaxProgress() const;
     void cancel() { m_wasCanceled = 1; }
     std::function<void(int)> progress;                            // the progress(int) signal
@@ -110,7 +116,9 @@ private:
     mm_engine* m_engine = nullptr;
     Image m_img;
     std::vector<Image> m_lib;
-    bool m_staleInputs = true;
+    std::vector<std::vector<uint8_t>> m_libBgr;
+    bool m_staleInputs = true, m_staleBgr = true;
+    std::vector<mm_cell> cellRecords(bool onlyWithValue) const;
     ColourDifference::Type m_colourDiffType = ColourDifference::Type::RGB_EUCLIDEAN;
     CellGroup m_cells;
     GridUtility::MosaicBestFit m_bestFits;

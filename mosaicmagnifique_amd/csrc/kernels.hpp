@@ -1031,6 +1031,54 @@ resolve_rows_kernel(ResolveArgs a, const int* __restrict__ row_first, const int*
 }
 
 // ---------------------------------------------------------------------------
+// buildPhotomosaic (PhotomosaicGeneratorBase.cpp:110-207), one size step
+// ---------------------------------------------------------------------------
+//
+// The reference paints cells in raster order through their flipped masks
+// (cv::Mat::copyTo with mask, :176-178): where shapes overlap, the LATER cell wins.
+// On the device that painter's order becomes an owner map: pass 1 raises
+// owner[pixel] to (cell order + 1) with atomicMax for every masked in-bounds pixel of
+// every placed cell (order-independent, exact); pass 2 reads one owner per output
+// pixel and copies that cell's library pixel (+ alpha 255) or the background.
+// Pure byte / index work: HBM-bound, 4 B owner + 4 B output per pixel.
+
+__global__ void __launch_bounds__(kBlock)
+mosaic_owner_kernel(const mm_cell* __restrict__ recs, const long long* __restrict__ best_fit,
+                    int grid_w, int L, const uint8_t* __restrict__ masks, int size, int P, int ppad,
+                    int cols, unsigned int* __restrict__ owner)
+{
+    const mm_cell rec = recs[blockIdx.y];
+    const long long fit = best_fit[(size_t)rec.grid_y * grid_w + rec.grid_x];
+    if (fit < 0 || fit >= L) return;                       // cell without a value: skipped (:147-150)
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= P) return;
+    const int row = p / size, col = p - row * size;
+    if (row < rec.row_min || row >= rec.row_max || col < rec.col_min || col >= rec.col_max) return;
+    if (masks[(size_t)rec.mask_id * ppad + p] == 0) return;
+    atomicMax(&owner[(size_t)(rec.y + row) * cols + (rec.x + col)], (unsigned int)blockIdx.y + 1u);
+}
+
+__global__ void __launch_bounds__(kBlock)
+mosaic_compose_kernel(const unsigned int* __restrict__ owner, const mm_cell* __restrict__ recs,
+                      const long long* __restrict__ best_fit, int grid_w,
+                      const uint8_t* __restrict__ lib_bgr, int size, int cols, size_t n_pixels,
+                      uint32_t background, uint32_t* __restrict__ mosaic)
+{
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_pixels; i += (size_t)gridDim.x * kBlock) {
+        const unsigned int o = owner[i];
+        uint32_t px = background;
+        if (o != 0) {
+            const mm_cell rec = recs[o - 1];
+            const int y = (int)(i / cols), x = (int)(i - (size_t)y * cols);
+            const long long fit = best_fit[(size_t)rec.grid_y * grid_w + rec.grid_x];
+            const uint8_t* src = lib_bgr + ((size_t)fit * size * size + (size_t)(y - rec.y) * size + (x - rec.x)) * 3;
+            px = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | 0xff000000u;
+        }
+        mosaic[i] = px;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // per-pair batch (KATs, differential tests)
 // ---------------------------------------------------------------------------
 

@@ -142,6 +142,24 @@ class Engine:
             int(repeat_addition), int(k), pi, ps, 1 if on_device else 0, _lib.ptr(best), _lib.ptr(score)))
         return best, score
 
+    def set_library_bgr(self, images):
+        """u8 BGR ``[n][size][size][3]`` as setLibrary received it (for build_photomosaic)."""
+        a = np.ascontiguousarray(images, dtype=np.uint8)
+        if a.ndim != 4 or a.shape[1] != a.shape[2] or a.shape[3] != 3:
+            raise ValueError("library must be [n][size][size][3]")
+        self._check(self._lib.mm_set_library_bgr(self._h, _lib.ptr(a), a.shape[0], a.shape[1]))
+
+    def build_photomosaic(self, cells, grid_w, grid_h, best_fit, rows, cols, background=(0, 0, 0, 0)):
+        """mm_build_photomosaic -> u8 BGRA [rows][cols][4]."""
+        rec = _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
+        fit = np.ascontiguousarray(best_fit, dtype=np.int64)
+        assert fit.shape == (grid_h, grid_w)
+        bg = np.array(background, dtype=np.uint8)
+        out = np.empty((rows, cols, 4), dtype=np.uint8)
+        self._check(self._lib.mm_build_photomosaic(self._h, _lib.ptr(rec), len(rec), grid_w, grid_h, _lib.ptr(fit),
+                                                   _lib.ptr(bg), rows, cols, _lib.ptr(out)))
+        return out
+
     def set_option(self, name, value):
         """mm_set_option: "filter" 1 (default, two-tier fp32 filter + fp64 re-score) or 0 (fp64 only)."""
         self._check(self._lib.mm_set_option(self._h, name.encode(), int(value)))

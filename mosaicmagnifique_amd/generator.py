@@ -41,6 +41,7 @@ class HIPPhotomosaicGenerator:
         self.m_bestScores = []
         self._progress_listeners = []
         self._staged = None          # what is resident on the device: (lib id, img id, type, mask id)
+        self._staged_bgr = None
         self.lastError = ""
 
     # -- setters (PhotomosaicGeneratorBase.cpp:44-93) -------------------------
@@ -157,6 +158,23 @@ class HIPPhotomosaicGenerator:
         for fn in self._progress_listeners:
             fn(self.getMaxProgress())
         return True
+
+    def buildPhotomosaic(self, backgroundColour=(0, 0, 0, 0)):
+        """PhotomosaicGeneratorBase::buildPhotomosaic (PhotomosaicGeneratorBase.cpp:110-207) on the
+        device: u8 BGRA ``[rows][cols][4]``.  Needs the library as u8 BGR (what setLibrary got)."""
+        if self.m_lib is None or self.m_lib.dtype != np.uint8:
+            raise ValueError("buildPhotomosaic needs the u8 BGR library given to setLibrary")
+        step = self.m_bestFits[0]
+        rows, cols = self.m_img.shape[0], self.m_img.shape[1]
+        # every cell the grid names (with or without a value: the engine skips the latter)
+        state = np.where(step >= 0, 0, GridUtility.NULLOPT)
+        cells = GridUtility.cell_records(self.m_cells, state, rows, cols)
+        if self._staged_bgr is not self.m_lib:
+            self.m_engine.set_library_bgr(self.m_lib)
+            self.m_engine.set_masks(self.m_cells.getCell(0).masks4())
+            self._staged_bgr = self.m_lib
+        return self.m_engine.build_photomosaic(cells, step.shape[1], step.shape[0], step, rows, cols,
+                                               backgroundColour)
 
     def getBestFits(self):
         return [s.copy() for s in self.m_bestFits]

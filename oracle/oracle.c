@@ -384,3 +384,43 @@ out:
     free(rep_vals);
     return done;
 }
+
+/* PhotomosaicGeneratorBase::buildPhotomosaic, PhotomosaicGeneratorBase.cpp:110-207,
+ * single size step (so `mosaic = mosaicStep`, :197-201).  Library images get an
+ * alpha channel of 255 (ImageUtility::addAlphaChannel, Other/ImageUtility.cpp:173-186). */
+void orc_build_photomosaic(const orc_shape *s, int rows, int cols, const uint8_t *lib_bgr,
+                           const uint8_t *masks, int grid_w, int grid_h, const int64_t *grid,
+                           const uint8_t background[4], uint8_t *mosaic_out)
+{
+    const int size = s->size;
+    const size_t px = (size_t)size * size;
+    for (size_t i = 0; i < (size_t)rows * cols; ++i)
+        memcpy(mosaic_out + 4 * i, background, 4);
+
+    for (int y = -ORC_PAD_GRID; y < grid_h - ORC_PAD_GRID; ++y) {
+        for (int x = -ORC_PAD_GRID; x < grid_w - ORC_PAD_GRID; ++x) {
+            const int64_t fit = grid[(size_t)(y + ORC_PAD_GRID) * grid_w + (x + ORC_PAD_GRID)];
+            if (fit < 0)
+                continue;                                          /* :147-150 */
+            const orc_rect g = orc_rect_at(s, x, y);
+            const int y0 = clampi(g.y, 0, rows), y1 = clampi(g.y + g.h, 0, rows);
+            const int x0 = clampi(g.x, 0, cols), x1 = clampi(g.x + g.w, 0, cols);
+            int fh, fv;
+            orc_flip_state_at(s, x, y, &fh, &fv);
+            const uint8_t *mask = masks + (size_t)(fh + 2 * fv) * px;
+            const uint8_t *im = lib_bgr + (size_t)fit * px * 3u;
+            for (int r = y0; r < y1; ++r) {
+                for (int c = x0; c < x1; ++c) {
+                    const size_t local = (size_t)(r - g.y) * size + (c - g.x);
+                    if (mask[local] == 0)
+                        continue;
+                    uint8_t *dst = mosaic_out + ((size_t)r * cols + c) * 4u;
+                    dst[0] = im[3 * local];
+                    dst[1] = im[3 * local + 1];
+                    dst[2] = im[3 * local + 2];
+                    dst[3] = 255;
+                }
+            }
+        }
+    }
+}

@@ -106,6 +106,17 @@ int orc_generate_best_fits(const orc_shape *s, const float *img, int rows, int c
                            int grid_w, int grid_h, int64_t *grid, double *scores,
                            int max_cells, int early_exit);
 
+/* PhotomosaicGeneratorBase::buildPhotomosaic for one size step
+ * (Photomosaic/PhotomosaicGeneratorBase.cpp:110-207).  lib_bgr: the library as
+ * setLibrary received it, u8 BGR [n][size][size][3]; masks: 4 masks of the NORMAL
+ * cell shape (= the detail shape at detail 1); grid: best fits (-1 = nullopt);
+ * background: BGRA; mosaic_out: u8 BGRA [rows][cols][4].  Cells are painted in
+ * raster order through their flipped mask (cv::Mat::copyTo with mask, :176-178), so
+ * where cell shapes overlap the later cell wins. */
+void orc_build_photomosaic(const orc_shape *s, int rows, int cols, const uint8_t *lib_bgr,
+                           const uint8_t *masks, int grid_w, int grid_h, const int64_t *grid,
+                           const uint8_t background[4], uint8_t *mosaic_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,8 @@
 // (test/tst_CUDAGenerator.h:163-212), writes the best-fit grid.
 //   scenario.bin: int32 header {rows, cols, size, L, type, range, addition, 6 spacings/offsets, 4 flips}
 //                 then f32 image, f32 library, u8 mask (size*size)
-//   result.bin:   int32 gridH, gridW, then int64 grid (-1 = nullopt)
+//                 then u8 BGR library (L x size x size x 3) for buildPhotomosaic
+//   result.bin:   int32 gridH, gridW, then int64 grid (-1 = nullopt), then the BGRA mosaic
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -25,6 +26,9 @@ int main(int argc, char** argv)
         if (fread(im.data.data(), sizeof(float), im.data.size(), f) != im.data.size()) return 2;
     std::vector<uint8_t> mask((size_t)size * size);
     if (fread(mask.data(), 1, mask.size(), f) != mask.size()) return 2;
+    std::vector<std::vector<uint8_t>> libBgr((size_t)L, std::vector<uint8_t>((size_t)size * size * 3));
+    for (auto& im : libBgr)
+        if (fread(im.data(), 1, im.size(), f) != im.size()) return 2;
     fclose(f);
 
     CellShape shape(size, mask);
@@ -38,6 +42,7 @@ int main(int argc, char** argv)
     HIPPhotomosaicGenerator generator(0);
     generator.setMainImage(img);
     generator.setLibrary(lib);
+    generator.setLibraryBGR(libBgr);
     generator.setColourDifference(static_cast<ColourDifference::Type>(h[4]));
     generator.setCellGroup(group);
     generator.setGridState(GridUtility::getGridState(group, rows, cols));
@@ -56,6 +61,10 @@ int main(int argc, char** argv)
             const int64_t v = cell.has_value() ? (int64_t)cell.value() : -1;
             fwrite(&v, sizeof v, 1, o);
         }
+    const uint8_t background[4] = {7, 8, 9, 10};
+    const std::vector<uint8_t> mosaic = generator.buildPhotomosaic(background);
+    if (mosaic.empty()) { fprintf(stderr, "buildPhotomosaic failed: %s\n", generator.lastError().c_str()); return 1; }
+    fwrite(mosaic.data(), 1, mosaic.size(), o);
     fclose(o);
     return 0;
 }

@@ -69,6 +69,8 @@ class Oracle:
         lib.orc_repeats.argtypes = [vp, i, i, i, i, i, i, vp, vp, i]
         lib.orc_find_cell_best_fit.restype = ctypes.c_int64
         lib.orc_find_cell_best_fit.argtypes = [i, vp, Rect, vp, i, vp, ctypes.c_int64, vp, vp, i, i, dp]
+        lib.orc_build_photomosaic.restype = None
+        lib.orc_build_photomosaic.argtypes = [ctypes.POINTER(Shape), i, i, vp, vp, i, i, vp, vp, vp]
         lib.orc_generate_best_fits.restype = i
         lib.orc_generate_best_fits.argtypes = [ctypes.POINTER(Shape), vp, i, i, vp, ctypes.c_int64, vp,
                                                i, i, i, i, i, vp, vp, i, i]
@@ -140,6 +142,18 @@ class Oracle:
             grid.shape[1], grid.shape[0], grid.ctypes.data, scores.ctypes.data, int(max_cells),
             1 if early_exit else 0)
         return grid, scores, done
+
+
+    def build_photomosaic(self, shape, rows, cols, lib_bgr, masks, grid, background=(0, 0, 0, 0)):
+        lib_bgr = np.ascontiguousarray(lib_bgr, dtype=np.uint8)
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        grid = np.ascontiguousarray(grid, dtype=np.int64)
+        bg = np.array(background, dtype=np.uint8)
+        out = np.empty((rows, cols, 4), dtype=np.uint8)
+        self.lib.orc_build_photomosaic(ctypes.byref(shape), rows, cols, lib_bgr.ctypes.data, masks.ctypes.data,
+                                       grid.shape[1], grid.shape[0], grid.ctypes.data, bg.ctypes.data,
+                                       out.ctypes.data)
+        return out
 
 
 _oracle = None
