@@ -188,7 +188,10 @@ mm_status mm_build_photomosaic(mm_engine *e, const mm_cell *cells, int n_cells, 
  * every (cell, candidate), then the fp64 reference-form score of each cell's
  * contenders only; 0 scores everything in fp64.  "prune" (default 1): the filter pass
  * abandons a candidate once its running sum passes a per-cell upper bound (the device
- * form of the reference's early exit).  Results are identical whatever the options. */
+ * form of the reference's early exit).  "wave_resolve" / "row_pipeline" (default 1): the
+ * single-wave and the row-pipelined forms of the resolve.  "max_batch" (default 0 = sized
+ * from free device memory): cap on the cells scored per device batch.  Results are identical
+ * whatever the options. */
 mm_status mm_set_option(mm_engine *e, const char *name, int value);
 
 /* Timings of the last mm_generate / mm_score_cells (+ mm_resolve) on e. */

@@ -55,6 +55,7 @@ struct mm_engine {
     DevBuf lib_chroma, cell_chroma, hue_lut;
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
+    int max_batch_cells = 0;     // mm_set_option("max_batch", n): cap on cells per device batch (0 = from memory)
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
     int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
     int use_prune = 1;           // mm_set_option("prune", 0): filter pass without early exit
@@ -277,7 +278,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                 per_cell, free_b);
         return MM_OUT_OF_MEMORY;
     }
-    const int batch = (int)std::min<size_t>((size_t)n, std::min<size_t>(budget / per_cell, 32768));
+    int batch = (int)std::min<size_t>((size_t)n, std::min<size_t>(budget / per_cell, 32768));
+    if (e->max_batch_cells > 0) batch = std::min(batch, e->max_batch_cells);
     mm_status st;
     if ((st = ensure(e, e->cells, (size_t)batch * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
         (st = ensure(e, e->cmask, (size_t)batch * ppad, "Failed to allocate cell masks")) ||
@@ -947,6 +949,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "prune") == 0) { e->use_prune = value != 0; return MM_OK; }
     if (strcmp(name, "wave_resolve") == 0) { e->use_wave_resolve = value != 0; return MM_OK; }
     if (strcmp(name, "row_pipeline") == 0) { e->use_row_pipeline = value != 0; return MM_OK; }
+    if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);
     return MM_INVALID_ARGUMENT;
 }

@@ -296,3 +296,39 @@ def test_resolve_forms_on_ragged_rows(oracle, wave_resolve):
     img, lib = cases.inputs(500, 430, 64, 30, Type.RGB_EUCLIDEAN, lattice=500)
     compare(oracle, shape, img, lib, Type.RGB_EUCLIDEAN, rep=(3, 2000), wave_resolve=wave_resolve)
     compare(oracle, shape, img, lib, Type.RGB_EUCLIDEAN, rep=(1, 100000), wave_resolve=wave_resolve)
+
+
+def test_many_small_batches_progress_and_cancel_between_batches(oracle, engine):
+    """Cells are scored in device batches; with a 7-cell cap a 6 x 7 grid takes 6 batches.
+    Same result, progress after every batch, and a cancel raised from the progress callback
+    stops at the next batch boundary (PhotomosaicGeneratorBase::cancel, :217-220)."""
+    import ctypes
+    from mosaicmagnifique_amd.engine import Cancelled
+    shape = cases.flippy_shape()
+    group = cases.group_of(shape)
+    t, rep = Type.CIEDE2000, (2, 120)
+    img, lib = cases.inputs(120, 130, 24, 60, t)
+    state = G.getGridState(group, 120, 130)[0]
+    cells = G.cell_records(group, state, 120, 130)
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    whole, whole_score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    engine.set_option("max_batch", 7)
+    try:
+        seen = []
+        best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep, progress=seen.append)
+        assert np.array_equal(best, whole) and np.array_equal(score[state >= 0], whole_score[state >= 0])
+        assert seen == list(range(7, len(cells), 7)) + [len(cells)]
+        want, _, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), *rep)
+        assert np.array_equal(np.where(best == len(lib), -1, best), want)
+        flag = ctypes.c_int(0)
+        calls = []
+
+        def stop_after_two(done):
+            calls.append(done)
+            if len(calls) == 2:
+                flag.value = 1
+        with pytest.raises(Cancelled):
+            engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep, progress=stop_after_two, cancel=flag)
+        assert calls == [7, 14]
+    finally:
+        engine.set_option("max_batch", 0)
