@@ -54,6 +54,12 @@ struct mm_engine {
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut;
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
+    // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
+    // per distinct mask in that mask's active-pixels-first order whenever either changes
+    DevBuf lib_hwc, perm, inv_perm, cell_var;
+    std::vector<uint8_t> masks_host;
+    bool planes_dirty = true;
+    int n_var = 0, var_of_mask[4] = {0, 0, 0, 0}, var_groups[4] = {0, 0, 0, 0};
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
     int max_batch_cells = 0;     // mm_set_option("max_batch", n): cap on cells per device batch (0 = from memory)
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
@@ -119,7 +125,7 @@ inline bool known_type(int t) { return t == MM_RGB_EUCLIDEAN || t == MM_CIE76 ||
 
 mm_status check_ready(mm_engine* e)
 {
-    if (!e->lib.p || !e->masks.p || !e->target.p) {
+    if (!e->lib_hwc.p || !e->masks.p || !e->target.p) {
         set_err(e, "library, masks and target must be staged before generating");
         return MM_NOT_READY;
     }
@@ -166,6 +172,76 @@ mm_status by_type(int diff_type, F&& f)
 {
     if (diff_type == MM_CIEDE2000) return f(std::integral_constant<int, mm::CIEDE2000>{});
     return f(std::integral_constant<int, mm::RGB_EUCLIDEAN>{});   // CIE76 == Euclid on Lab
+}
+
+// De-duplicates the 4 mask variants, builds each distinct variant's pixel permutation
+// (active pixels first, row-major among themselves, then the inactive ones) and re-planes
+// the library in that order: [V][L][3][ppad] + chroma planes [V][L][ppad] + means.
+mm_status prepare_planes(mm_engine* e)
+{
+    if (!e->planes_dirty) return MM_OK;
+    const int size = e->lib_size, P = size * size, ppad = round_up(P, 256), L = e->n_lib;
+    int n_var = 0;
+    int first_mask_of_var[4];
+    for (int m = 0; m < 4; ++m) {
+        int v = -1;
+        for (int u = 0; u < n_var && v < 0; ++u) {
+            const uint8_t* a = e->masks_host.data() + (size_t)m * P;
+            const uint8_t* b = e->masks_host.data() + (size_t)first_mask_of_var[u] * P;
+            bool same = true;
+            for (int p = 0; p < P && same; ++p) same = (a[p] != 0) == (b[p] != 0);
+            if (same) v = u;
+        }
+        if (v < 0) { v = n_var; first_mask_of_var[n_var++] = m; }
+        e->var_of_mask[m] = v;
+    }
+    std::vector<int> perm((size_t)n_var * ppad, -1), inv((size_t)n_var * P, 0);
+    for (int v = 0; v < n_var; ++v) {
+        const uint8_t* mk = e->masks_host.data() + (size_t)first_mask_of_var[v] * P;
+        int k = 0;
+        for (int p = 0; p < P; ++p) if (mk[p] != 0) { perm[(size_t)v * ppad + k] = p; inv[(size_t)v * P + p] = k; ++k; }
+        e->var_groups[v] = (k + 255) / 256;
+        for (int p = 0; p < P; ++p) if (mk[p] == 0) { perm[(size_t)v * ppad + k] = p; inv[(size_t)v * P + p] = k; ++k; }
+    }
+    for (int v = n_var; v < 4; ++v) e->var_groups[v] = 0;
+    e->n_var = n_var;
+
+    mm_status st;
+    if ((st = ensure(e, e->perm, perm.size() * sizeof(int), "Failed to allocate pixel order")) ||
+        (st = ensure(e, e->inv_perm, inv.size() * sizeof(int), "Failed to allocate pixel order")) ||
+        (st = ensure(e, e->lib, (size_t)n_var * L * 3 * ppad * sizeof(float), "Failed to allocate library planes")) ||
+        (st = ensure(e, e->lib_chroma, (size_t)n_var * L * ppad * sizeof(float), "Failed to allocate library chroma planes")) ||
+        (st = ensure(e, e->lib_means, (size_t)L * 3 * sizeof(float), "Failed to allocate library means")))
+        return st;
+    HIP_TRY(e, hipMemcpyAsync(e->perm.p, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, e->stream),
+            "Failed to copy pixel order to device");
+    HIP_TRY(e, hipMemcpyAsync(e->inv_perm.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice, e->stream),
+            "Failed to copy pixel order to device");
+    for (int v = 0; v < n_var; ++v) {
+        const int blocks = (int)std::min<size_t>(((size_t)L * ppad + mm::kBlock - 1) / mm::kBlock, 65536);
+        mm::hwc_to_planar_kernel<<<blocks, mm::kBlock, 0, e->stream>>>(
+            (const float*)e->lib_hwc.p, (float*)e->lib.p + (size_t)v * L * 3 * ppad, L, P, ppad,
+            (const int*)e->perm.p + (size_t)v * ppad);
+        HIP_TRY(e, hipGetLastError(), "Error during library plane kernel");
+    }
+    HIP_TRY(e, mm::launch_chroma_planes((const float*)e->lib.p, (float*)e->lib_chroma.p, (size_t)n_var * L, ppad, e->stream),
+            "Error during library chroma kernel");
+    HIP_TRY(e, mm::launch_image_means((const float*)e->lib.p, (float*)e->lib_means.p, L, P, ppad, e->stream),
+            "Error during library mean kernel");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");   // host vectors go out of scope
+    e->planes_dirty = false;
+    return MM_OK;
+}
+
+mm::Variants variants_of(const mm_engine* e)
+{
+    const int P = e->lib_size * e->lib_size, ppad = round_up(P, 256);
+    mm::Variants v{};
+    v.cell_var = (const uint8_t*)e->cell_var.p;
+    v.lib_stride = (size_t)e->n_lib * 3 * ppad;
+    v.chroma_stride = (size_t)e->n_lib * ppad;
+    for (int i = 0; i < 4; ++i) v.groups[i] = e->var_groups[i];
+    return v;
 }
 
 // The hue table of colour_diff_fast.hpp, in fp64 from the reference formulas: entry i is the
@@ -235,9 +311,14 @@ mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_typ
 {
     const int L = e->n_lib, size = e->lib_size, P = size * size, ppad = round_up(P, 256);
     const int cand_per_block = 16, cell_group = 512;
+    mm_status stv = ensure(e, e->cell_var, (size_t)std::max(b, 1), "Failed to allocate cell variants");
+    if (stv) return stv;
+    const mm::Variants var = variants_of(e);
+    const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
         recs_dev, (const float*)e->target.p, e->cols, (const uint8_t*)e->masks.p,
-        (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad);
+        (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
+        (uint8_t*)e->cell_var.p);
     HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
     if (after_gather) HIP_TRY(e, hipEventRecord(after_gather, e->stream), "event");
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
@@ -246,7 +327,7 @@ mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_typ
     by_type(diff_type, [&](auto T) {
         mm::score_kernel<decltype(T)::value><<<dim3((unsigned)blocks), mm::kBlock, 0, e->stream>>>(
             (const float*)e->cells.p, (const uint8_t*)e->cmask.p, (const float*)e->lib.p,
-            (double*)e->scores.p, b, L, ppad, cand_per_block, cell_group);
+            (double*)e->scores.p, b, L, ppad, cand_per_block, cell_group, var);
         return MM_OK;
     });
     HIP_TRY(e, hipGetLastError(), "Error during colour difference / add reduction kernel");
@@ -264,6 +345,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                              mm_progress_cb progress, void* user, volatile int* cancel)
 {
     const int L = e->n_lib, size = e->lib_size, P = size * size, ppad = round_up(P, 256);
+    mm_status stp = prepare_planes(e);
+    if (stp) return stp;
     const bool two_tier = e->use_filter != 0 && K < L;
     const int Kc = two_tier ? std::min(L, round_up(K + 32, 4)) : 0;
 
@@ -281,7 +364,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     int batch = (int)std::min<size_t>((size_t)n, std::min<size_t>(budget / per_cell, 32768));
     if (e->max_batch_cells > 0) batch = std::min(batch, e->max_batch_cells);
     mm_status st;
-    if ((st = ensure(e, e->cells, (size_t)batch * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
+    if ((st = ensure(e, e->cell_var, (size_t)batch, "Failed to allocate cell variants")) ||
+        (st = ensure(e, e->cells, (size_t)batch * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
         (st = ensure(e, e->cmask, (size_t)batch * ppad, "Failed to allocate cell masks")) ||
         (st = ensure(e, e->scores, (size_t)batch * L * sizeof(double), "Failed to allocate variants")))
         return st;
@@ -308,6 +392,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.cells = (const float*)e->cells.p; fin.cmask = (const uint8_t*)e->cmask.p;
     fin.cell_chroma = (const float*)e->cell_chroma.p; fin.lib = (const float*)e->lib.p;
     fin.lib_chroma = (const float*)e->lib_chroma.p; fin.hue_lut = (const float4*)e->hue_lut.p;
+    fin.var = variants_of(e);
+    const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     // Early exit needs seeds: K <= M <= 256 of them, and the L proxy distances in LDS.
     const int M = std::min(L, std::min(256, round_up(K + 22, 4)));
     const bool prune = two_tier && e->use_prune != 0 && K <= M && (size_t)L * sizeof(float) <= 100 * 1024;
@@ -341,7 +427,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
 
         mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
             recs_dev + done, (const float*)e->target.p, e->cols, (const uint8_t*)e->masks.p,
-            (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad);
+            (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
+            (uint8_t*)e->cell_var.p);
         HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
         if (diff_type == MM_CIEDE2000)
             HIP_TRY(e, mm::launch_chroma_planes((const float*)e->cells.p, (float*)e->cell_chroma.p, (size_t)b, ppad, e->stream),
@@ -373,7 +460,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         by_type(diff_type, [&](auto T) {
             mm::rescore_kernel<decltype(T)::value><<<(unsigned)((waves + 3) / 4), mm::kBlock, 0, e->stream>>>(
                 (const float*)e->cells.p, (const uint8_t*)e->cmask.p, (const float*)e->lib.p,
-                (const int32_t*)e->cont_i.p, (double*)e->cont_s.p, b, Kc, ppad);
+                (const int32_t*)e->cont_i.p, (double*)e->cont_s.p, b, Kc, ppad, fin.var);
             return MM_OK;
         });
         HIP_TRY(e, hipGetLastError(), "Error during contender re-score kernel");
@@ -439,6 +526,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
 {
     const size_t cells_total = (size_t)grid_w * grid_h;
     mm_status st;
+    if ((st = prepare_planes(e))) return st;
     if ((st = ensure(e, e->grid, cells_total * sizeof(long long), "Failed to allocate best fits")) ||
         (st = ensure(e, e->best, cells_total * sizeof(double), "Failed to allocate best scores")) ||
         (st = ensure(e, e->counter, 2 * sizeof(unsigned long long), "Failed to allocate counter")))
@@ -462,6 +550,8 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
     a.grid = (long long*)e->grid.p; a.best_score = (double*)e->best.p;
     a.target = (const float*)e->target.p; a.rows = e->rows; a.cols = e->cols;
     a.masks = (const uint8_t*)e->masks.p; a.lib = (const float*)e->lib.p;
+    a.lib_stride = (size_t)e->n_lib * 3 * ppad; a.inv_perm = (const int*)e->inv_perm.p;
+    for (int i = 0; i < 4; ++i) a.var_of_mask[i] = e->var_of_mask[i];
     a.size = size; a.P = P; a.ppad = ppad;
     a.tie_band = kTieBand;
     a.exact_count = (unsigned long long*)e->counter.p;
@@ -626,7 +716,8 @@ void mm_destroy(mm_engine* e)
                        &e->cont_i, &e->cont_f, &e->cont_s, &e->flags, &e->edges, &e->edge_count,
                        &e->dense_recs, &e->dense_i, &e->dense_s, &e->lib_means, &e->seeds,
                        &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
-                       &e->hue_lut, &e->lib_bgr, &e->owner, &e->mosaic })
+                       &e->hue_lut, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
+                       &e->cell_var })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -643,43 +734,11 @@ mm_status mm_set_library(mm_engine* e, const float* images, int n_images, int si
         return MM_INVALID_ARGUMENT;
     }
     HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
-    const int P = size * size, ppad = round_up(P, 256);
-    const size_t planar_bytes = (size_t)n_images * 3 * ppad * sizeof(float);
-    mm_status st = ensure(e, e->lib, planar_bytes, "Failed to allocate library images");
+    const size_t bytes = (size_t)n_images * size * size * 3 * sizeof(float);
+    mm_status st = ensure(e, e->lib_hwc, bytes, "Failed to allocate library images");
     if (st) return st;
-    HIP_TRY(e, hipMemsetAsync(e->lib.p, 0, planar_bytes, e->stream), "Failed to clear library images");
-
-    // H2D in chunks through a bounded staging buffer, transposed to planes on the device.
-    const int chunk = std::max(1, (int)std::min<size_t>((size_t)n_images, ((size_t)256 << 20) / ((size_t)P * 12)));
-    DevBuf stage;
-    st = ensure(e, stage, (size_t)chunk * P * 3 * sizeof(float), "Failed to allocate library staging buffer");
-    if (st) return st;
-    for (int i0 = 0; i0 < n_images; i0 += chunk) {
-        const int c = std::min(chunk, n_images - i0);
-        hipError_t code = hipMemcpyAsync(stage.p, images + (size_t)i0 * P * 3, (size_t)c * P * 3 * sizeof(float),
-                                         hipMemcpyHostToDevice, e->stream);
-        if (code == hipSuccess) {
-            const int blocks = (int)std::min<size_t>(((size_t)c * P + mm::kBlock - 1) / mm::kBlock, 16384);
-            mm::hwc_to_planar_kernel<<<blocks, mm::kBlock, 0, e->stream>>>(
-                (const float*)stage.p, (float*)e->lib.p + (size_t)i0 * 3 * ppad, c, P, ppad);
-            code = hipGetLastError();
-        }
-        if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
-        if (code != hipSuccess) {
-            release(stage);
-            return hip_fail(e, code, "Failed to copy library image to device", __FILE__, __LINE__);
-        }
-    }
-    release(stage);
-    if ((st = ensure(e, e->lib_means, (size_t)n_images * 3 * sizeof(float), "Failed to allocate library means")))
-        return st;
-    HIP_TRY(e, mm::launch_image_means((const float*)e->lib.p, (float*)e->lib_means.p, n_images, P, ppad, e->stream),
-            "Error during library mean kernel");
-    if ((st = ensure(e, e->lib_chroma, (size_t)n_images * ppad * sizeof(float), "Failed to allocate library chroma planes")))
-        return st;
-    HIP_TRY(e, mm::launch_chroma_planes((const float*)e->lib.p, (float*)e->lib_chroma.p, (size_t)n_images, ppad, e->stream),
-            "Error during library chroma kernel");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    HIP_TRY(e, hipMemcpy(e->lib_hwc.p, images, bytes, hipMemcpyHostToDevice), "Failed to copy library image to device");
+    e->planes_dirty = true;        // planes are (re)built by prepare_planes() once the masks are known
     e->n_lib = n_images;
     e->lib_size = size;
     return MM_OK;
@@ -700,6 +759,8 @@ mm_status mm_set_masks(mm_engine* e, const uint8_t* masks, int size)
     if (st) return st;
     HIP_TRY(e, hipMemcpy(e->masks.p, padded.data(), padded.size(), hipMemcpyHostToDevice),
             "Failed to copy cell mask to device");
+    e->masks_host.assign(masks, masks + (size_t)4 * P);
+    e->planes_dirty = true;
     e->mask_size = size;
     return MM_OK;
 }

@@ -60,7 +60,7 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
               int n_cells, int L, int ppad, int cand_per_block, int cell_group,
               EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
               unsigned int edge_cap, const float* __restrict__ prune_above, int check_every,
-              const float4* __restrict__ hue_lut)
+              const float4* __restrict__ hue_lut, Variants var)
 {
     __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
@@ -75,7 +75,10 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
     if (tile >= n_tiles || cell >= n_cells) return;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int groups = ppad / (4 * kWave);
+    const int v = var.cell_var[cell];
+    const int groups = var.groups[v];                    // only the variant's active pixels
+    lib += (size_t)v * var.lib_stride;
+    lib_chroma += (size_t)v * var.chroma_stride;
     const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
     const float4* c1 = c0 + ppad / 4;
     const float4* c2 = c1 + ppad / 4;
@@ -151,7 +154,7 @@ seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
                   const float* __restrict__ cell_chroma, const float* __restrict__ lib,
                   const float* __restrict__ lib_chroma, const int32_t* __restrict__ seeds,
                   float* __restrict__ seed_score, int n_cells, int M, int ppad,
-                  const float4* __restrict__ hue_lut)
+                  const float4* __restrict__ hue_lut, Variants var)
 {
     __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
@@ -161,7 +164,10 @@ seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
     if (cell >= n_cells) return;
     const int l = seeds[w];
     if (l < 0) { if (lane == 0) seed_score[w] = __builtin_huge_valf(); return; }
-    const int groups = ppad / (4 * kWave);
+    const int v = var.cell_var[cell];
+    const int groups = var.groups[v];
+    lib += (size_t)v * var.lib_stride;
+    lib_chroma += (size_t)v * var.chroma_stride;
     const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
     const float4* c1 = c0 + ppad / 4;
     const float4* c2 = c1 + ppad / 4;
@@ -333,7 +339,7 @@ edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ cell_
                 const float* __restrict__ lib, const float* __restrict__ lib_chroma,
                 float* __restrict__ scores, int L, int ppad,
                 const EdgeEntry* __restrict__ edges, const unsigned int* __restrict__ edge_count,
-                unsigned int edge_cap, const float4* __restrict__ hue_lut)
+                unsigned int edge_cap, const float4* __restrict__ hue_lut, Variants var)
 {
     __shared__ float4 lut[kHueLutSize + 1];
     load_hue_lut(lut, hue_lut);
@@ -341,11 +347,13 @@ edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ cell_
     for (unsigned int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const EdgeEntry en = edges[i];
         const float* c = cells + (size_t)en.cell * 3 * ppad + en.pixel;
-        const float* b = lib + (size_t)en.cand * 3 * ppad + en.pixel;
+        const int v = var.cell_var[en.cell];
+        const float* b = lib + (size_t)v * var.lib_stride + (size_t)en.cand * 3 * ppad + en.pixel;
         const PxF p{c[0], c[ppad], c[2 * (size_t)ppad]}, q{b[0], b[ppad], b[2 * (size_t)ppad]};
         bool edge;
         const float fast = ciede2000_fast(p, q, cell_chroma[(size_t)en.cell * ppad + en.pixel],
-                                          lib_chroma[(size_t)en.cand * ppad + en.pixel], lut, &edge);
+                                          lib_chroma[(size_t)v * var.chroma_stride + (size_t)en.cand * ppad + en.pixel],
+                                          lut, &edge);
         const double exact = ciede2000(Px{p.c0, p.c1, p.c2}, Px{q.c0, q.c1, q.c2});
         atomicAdd(&scores[(size_t)en.cell * L + en.cand], (float)(exact - (double)fast));
     }
@@ -380,21 +388,21 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long blocks = (long long)n_cells * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const int groups = ppad / 256;
+    const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
     const int check_every = groups > 16 ? groups / 16 : 1;
     hipError_t code = hipMemsetAsync(edge_count, 0, sizeof(unsigned int), stream);
     if (code != hipSuccess) return code;
     if (type == CIEDE2000) {
         filter_kernel<CIEDE2000><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
             in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut);
+            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
-                                                     edges, edge_count, edge_cap, in.hue_lut);
+                                                     edges, edge_count, edge_cap, in.hue_lut, in.var);
     } else {
         filter_kernel<RGB_EUCLIDEAN><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
             in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut);
+            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var);
     }
     return hipGetLastError();
 }
@@ -424,11 +432,11 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
     if (type == CIEDE2000) {
         seed_kernel<CIEDE2000><<<n_cells, kBlock, lds, stream>>>(in.cells, in.cmask, lib_means, L, ppad, M, seeds, in.hue_lut);
         seed_score_kernel<CIEDE2000><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(
-            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut);
+            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut, in.var);
     } else {
         seed_kernel<RGB_EUCLIDEAN><<<n_cells, kBlock, lds, stream>>>(in.cells, in.cmask, lib_means, L, ppad, M, seeds, in.hue_lut);
         seed_score_kernel<RGB_EUCLIDEAN><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(
-            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut);
+            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut, in.var);
     }
     hipError_t code = hipGetLastError();
     if (code != hipSuccess) return code;

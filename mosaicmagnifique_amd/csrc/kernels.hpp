@@ -1,10 +1,12 @@
 // kernels.hpp -- device kernels of the best-fit engine (gfx950 / CDNA4, wave64).
 //
 // Data layout in HBM (DESIGN.md "Layout"):
-//   library   f32 planar  [L][3][ppad]      ppad = P rounded up to 256, pad = 0
+//   library   f32 planar  [V][L][3][ppad]   ppad = P rounded up to 256, pad = 0; one copy per
+//                                           distinct mask variant, pixels permuted so the
+//                                           variant's active pixels come first (launch.hpp)
 //   masks     u8          [4][ppad]         pad = 0
 //   target    f32 HWC     [rows][cols][3]   as handed over by the host
-//   cells     f32 planar  [B][3][ppad]      gathered per batch, zero outside the image
+//   cells     f32 planar  [B][3][ppad]      gathered per batch in the cell's variant order, zero outside the image
 //   cmask     u8          [B][ppad]         mask variant AND local bound, per cell
 //   scores    f64         [B][L]            base score of every (cell, candidate)
 //   cand_*    i32/f64     [N][K]            K lowest (score, index) per cell, ascending
@@ -19,6 +21,7 @@
 
 #include "../../include/mosaic_hip.h"
 #include "colour_diff.hpp"
+#include "launch.hpp"
 
 namespace mm {
 
@@ -76,21 +79,27 @@ __device__ __forceinline__ ScoreIdx block_min(ScoreIdx v, ScoreIdx* sh)
 // staging kernels
 // ---------------------------------------------------------------------------
 
-// HWC [n][P][3] -> planar [n][3][ppad] (pad region pre-zeroed by the caller).
+// HWC [n][P][3] -> planar [n][3][ppad] in a mask variant's pixel order: plane position k
+// holds original pixel perm[k] (perm[k] < 0: padding, written as 0).
 __global__ void __launch_bounds__(kBlock)
 hwc_to_planar_kernel(const float* __restrict__ hwc, float* __restrict__ planar,
-                     int n_images, int P, int ppad)
+                     int n_images, int P, int ppad, const int* __restrict__ perm)
 {
-    const size_t total = (size_t)n_images * P;
+    const size_t total = (size_t)n_images * ppad;
     for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
          t += (size_t)gridDim.x * kBlock) {
-        const size_t img = t / P;
-        const int p = (int)(t - img * P);
-        const float* src = hwc + t * 3;
-        float* dst = planar + img * 3 * (size_t)ppad + p;
-        dst[0] = src[0];
-        dst[ppad] = src[1];
-        dst[2 * (size_t)ppad] = src[2];
+        const size_t img = t / ppad;
+        const int k = (int)(t - img * ppad);
+        const int p = perm[k];
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (p >= 0) {
+            const float* src = hwc + (img * P + p) * 3;
+            v0 = src[0]; v1 = src[1]; v2 = src[2];
+        }
+        float* dst = planar + img * 3 * (size_t)ppad + k;
+        dst[0] = v0;
+        dst[ppad] = v1;
+        dst[2 * (size_t)ppad] = v2;
     }
 }
 
@@ -102,14 +111,19 @@ __global__ void __launch_bounds__(kBlock)
 gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ target,
                     int cols, const uint8_t* __restrict__ masks,
                     float* __restrict__ cells, uint8_t* __restrict__ cmask,
-                    int size, int P, int ppad)
+                    int size, int P, int ppad, const int* __restrict__ perm, int4 var_of_mask,
+                    uint8_t* __restrict__ cell_var)
 {
     const mm_cell rec = recs[blockIdx.y];
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= ppad) return;
+    const int vm[4] = {var_of_mask.x, var_of_mask.y, var_of_mask.z, var_of_mask.w};
+    const int v = vm[rec.mask_id];
+    const int k = blockIdx.x * kBlock + threadIdx.x;     // position in the variant's pixel order
+    if (k == 0) cell_var[blockIdx.y] = (uint8_t)v;
+    if (k >= ppad) return;
+    const int p = perm[(size_t)v * ppad + k];            // original pixel, < 0 = padding
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;
     uint8_t m = 0;
-    if (p < P) {
+    if (p >= 0) {
         const int row = p / size, col = p - row * size;
         if (row >= rec.row_min && row < rec.row_max && col >= rec.col_min && col < rec.col_max) {
             const float* src = target + ((size_t)(rec.y + row) * cols + (rec.x + col)) * 3;
@@ -117,11 +131,11 @@ gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ 
             m = masks[(size_t)rec.mask_id * ppad + p] != 0;
         }
     }
-    float* dst = cells + (size_t)blockIdx.y * 3 * ppad + p;
+    float* dst = cells + (size_t)blockIdx.y * 3 * ppad + k;
     dst[0] = v0;
     dst[ppad] = v1;
     dst[2 * (size_t)ppad] = v2;
-    cmask[(size_t)blockIdx.y * ppad + p] = m;
+    cmask[(size_t)blockIdx.y * ppad + k] = m;
 }
 
 // ---------------------------------------------------------------------------
@@ -142,7 +156,7 @@ template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
 score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
              const float* __restrict__ lib, double* __restrict__ scores,
-             int n_cells, int L, int ppad, int cand_per_block, int cell_group)
+             int n_cells, int L, int ppad, int cand_per_block, int cell_group, Variants var)
 {
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long bid = blockIdx.x;
@@ -155,7 +169,9 @@ score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
     if (tile >= n_tiles || cell >= n_cells) return;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int groups = ppad / (4 * kWave);            // float4 groups per lane
+    const int v = var.cell_var[cell];
+    const int groups = var.groups[v];                 // float4 groups per lane holding active pixels
+    lib += (size_t)v * var.lib_stride;
     const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
     const float4* c1 = c0 + ppad / 4;
     const float4* c2 = c1 + ppad / 4;
@@ -309,7 +325,7 @@ template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
 rescore_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
                const float* __restrict__ lib, const int32_t* __restrict__ cont_index,
-               double* __restrict__ cont_score, int n_cells, int Kc, int ppad)
+               double* __restrict__ cont_score, int n_cells, int Kc, int ppad, Variants var)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long w = (long long)blockIdx.x * (kBlock / kWave) + wave;
@@ -318,7 +334,9 @@ rescore_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmas
     const int l = cont_index[w];
     if (l < 0) { if (lane == 0) cont_score[w] = kInf; return; }
 
-    const int groups = ppad / (4 * kWave);
+    const int v = var.cell_var[cell];
+    const int groups = var.groups[v];
+    lib += (size_t)v * var.lib_stride;
     const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
     const float4* c1 = c0 + ppad / 4;
     const float4* c2 = c1 + ppad / 4;
@@ -427,7 +445,10 @@ struct ResolveArgs {
     // pixel data for the exact tie-break
     const float* target; int rows, cols;
     const uint8_t* masks;
-    const float* lib;
+    const float* lib;           // [variants][L][3][ppad], permuted pixel order per variant
+    size_t lib_stride;          // floats between two variants
+    const int* inv_perm;        // [variants][P]: plane position of original pixel p
+    int var_of_mask[4];
     int size, P, ppad;
     double tie_band;            // relative gap under which two totals count as a near-tie
     unsigned long long* exact_count;
@@ -470,7 +491,9 @@ __device__ double exact_total(const ResolveArgs& a, const mm_cell& rec, int cand
                               double* buf, double* bcast)
 {
     double running = (double)rep;
-    const float* l0 = a.lib + (size_t)cand * 3 * a.ppad;
+    const int v = a.var_of_mask[rec.mask_id];
+    const float* l0 = a.lib + (size_t)v * a.lib_stride + (size_t)cand * 3 * a.ppad;
+    const int* ip = a.inv_perm + (size_t)v * a.P;
     const uint8_t* mk = a.masks + (size_t)rec.mask_id * a.ppad;
     for (int base = 0; base < a.P; base += kExactChunk) {
         const int n = min(kExactChunk, a.P - base);
@@ -481,8 +504,9 @@ __device__ double exact_total(const ResolveArgs& a, const mm_cell& rec, int cand
             if (mk[p] != 0 && row >= rec.row_min && row < rec.row_max &&
                 col >= rec.col_min && col < rec.col_max) {
                 const float* src = a.target + ((size_t)(rec.y + row) * a.cols + (rec.x + col)) * 3;
+                const int k = ip[p];
                 term = colour_diff<TYPE>(Px{src[0], src[1], src[2]},
-                                         Px{l0[p], l0[a.ppad + p], l0[2 * (size_t)a.ppad + p]});
+                                         Px{l0[k], l0[a.ppad + k], l0[2 * (size_t)a.ppad + k]});
             }
             buf[t] = term;
         }
@@ -506,15 +530,18 @@ __device__ void dense_row(const ResolveArgs& a, const mm_cell& rec, double* row,
 {
     const uint8_t* mk = a.masks + (size_t)rec.mask_id * a.ppad;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int v = a.var_of_mask[rec.mask_id];
+    const int* ip = a.inv_perm + (size_t)v * a.P;
     for (int l = 0; l < a.L; ++l) {
-        const float* l0 = a.lib + (size_t)l * 3 * a.ppad;
+        const float* l0 = a.lib + (size_t)v * a.lib_stride + (size_t)l * 3 * a.ppad;
         double acc = 0.0;
         for (int p = threadIdx.x; p < a.P; p += kBlock) {
             const int r = p / a.size, c = p - r * a.size;
             if (mk[p] != 0 && r >= rec.row_min && r < rec.row_max && c >= rec.col_min && c < rec.col_max) {
                 const float* src = a.target + ((size_t)(rec.y + r) * a.cols + (rec.x + c)) * 3;
+                const int k = ip[p];
                 acc += colour_diff<TYPE>(Px{src[0], src[1], src[2]},
-                                         Px{l0[p], l0[a.ppad + p], l0[2 * (size_t)a.ppad + p]});
+                                         Px{l0[k], l0[a.ppad + k], l0[2 * (size_t)a.ppad + k]});
             }
         }
         acc = wave_sum(acc);
@@ -845,7 +872,9 @@ __device__ double exact_total_wave(const ResolveArgs& a, const mm_cell& rec, int
 {
     const int lane = threadIdx.x & 63;
     double running = (double)rep;
-    const float* l0 = a.lib + (size_t)cand * 3 * a.ppad;
+    const int v = a.var_of_mask[rec.mask_id];
+    const float* l0 = a.lib + (size_t)v * a.lib_stride + (size_t)cand * 3 * a.ppad;
+    const int* ip = a.inv_perm + (size_t)v * a.P;
     const uint8_t* mk = a.masks + (size_t)rec.mask_id * a.ppad;
     for (int base = 0; base < a.P; base += kRowExactChunk) {
         const int n = min(kRowExactChunk, a.P - base);
@@ -856,8 +885,9 @@ __device__ double exact_total_wave(const ResolveArgs& a, const mm_cell& rec, int
             if (mk[p] != 0 && row >= rec.row_min && row < rec.row_max &&
                 col >= rec.col_min && col < rec.col_max) {
                 const float* src = a.target + ((size_t)(rec.y + row) * a.cols + (rec.x + col)) * 3;
+                const int k = ip[p];
                 term = colour_diff<TYPE>(Px{src[0], src[1], src[2]},
-                                         Px{l0[p], l0[a.ppad + p], l0[2 * (size_t)a.ppad + p]});
+                                         Px{l0[k], l0[a.ppad + k], l0[2 * (size_t)a.ppad + k]});
             }
             wbuf[t] = term;
         }

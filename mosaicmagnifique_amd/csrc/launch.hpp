@@ -11,8 +11,21 @@ namespace mm {
 // A pixel pair the fp32 CIEDE2000 form must not judge (opposite-hue discontinuity).
 struct EdgeEntry { int cell, cand, pixel; };
 
+// Mask variants.  The 4 flip variants of the cell mask are de-duplicated into n <= 4
+// distinct ones; for each, library and cell planes are stored in a PERMUTED pixel order
+// with the variant's active pixels first (row-major among themselves), so the scoring
+// kernels walk only groups[v] = ceil(active / 256) float4-groups per lane instead of
+// ppad / 256.  cell_var[c] = variant of cell c's mask in the current batch.
+struct Variants {
+    const uint8_t* cell_var;    // [B]
+    size_t lib_stride;          // floats between the planar libraries of two variants (L*3*ppad)
+    size_t chroma_stride;       // floats between their chroma planes (L*ppad)
+    int groups[4];
+};
+
 // Device inputs of the fp32 filter kernels.
 struct FilterInputs {
+    Variants var;
     const float* cells;         // f32 planar [B][3][ppad]
     const uint8_t* cmask;       // u8 [B][ppad]
     const float* cell_chroma;   // f32 [B][ppad]  sqrt(a^2+b^2) per cell pixel (CIEDE2000 only)
