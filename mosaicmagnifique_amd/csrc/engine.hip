@@ -332,7 +332,10 @@ mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_typ
     });
     HIP_TRY(e, hipGetLastError(), "Error during colour difference / add reduction kernel");
     if (after_score) HIP_TRY(e, hipEventRecord(after_score, e->stream), "event");
-    mm::select_kernel<<<b, mm::kBlock, 0, e->stream>>>((const double*)e->scores.p, L, K, kTieBand, ci, cs);
+    if (K >= L)
+        mm::full_list_kernel<<<b, mm::kBlock, 0, e->stream>>>((const double*)e->scores.p, L, K, ci, cs);
+    else
+        mm::select_kernel<<<b, mm::kBlock, 0, e->stream>>>((const double*)e->scores.p, L, K, kTieBand, ci, cs);
     HIP_TRY(e, hipGetLastError(), "Error during candidate selection kernel");
     return MM_OK;
 }

@@ -249,6 +249,19 @@ select_kernel(const double* __restrict__ scores, int L, int K, double tie_band,
     }
 }
 
+// K >= L (a negative repeat "penalty" can promote any candidate): the list is the whole
+// row, in index order; nothing to select.
+__global__ void __launch_bounds__(kBlock)
+full_list_kernel(const double* __restrict__ scores, int L, int K,
+                 int32_t* __restrict__ cand_index, double* __restrict__ cand_score)
+{
+    const double* row = scores + (size_t)blockIdx.x * L;
+    for (int k = threadIdx.x; k < K; k += kBlock) {
+        cand_index[(size_t)blockIdx.x * K + k] = k < L ? k : -1;
+        cand_score[(size_t)blockIdx.x * K + k] = k < L ? row[k] : kInf;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // two-tier scoring: contenders from the fp32 filter scores, fp64 re-score, re-rank
 // ---------------------------------------------------------------------------

@@ -54,7 +54,7 @@ def compare(oracle, shape, img, lib, t, rep=(0, 0), use_filter=1, wave_resolve="
     assert len(mism) == 0, "first mismatches (gy,gx): %s got %s want %s" % (
         mism[:5].tolist(), got[tuple(mism[:5].T)].tolist(), want[tuple(mism[:5].T)].tolist())
     valid = want >= 0
-    rel = np.abs(score[valid] - want_score[valid]) / np.maximum(want_score[valid], 1e-300)
+    rel = np.abs(score[valid] - want_score[valid]) / np.maximum(np.abs(want_score[valid]), 1e-300)
     assert rel.max() <= REL_TOL[int(t)], rel.max()
     assert np.isnan(score[~valid]).all()
     return gen
@@ -332,3 +332,16 @@ def test_many_small_batches_progress_and_cancel_between_batches(oracle, engine):
         assert calls == [7, 14]
     finally:
         engine.set_option("max_batch", 0)
+
+
+@pytest.mark.parametrize("wave_resolve", list(RESOLVE_MODES))
+def test_negative_repeat_addition_promotes_any_candidate(oracle, wave_resolve):
+    """setRepeat takes any int: a negative addition is a bonus for repeating neighbours, so
+    the winner may be ANY library image and the whole score row is the candidate list."""
+    shape = cases.square_shape(16)
+    img, lib = cases.inputs(80, 96, 16, 90, Type.CIE76, lattice=96)
+    gen = compare(oracle, shape, img, lib, Type.CIE76, rep=(2, -4000), wave_resolve=wave_resolve)
+    assert gen.m_engine.candidates_per_cell(2, -4000) == 90
+    fits = gen.getBestFits()[0]
+    inner = fits[2:, 2:]
+    assert (inner[:, 1:] == inner[:, :-1]).mean() > 0.5        # the bonus makes neighbours agree
