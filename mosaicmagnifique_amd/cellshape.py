@@ -185,6 +185,24 @@ class CellShape:
             [bool(b) for b in take("BBBB")]
         return shape
 
+    def saveToFile(self, filename):
+        """CellShape::saveToFile (CellShape.cpp:321-370), version 8 (PNG-encoded mask)."""
+        from PIL import Image
+        with open(filename, "wb") as out:
+            out.write(struct.pack(">II", MCS_MAGIC, MCS_VERSION))
+            raw = self.name.encode("utf-16-be")
+            out.write(struct.pack(">I", len(raw)))
+            out.write(raw)
+            png = io.BytesIO()
+            Image.fromarray(self._mask, mode="L").save(png, format="PNG")
+            blob = png.getvalue()
+            out.write(struct.pack(">I", len(blob)))
+            out.write(blob)
+            out.write(struct.pack(">iiiiii", self.rowSpacing, self.colSpacing, self.alternateRowSpacing,
+                                  self.alternateColSpacing, self.alternateRowOffset, self.alternateColOffset))
+            out.write(struct.pack(">BBBB", self.alternateColFlipHorizontal, self.alternateColFlipVertical,
+                                  self.alternateRowFlipHorizontal, self.alternateRowFlipVertical))
+
     def to_dict(self):
         return {k: v for k, v in self.__dict__.items() if k != "_mask"}
 
