@@ -214,6 +214,11 @@ mm_status mm_filter_diff_batch(mm_engine *e, int diff_type,
                                const float *first, const float *second,
                                size_t n, float *out);
 
+/* Diagnostics: {pixel groups visited by the filter kernel, groups a full visit takes,
+ * candidates dropped outright by the lightness bound} of the last batch.  Only builds
+ * with -DMM_COUNT_VISITS count; otherwise zeros. */
+mm_status mm_debug_visit_counters(mm_engine *e, unsigned long long out[3]);
+
 #ifdef __cplusplus
 }
 #endif

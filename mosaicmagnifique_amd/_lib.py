@@ -63,6 +63,7 @@ SIGNATURES = {
     "mm_get_timing": (ctypes.c_int, [_VP, ctypes.POINTER(MMTiming)]),
     "mm_colour_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),
     "mm_filter_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),
+    "mm_debug_visit_counters": (ctypes.c_int, [_VP, _VP]),
 }
 
 _lib = None

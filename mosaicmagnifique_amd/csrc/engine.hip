@@ -56,11 +56,13 @@ struct mm_engine {
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
     // per distinct mask in that mask's active-pixels-first order whenever either changes
-    DevBuf lib_hwc, perm, inv_perm, cell_var;
+    DevBuf lib_hwc, perm, inv_perm, cell_var, cell_full, pos_mask, lib_lsum, cell_lsum;
     std::vector<uint8_t> masks_host;
     bool planes_dirty = true;
+    float lib_dmax = 50.0f, target_dmax = 50.0f;    // max |c0 - 50| over the library / the target
     int n_var = 0, var_of_mask[4] = {0, 0, 0, 0}, var_groups[4] = {0, 0, 0, 0};
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
+    int use_lds_filter = -1;     // mm_set_option("lds_filter", 0/1); -1 = auto (Euclid only: it is the L2-bound one)
     int max_batch_cells = 0;     // mm_set_option("max_batch", n): cap on cells per device batch (0 = from memory)
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
     int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
@@ -196,10 +198,12 @@ mm_status prepare_planes(mm_engine* e)
         e->var_of_mask[m] = v;
     }
     std::vector<int> perm((size_t)n_var * ppad, -1), inv((size_t)n_var * P, 0);
+    std::vector<uint8_t> pos_mask((size_t)n_var * ppad, 0);     // 1 on the plane positions holding active pixels
     for (int v = 0; v < n_var; ++v) {
         const uint8_t* mk = e->masks_host.data() + (size_t)first_mask_of_var[v] * P;
         int k = 0;
         for (int p = 0; p < P; ++p) if (mk[p] != 0) { perm[(size_t)v * ppad + k] = p; inv[(size_t)v * P + p] = k; ++k; }
+        for (int a = 0; a < k; ++a) pos_mask[(size_t)v * ppad + a] = 1;
         e->var_groups[v] = (k + 255) / 256;
         for (int p = 0; p < P; ++p) if (mk[p] == 0) { perm[(size_t)v * ppad + k] = p; inv[(size_t)v * P + p] = k; ++k; }
     }
@@ -211,8 +215,12 @@ mm_status prepare_planes(mm_engine* e)
         (st = ensure(e, e->inv_perm, inv.size() * sizeof(int), "Failed to allocate pixel order")) ||
         (st = ensure(e, e->lib, (size_t)n_var * L * 3 * ppad * sizeof(float), "Failed to allocate library planes")) ||
         (st = ensure(e, e->lib_chroma, (size_t)n_var * L * ppad * sizeof(float), "Failed to allocate library chroma planes")) ||
-        (st = ensure(e, e->lib_means, (size_t)L * 3 * sizeof(float), "Failed to allocate library means")))
+        (st = ensure(e, e->lib_means, (size_t)L * 3 * sizeof(float), "Failed to allocate library means")) ||
+        (st = ensure(e, e->pos_mask, pos_mask.size(), "Failed to allocate position masks")) ||
+        (st = ensure(e, e->lib_lsum, (size_t)n_var * L * (ppad / 256) * sizeof(float), "Failed to allocate group sums")))
         return st;
+    HIP_TRY(e, hipMemcpyAsync(e->pos_mask.p, pos_mask.data(), pos_mask.size(), hipMemcpyHostToDevice, e->stream),
+            "Failed to copy position masks to device");
     HIP_TRY(e, hipMemcpyAsync(e->perm.p, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, e->stream),
             "Failed to copy pixel order to device");
     HIP_TRY(e, hipMemcpyAsync(e->inv_perm.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice, e->stream),
@@ -223,12 +231,25 @@ mm_status prepare_planes(mm_engine* e)
             (const float*)e->lib_hwc.p, (float*)e->lib.p + (size_t)v * L * 3 * ppad, L, P, ppad,
             (const int*)e->perm.p + (size_t)v * ppad);
         HIP_TRY(e, hipGetLastError(), "Error during library plane kernel");
+        HIP_TRY(e, mm::launch_group_sums((const float*)e->lib.p + (size_t)v * L * 3 * ppad,
+                                         (const uint8_t*)e->pos_mask.p + (size_t)v * ppad, 0,
+                                         (float*)e->lib_lsum.p + (size_t)v * L * (ppad / 256), (size_t)L, ppad / 256,
+                                         ppad / 256, ppad, e->stream),
+                "Error during library group-sum kernel");
     }
     HIP_TRY(e, mm::launch_chroma_planes((const float*)e->lib.p, (float*)e->lib_chroma.p, (size_t)n_var * L, ppad, e->stream),
             "Error during library chroma kernel");
     HIP_TRY(e, mm::launch_image_means((const float*)e->lib.p, (float*)e->lib_means.p, L, P, ppad, e->stream),
             "Error during library mean kernel");
+    // range of the first channel (L for Lab inputs): bounds S_L for the filter's lightness bound
+    if ((st = ensure(e, e->counter, 2 * sizeof(unsigned long long), "Failed to allocate counter"))) return st;
+    HIP_TRY(e, hipMemsetAsync(e->counter.p, 0, sizeof(unsigned int), e->stream), "Failed to clear counter");
+    HIP_TRY(e, mm::launch_absmax_offset((const float*)e->lib.p, (size_t)L, (size_t)3 * ppad, ppad, 50.0f,
+                                        (unsigned int*)e->counter.p, e->stream), "Error during range kernel");
+    unsigned int bits = 0;
+    HIP_TRY(e, hipMemcpyAsync(&bits, e->counter.p, sizeof bits, hipMemcpyDeviceToHost, e->stream), "range");
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");   // host vectors go out of scope
+    memcpy(&e->lib_dmax, &bits, sizeof bits);
     e->planes_dirty = false;
     return MM_OK;
 }
@@ -241,6 +262,10 @@ mm::Variants variants_of(const mm_engine* e)
     v.lib_stride = (size_t)e->n_lib * 3 * ppad;
     v.chroma_stride = (size_t)e->n_lib * ppad;
     for (int i = 0; i < 4; ++i) v.groups[i] = e->var_groups[i];
+    v.lib_lsum = (const float*)e->lib_lsum.p;
+    v.cell_lsum = (const float*)e->cell_lsum.p;
+    v.cell_full = (const uint8_t*)e->cell_full.p;
+    v.lsum_stride = ppad / 256;
     return v;
 }
 
@@ -313,12 +338,13 @@ mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_typ
     const int cand_per_block = 16, cell_group = 512;
     mm_status stv = ensure(e, e->cell_var, (size_t)std::max(b, 1), "Failed to allocate cell variants");
     if (stv) return stv;
+    if ((stv = ensure(e, e->cell_full, (size_t)std::max(b, 1), "Failed to allocate cell flags"))) return stv;
     const mm::Variants var = variants_of(e);
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
         recs_dev, (const float*)e->target.p, e->cols, (const uint8_t*)e->masks.p,
         (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
-        (uint8_t*)e->cell_var.p);
+        (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p);
     HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
     if (after_gather) HIP_TRY(e, hipEventRecord(after_gather, e->stream), "event");
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
@@ -368,6 +394,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     if (e->max_batch_cells > 0) batch = std::min(batch, e->max_batch_cells);
     mm_status st;
     if ((st = ensure(e, e->cell_var, (size_t)batch, "Failed to allocate cell variants")) ||
+        (st = ensure(e, e->cell_full, (size_t)batch, "Failed to allocate cell flags")) ||
+        (st = ensure(e, e->cell_lsum, (size_t)batch * (ppad / 256) * sizeof(float), "Failed to allocate group sums")) ||
         (st = ensure(e, e->cells, (size_t)batch * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
         (st = ensure(e, e->cmask, (size_t)batch * ppad, "Failed to allocate cell masks")) ||
         (st = ensure(e, e->scores, (size_t)batch * L * sizeof(double), "Failed to allocate variants")))
@@ -380,7 +408,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             (st = ensure(e, e->cont_f, (size_t)batch * Kc * sizeof(float), "Failed to allocate contenders")) ||
             (st = ensure(e, e->cont_s, (size_t)batch * Kc * sizeof(double), "Failed to allocate contenders")) ||
             (st = ensure(e, e->flags, (size_t)batch, "Failed to allocate cell flags")) ||
-            (st = ensure(e, e->edge_count, sizeof(unsigned int), "Failed to allocate edge counter")) ||
+            (st = ensure(e, e->edge_count, 8 * sizeof(unsigned int), "Failed to allocate edge counter")) ||
             (st = ensure(e, e->edges, (size_t)edge_cap * sizeof(mm::EdgeEntry), "Failed to allocate edge list")))
             return st;
     }
@@ -396,6 +424,12 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.cell_chroma = (const float*)e->cell_chroma.p; fin.lib = (const float*)e->lib.p;
     fin.lib_chroma = (const float*)e->lib_chroma.p; fin.hue_lut = (const float4*)e->hue_lut.p;
     fin.var = variants_of(e);
+    fin.use_lds_form = e->use_lds_filter < 0 ? (diff_type != MM_CIEDE2000) : e->use_lds_filter;
+    {   // dE00 >= |dL| / S_L(max |L - 50|): S_L = 1 + 0.015 d^2 / sqrt(20 + d^2) grows with d (:138-139)
+        const double d = std::max(50.0, (double)std::max(e->lib_dmax, e->target_dmax));
+        const double s_l_max = 1.0 + 0.015 * d * d / std::sqrt(20.0 + d * d);
+        fin.lb_scale = std::isfinite(d) ? (float)((1.0 - 1e-5) / s_l_max) : 0.0f;
+    }
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     // Early exit needs seeds: K <= M <= 256 of them, and the L proxy distances in LDS.
     const int M = std::min(L, std::min(256, round_up(K + 22, 4)));
@@ -431,11 +465,15 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
             recs_dev + done, (const float*)e->target.p, e->cols, (const uint8_t*)e->masks.p,
             (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
-            (uint8_t*)e->cell_var.p);
+            (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p);
         HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
-        if (diff_type == MM_CIEDE2000)
+        if (diff_type == MM_CIEDE2000) {
             HIP_TRY(e, mm::launch_chroma_planes((const float*)e->cells.p, (float*)e->cell_chroma.p, (size_t)b, ppad, e->stream),
                     "Error during cell chroma kernel");
+            HIP_TRY(e, mm::launch_group_sums((const float*)e->cells.p, (const uint8_t*)e->cmask.p, (size_t)ppad,
+                                             (float*)e->cell_lsum.p, (size_t)b, ppad / 256, ppad / 256, ppad, e->stream),
+                    "Error during cell group-sum kernel");
+        }
         HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
 
         // tier 1: fp32 filter score of every (cell, candidate), with early exit against a
@@ -720,7 +758,7 @@ void mm_destroy(mm_engine* e)
                        &e->dense_recs, &e->dense_i, &e->dense_s, &e->lib_means, &e->seeds,
                        &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
                        &e->hue_lut, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
-                       &e->cell_var })
+                       &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -780,6 +818,14 @@ mm_status mm_set_target(mm_engine* e, const float* image, int rows, int cols)
     mm_status st = ensure(e, e->target, bytes, "Failed to allocate main image");
     if (st) return st;
     HIP_TRY(e, hipMemcpy(e->target.p, image, bytes, hipMemcpyHostToDevice), "Failed to copy main image to device");
+    if ((st = ensure(e, e->counter, 2 * sizeof(unsigned long long), "Failed to allocate counter"))) return st;
+    HIP_TRY(e, hipMemsetAsync(e->counter.p, 0, sizeof(unsigned int), e->stream), "Failed to clear counter");
+    HIP_TRY(e, mm::launch_absmax_offset((const float*)e->target.p, (size_t)rows * cols, 3, 1, 50.0f,
+                                        (unsigned int*)e->counter.p, e->stream), "Error during range kernel");
+    unsigned int bits = 0;
+    HIP_TRY(e, hipMemcpyAsync(&bits, e->counter.p, sizeof bits, hipMemcpyDeviceToHost, e->stream), "range");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    memcpy(&e->target_dmax, &bits, sizeof bits);
     e->rows = rows;
     e->cols = cols;
     return MM_OK;
@@ -1006,6 +1052,17 @@ mm_status mm_build_photomosaic(mm_engine* e, const mm_cell* cells, int n_cells, 
     return MM_OK;
 }
 
+// Diagnostics (builds with -DMM_COUNT_VISITS only fill them): pixel groups visited by the
+// filter kernel, groups a full visit would take, candidates dropped by the lightness bound.
+mm_status mm_debug_visit_counters(mm_engine* e, unsigned long long out[3])
+{
+    if (!e || !out || !e->edge_count.p) return MM_INVALID_ARGUMENT;
+    unsigned int raw[8] = {0};
+    HIP_TRY(e, hipMemcpy(raw, e->edge_count.p, sizeof raw, hipMemcpyDeviceToHost), "counters");
+    memcpy(out, raw + 2, 3 * sizeof(unsigned long long));
+    return MM_OK;
+}
+
 mm_status mm_set_option(mm_engine* e, const char* name, int value)
 {
     if (!e || !name) return MM_INVALID_ARGUMENT;
@@ -1013,6 +1070,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "prune") == 0) { e->use_prune = value != 0; return MM_OK; }
     if (strcmp(name, "wave_resolve") == 0) { e->use_wave_resolve = value != 0; return MM_OK; }
     if (strcmp(name, "row_pipeline") == 0) { e->use_row_pipeline = value != 0; return MM_OK; }
+    if (strcmp(name, "lds_filter") == 0) { e->use_lds_filter = value < 0 ? -1 : (value != 0); return MM_OK; }
     if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);
     return MM_INVALID_ARGUMENT;

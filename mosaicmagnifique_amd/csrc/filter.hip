@@ -26,6 +26,33 @@ __device__ __forceinline__ float wave_sum_f(float v)
     return v;
 }
 
+// Wave-wide sum with DPP row rotations (no LDS crossbar): every lane of a 16-lane row
+// gets the row total after 4 rotate-adds, the 4 row totals are read with v_readlane.
+// ~11 short-latency instructions; used for the per-group exit test.  Uniform result.
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    auto ror = [](float x, const int ctrl_tag) {
+        int r;
+        switch (ctrl_tag) {
+        case 8: r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false); break;
+        case 4: r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false); break;
+        case 2: r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false); break;
+        default: r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false); break;
+        }
+        return __builtin_bit_cast(float, r);
+    };
+    v += ror(v, 8);
+    v += ror(v, 4);
+    v += ror(v, 2);
+    v += ror(v, 1);
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // One pair through the fp32 form.  For CIEDE2000 `edge` reports a pair on the
 // opposite-hue discontinuity (colour_diff_fast.hpp): the filter kernel logs it and
 // edge_fix_kernel later replaces its fp32 term by the fp64 one.  cp, cq = chroma of
@@ -49,6 +76,18 @@ __device__ __forceinline__ void load_hue_lut(float4* lds, const float4* __restri
     __syncthreads();
 }
 
+struct LibGroup { float4 q0, q1, q2, qc; };
+
+template <int TYPE>
+__device__ __forceinline__ LibGroup load_lib_group(const float4* b0, const float4* b1, const float4* b2,
+                                                   const float4* bc, int q)
+{
+    LibGroup g;
+    g.q0 = b0[q]; g.q1 = b1[q]; g.q2 = b2[q];
+    if constexpr (TYPE == CIEDE2000) g.qc = bc[q]; else g.qc = float4{0.f, 0.f, 0.f, 0.f};
+    return g;
+}
+
 // Same work decomposition as score_kernel (kernels.hpp): one wave per
 // (cell, candidate), lanes over float4 pixel groups, 4 waves = 4 candidates of
 // one cell; cells fastest within a group so resident workgroups share library tiles.
@@ -60,10 +99,12 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
               int n_cells, int L, int ppad, int cand_per_block, int cell_group,
               EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
               unsigned int edge_cap, const float* __restrict__ prune_above, int check_every,
-              const float4* __restrict__ hue_lut, Variants var)
+              const float4* __restrict__ hue_lut, Variants var, float lb_scale)
 {
     __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
-    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
+    __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
+    if (threadIdx.x == 0) next_candidate = kBlock / kWave;
+    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut); else __syncthreads();
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long bid = blockIdx.x;
     const long long per_group = (long long)cell_group * n_tiles;
@@ -88,49 +129,250 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
     // Early exit, the device form of the reference's `variant < bestVariant` loop guards
     // (CPUPhotomosaicGenerator.cpp:149,153): every term is >= 0, so once the running
     // sum of a candidate exceeds `limit` -- an upper bound on the score a contender of
-    // this cell can have (prune_kernel) -- the candidate cannot be one and gets +inf.
+    // this cell can have (prune_limit_kernel) -- the candidate cannot be one and gets +inf.
     // The test is wave-uniform: one wave owns the whole candidate.
+    //
+    // CIEDE2000 exits earlier still, through a lower bound on the pixels NOT yet visited:
+    //   dE00^2 = tL^2 + (tC^2 + tH^2 + R_T tC tH) >= tL^2      (|R_T| < 2, :145,:153-157)
+    //   tL = dL / S_L,  S_L <= S_L(max |L - 50| over library and target) =: S_max
+    // so dE00 >= |dL| / S_max, and for a 256-pixel group g of the plane order
+    //   sum_{p in g} |L_cell - L_lib|  >=  | sum_{p in g} L_cell  -  sum_{p in g} L_lib |,
+    // which needs only ONE precomputed number per image and group (lsum planes) -- no pass
+    // over the pixels.  Lane g holds group g's bound; a suffix scan turns it into "bound
+    // of groups >= j".  The candidate is dropped once
+    //   (trusted partial sum of groups < j) + (bound of groups >= j) > limit.
+    // Valid only for cells whose active set is the whole mask (unclipped): the library's
+    // group sums are over the mask's pixels.  Clipped cells use the plain partial-sum exit.
+    // Terms of pairs flagged for the fp64 patch (hue discontinuity) are summed apart and
+    // never enter the exit test: only terms with a proven error bound may prune.
     const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
+    bool use_lb = false;
+    float cell_ls = 0.0f;
+    if constexpr (TYPE == CIEDE2000) {
+        use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;
+        if (use_lb && lane < groups) cell_ls = var.cell_lsum[(size_t)cell * var.lsum_stride + lane];
+    }
 
-    const int l_end = min((tile + 1) * cand_per_block, L);
-    for (int l = tile * cand_per_block + wave; l < l_end; l += kBlock / kWave) {
+    const int l_base = tile * cand_per_block;
+    const int n_here = min(cand_per_block, L - l_base);
+    for (int idx = wave; idx < n_here;) {
+        const int l = l_base + idx;
+        {   // the next candidate of this tile not yet taken by any wave
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(&next_candidate, 1);
+            idx = __shfl(nxt, 0, kWave);
+        }
         const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
         const float4* b1 = b0 + ppad / 4;
         const float4* b2 = b1 + ppad / 4;
         const float4* bc = reinterpret_cast<const float4*>(lib_chroma + (size_t)l * ppad);
-        float acc = 0.0f;
         bool pruned = false;
-        for (int j = 0; j < groups; ++j) {
-            if (j != 0 && j % check_every == 0 && wave_sum_f(acc) > limit) { pruned = true; break; }
-            const int q = lane + kWave * j;
-            const uint32_t m = mk[q];
-            if (m == 0) continue;
-            const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
-            const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
-            float4 pc{0.f, 0.f, 0.f, 0.f}, qc{0.f, 0.f, 0.f, 0.f};
-            if constexpr (TYPE == CIEDE2000) { pc = cc[q]; qc = bc[q]; }
-            bool e0, e1, e2, e3;
-            const float v0 = pair_fast<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
-            const float v1 = pair_fast<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
-            const float v2 = pair_fast<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
-            const float v3 = pair_fast<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
-            acc += ((m & 0x000000ffu) ? v0 : 0.0f) + ((m & 0x0000ff00u) ? v1 : 0.0f)
-                 + ((m & 0x00ff0000u) ? v2 : 0.0f) + ((m & 0xff000000u) ? v3 : 0.0f);
-            if constexpr (TYPE == CIEDE2000) {
-                const uint32_t em = (e0 ? 0x000000ffu : 0u) | (e1 ? 0x0000ff00u : 0u) |
-                                   (e2 ? 0x00ff0000u : 0u) | (e3 ? 0xff000000u : 0u);
-                if (em & m) {                               // rare: ~1e-5 of pairs
-                    for (int k = 0; k < 4; ++k)
-                        if ((em & m) >> (8 * k) & 0xffu) {
-                            const unsigned int slot = atomicAdd(edge_count, 1u);
-                            if (slot < edge_cap) edges[slot] = EdgeEntry{cell, l, 4 * q + k};
-                        }
+        float rest = 0.0f;                 // lane j: lightness bound of groups >= j
+        if constexpr (TYPE == CIEDE2000) {
+            if (use_lb) {
+                float d = 0.0f;
+                if (lane < groups) {
+                    const float ls = var.lib_lsum[((size_t)v * L + l) * var.lsum_stride + lane];
+                    // 1e-2: fp32 rounding of two 256-term sums of values <= ~100, with margin
+                    d = fmaxf(fabsf(cell_ls - ls) - 1e-2f, 0.0f) * lb_scale;
+                }
+                // inclusive suffix scan over lanes (lane j <- sum of lanes >= j)
+                for (int off = 1; off < kWave; off <<= 1) {
+                    const float up = __shfl_down(d, off, kWave);
+                    if (lane + off < kWave) d += up;
+                }
+                rest = d;
+                pruned = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), 0)) > limit;
+            }
+        }
+        float acc = 0.0f;          // terms with a proven error bound
+        float acc_edge = 0.0f;     // terms awaiting the fp64 patch
+#ifdef MM_COUNT_VISITS
+        int visited = 0;
+#endif
+        if (!pruned && groups > 0) {
+            LibGroup nxt = load_lib_group<TYPE>(b0, b1, b2, bc, lane);
+            for (int j = 0; j < groups; ++j) {
+                if (j != 0 && j % check_every == 0) {
+                    const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), j)) : 0.0f;
+                    if (wave_sum_dpp(acc) + rest_j > limit) { pruned = true; break; }
+                }
+                const int q = lane + kWave * j;
+                const LibGroup cur = nxt;
+                if (j + 1 < groups) nxt = load_lib_group<TYPE>(b0, b1, b2, bc, q + kWave);   // one group ahead
+                const uint32_t m = mk[q];
+#ifdef MM_COUNT_VISITS
+                visited += 1;
+#endif
+                if (m == 0) continue;
+                const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
+                float4 pc{0.f, 0.f, 0.f, 0.f};
+                if constexpr (TYPE == CIEDE2000) pc = cc[q];
+                const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, qc = cur.qc;
+                bool e0, e1, e2, e3;
+                const float v0 = pair_fast<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
+                const float v1 = pair_fast<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
+                const float v2 = pair_fast<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
+                const float v3 = pair_fast<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
+                const bool a0 = m & 0x000000ffu, a1 = m & 0x0000ff00u, a2 = m & 0x00ff0000u, a3 = m & 0xff000000u;
+                if constexpr (TYPE == CIEDE2000) {
+                    acc += ((a0 && !e0) ? v0 : 0.0f) + ((a1 && !e1) ? v1 : 0.0f)
+                         + ((a2 && !e2) ? v2 : 0.0f) + ((a3 && !e3) ? v3 : 0.0f);
+                    const uint32_t em = (e0 ? 0x000000ffu : 0u) | (e1 ? 0x0000ff00u : 0u) |
+                                       (e2 ? 0x00ff0000u : 0u) | (e3 ? 0xff000000u : 0u);
+                    if (em & m) {                               // rare: ~1e-5 of pairs
+                        acc_edge += ((a0 && e0) ? v0 : 0.0f) + ((a1 && e1) ? v1 : 0.0f)
+                                  + ((a2 && e2) ? v2 : 0.0f) + ((a3 && e3) ? v3 : 0.0f);
+                        for (int k = 0; k < 4; ++k)
+                            if ((em & m) >> (8 * k) & 0xffu) {
+                                const unsigned int slot = atomicAdd(edge_count, 1u);
+                                if (slot < edge_cap) edges[slot] = EdgeEntry{cell, l, 4 * q + k};
+                            }
+                    }
+                } else {
+                    acc += (a0 ? v0 : 0.0f) + (a1 ? v1 : 0.0f) + (a2 ? v2 : 0.0f) + (a3 ? v3 : 0.0f);
                 }
             }
         }
-        acc = wave_sum_f(acc);
+#ifdef MM_COUNT_VISITS
+        if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(edge_count + 2), (unsigned long long)visited);
+                         atomicAdd(reinterpret_cast<unsigned long long*>(edge_count + 4), (unsigned long long)groups);
+                         if (pruned && visited == 0) atomicAdd(reinterpret_cast<unsigned long long*>(edge_count + 6), 1ull); }
+#endif
+        acc = wave_sum_f(acc + acc_edge);
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }
+}
+
+// LDS-resident form of filter_kernel: a 1024-thread workgroup (16 waves) stages ONE cell
+// -- its three colour planes, chroma plane and mask, only the groups holding active
+// pixels -- in LDS once, then each wave walks its share of a 64-candidate tile against
+// it.  Global loads are then the library planes only (16 B per pixel pair instead of 33 B
+// with the cell coming back from L2 for every candidate), and each library group is
+// fetched one iteration ahead of its use.  Same arithmetic, same exits, same results as
+// filter_kernel; used whenever the cell fits LDS beside the hue table.
+constexpr int kLdsBlock = 1024;
+
+template <int TYPE>
+__global__ void __launch_bounds__(kLdsBlock)
+filter_lds_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
+                  const float* __restrict__ cell_chroma, const float* __restrict__ lib,
+                  const float* __restrict__ lib_chroma, float* __restrict__ scores,
+                  int n_cells, int L, int ppad, int cand_per_block, int cell_group,
+                  EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
+                  unsigned int edge_cap, const float* __restrict__ prune_above,
+                  const float4* __restrict__ hue_lut, Variants var, float lb_scale)
+{
+    extern __shared__ float4 smem[];
+    float4* lut = smem;                                             // [kHueLutSize + 1] (CIEDE2000)
+    float4* s0 = smem + (TYPE == CIEDE2000 ? kHueLutSize + 1 : 0);  // cell planes, ppad/4 float4 each
+    const int pq = ppad / 4;
+    float4* s1 = s0 + pq;
+    float4* s2 = s1 + pq;
+    float4* sc = s2 + pq;
+    uint32_t* sm = reinterpret_cast<uint32_t*>(sc + (TYPE == CIEDE2000 ? pq : 0));
+
+    const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
+    const long long bid = blockIdx.x;
+    const long long per_group = (long long)cell_group * n_tiles;
+    const int group = (int)(bid / per_group);
+    const long long rem = bid - (long long)group * per_group;
+    const int cells_here = min(cell_group, n_cells - group * cell_group);
+    const int tile = (int)(rem / cells_here);
+    const int cell = group * cell_group + (int)(rem - (long long)tile * cells_here);
+    if (tile >= n_tiles || cell >= n_cells) return;           // whole workgroup: uniform
+
+    const int v = var.cell_var[cell];
+    const int groups = var.groups[v];
+    lib += (size_t)v * var.lib_stride;
+    lib_chroma += (size_t)v * var.chroma_stride;
+
+    // stage the hue table and the cell (active groups only)
+    if constexpr (TYPE == CIEDE2000)
+        for (int i = threadIdx.x; i <= kHueLutSize; i += kLdsBlock) lut[i] = hue_lut[i];
+    {
+        const float4* g0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
+        const float4* gc = reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
+        const uint32_t* gm = reinterpret_cast<const uint32_t*>(cmask + (size_t)cell * ppad);
+        const int nq = groups * kWave;
+        for (int q = threadIdx.x; q < nq; q += kLdsBlock) {
+            s0[q] = g0[q];
+            s1[q] = g0[pq + q];
+            s2[q] = g0[2 * pq + q];
+            if constexpr (TYPE == CIEDE2000) sc[q] = gc[q];
+            sm[q] = gm[q];
+        }
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
+    const int l_end = min((tile + 1) * cand_per_block, L);
+    for (int l = tile * cand_per_block + wave; l < l_end; l += kLdsBlock / kWave) {
+        const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
+        const float4* b1 = b0 + pq;
+        const float4* b2 = b1 + pq;
+        const float4* bc = reinterpret_cast<const float4*>(lib_chroma + (size_t)l * ppad);
+        bool pruned = false;
+        float acc = 0.0f, acc_edge = 0.0f;
+        if (groups > 0) {
+            LibGroup nxt = load_lib_group<TYPE>(b0, b1, b2, bc, lane);
+            for (int j = 0; j < groups; ++j) {
+                if (j != 0 && wave_sum_dpp(acc) > limit) { pruned = true; break; }
+                const int q = lane + kWave * j;
+                const LibGroup cur = nxt;
+                if (j + 1 < groups) nxt = load_lib_group<TYPE>(b0, b1, b2, bc, q + kWave);   // one group ahead
+                const uint32_t m = sm[q];
+                if (m == 0) continue;
+                const float4 p0 = s0[q], p1 = s1[q], p2 = s2[q];
+                float4 pc{0.f, 0.f, 0.f, 0.f};
+                if constexpr (TYPE == CIEDE2000) pc = sc[q];
+                const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, qc = cur.qc;
+                bool e0, e1, e2, e3;
+                const float v0 = pair_fast<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
+                const float v1 = pair_fast<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
+                const float v2 = pair_fast<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
+                const float v3 = pair_fast<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
+                const bool a0 = m & 0x000000ffu, a1 = m & 0x0000ff00u, a2 = m & 0x00ff0000u, a3 = m & 0xff000000u;
+                if constexpr (TYPE == CIEDE2000) {
+                    acc += ((a0 && !e0) ? v0 : 0.0f) + ((a1 && !e1) ? v1 : 0.0f)
+                         + ((a2 && !e2) ? v2 : 0.0f) + ((a3 && !e3) ? v3 : 0.0f);
+                    const uint32_t em = (e0 ? 0x000000ffu : 0u) | (e1 ? 0x0000ff00u : 0u) |
+                                       (e2 ? 0x00ff0000u : 0u) | (e3 ? 0xff000000u : 0u);
+                    if (em & m) {
+                        acc_edge += ((a0 && e0) ? v0 : 0.0f) + ((a1 && e1) ? v1 : 0.0f)
+                                  + ((a2 && e2) ? v2 : 0.0f) + ((a3 && e3) ? v3 : 0.0f);
+                        for (int k = 0; k < 4; ++k)
+                            if ((em & m) >> (8 * k) & 0xffu) {
+                                const unsigned int slot = atomicAdd(edge_count, 1u);
+                                if (slot < edge_cap) edges[slot] = EdgeEntry{cell, l, 4 * q + k};
+                            }
+                    }
+                } else {
+                    acc += (a0 ? v0 : 0.0f) + (a1 ? v1 : 0.0f) + (a2 ? v2 : 0.0f) + (a3 ? v3 : 0.0f);
+                }
+            }
+        }
+        acc = wave_sum_f(acc + acc_edge);
+        if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
+    }
+}
+
+// max over i < n_outer, k < n_inner of |x[i*outer_stride + k] - offset|, as float bits (>= 0, so
+// unsigned compare = float compare).  Used for max |L - 50| of the library / target.
+__global__ void __launch_bounds__(kBlock)
+absmax_offset_kernel(const float* __restrict__ x, size_t n_outer, size_t outer_stride, int n_inner,
+                     float offset, unsigned int* __restrict__ out_bits)
+{
+    float m = 0.0f;
+    const size_t total = n_outer * (size_t)n_inner;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const size_t i = t / n_inner;
+        const float d = fabsf(x[i * outer_stride + (t - i * n_inner)] - offset);
+        m = d > m ? d : m;               // NaN never raises the maximum
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
 }
 
 // One pair for the seed scores: fp32 form, with the fp64 form taken inline on the
@@ -210,6 +452,28 @@ chroma_planes_kernel(const float* __restrict__ planar, float* __restrict__ chrom
         reinterpret_cast<float4*>(chroma + img * (size_t)ppad)[q] =
             float4{chroma_of(a.x, b.x), chroma_of(a.y, b.y), chroma_of(a.z, b.z), chroma_of(a.w, b.w)};
     }
+}
+
+// First-channel sums over each 256-position group of the plane order, counting only the
+// positions flagged in `mask` (per image if mask_stride != 0, else shared):
+//   lsum[img][g] = sum_{k in [256 g, 256 g + 256), mask[k] != 0} planar[img][0][k]
+// One wave per (image, group).  Feeds the lightness bound of filter_kernel.
+__global__ void __launch_bounds__(kBlock)
+group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ mask, size_t mask_stride,
+                  float* __restrict__ lsum, size_t n_images, int n_groups, int lsum_stride, int ppad)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t w = (size_t)blockIdx.x * (kBlock / kWave) + wave;
+    if (w >= n_images * (size_t)n_groups) return;
+    const size_t img = w / n_groups;
+    const int g = (int)(w - img * n_groups);
+    const int q = g * kWave + lane;
+    const float4 x = reinterpret_cast<const float4*>(planar + img * 3 * (size_t)ppad)[q];
+    const uint32_t m = reinterpret_cast<const uint32_t*>(mask + img * mask_stride)[q];
+    float s = ((m & 0x000000ffu) ? x.x : 0.0f) + ((m & 0x0000ff00u) ? x.y : 0.0f)
+            + ((m & 0x00ff0000u) ? x.z : 0.0f) + ((m & 0xff000000u) ? x.w : 0.0f);
+    s = wave_sum_f(s);
+    if (lane == 0) lsum[img * lsum_stride + g] = s;
 }
 
 // Mean colour of every library image (over all pixels), f32 [L][3]: a proxy used only
@@ -384,26 +648,74 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream)
 {
-    const int cand_per_block = 16, cell_group = 512;
+    const int cand_per_block = 64, cell_group = 512;
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long blocks = (long long)n_cells * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
     const int check_every = groups > 16 ? groups / 16 : 1;
-    hipError_t code = hipMemsetAsync(edge_count, 0, sizeof(unsigned int), stream);
+    hipError_t code = hipMemsetAsync(edge_count, 0, 8 * sizeof(unsigned int), stream);   // + diagnostics counters
     if (code != hipSuccess) return code;
+    // LDS-resident form when the cell (4 planes + mask) fits beside the hue table
+    const size_t lds_bytes = (type == CIEDE2000 ? (size_t)(kHueLutSize + 1) * 16 + (size_t)ppad * 16 : (size_t)ppad * 12) +
+                             (size_t)ppad;
+    if (in.use_lds_form && lds_bytes <= 156 * 1024) {
+        const int cpb = 64;
+        const long long tiles = (L + cpb - 1) / cpb;
+        const long long nblk = (long long)n_cells * tiles;
+        if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+        if (type == CIEDE2000) {
+            auto kern = filter_lds_kernel<CIEDE2000>;
+            if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds_bytes)) != hipSuccess) return code;
+            kern<<<dim3((unsigned)nblk), kLdsBlock, lds_bytes, stream>>>(
+                in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
+                edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, in.lb_scale);
+            if ((code = hipGetLastError()) != hipSuccess) return code;
+            edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
+                                                         edges, edge_count, edge_cap, in.hue_lut, in.var);
+        } else {
+            auto kern = filter_lds_kernel<RGB_EUCLIDEAN>;
+            if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds_bytes)) != hipSuccess) return code;
+            kern<<<dim3((unsigned)nblk), kLdsBlock, lds_bytes, stream>>>(
+                in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
+                edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, in.lb_scale);
+        }
+        return hipGetLastError();
+    }
     if (type == CIEDE2000) {
         filter_kernel<CIEDE2000><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
             in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var);
+            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
     } else {
         filter_kernel<RGB_EUCLIDEAN><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
             in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var);
+            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* lsum,
+                             size_t n_images, int n_groups, int lsum_stride, int ppad, hipStream_t stream)
+{
+    const size_t waves = n_images * (size_t)n_groups;
+    if (waves == 0) return hipSuccess;
+    group_sums_kernel<<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, lsum, n_images,
+                                                                        n_groups, lsum_stride, ppad);
+    return hipGetLastError();
+}
+
+hipError_t launch_absmax_offset(const float* x, size_t n_outer, size_t outer_stride, int n_inner, float offset,
+                                unsigned int* out_bits, hipStream_t stream)
+{
+    const size_t total = n_outer * (size_t)n_inner;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 4096);
+    if (blocks == 0) return hipSuccess;
+    absmax_offset_kernel<<<blocks, kBlock, 0, stream>>>(x, n_outer, outer_stride, n_inner, offset, out_bits);
     return hipGetLastError();
 }
 

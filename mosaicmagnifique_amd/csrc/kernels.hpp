@@ -112,13 +112,17 @@ gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ 
                     int cols, const uint8_t* __restrict__ masks,
                     float* __restrict__ cells, uint8_t* __restrict__ cmask,
                     int size, int P, int ppad, const int* __restrict__ perm, int4 var_of_mask,
-                    uint8_t* __restrict__ cell_var)
+                    uint8_t* __restrict__ cell_var, uint8_t* __restrict__ cell_full)
 {
     const mm_cell rec = recs[blockIdx.y];
     const int vm[4] = {var_of_mask.x, var_of_mask.y, var_of_mask.z, var_of_mask.w};
     const int v = vm[rec.mask_id];
     const int k = blockIdx.x * kBlock + threadIdx.x;     // position in the variant's pixel order
-    if (k == 0) cell_var[blockIdx.y] = (uint8_t)v;
+    if (k == 0) {
+        cell_var[blockIdx.y] = (uint8_t)v;
+        // not clipped: the local bound is the whole cell, so the active set is the mask itself
+        cell_full[blockIdx.y] = rec.row_min == 0 && rec.col_min == 0 && rec.row_max == size && rec.col_max == size;
+    }
     if (k >= ppad) return;
     const int p = perm[(size_t)v * ppad + k];            // original pixel, < 0 = padding
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;

@@ -21,6 +21,12 @@ struct Variants {
     size_t lib_stride;          // floats between the planar libraries of two variants (L*3*ppad)
     size_t chroma_stride;       // floats between their chroma planes (L*ppad)
     int groups[4];
+    // lightness bound of the filter's early exit (filter.hip): first-channel sums per
+    // 256-position group, over the mask's active positions
+    const float* lib_lsum;      // [V][L][lsum_stride]
+    const float* cell_lsum;     // [B][lsum_stride]
+    const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask (not clipped)
+    int lsum_stride;
 };
 
 // Device inputs of the fp32 filter kernels.
@@ -32,6 +38,8 @@ struct FilterInputs {
     const float* lib;           // f32 planar [L][3][ppad]
     const float* lib_chroma;    // f32 [L][ppad]
     const float4* hue_lut;      // [kHueLutSize + 1] {T, dT, sin(2 d_theta), d}  (colour_diff_fast.hpp)
+    float lb_scale;             // slightly under 1 / S_L,max: dE00 >= |dL| * lb_scale (filter.hip)
+    int use_lds_form;           // 1: cell tile staged in LDS by 1024-thread workgroups when it fits
 };
 
 // Tier-1 filter scores f32 [n_cells][L] (see filter.hip).  Pairs on the discontinuity
@@ -42,6 +50,15 @@ struct FilterInputs {
 hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream);
+
+// lsum[img][g] = masked sum of channel 0 over plane positions [256 g, 256 g + 256).
+hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* lsum,
+                             size_t n_images, int n_groups, int lsum_stride, int ppad, hipStream_t stream);
+
+// max |x - offset| over a strided set, written with atomicMax as float bits into *out_bits
+// (zero it first).
+hipError_t launch_absmax_offset(const float* x, size_t n_outer, size_t outer_stride, int n_inner, float offset,
+                                unsigned int* out_bits, hipStream_t stream);
 
 // Chroma planes of n planar images: [n][3][ppad] -> [n][ppad].
 hipError_t launch_chroma_planes(const float* planar, float* chroma, size_t n_images, int ppad, hipStream_t stream);

@@ -74,6 +74,11 @@ def run_both(oracle, engine, shape, img, lib, t, rep=(0, 0)):
     engine.set_option("prune", 0)
     bestn, scoren = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
     engine.set_option("prune", 1)
+    for lds in (0, 1):                                       # filter kernel without / with the LDS cell tile
+        engine.set_option("lds_filter", lds)
+        bestg, scoreg = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+        assert np.array_equal(bestg, bestn) and np.array_equal(scoreg[state >= 0], scoren[state >= 0])
+    engine.set_option("lds_filter", -1)
     best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
     tm = engine.timing()
     assert np.array_equal(best, bestn) and np.array_equal(score[state >= 0], scoren[state >= 0])
