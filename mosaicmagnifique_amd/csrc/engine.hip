@@ -63,6 +63,7 @@ struct mm_engine {
     int n_var = 0, var_of_mask[4] = {0, 0, 0, 0}, var_groups[4] = {0, 0, 0, 0};
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
     int use_lds_filter = -1;     // mm_set_option("lds_filter", 0/1); -1 = auto (Euclid only: it is the L2-bound one)
+    int tile_candidates = 0;     // mm_set_option("tile", n): candidates per filter workgroup (0 = default)
     int max_batch_cells = 0;     // mm_set_option("max_batch", n): cap on cells per device batch (0 = from memory)
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
     int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
@@ -424,6 +425,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.cell_chroma = (const float*)e->cell_chroma.p; fin.lib = (const float*)e->lib.p;
     fin.lib_chroma = (const float*)e->lib_chroma.p; fin.hue_lut = (const float4*)e->hue_lut.p;
     fin.var = variants_of(e);
+    fin.tile_candidates = e->tile_candidates;
     fin.use_lds_form = e->use_lds_filter < 0 ? (diff_type != MM_CIEDE2000) : e->use_lds_filter;
     {   // dE00 >= |dL| / S_L(max |L - 50|): S_L = 1 + 0.015 d^2 / sqrt(20 + d^2) grows with d (:138-139)
         const double d = std::max(50.0, (double)std::max(e->lib_dmax, e->target_dmax));
@@ -1071,6 +1073,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "wave_resolve") == 0) { e->use_wave_resolve = value != 0; return MM_OK; }
     if (strcmp(name, "row_pipeline") == 0) { e->use_row_pipeline = value != 0; return MM_OK; }
     if (strcmp(name, "lds_filter") == 0) { e->use_lds_filter = value < 0 ? -1 : (value != 0); return MM_OK; }
+    if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }
     if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);
     return MM_INVALID_ARGUMENT;

@@ -648,7 +648,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream)
 {
-    const int cand_per_block = 64, cell_group = 512;
+    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : 32, cell_group = 512;
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long blocks = (long long)n_cells * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
