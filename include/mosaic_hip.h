@@ -91,6 +91,8 @@ typedef struct mm_timing {
     int64_t edge_pairs;       /* pixel pairs on the CIEDE2000 hue discontinuity patched in fp64 */
     double seed_ms;           /* seeds + pruning limits ahead of the filter pass */
     double build_ms;          /* mm_build_photomosaic: owner map + compose kernels */
+    int64_t spec_rounds;      /* resolve passes of the speculate-and-verify loop (1 = no cell needed deepening) */
+    int64_t deepened_cells;   /* cells whose short candidate list had to be extended to the full length */
 } mm_timing;
 
 /* Progress: called on the calling thread between device batches with
@@ -162,6 +164,25 @@ mm_status mm_score_cells(mm_engine *e, const mm_cell *cells, int n_cells,
                          int outputs_on_device,
                          mm_progress_cb progress, void *progress_user,
                          volatile int *cancel);
+/* Speculative short lists.  With a repeat penalty, mm_candidates_per_cell is a worst-case
+ * bound that is almost never needed.  mm_speculative_candidates gives the length K_s of the
+ * short lists worth scoring first (= the full length when speculation does not pay; spec_k
+ * 0 = off, 10 = the engine's default).  mm_score_cells_partial fills only the first k_fill
+ * entries of k-wide rows.  mm_resolve_verify resolves rows of which deep[c] != 0 hold the
+ * full length and the others k_fill entries, and reports in insufficient_out[c] the cells
+ * whose pick it could not prove right (an unlisted candidate has a base score >= the list's
+ * last one and a penalty >= 0): re-score those with the full length, mark them deep, resolve
+ * again.  mm_generate runs this loop itself. */
+int mm_speculative_candidates(int n_images, int repeat_range, int repeat_addition, int spec_k);
+mm_status mm_score_cells_partial(mm_engine *e, const mm_cell *cells, int n_cells, int diff_type, int k, int k_fill,
+                                 int32_t *cand_index_out, double *cand_score_out, int outputs_on_device,
+                                 mm_progress_cb progress, void *progress_user, volatile int *cancel);
+mm_status mm_resolve_verify(mm_engine *e, const mm_cell *cells, int n_cells, int grid_w, int grid_h, int diff_type,
+                            int repeat_range, int repeat_addition, int k, int k_fill,
+                            const int32_t *cand_index, const double *cand_score, int inputs_on_device,
+                            const uint8_t *deep, uint8_t *insufficient_out,
+                            int64_t *best_fit_out, double *best_score_out);
+
 /* cells = ALL valid cells of the grid in raster order with their candidate lists. */
 mm_status mm_resolve(mm_engine *e, const mm_cell *cells, int n_cells,
                      int grid_w, int grid_h, int diff_type,
@@ -190,8 +211,9 @@ mm_status mm_build_photomosaic(mm_engine *e, const mm_cell *cells, int n_cells, 
  * abandons a candidate once its running sum passes a per-cell upper bound (the device
  * form of the reference's early exit).  "wave_resolve" / "row_pipeline" (default 1): the
  * single-wave and the row-pipelined forms of the resolve.  "max_batch" (default 0 = sized
- * from free device memory): cap on the cells scored per device batch.  Results are identical
- * whatever the options. */
+ * from free device memory): cap on the cells scored per device batch.  "spec_k" (default 10):
+ * length of mm_generate's speculative short lists, 0 = always the full length.  Results are
+ * identical whatever the options. */
 mm_status mm_set_option(mm_engine *e, const char *name, int value);
 
 /* Timings of the last mm_generate / mm_score_cells (+ mm_resolve) on e. */

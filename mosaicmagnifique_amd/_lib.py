@@ -26,7 +26,8 @@ class MMTiming(ctypes.Structure):
                 ("pair_evals", ctypes.c_int64), ("exact_rescored", ctypes.c_int64),
                 ("dense_rows", ctypes.c_int64), ("rescore_ms", ctypes.c_double),
                 ("dense_cells", ctypes.c_int64), ("edge_pairs", ctypes.c_int64),
-                ("seed_ms", ctypes.c_double), ("build_ms", ctypes.c_double)]
+                ("seed_ms", ctypes.c_double), ("build_ms", ctypes.c_double),
+                ("spec_rounds", ctypes.c_int64), ("deepened_cells", ctypes.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -54,6 +55,12 @@ SIGNATURES = {
     "mm_candidates_per_cell": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mm_score_cells": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP,
                                       ctypes.c_int, _VP, _VP, _VP]),
+    "mm_speculative_candidates": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mm_score_cells_partial": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP,
+                                              ctypes.c_int, _VP, _VP, _VP]),
+    "mm_resolve_verify": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP, ctypes.c_int,
+                                         _VP, _VP, _VP, _VP]),
     "mm_resolve": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP, ctypes.c_int, _VP, _VP]),
     "mm_set_library_bgr": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),

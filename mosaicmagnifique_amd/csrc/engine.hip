@@ -53,6 +53,8 @@ struct mm_engine {
     DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s;
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut;
+    DevBuf row_map, spec_recs, deep, insufficient;
+    int spec_k = 10;             // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
     // per distinct mask in that mask's active-pixels-first order whenever either changes
@@ -332,8 +334,8 @@ mm::FilterBand filter_band(int diff_type, int ppad)
 
 // fp64-only scoring of `b` cells whose records are at recs_dev: gather, score every
 // (cell, candidate), keep the K lowest.  Results to ci / cs ([b][K]).
-mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_type, int K,
-                      int32_t* ci, double* cs, hipEvent_t after_gather, hipEvent_t after_score)
+mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_type, int K, int KW,
+                      int32_t* ci, double* cs, const int* row_map_dev, hipEvent_t after_gather, hipEvent_t after_score)
 {
     const int L = e->n_lib, size = e->lib_size, P = size * size, ppad = round_up(P, 256);
     const int cand_per_block = 16, cell_group = 512;
@@ -360,23 +362,32 @@ mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_typ
     HIP_TRY(e, hipGetLastError(), "Error during colour difference / add reduction kernel");
     if (after_score) HIP_TRY(e, hipEventRecord(after_score, e->stream), "event");
     if (K >= L)
-        mm::full_list_kernel<<<b, mm::kBlock, 0, e->stream>>>((const double*)e->scores.p, L, K, ci, cs);
+        mm::full_list_kernel<<<b, mm::kBlock, 0, e->stream>>>((const double*)e->scores.p, L, K, ci, cs, KW, row_map_dev);
     else
-        mm::select_kernel<<<b, mm::kBlock, 0, e->stream>>>((const double*)e->scores.p, L, K, kTieBand, ci, cs);
+        mm::select_kernel<<<b, mm::kBlock, 0, e->stream>>>((const double*)e->scores.p, L, K, kTieBand, ci, cs, KW, row_map_dev);
     HIP_TRY(e, hipGetLastError(), "Error during candidate selection kernel");
     return MM_OK;
 }
 
-// Scores `n` cells in batches and leaves the K lowest candidates per cell in
-// cand_i_dev / cand_s_dev.  cells_host = the same records on the host (needed to
-// re-run flagged cells through the fp64-only path).
+// Scores `n` cells in batches and leaves the K lowest candidates per cell in rows of
+// cand_i_dev / cand_s_dev that are KW >= K entries wide (the rest of a row is emptied).
+// Cell i goes to row row_map_host[i] (null: row i).  cells_host = the same records on the
+// host (needed to re-run flagged cells through the fp64-only path).
 mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_cell* recs_dev, int n,
-                             int diff_type, int K, int32_t* cand_i_dev, double* cand_s_dev,
+                             int diff_type, int K, int KW, int32_t* cand_i_dev, double* cand_s_dev,
+                             const int* row_map_host,
                              mm_progress_cb progress, void* user, volatile int* cancel)
 {
     const int L = e->n_lib, size = e->lib_size, P = size * size, ppad = round_up(P, 256);
     mm_status stp = prepare_planes(e);
     if (stp) return stp;
+    const int* row_map_dev = nullptr;
+    if (row_map_host) {
+        if ((stp = ensure(e, e->row_map, (size_t)n * sizeof(int), "Failed to allocate row map"))) return stp;
+        HIP_TRY(e, hipMemcpyAsync(e->row_map.p, row_map_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream),
+                "Failed to copy row map to device");
+        row_map_dev = (const int*)e->row_map.p;
+    }
     const bool two_tier = e->use_filter != 0 && K < L;
     const int Kc = two_tier ? std::min(L, round_up(K + 32, 4)) : 0;
 
@@ -449,11 +460,12 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     for (int done = 0; done < n; done += batch) {
         if (cancel && *cancel) return MM_CANCELLED;
         const int b = std::min(batch, n - done);
-        int32_t* ci = cand_i_dev + (size_t)done * K;
-        double* cs = cand_s_dev + (size_t)done * K;
+        int32_t* ci = row_map_dev ? cand_i_dev : cand_i_dev + (size_t)done * KW;
+        double* cs = row_map_dev ? cand_s_dev : cand_s_dev + (size_t)done * KW;
+        const int* rmap = row_map_dev ? row_map_dev + done : nullptr;
         HIP_TRY(e, hipEventRecord(e->ev[0], e->stream), "event");
         if (!two_tier) {
-            if ((st = dense_batch(e, recs_dev + done, b, diff_type, K, ci, cs, e->ev[1], e->ev[2]))) return st;
+            if ((st = dense_batch(e, recs_dev + done, b, diff_type, K, KW, ci, cs, rmap, e->ev[1], e->ev[2]))) return st;
             HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
             HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
             e->timing.stage_ms += elapsed(e->ev[0], e->ev[1]);
@@ -511,7 +523,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
 
         mm::rerank_kernel<<<b, mm::kBlock, 0, e->stream>>>(
             (const int32_t*)e->cont_i.p, (const float*)e->cont_f.p, (const double*)e->cont_s.p,
-            (const uint8_t*)e->cmask.p, Kc, K, ppad, band, kTieBand, ci, cs, (uint8_t*)e->flags.p);
+            (const uint8_t*)e->cmask.p, Kc, K, ppad, band, kTieBand, ci, cs, (uint8_t*)e->flags.p, KW, rmap);
         HIP_TRY(e, hipGetLastError(), "Error during re-rank kernel");
         HIP_TRY(e, hipEventRecord(e->ev[9], e->stream), "event");
 
@@ -537,20 +549,21 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         if (!dense_cells.empty()) {
             const int nd = (int)dense_cells.size();
             if ((st = ensure(e, e->dense_recs, (size_t)nd * sizeof(mm_cell), "Failed to allocate cell records")) ||
-                (st = ensure(e, e->dense_i, (size_t)nd * K * sizeof(int32_t), "Failed to allocate candidates")) ||
-                (st = ensure(e, e->dense_s, (size_t)nd * K * sizeof(double), "Failed to allocate candidates")))
+                (st = ensure(e, e->dense_i, (size_t)nd * KW * sizeof(int32_t), "Failed to allocate candidates")) ||
+                (st = ensure(e, e->dense_s, (size_t)nd * KW * sizeof(double), "Failed to allocate candidates")))
                 return st;
             HIP_TRY(e, hipMemcpyAsync(e->dense_recs.p, dense_cells.data(), (size_t)nd * sizeof(mm_cell),
                                       hipMemcpyHostToDevice, e->stream), "Failed to copy cell records to device");
             HIP_TRY(e, hipEventRecord(e->ev[10], e->stream), "event");
-            if ((st = dense_batch(e, (const mm_cell*)e->dense_recs.p, nd, diff_type, K, (int32_t*)e->dense_i.p,
-                                  (double*)e->dense_s.p, nullptr, nullptr)))
+            if ((st = dense_batch(e, (const mm_cell*)e->dense_recs.p, nd, diff_type, K, KW, (int32_t*)e->dense_i.p,
+                                  (double*)e->dense_s.p, nullptr, nullptr, nullptr)))
                 return st;
             for (int i = 0; i < nd; ++i) {
-                HIP_TRY(e, hipMemcpyAsync(cand_i_dev + (size_t)dense_slots[(size_t)i] * K, (int32_t*)e->dense_i.p + (size_t)i * K,
-                                          (size_t)K * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream), "scatter");
-                HIP_TRY(e, hipMemcpyAsync(cand_s_dev + (size_t)dense_slots[(size_t)i] * K, (double*)e->dense_s.p + (size_t)i * K,
-                                          (size_t)K * sizeof(double), hipMemcpyDeviceToDevice, e->stream), "scatter");
+                const size_t r = row_map_host ? (size_t)row_map_host[dense_slots[(size_t)i]] : (size_t)dense_slots[(size_t)i];
+                HIP_TRY(e, hipMemcpyAsync(cand_i_dev + r * KW, (int32_t*)e->dense_i.p + (size_t)i * KW,
+                                          (size_t)KW * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream), "scatter");
+                HIP_TRY(e, hipMemcpyAsync(cand_s_dev + r * KW, (double*)e->dense_s.p + (size_t)i * KW,
+                                          (size_t)KW * sizeof(double), hipMemcpyDeviceToDevice, e->stream), "scatter");
             }
             HIP_TRY(e, hipEventRecord(e->ev[11], e->stream), "event");
             HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
@@ -562,10 +575,14 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     return MM_OK;
 }
 
+// deep_dev (may be null = every list is full): 1 where the list holds the full K; the
+// others are speculative lists of k_fill entries whose pick is verified on the device;
+// insufficient_dev receives the verdict per cell.
 mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_w, int grid_h,
                          int diff_type, int range, int addition, int K,
                          const int32_t* cand_i_dev, const double* cand_s_dev,
-                         int64_t* best_fit_out, double* best_score_out)
+                         int64_t* best_fit_out, double* best_score_out,
+                         const uint8_t* deep_dev = nullptr, uint8_t* insufficient_dev = nullptr, int k_fill = 0)
 {
     const size_t cells_total = (size_t)grid_w * grid_h;
     mm_status st;
@@ -597,6 +614,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
     for (int i = 0; i < 4; ++i) a.var_of_mask[i] = e->var_of_mask[i];
     a.size = size; a.P = P; a.ppad = ppad;
     a.tie_band = kTieBand;
+    a.deep = deep_dev; a.insufficient = insufficient_dev; a.k_fill = k_fill > 0 ? k_fill : K;
     a.exact_count = (unsigned long long*)e->counter.p;
     a.dense_count = a.exact_count + 1;
 
@@ -611,7 +629,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
         int* mark_count = slot + n;
         HIP_TRY(e, hipMemsetAsync(mark_count, 0, sizeof(int), e->stream), "Failed to clear counter");
         mm::mark_scan_kernel<<<std::min((n + mm::kBlock - 1) / mm::kBlock, 256), mm::kBlock, 0, e->stream>>>(
-            cand_i_dev, n, K, slot, mark_count);
+            cand_i_dev, n, K, deep_dev, slot, mark_count);
         HIP_TRY(e, hipGetLastError(), "Error during mark scan kernel");
         int marked = 0;
         HIP_TRY(e, hipMemcpyAsync(&marked, mark_count, sizeof(int), hipMemcpyDeviceToHost, e->stream), "mark count");
@@ -759,7 +777,7 @@ void mm_destroy(mm_engine* e)
                        &e->cont_i, &e->cont_f, &e->cont_s, &e->flags, &e->edges, &e->edge_count,
                        &e->dense_recs, &e->dense_i, &e->dense_s, &e->lib_means, &e->seeds,
                        &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
-                       &e->hue_lut, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
+                       &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -848,13 +866,21 @@ int mm_candidates_per_cell(int n_images, int repeat_range, int repeat_addition)
     return (int)std::min<long long>(k, n_images);
 }
 
-mm_status mm_score_cells(mm_engine* e, const mm_cell* cells, int n_cells, int diff_type, int k,
-                         int32_t* cand_index_out, double* cand_score_out, int outputs_on_device,
-                         mm_progress_cb progress, void* progress_user, volatile int* cancel)
+int mm_speculative_candidates(int n_images, int repeat_range, int repeat_addition, int spec_k)
+{
+    const int k = mm_candidates_per_cell(n_images, repeat_range, repeat_addition);
+    // Short lists pay off only when the full bound is long and penalties can only push back.
+    if (spec_k <= 0 || repeat_range <= 0 || repeat_addition <= 0 || k <= spec_k + 2 || spec_k > 64) return k;
+    return spec_k;
+}
+
+mm_status mm_score_cells_partial(mm_engine* e, const mm_cell* cells, int n_cells, int diff_type, int k, int k_fill,
+                                 int32_t* cand_index_out, double* cand_score_out, int outputs_on_device,
+                                 mm_progress_cb progress, void* progress_user, volatile int* cancel)
 {
     if (!e) return MM_INVALID_ARGUMENT;
     if (!known_type(diff_type)) { set_err(e, "No function for given type %d", diff_type); return MM_INVALID_ARGUMENT; }
-    if (n_cells < 0 || (n_cells > 0 && !cells) || k <= 0 || !cand_index_out || !cand_score_out) {
+    if (n_cells < 0 || (n_cells > 0 && !cells) || k <= 0 || k_fill <= 0 || k_fill > k || !cand_index_out || !cand_score_out) {
         set_err(e, "mm_score_cells: bad arguments");
         return MM_INVALID_ARGUMENT;
     }
@@ -878,7 +904,8 @@ mm_status mm_score_cells(mm_engine* e, const mm_cell* cells, int n_cells, int di
         ci = (int32_t*)e->cand_i.p;
         cs = (double*)e->cand_s.p;
     }
-    st = score_cells_device(e, cells, (const mm_cell*)e->recs.p, n_cells, diff_type, k, ci, cs, progress, progress_user, cancel);
+    st = score_cells_device(e, cells, (const mm_cell*)e->recs.p, n_cells, diff_type, k_fill, k, ci, cs, nullptr,
+                            progress, progress_user, cancel);
     if (st) return st;
     if (!outputs_on_device) {
         HIP_TRY(e, hipMemcpyAsync(cand_index_out, ci, (size_t)n_cells * k * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream),
@@ -893,15 +920,24 @@ mm_status mm_score_cells(mm_engine* e, const mm_cell* cells, int n_cells, int di
     return MM_OK;
 }
 
-mm_status mm_resolve(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w, int grid_h, int diff_type,
-                     int repeat_range, int repeat_addition, int k,
-                     const int32_t* cand_index, const double* cand_score, int inputs_on_device,
-                     int64_t* best_fit_out, double* best_score_out)
+mm_status mm_score_cells(mm_engine* e, const mm_cell* cells, int n_cells, int diff_type, int k,
+                         int32_t* cand_index_out, double* cand_score_out, int outputs_on_device,
+                         mm_progress_cb progress, void* progress_user, volatile int* cancel)
+{
+    return mm_score_cells_partial(e, cells, n_cells, diff_type, k, k, cand_index_out, cand_score_out,
+                                  outputs_on_device, progress, progress_user, cancel);
+}
+
+mm_status mm_resolve_verify(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w, int grid_h, int diff_type,
+                            int repeat_range, int repeat_addition, int k, int k_fill,
+                            const int32_t* cand_index, const double* cand_score, int inputs_on_device,
+                            const uint8_t* deep, uint8_t* insufficient_out,
+                            int64_t* best_fit_out, double* best_score_out)
 {
     if (!e) return MM_INVALID_ARGUMENT;
     if (!known_type(diff_type)) { set_err(e, "No function for given type %d", diff_type); return MM_INVALID_ARGUMENT; }
     if (n_cells < 0 || (n_cells > 0 && (!cells || !cand_index || !cand_score)) || k <= 0 || grid_w <= 0 ||
-        grid_h <= 0 || !best_fit_out || repeat_range < 0) {
+        grid_h <= 0 || !best_fit_out || repeat_range < 0 || k_fill <= 0 || k_fill > k || (deep && !insufficient_out)) {
         set_err(e, "mm_resolve: bad arguments");
         return MM_INVALID_ARGUMENT;
     }
@@ -925,10 +961,41 @@ mm_status mm_resolve(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w
         ci = (const int32_t*)e->cand_i.p;
         cs = (const double*)e->cand_s.p;
     }
-    return resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
-                          repeat_addition, k, ci, cs, best_fit_out, best_score_out);
+    const uint8_t* deep_dev = nullptr;
+    uint8_t* insuff_dev = nullptr;
+    if (deep && n_cells > 0) {
+        if ((st = ensure(e, e->deep, (size_t)n_cells, "Failed to allocate list flags")) ||
+            (st = ensure(e, e->insufficient, (size_t)n_cells, "Failed to allocate list flags")))
+            return st;
+        HIP_TRY(e, hipMemcpyAsync(e->deep.p, deep, (size_t)n_cells, hipMemcpyHostToDevice, e->stream), "Failed to copy list flags");
+        HIP_TRY(e, hipMemsetAsync(e->insufficient.p, 0, (size_t)n_cells, e->stream), "Failed to clear list flags");
+        deep_dev = (const uint8_t*)e->deep.p;
+        insuff_dev = (uint8_t*)e->insufficient.p;
+    }
+    st = resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
+                        repeat_addition, k, ci, cs, best_fit_out, best_score_out, deep_dev, insuff_dev, k_fill);
+    if (st) return st;
+    if (insuff_dev)
+        HIP_TRY(e, hipMemcpy(insufficient_out, insuff_dev, (size_t)n_cells, hipMemcpyDeviceToHost), "Error copying list flags to host");
+    return MM_OK;
 }
 
+mm_status mm_resolve(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w, int grid_h, int diff_type,
+                     int repeat_range, int repeat_addition, int k,
+                     const int32_t* cand_index, const double* cand_score, int inputs_on_device,
+                     int64_t* best_fit_out, double* best_score_out)
+{
+    return mm_resolve_verify(e, cells, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, k, k,
+                             cand_index, cand_score, inputs_on_device, nullptr, nullptr, best_fit_out, best_score_out);
+}
+
+// generateBestFits.  With a repeat penalty the counting bound asks for K = R(2R+1)+R+2
+// candidates per cell, which is almost never needed: score short lists of K_s entries
+// first ("speculate"), let the resolve verify every pick on the device (an unlisted
+// candidate has a base score >= the list's last one and a penalty >= 0), then deepen the
+// few cells it could not vouch for to the full K and resolve again, until none is left.
+// Deep lists are sufficient by the counting argument, so the loop ends, and the result is
+// the one the full-K path gives.
 mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w, int grid_h, int diff_type,
                       int repeat_range, int repeat_addition, int64_t* best_fit_out, double* best_score_out,
                       mm_progress_cb progress, void* progress_user, volatile int* cancel)
@@ -946,6 +1013,8 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     e->timing = mm_timing{};
 
     const int K = std::max(1, mm_candidates_per_cell(e->n_lib, repeat_range, repeat_addition));
+    const int Ks = std::max(1, mm_speculative_candidates(e->n_lib, repeat_range, repeat_addition, e->spec_k));
+    const bool speculate = Ks < K && n_cells > 0;
     HIP_TRY(e, hipEventRecord(e->ev[6], e->stream), "event");
     if ((st = ensure(e, e->recs, (size_t)std::max(n_cells, 1) * sizeof(mm_cell), "Failed to allocate cell records")) ||
         (st = ensure(e, e->cand_i, (size_t)std::max(n_cells, 1) * K * sizeof(int32_t), "Failed to allocate candidates")) ||
@@ -954,15 +1023,51 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     HIP_TRY(e, hipMemcpyAsync(e->recs.p, cells, (size_t)n_cells * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
             "Failed to copy cell records to device");
     if (n_cells > 0) {
-        st = score_cells_device(e, cells, (const mm_cell*)e->recs.p, n_cells, diff_type, K, (int32_t*)e->cand_i.p,
-                                (double*)e->cand_s.p, progress, progress_user, cancel);
+        st = score_cells_device(e, cells, (const mm_cell*)e->recs.p, n_cells, diff_type, Ks, K, (int32_t*)e->cand_i.p,
+                                (double*)e->cand_s.p, nullptr, progress, progress_user, cancel);
         if (st) return st;
     }
     if (cancel && *cancel) return MM_CANCELLED;
-    st = resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
-                        repeat_addition, K, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p,
-                        best_fit_out, best_score_out);
-    if (st) return st;
+
+    std::vector<uint8_t> deep, insufficient;
+    std::vector<mm_cell> sub_cells;
+    std::vector<int> sub_rows;
+    if (speculate) {
+        deep.assign((size_t)n_cells, 0);
+        insufficient.assign((size_t)n_cells, 0);
+        if ((st = ensure(e, e->deep, (size_t)n_cells, "Failed to allocate list flags")) ||
+            (st = ensure(e, e->insufficient, (size_t)n_cells, "Failed to allocate list flags")))
+            return st;
+    }
+    for (int round = 0;; ++round) {
+        if (speculate) {
+            HIP_TRY(e, hipMemcpyAsync(e->deep.p, deep.data(), (size_t)n_cells, hipMemcpyHostToDevice, e->stream), "Failed to copy list flags");
+            HIP_TRY(e, hipMemsetAsync(e->insufficient.p, 0, (size_t)n_cells, e->stream), "Failed to clear list flags");
+        }
+        // resolve_device re-uploads the cell records it was given on the device already
+        st = resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
+                            repeat_addition, K, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p,
+                            best_fit_out, best_score_out,
+                            speculate ? (const uint8_t*)e->deep.p : nullptr, speculate ? (uint8_t*)e->insufficient.p : nullptr, Ks);
+        if (st) return st;
+        e->timing.spec_rounds = round + 1;
+        if (!speculate) break;
+        HIP_TRY(e, hipMemcpy(insufficient.data(), e->insufficient.p, (size_t)n_cells, hipMemcpyDeviceToHost), "Error copying list flags to host");
+        sub_cells.clear();
+        sub_rows.clear();
+        for (int c = 0; c < n_cells; ++c)
+            if (insufficient[(size_t)c] && !deep[(size_t)c]) { sub_cells.push_back(cells[c]); sub_rows.push_back(c); deep[(size_t)c] = 1; }
+        if (sub_cells.empty()) break;
+        if (cancel && *cancel) return MM_CANCELLED;
+        const int ns = (int)sub_cells.size();
+        if ((st = ensure(e, e->spec_recs, (size_t)ns * sizeof(mm_cell), "Failed to allocate cell records"))) return st;
+        HIP_TRY(e, hipMemcpyAsync(e->spec_recs.p, sub_cells.data(), (size_t)ns * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
+                "Failed to copy cell records to device");
+        st = score_cells_device(e, sub_cells.data(), (const mm_cell*)e->spec_recs.p, ns, diff_type, K, K,
+                                (int32_t*)e->cand_i.p, (double*)e->cand_s.p, sub_rows.data(), nullptr, nullptr, cancel);
+        if (st) return st;
+        e->timing.deepened_cells += ns;
+    }
     HIP_TRY(e, hipEventRecord(e->ev[7], e->stream), "event");
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
     e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
@@ -1073,6 +1178,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "wave_resolve") == 0) { e->use_wave_resolve = value != 0; return MM_OK; }
     if (strcmp(name, "row_pipeline") == 0) { e->use_row_pipeline = value != 0; return MM_OK; }
     if (strcmp(name, "lds_filter") == 0) { e->use_lds_filter = value < 0 ? -1 : (value != 0); return MM_OK; }
+    if (strcmp(name, "spec_k") == 0) { e->spec_k = std::max(0, value); return MM_OK; }
     if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }
     if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);

@@ -218,10 +218,14 @@ score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
 // resolve recomputes that cell's whole row instead of trusting the list.
 __global__ void __launch_bounds__(kBlock)
 select_kernel(const double* __restrict__ scores, int L, int K, double tie_band,
-              int32_t* __restrict__ cand_index, double* __restrict__ cand_score)
+              int32_t* __restrict__ cand_index, double* __restrict__ cand_score,
+              int KW, const int* __restrict__ row_map)
 {
     __shared__ ScoreIdx sh[kBlock / kWave];
     const double* row = scores + (size_t)blockIdx.x * L;
+    // rows of the output are KW wide (K <= KW filled, the rest empty); row_map scatters
+    const size_t out = (size_t)(row_map ? row_map[blockIdx.x] : (int)blockIdx.x) * KW;
+    for (int t = K + threadIdx.x; t < KW; t += kBlock) { cand_index[out + t] = -1; cand_score[out + t] = kInf; }
     double prev_s = -kInf;
     int prev_i = -1;
     for (int r = 0; r <= K; ++r) {
@@ -234,17 +238,17 @@ select_kernel(const double* __restrict__ scores, int L, int K, double tie_band,
         const bool none = best.i == 0x7fffffff;
         if (r == K) {        // one past the list: does it belong to the last entry's cluster?
             if (!none && threadIdx.x == 0 && best.s <= prev_s + fabs(prev_s) * (4.0 * tie_band))
-                cand_index[(size_t)blockIdx.x * K + K - 1] = -(prev_i + 2);
+                cand_index[out + K - 1] = -(prev_i + 2);
             break;
         }
         if (threadIdx.x == 0) {
-            cand_index[(size_t)blockIdx.x * K + r] = none ? -1 : best.i;
-            cand_score[(size_t)blockIdx.x * K + r] = none ? kInf : best.s;
+            cand_index[out + r] = none ? -1 : best.i;
+            cand_score[out + r] = none ? kInf : best.s;
         }
         if (none) {          // row exhausted (K > L, or NaN / +inf tail): fill the rest
             for (int t = r + 1 + threadIdx.x; t < K; t += kBlock) {
-                cand_index[(size_t)blockIdx.x * K + t] = -1;
-                cand_score[(size_t)blockIdx.x * K + t] = kInf;
+                cand_index[out + t] = -1;
+                cand_score[out + t] = kInf;
             }
             break;
         }
@@ -257,12 +261,14 @@ select_kernel(const double* __restrict__ scores, int L, int K, double tie_band,
 // row, in index order; nothing to select.
 __global__ void __launch_bounds__(kBlock)
 full_list_kernel(const double* __restrict__ scores, int L, int K,
-                 int32_t* __restrict__ cand_index, double* __restrict__ cand_score)
+                 int32_t* __restrict__ cand_index, double* __restrict__ cand_score,
+                 int KW, const int* __restrict__ row_map)
 {
     const double* row = scores + (size_t)blockIdx.x * L;
-    for (int k = threadIdx.x; k < K; k += kBlock) {
-        cand_index[(size_t)blockIdx.x * K + k] = k < L ? k : -1;
-        cand_score[(size_t)blockIdx.x * K + k] = k < L ? row[k] : kInf;
+    const size_t out = (size_t)(row_map ? row_map[blockIdx.x] : (int)blockIdx.x) * KW;
+    for (int k = threadIdx.x; k < KW; k += kBlock) {
+        cand_index[out + k] = (k < L && k < K) ? k : -1;
+        cand_score[out + k] = (k < L && k < K) ? row[k] : kInf;
     }
 }
 
@@ -388,10 +394,12 @@ rerank_kernel(const int32_t* __restrict__ cont_index, const float* __restrict__ 
               const double* __restrict__ cont_score, const uint8_t* __restrict__ cmask,
               int Kc, int K, int ppad, FilterBand band, double tie_band,
               int32_t* __restrict__ cand_index, double* __restrict__ cand_score,
-              uint8_t* __restrict__ flags)
+              uint8_t* __restrict__ flags, int KW, const int* __restrict__ row_map)
 {
     __shared__ ScoreIdx sh[kBlock / kWave];
     __shared__ int n_active;
+    const size_t out = (size_t)(row_map ? row_map[blockIdx.x] : (int)blockIdx.x) * KW;
+    for (int t = K + threadIdx.x; t < KW; t += kBlock) { cand_index[out + t] = -1; cand_score[out + t] = kInf; }
     const int32_t* ci = cont_index + (size_t)blockIdx.x * Kc;
     const float* cf = cont_filter + (size_t)blockIdx.x * Kc;
     const double* cs = cont_score + (size_t)blockIdx.x * Kc;
@@ -425,17 +433,17 @@ rerank_kernel(const int32_t* __restrict__ cont_index, const float* __restrict__ 
         const bool none = best.i == 0x7fffffff;
         if (r == K) {
             if (!none && threadIdx.x == 0 && best.s <= prev_s + fabs(prev_s) * (4.0 * tie_band))
-                cand_index[(size_t)blockIdx.x * K + K - 1] = -(prev_i + 2);
+                cand_index[out + K - 1] = -(prev_i + 2);
             break;
         }
         if (threadIdx.x == 0) {
-            cand_index[(size_t)blockIdx.x * K + r] = none ? -1 : best.i;
-            cand_score[(size_t)blockIdx.x * K + r] = none ? kInf : best.s;
+            cand_index[out + r] = none ? -1 : best.i;
+            cand_score[out + r] = none ? kInf : best.s;
         }
         if (none) {
             for (int t = r + 1 + threadIdx.x; t < K; t += kBlock) {
-                cand_index[(size_t)blockIdx.x * K + t] = -1;
-                cand_score[(size_t)blockIdx.x * K + t] = kInf;
+                cand_index[out + t] = -1;
+                cand_score[out + t] = kInf;
             }
             break;
         }
@@ -472,6 +480,10 @@ struct ResolveArgs {
     double* scratch;            // [gridDim.x][L]: full score row of a cell whose list overflowed
     unsigned long long* dense_count;
     // wave resolve: rows precomputed by dense_rows_kernel for the marked cells
+    // speculative short lists (engine.hip "speculate and verify")
+    const uint8_t* deep;        // [n_cells] 1 = the list holds the full K the counting bound needs; null = all
+    int k_fill;                 // entries filled in a non-deep (speculative) list
+    uint8_t* insufficient;      // [n_cells] out: 1 = the pick of a non-deep cell could not be verified
     const int* row_slot;        // [n_cells] slot in `rows`, -1 = list is complete
     const double* dense_rows;   // [marked][L]
 };
@@ -588,9 +600,10 @@ resolve_kernel(ResolveArgs a, int sequential)
         const mm_cell rec = a.recs[c];
         const int32_t* ci = a.cand_index + (size_t)c * a.K;
         const double* cs = a.cand_score + (size_t)c * a.K;
-        int K = a.K;
+        const bool is_deep = !a.deep || a.deep[c] != 0;
+        int K = is_deep ? a.K : min(a.K, a.k_fill);
         const bool penalise = a.repeat_range > 0 && a.repeat_addition != 0;
-        if (ci[K - 1] <= -2) {             // overflow mark: take the whole row instead
+        if (is_deep && ci[a.K - 1] <= -2) {   // overflow mark: take the whole row instead
             double* row = a.scratch + (size_t)blockIdx.x * a.L;
             dense_row<TYPE>(a, rec, row, sh4);
             if (threadIdx.x == 0) atomicAdd(a.dense_count, 1ull);
@@ -598,7 +611,8 @@ resolve_kernel(ResolveArgs a, int sequential)
             cs = row;
             K = a.L;
         }
-        auto cand_at = [&](int k) { return ci ? ci[k] : k; };
+        // a mark (<= -2) on a speculative list is just an entry
+        auto cand_at = [&](int k) { const int v = ci ? ci[k] : k; return (!is_deep && v <= -2) ? -(v + 2) : v; };
 
         // pass 1: lowest (total, index) over the cell's candidates
         ScoreIdx best{kInf, 0x7fffffff};
@@ -664,6 +678,16 @@ resolve_kernel(ResolveArgs a, int sequential)
         if (threadIdx.x == 0) {
             a.grid[pos] = chosen;
             a.best_score[pos] = chosen_total;
+            if (a.insufficient) {
+                bool insuff = false;
+                if (!is_deep) {           // see resolve_wave_kernel
+                    int nvalid = 0;
+                    while (nvalid < K && cand_at(nvalid) >= 0) ++nvalid;
+                    const double b_last = nvalid > 0 ? cs[nvalid - 1] : -kInf;
+                    insuff = !(chosen != a.L && chosen_total + fabs(chosen_total) * a.tie_band < b_last);
+                }
+                a.insufficient[c] = insuff ? 1 : 0;
+            }
         }
         __syncthreads();          // workgroup-scope release/acquire: the next cell reads grid[]
     }
@@ -676,10 +700,12 @@ resolve_kernel(ResolveArgs a, int sequential)
 // Which cells carry the overflow mark, and a dense slot number for each of them.
 __global__ void __launch_bounds__(kBlock)
 mark_scan_kernel(const int32_t* __restrict__ cand_index, int n_cells, int K,
-                 int* __restrict__ row_slot, int* __restrict__ count)
+                 const uint8_t* __restrict__ deep, int* __restrict__ row_slot, int* __restrict__ count)
 {
+    // a mark on a speculative (non-deep) list is ignored: such a cell is verified by the
+    // sufficiency test instead and deepened if that fails
     for (int c = blockIdx.x * kBlock + threadIdx.x; c < n_cells; c += gridDim.x * kBlock)
-        row_slot[c] = (cand_index[(size_t)c * K + K - 1] <= -2) ? atomicAdd(count, 1) : -1;
+        row_slot[c] = ((!deep || deep[c]) && cand_index[(size_t)c * K + K - 1] <= -2) ? atomicAdd(count, 1) : -1;
 }
 
 // Full fp64 score rows of the marked cells, one workgroup per cell (parallel: base
@@ -759,7 +785,8 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
         // dense row instead of the list?
         const int slot = a.row_slot ? a.row_slot[c] : -1;
         const bool dense = slot >= 0;
-        const int K = dense ? a.L : a.K;
+        const bool is_deep = !a.deep || a.deep[c] != 0;
+        const int K = dense ? a.L : (is_deep ? a.K : min(a.K, a.k_fill));
         const double* row = dense ? a.dense_rows + (size_t)slot * a.L : nullptr;
 
         // candidate of this lane in chunk `base`, with its total
@@ -767,8 +794,9 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
             const int k = base + lane;
             double s;
             if (dense) { cand = k < K ? k : -1; s = k < K ? row[k] : kInf; }
-            else if (base == 0) { cand = my_ci; s = my_cs; }
+            else if (base == 0) { cand = k < K ? my_ci : -1; s = k < K ? my_cs : kInf; }
             else { cand = k < K ? a.cand_index[(size_t)c * a.K + k] : -1; s = k < K ? a.cand_score[(size_t)c * a.K + k] : kInf; }
+            if (!is_deep && cand <= -2) cand = -(cand + 2);     // a mark on a speculative list is just an entry
             int rep = 0;
             for (int t0 = 0; t0 < nn; t0 += kWave) {        // neighbours, 64 at a time
                 const int t = t0 + lane;
@@ -842,6 +870,17 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
             }
         }
 
+        if (a.insufficient) {
+            // Speculative list: any unlisted candidate has a base score >= the list's last (largest)
+            // one and a penalty >= 0, so the pick is certainly right when its total is below that.
+            bool insuff = false;
+            if (!is_deep) {
+                const int nvalid = __popcll(__ballot(c0 >= 0));
+                const double b_last = nvalid > 0 ? __shfl(s0, nvalid - 1, kWave) : -kInf;
+                insuff = !(chosen != a.L && chosen_total + fabs(chosen_total) * a.tie_band < b_last);
+            }
+            if (lane == 0) a.insufficient[c] = insuff ? 1 : 0;
+        }
         if (lane == 0) {
             const size_t pos = (size_t)py * gw + px;
             a.grid[pos] = chosen;
@@ -980,15 +1019,17 @@ resolve_rows_kernel(ResolveArgs a, const int* __restrict__ row_first, const int*
 
             const int slot = a.row_slot ? a.row_slot[c] : -1;
             const bool dense = slot >= 0;
-            const int K = dense ? a.L : a.K;
+            const bool is_deep = !a.deep || a.deep[c] != 0;
+            const int K = dense ? a.L : (is_deep ? a.K : min(a.K, a.k_fill));
             const double* row = dense ? a.dense_rows + (size_t)slot * a.L : nullptr;
 
             auto eval = [&](int base, int& cand, double& total, int& rep_out, double& base_out) {
                 const int k = base + lane;
                 double s;
                 if (dense) { cand = k < K ? k : -1; s = k < K ? row[k] : kInf; }
-                else if (base == 0) { cand = my_ci; s = my_cs; }
+                else if (base == 0) { cand = k < K ? my_ci : -1; s = k < K ? my_cs : kInf; }
                 else { cand = k < K ? a.cand_index[(size_t)c * a.K + k] : -1; s = k < K ? a.cand_score[(size_t)c * a.K + k] : kInf; }
+                if (!is_deep && cand <= -2) cand = -(cand + 2);     // a mark on a speculative list is just an entry
                 int rep = 0;
                 for (int t0 = 0; t0 < nn; t0 += kWave) {
                     const int t = t0 + lane;
@@ -1059,6 +1100,15 @@ resolve_rows_kernel(ResolveArgs a, const int* __restrict__ row_first, const int*
                 }
             }
 
+            if (a.insufficient) {
+                bool insuff = false;
+                if (!is_deep) {
+                    const int nvalid = __popcll(__ballot(c0 >= 0));
+                    const double b_last = nvalid > 0 ? __shfl(s0, nvalid - 1, kWave) : -kInf;
+                    insuff = !(chosen != a.L && chosen_total + fabs(chosen_total) * a.tie_band < b_last);
+                }
+                if (lane == 0) a.insufficient[c] = insuff ? 1 : 0;
+            }
             if (lane == 0) {
                 const size_t pos = (size_t)py * gw + px;
                 a.grid[pos] = chosen;

@@ -71,12 +71,19 @@ class ShardedBestFit:
                           torch.full((max(per, 1), k), float("inf"), dtype=torch.float64, device=dev))
         return self._bufs[1], self._bufs[2]
 
-    def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0):
+    def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0, spec_k=10):
         """cells: ALL valid cells in raster order (every rank passes the same array).
-        Returns (best_fit, best_score) as Engine.generate does, identical on all ranks."""
+        Returns (best_fit, best_score) as Engine.generate does, identical on all ranks.
+
+        Same speculate-and-verify loop as mm_generate (engine.hip): short lists first, one
+        all-gather, a verifying resolve on every rank (identical verdicts everywhere), then
+        each rank deepens the unverified cells of its own block and the lists are gathered
+        and resolved again, until no cell is left unverified."""
         import torch
         n = len(cells)
         k = self.engine.candidates_per_cell(repeat_range, repeat_addition)
+        ks = self.engine.speculative_candidates(repeat_range, repeat_addition, spec_k)
+        speculate = ks < k and n > 0
         per = padded_len(n, self.world)
         lo, hi = shard_range(n, self.world, self.rank)
         idx, score = self._buffers(per, k)
@@ -85,11 +92,29 @@ class ShardedBestFit:
             score[hi - lo:] = float("inf")
         if hi > lo:
             self.engine.score_cells(cells[lo:hi], diff_type, k, out_index=idx.data_ptr(),
-                                    out_score=score.data_ptr(), on_device=True)
-        idx_all, score_all = allgather_candidates(idx[:per], score[:per], n, self.world, self.group)
-        torch.cuda.synchronize(idx.device)      # the engine runs on its own stream
-        return self.engine.resolve(cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, k,
-                                   idx_all.data_ptr(), score_all.data_ptr(), on_device=True)
+                                    out_score=score.data_ptr(), on_device=True, k_fill=ks)
+        deep = np.zeros(n, dtype=np.uint8) if speculate else None
+        while True:
+            idx_all, score_all = allgather_candidates(idx[:per], score[:per], n, self.world, self.group)
+            torch.cuda.synchronize(idx.device)      # the engine runs on its own stream
+            out = self.engine.resolve(cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, k,
+                                      idx_all.data_ptr(), score_all.data_ptr(), on_device=True, deep=deep, k_fill=ks)
+            if not speculate:
+                return out
+            best, best_score, insufficient = out
+            todo = np.nonzero((insufficient != 0) & (deep == 0))[0]
+            if len(todo) == 0:
+                return best, best_score
+            deep[todo] = 1
+            mine = todo[(todo >= lo) & (todo < hi)]
+            if len(mine):                           # deepen this rank's own unverified cells
+                di = torch.empty((len(mine), k), dtype=torch.int32, device=idx.device)
+                ds = torch.empty((len(mine), k), dtype=torch.float64, device=idx.device)
+                self.engine.score_cells(cells[mine], diff_type, k, out_index=di.data_ptr(),
+                                        out_score=ds.data_ptr(), on_device=True)
+                rows = torch.as_tensor(mine - lo, device=idx.device)
+                idx[rows] = di
+                score[rows] = ds
 
 
 def merge_on_host(shards, n_cells):

@@ -107,10 +107,15 @@ class Engine:
     def candidates_per_cell(self, repeat_range, repeat_addition):
         return self._lib.mm_candidates_per_cell(self.n_library, int(repeat_range), int(repeat_addition))
 
+    def speculative_candidates(self, repeat_range, repeat_addition, spec_k=10):
+        """Length of the short lists worth scoring first (= candidates_per_cell when speculation does not pay)."""
+        return self._lib.mm_speculative_candidates(self.n_library, int(repeat_range), int(repeat_addition), int(spec_k))
+
     def score_cells(self, cells, diff_type, k, out_index=None, out_score=None, on_device=False,
-                    progress=None, cancel=None):
-        """mm_score_cells.  Host mode returns (index int32 [n][k], score f64 [n][k]);
-        device mode writes to the given raw device addresses (ints)."""
+                    progress=None, cancel=None, k_fill=None):
+        """mm_score_cells[_partial].  Host mode returns (index int32 [n][k], score f64 [n][k]);
+        device mode writes to the given raw device addresses (ints).  k_fill < k fills only the
+        first k_fill entries of each k-wide row (speculative short lists)."""
         rec = _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
         cb, cflag = self._callbacks(progress, cancel)
         if on_device:
@@ -120,14 +125,16 @@ class Engine:
             idx = np.empty((len(rec), k), dtype=np.int32)
             sc = np.empty((len(rec), k), dtype=np.float64)
             pi, ps = _lib.ptr(idx), _lib.ptr(sc)
-        self._check(self._lib.mm_score_cells(
-            self._h, _lib.ptr(rec), len(rec), int(diff_type), int(k), pi, ps, 1 if on_device else 0,
-            ctypes.cast(cb, ctypes.c_void_p) if cb else None, None, cflag))
+        self._check(self._lib.mm_score_cells_partial(
+            self._h, _lib.ptr(rec), len(rec), int(diff_type), int(k), int(k if k_fill is None else k_fill), pi, ps,
+            1 if on_device else 0, ctypes.cast(cb, ctypes.c_void_p) if cb else None, None, cflag))
         return idx, sc
 
     def resolve(self, cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, k,
-                cand_index, cand_score, on_device=False, want_scores=True):
-        """mm_resolve over ALL cells of the grid with their gathered candidate lists."""
+                cand_index, cand_score, on_device=False, want_scores=True, deep=None, k_fill=None):
+        """mm_resolve[_verify] over ALL cells of the grid with their gathered candidate lists.
+        With ``deep`` (u8 per cell: 1 = full-length list) the picks of the other cells are verified
+        and a third value is returned: u8 per cell, 1 = could not be verified (deepen and retry)."""
         rec = _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
         best = np.empty((grid_h, grid_w), dtype=np.int64)
         score = np.empty((grid_h, grid_w), dtype=np.float64) if want_scores else None
@@ -137,10 +144,18 @@ class Engine:
             ci = np.ascontiguousarray(cand_index, dtype=np.int32)
             cs = np.ascontiguousarray(cand_score, dtype=np.float64)
             pi, ps = _lib.ptr(ci), _lib.ptr(cs)
-        self._check(self._lib.mm_resolve(
+        if deep is None:
+            self._check(self._lib.mm_resolve(
+                self._h, _lib.ptr(rec), len(rec), grid_w, grid_h, int(diff_type), int(repeat_range),
+                int(repeat_addition), int(k), pi, ps, 1 if on_device else 0, _lib.ptr(best), _lib.ptr(score)))
+            return best, score
+        deep = np.ascontiguousarray(deep, dtype=np.uint8)
+        insufficient = np.zeros(len(rec), dtype=np.uint8)
+        self._check(self._lib.mm_resolve_verify(
             self._h, _lib.ptr(rec), len(rec), grid_w, grid_h, int(diff_type), int(repeat_range),
-            int(repeat_addition), int(k), pi, ps, 1 if on_device else 0, _lib.ptr(best), _lib.ptr(score)))
-        return best, score
+            int(repeat_addition), int(k), int(k if k_fill is None else k_fill), pi, ps, 1 if on_device else 0,
+            _lib.ptr(deep), _lib.ptr(insufficient), _lib.ptr(best), _lib.ptr(score)))
+        return best, score, insufficient
 
     def set_library_bgr(self, images):
         """u8 BGR ``[n][size][size][3]`` as setLibrary received it (for build_photomosaic)."""

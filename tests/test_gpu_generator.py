@@ -76,7 +76,7 @@ def test_compare_matrix(oracle, t, shape_name, rep, use_filter):
     img, lib = cases.inputs(rows, cols, size, n_lib, t, lattice=2 * size)
     gen = compare(oracle, shape, img, lib, t, rep, use_filter)
     tm = gen.timing()
-    assert (tm["rescore_ms"] > 0) == bool(use_filter and gen.m_engine.candidates_per_cell(*rep) < n_lib)
+    assert (tm["rescore_ms"] > 0) == bool(use_filter and gen.m_engine.speculative_candidates(*rep) < n_lib)
 
 
 @pytest.mark.parametrize("wave_resolve", list(RESOLVE_MODES))
@@ -345,3 +345,68 @@ def test_negative_repeat_addition_promotes_any_candidate(oracle, wave_resolve):
     fits = gen.getBestFits()[0]
     inner = fits[2:, 2:]
     assert (inner[:, 1:] == inner[:, :-1]).mean() > 0.5        # the bonus makes neighbours agree
+
+
+@pytest.mark.parametrize("spec_k", [0, 2, 3, 10])
+def test_speculative_short_lists_are_verified_and_deepened(oracle, engine, spec_k):
+    """mm_generate scores short candidate lists first and lets the resolve verify each pick;
+    unverified cells are deepened to the full list.  spec_k = 2 / 3 make that happen all the
+    time, 0 switches speculation off: the grid never changes."""
+    shape = cases.square_shape(16)
+    group = cases.group_of(shape)
+    t, rep = Type.CIE76, (3, 900)
+    img, lib = cases.inputs(160, 176, 16, 120, t, lattice=200)       # smooth target: neighbours collide
+    state = G.getGridState(group, 160, 176)[0]
+    cells = G.cell_records(group, state, 160, 176)
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    want, want_score, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), *rep)
+    engine.set_option("spec_k", spec_k)
+    try:
+        best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+        tm = engine.timing()
+    finally:
+        engine.set_option("spec_k", 10)
+    assert np.array_equal(np.where(best == len(lib), -1, best), want)
+    valid = state >= 0
+    assert (np.abs(score[valid] - want_score[valid]) <= 1e-12 * want_score[valid]).all()
+    full = engine.candidates_per_cell(*rep)
+    assert full == 3 * 7 + 3 + 2
+    if spec_k == 0:
+        assert tm["spec_rounds"] == 1 and tm["deepened_cells"] == 0
+    elif spec_k <= 3:
+        assert tm["spec_rounds"] >= 2 and tm["deepened_cells"] > 0
+
+
+def test_split_api_speculation_matches_generate(oracle, engine):
+    """The speculate / verify / deepen loop driven from the host through mm_score_cells_partial
+    and mm_resolve_verify (what the multi-GPU step does), on two shards."""
+    shape = cases.flippy_shape()
+    group = cases.group_of(shape)
+    t, rep = Type.CIEDE2000, (3, 400)
+    img, lib = cases.inputs(150, 170, 24, 90, t, lattice=300)
+    state = G.getGridState(group, 150, 170)[0]
+    cells = G.cell_records(group, state, 150, 170)
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    whole, whole_score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    k = engine.candidates_per_cell(*rep)
+    ks = engine.speculative_candidates(*rep, spec_k=3)
+    assert ks == 3 < k
+    half = len(cells) // 2
+    i0, s0 = engine.score_cells(cells[:half], int(t), k, k_fill=ks)
+    i1, s1 = engine.score_cells(cells[half:], int(t), k, k_fill=ks)
+    idx, sc = np.concatenate([i0, i1]), np.concatenate([s0, s1])
+    assert (idx[:, ks:] == -1).all() and (idx[:, :ks] != -1).all()
+    deep = np.zeros(len(cells), np.uint8)
+    rounds = 0
+    while True:
+        best, score, insufficient = engine.resolve(cells, state.shape[1], state.shape[0], int(t), rep[0], rep[1], k,
+                                                   idx, sc, deep=deep, k_fill=ks)
+        rounds += 1
+        todo = np.nonzero((insufficient != 0) & (deep == 0))[0]
+        if len(todo) == 0:
+            break
+        di, ds = engine.score_cells(cells[todo], int(t), k)
+        idx[todo], sc[todo] = di, ds
+        deep[todo] = 1
+    assert rounds >= 2 and deep.sum() > 0
+    assert np.array_equal(best, whole) and np.array_equal(score[state >= 0], whole_score[state >= 0])
