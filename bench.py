@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="D", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine tuning option (mm_set_option), for experiments")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,6 +147,9 @@ def main():
 
     w = build_workload(args.config, world)
     engine = Engine(local_rank)
+    for item in args.opt:
+        name, value = item.split("=")
+        engine.set_option(name, int(value))
     t_stage = time.perf_counter()
     engine.set_library(w["lib"])
     engine.set_masks(w["shape"].masks4())

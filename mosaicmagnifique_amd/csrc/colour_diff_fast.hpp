@@ -8,18 +8,16 @@
 // fp64 form and (b) instruction count: CIEDE2000 is VALU-bound, not HBM-bound.
 //
 // CIEDE2000 (ColourDifference.cpp:42-158) restated without atan2 / sin / cos calls:
-//   * hue angles never materialise.  With u_i = (a_i', b_i) / C_i' the unit hue
-//     vectors, cos(dh) = u1.u2 and sin(dh) = u1 x u2; half-angle identities give
-//     sin(dh/2), cos(dh/2) with ONE rsq, hence dH' = 2 sqrt(C1'C2') sin(dh/2) and
-//     the mean hue direction (cos, sin)(h1 + dh/2) -- exactly the reference's
-//     mean-hue case analysis (:107-122), which is "h1 plus half the wrapped
-//     difference" in all three branches;
+//   * hue angles never materialise: dH' = 2 sqrt(C1'C2') sin(dh/2) and the mean hue
+//     direction follow from the dot and cross products of (a_i', b_i) with ONE rsq --
+//     exactly the reference's mean-hue case analysis (:107-122), which is "h1 plus
+//     half the wrapped difference" in all three branches (see ciede2000_fast);
 //   * T (:124-127) and the rotation term's sin(2 d_theta) (:132-133,:145) depend on the
 //     mean hue angle alone: one interpolated lookup in a 2048-entry LDS table indexed
 //     by the "diamond angle" of the mean-hue vector (no inverse trig, one v_rcp_f32);
 //   * the per-pixel chroma sqrt(a^2+b^2) is read from precomputed planes;
 //   * sqrt(x/(x+k)) = x * rsq(x*(x+k)); divisions are v_rcp_f32.
-// About 13 quarter-rate ops + ~100 full-rate ops per pixel pair, against ~900 fp64
+// About 10 quarter-rate ops + ~90 full-rate ops per pixel pair, against ~900 fp64
 // instructions for the reference form.
 //
 // The formula is DISCONTINUOUS where the two hues are opposite (|dh| = 180 deg: the
@@ -68,59 +66,73 @@ constexpr int kHueLutSize = 2048;
 // opposite-hue discontinuity and the caller must use the fp64 form instead.
 // c1, c2: chroma sqrt(a^2 + b^2) of p and q, precomputed per pixel (stored planes).
 // lut: the hue table in LDS.
+//
+// Hue terms without unit vectors.  With v_i = (a_i', b_i), C_i = |v_i|, P = C1 C2,
+// dot = v1.v2 = P cos(dh), cross = v1 x v2 = P sin(dh):
+//   dH' = 2 sqrt(P) sin(dh/2)  (:102)  and  sin^2(dh/2) = (1 - cos dh)/2, so
+//     |dh| <= 90:  dH'^2 = 2 (P - dot) = 2 cross^2 / (P + dot)      (no cancellation)
+//     |dh| >  90:  dH'^2 = 2 (P + |dot|)
+//   i.e. with e = P + |dot|, r = rsq(2 e):  dH' = 2 cross r   or   sign(cross) 2 e r.
+//   mean hue direction (:104-122, "h1 plus half the wrapped difference"), any positive
+//   scale (the table index is scale-free): with s = C2 v1, t = C1 v2 (equal lengths)
+//     |dh| <= 90:  s + t                       (bisector, length >= sqrt(2) P)
+//     |dh| >  90:  sign(cross) rot_{-90}(t - s)  (same bisector, length >= sqrt(2) P)
+// A grey colour (C = 0: h = 0, dh' = 0, h_bar = h1 + h2 in the reference, :61-83,:108-109)
+// needs no case of its own: dot = cross = P = 0 gives dH' = 0 and the direction of the other
+// colour (C is floored at 1e-18 for the direction only); two greys give direction (0, 0),
+// where T and R_T are multiplied by a zero mean chroma.
 __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, float c1, float c2,
                                                 const float4* __restrict__ lut, bool* needs_exact)
 {
     // G, a', C' (:50-59)
     const float one_g = 1.5f - 0.5f * sqrt_ratio7(0.5f * (c1 + c2));     // 1 + G
     const float a1 = one_g * p.c1, a2 = one_g * q.c1;
-    const float m1 = fmaf(a1, a1, p.c2 * p.c2), m2 = fmaf(a2, a2, q.c2 * q.c2);
-    const bool grey1 = m1 < 1e-30f, grey2 = m2 < 1e-30f;
-    const float i1 = grey1 ? 0.0f : frsq(m1), i2 = grey2 ? 0.0f : frsq(m2);
-    const float c1p = m1 * i1, c2p = m2 * i2;
+    const float b1 = p.c2, b2 = q.c2;
+    const float m1 = fmaf(a1, a1, b1 * b1), m2 = fmaf(a2, a2, b2 * b2);
+    const float c1p = m1 * frsq(fmaxf(m1, 1e-36f)), c2p = m2 * frsq(fmaxf(m2, 1e-36f));
 
-    // unit hue vectors; a grey colour takes the other's hue (h' = 0 and h_bar =
-    // h1 + h2 in the reference, :61-83,:108-109), two greys take hue 0
-    float u1x = a1 * i1, u1y = p.c2 * i1, u2x = a2 * i2, u2y = q.c2 * i2;
-    if (grey1) { u1x = grey2 ? 1.0f : u2x; u1y = grey2 ? 0.0f : u2y; }
-    if (grey2) { u2x = u1x; u2y = u1y; }
+    const float dot = fmaf(a1, a2, b1 * b2);
+    const float cross = fmaf(a1, b2, -(b1 * a2));
+    const float pp = c1p * c2p;
+    const bool acute = !(dot < 0.0f);
+    *needs_exact = !acute && fabsf(cross) < 3e-5f * pp;
 
-    const float cosd = fmaf(u1x, u2x, u1y * u2y);          // cos(h2 - h1)
-    const float sind = fmaf(u1x, u2y, -(u1y * u2x));       // sin(h2 - h1)
-    *needs_exact = cosd < 0.0f && fabsf(sind) < 3e-5f;
+    const float e = pp + fabsf(dot);
+    const float r = frsq(fmaxf(e + e, 1e-36f));
+    const float half_dh = acute ? cross * r : copysignf(e * r, cross);      // dH' / 2  (:102)
 
-    // half angle: sh = sin(dh/2) (signed), ch = cos(dh/2) >= 0, dh wrapped to (-pi, pi]
-    const bool acute = cosd > 0.0f;
-    const float e = acute ? 1.0f + cosd : 1.0f - cosd;     // in [1, 2]
-    const float r = frsq(e + e);
-    const float sh = acute ? sind * r : copysignf(e * r, sind);
-    const float ch = acute ? e * r : fabsf(sind) * r;
-
-    const float d_l = q.c0 - p.c0;
-    const float d_c = c2p - c1p;
-    const float d_h = 2.0f * fsqrt(c1p * c2p) * sh;         // :102
-
-    // mean hue direction (:104-122) -> table index -> T and sin(2 d_theta)
-    const float hc = fmaf(u1x, ch, -(u1y * sh));
-    const float hs = fmaf(u1y, ch, u1x * sh);
-    const float qd = hc * frcp(fmaxf(fabsf(hc) + fabsf(hs), 1e-20f));
-    const float x = (2.0f - copysignf(1.0f + qd, hs)) * (float)(kHueLutSize / 4);
+    // mean hue direction -> table index -> T and sin(2 d_theta)
+    const float k1 = fmaxf(c1p, 1e-18f), k2 = fmaxf(c2p, 1e-18f);
+    const float sx = a1 * k2, sy = b1 * k2, tx = a2 * k1, ty = b2 * k1;
+    const float hx = acute ? sx + tx : copysignf(1.0f, cross) * (ty - sy);
+    const float hy = acute ? sy + ty : copysignf(1.0f, cross) * (sx - tx);
+    const float qd = hx * frcp(fmaxf(fabsf(hx) + fabsf(hy), 1e-36f));
+    const float x = (2.0f - copysignf(1.0f + qd, hy)) * (float)(kHueLutSize / 4);
     const int idx = min(max((int)x, 0), kHueLutSize - 1);      // x >= 0: truncation = floor
     const float fr = x - (float)idx;                            // x == N (angle 2 pi) -> entry N-1, fr = 1
     const float4 en = lut[idx];
     const float t = fmaf(fr, en.y, en.x);
     const float s2 = fmaf(fr, en.w, en.z);
 
-    const float cpb = 0.5f * (c1p + c2p);
-    const float r_t = -s2 * 2.0f * sqrt_ratio7(cpb);        // :136,:145
+    const float csum = c1p + c2p;                           // 2 * mean C'
+    const float r_t = -s2 * 2.0f * sqrt_ratio7(0.5f * csum);    // :136,:145
     const float lb = 0.5f * (p.c0 + q.c0) - 50.0f;
     const float l2 = lb * lb;
     const float s_l = fmaf(0.015f * l2, frsq(20.0f + l2), 1.0f);
-    const float s_c = fmaf(0.045f, cpb, 1.0f);
-    const float s_h = fmaf(0.015f * cpb, t, 1.0f);
+    const float s_c = fmaf(0.0225f, csum, 1.0f);
+    const float s_h = fmaf(0.0075f * csum, t, 1.0f);
 
-    const float t_l = d_l * frcp(s_l), t_c = d_c * frcp(s_c), t_h = d_h * frcp(s_h);
-    const float xx = fmaf(t_l, t_l, fmaf(t_c, t_c, fmaf(t_h, t_h, r_t * t_c * t_h)));
+    // (:153-157) with ONE reciprocal for the chroma and hue terms:
+    //   tC = dC/S_C = A/D, tH = dH/S_H = B/D,  D = S_C S_H, A = dC S_H, B = dH S_C
+    const float d_l = q.c0 - p.c0;
+    const float d_c = c2p - c1p;
+    const float big_d = s_c * s_h;
+    const float ta = d_c * s_h;
+    const float tb = (half_dh + half_dh) * s_c;
+    const float num = fmaf(ta, ta, fmaf(tb, tb, (r_t * ta) * tb));
+    const float inv_d = frcp(big_d);
+    const float t_l = d_l * frcp(s_l);
+    const float xx = fmaf(t_l, t_l, num * (inv_d * inv_d));
     return fsqrt(fmaxf(xx, 0.0f));
 }
 

@@ -65,6 +65,7 @@ struct mm_engine {
     int n_var = 0, var_of_mask[4] = {0, 0, 0, 0}, var_groups[4] = {0, 0, 0, 0};
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
     int use_lds_filter = -1;     // mm_set_option("lds_filter", 0/1); -1 = auto (Euclid only: it is the L2-bound one)
+    int extra_seeds = 22;        // mm_set_option("seeds", n): proxy-chosen seeds beyond the list length
     int tile_candidates = 0;     // mm_set_option("tile", n): candidates per filter workgroup (0 = default)
     int max_batch_cells = 0;     // mm_set_option("max_batch", n): cap on cells per device batch (0 = from memory)
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
@@ -445,7 +446,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     }
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     // Early exit needs seeds: K <= M <= 256 of them, and the L proxy distances in LDS.
-    const int M = std::min(L, std::min(256, round_up(K + 22, 4)));
+    const int M = std::min(L, std::min(256, round_up(K + e->extra_seeds, 4)));
     const bool prune = two_tier && e->use_prune != 0 && K <= M && (size_t)L * sizeof(float) <= 100 * 1024;
     if (prune) {
         if ((st = ensure(e, e->seeds, (size_t)batch * M * sizeof(int32_t), "Failed to allocate seeds")) ||
@@ -1179,6 +1180,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "row_pipeline") == 0) { e->use_row_pipeline = value != 0; return MM_OK; }
     if (strcmp(name, "lds_filter") == 0) { e->use_lds_filter = value < 0 ? -1 : (value != 0); return MM_OK; }
     if (strcmp(name, "spec_k") == 0) { e->spec_k = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "seeds") == 0) { e->extra_seeds = std::max(0, value); return MM_OK; }
     if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }
     if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);

@@ -191,20 +191,18 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
         int visited = 0;
 #endif
         if (!pruned && groups > 0) {
-            LibGroup nxt = load_lib_group<TYPE>(b0, b1, b2, bc, lane);
-            for (int j = 0; j < groups; ++j) {
+            // One 256-pixel group of the candidate against the cell; true = candidate dropped.
+            auto visit = [&](const LibGroup& cur, int j) -> bool {
                 if (j != 0 && j % check_every == 0) {
                     const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), j)) : 0.0f;
-                    if (wave_sum_dpp(acc) + rest_j > limit) { pruned = true; break; }
+                    if (wave_sum_dpp(acc) + rest_j > limit) return true;
                 }
                 const int q = lane + kWave * j;
-                const LibGroup cur = nxt;
-                if (j + 1 < groups) nxt = load_lib_group<TYPE>(b0, b1, b2, bc, q + kWave);   // one group ahead
                 const uint32_t m = mk[q];
 #ifdef MM_COUNT_VISITS
                 visited += 1;
 #endif
-                if (m == 0) continue;
+                if (m == 0) return false;
                 const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
                 float4 pc{0.f, 0.f, 0.f, 0.f};
                 if constexpr (TYPE == CIEDE2000) pc = cc[q];
@@ -232,6 +230,17 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
                 } else {
                     acc += (a0 ? v0 : 0.0f) + (a1 ? v1 : 0.0f) + (a2 ? v2 : 0.0f) + (a3 ? v3 : 0.0f);
                 }
+                return false;
+            };
+            // The library group of the next iteration is fetched while this one computes.  Two
+            // register sets take turns (unrolled by two) so the hand-over costs no moves.
+            LibGroup ga = load_lib_group<TYPE>(b0, b1, b2, bc, lane), gb = ga;
+            for (int j = 0; j < groups; j += 2) {
+                if (j + 1 < groups) gb = load_lib_group<TYPE>(b0, b1, b2, bc, lane + kWave * (j + 1));
+                if (visit(ga, j)) { pruned = true; break; }
+                if (j + 1 >= groups) break;
+                if (j + 2 < groups) ga = load_lib_group<TYPE>(b0, b1, b2, bc, lane + kWave * (j + 2));
+                if (visit(gb, j + 1)) { pruned = true; break; }
             }
         }
 #ifdef MM_COUNT_VISITS
