@@ -48,8 +48,8 @@ __device__ __forceinline__ float sqrt_ratio7(float x)
 {
     const float s = x * 0.04f;
     const float s2 = s * s, s4 = s2 * s2;
-    const float z = s4 * s2 * s;
-    return z * frsq(fmaxf(z * (z + 1.0f), 1e-36f));
+    const float z = fmaf(s4 * s2, s, 1e-30f);       // > 0: no 0 * inf below
+    return z * frsq(fmaf(z, z, z));
 }
 
 // Hue table: T (ColourDifference.cpp:124-127) and sin(2*d_theta) (:132-133,:145) depend
@@ -79,7 +79,7 @@ constexpr int kHueLutSize = 2048;
 //     |dh| >  90:  sign(cross) rot_{-90}(t - s)  (same bisector, length >= sqrt(2) P)
 // A grey colour (C = 0: h = 0, dh' = 0, h_bar = h1 + h2 in the reference, :61-83,:108-109)
 // needs no case of its own: dot = cross = P = 0 gives dH' = 0 and the direction of the other
-// colour (C is floored at 1e-18 for the direction only); two greys give direction (0, 0),
+// colour (C' is never below 1e-18); two greys give direction (0, 0),
 // where T and R_T are multiplied by a zero mean chroma.
 __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, float c1, float c2,
                                                 const float4* __restrict__ lut, bool* needs_exact)
@@ -88,8 +88,9 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     const float one_g = 1.5f - 0.5f * sqrt_ratio7(0.5f * (c1 + c2));     // 1 + G
     const float a1 = one_g * p.c1, a2 = one_g * q.c1;
     const float b1 = p.c2, b2 = q.c2;
-    const float m1 = fmaf(a1, a1, b1 * b1), m2 = fmaf(a2, a2, b2 * b2);
-    const float c1p = m1 * frsq(fmaxf(m1, 1e-36f)), c2p = m2 * frsq(fmaxf(m2, 1e-36f));
+    // + 1e-36: C' >= 1e-18 > 0 (rsq stays finite, a grey colour keeps a direction below)
+    const float m1 = fmaf(a1, a1, fmaf(b1, b1, 1e-36f)), m2 = fmaf(a2, a2, fmaf(b2, b2, 1e-36f));
+    const float c1p = m1 * frsq(m1), c2p = m2 * frsq(m2);
 
     const float dot = fmaf(a1, a2, b1 * b2);
     const float cross = fmaf(a1, b2, -(b1 * a2));
@@ -98,12 +99,11 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     *needs_exact = !acute && fabsf(cross) < 3e-5f * pp;
 
     const float e = pp + fabsf(dot);
-    const float r = frsq(fmaxf(e + e, 1e-36f));
+    const float r = frsq(e + e);                                            // e >= P >= 1e-36
     const float half_dh = acute ? cross * r : copysignf(e * r, cross);      // dH' / 2  (:102)
 
     // mean hue direction -> table index -> T and sin(2 d_theta)
-    const float k1 = fmaxf(c1p, 1e-18f), k2 = fmaxf(c2p, 1e-18f);
-    const float sx = a1 * k2, sy = b1 * k2, tx = a2 * k1, ty = b2 * k1;
+    const float sx = a1 * c2p, sy = b1 * c2p, tx = a2 * c1p, ty = b2 * c1p;
     const float hx = acute ? sx + tx : copysignf(1.0f, cross) * (ty - sy);
     const float hy = acute ? sy + ty : copysignf(1.0f, cross) * (sx - tx);
     const float qd = hx * frcp(fmaxf(fabsf(hx) + fabsf(hy), 1e-36f));
