@@ -78,13 +78,21 @@ __device__ __forceinline__ void load_hue_lut(float4* lds, const float4* __restri
 
 struct LibGroup { float4 q0, q1, q2, qc; };
 
+// Loads at (uniform base) + (32-bit byte offset): the form global_load takes with the
+// base in SGPRs and one VGPR offset shared by all planes -- no 64-bit address arithmetic.
+__device__ __forceinline__ float4 ld4(const float4* base, unsigned int byte_off)
+{
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 template <int TYPE>
 __device__ __forceinline__ LibGroup load_lib_group(const float4* b0, const float4* b1, const float4* b2,
                                                    const float4* bc, int q)
 {
+    const unsigned int off = (unsigned int)q * 16u;
     LibGroup g;
-    g.q0 = b0[q]; g.q1 = b1[q]; g.q2 = b2[q];
-    if constexpr (TYPE == CIEDE2000) g.qc = bc[q]; else g.qc = float4{0.f, 0.f, 0.f, 0.f};
+    g.q0 = ld4(b0, off); g.q1 = ld4(b1, off); g.q2 = ld4(b2, off);
+    if constexpr (TYPE == CIEDE2000) g.qc = ld4(bc, off); else g.qc = float4{0.f, 0.f, 0.f, 0.f};
     return g;
 }
 
@@ -115,7 +123,7 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
     const int cell = group * cell_group + (int)(rem - (long long)tile * cells_here);
     if (tile >= n_tiles || cell >= n_cells) return;
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int v = var.cell_var[cell];
     const int groups = var.groups[v];                    // only the variant's active pixels
     lib += (size_t)v * var.lib_stride;
@@ -160,7 +168,7 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
         {   // the next candidate of this tile not yet taken by any wave
             int nxt = 0;
             if (lane == 0) nxt = atomicAdd(&next_candidate, 1);
-            idx = __shfl(nxt, 0, kWave);
+            idx = __builtin_amdgcn_readfirstlane(nxt);      // scalar: library addresses stay in SGPRs
         }
         const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
         const float4* b1 = b0 + ppad / 4;
@@ -198,14 +206,15 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
                     if (wave_sum_dpp(acc) + rest_j > limit) return true;
                 }
                 const int q = lane + kWave * j;
-                const uint32_t m = mk[q];
+                const unsigned int off = (unsigned int)q * 16u;
+                const uint32_t m = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(mk) + off / 4u);
 #ifdef MM_COUNT_VISITS
                 visited += 1;
 #endif
                 if (m == 0) return false;
-                const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
+                const float4 p0 = ld4(c0, off), p1 = ld4(c1, off), p2 = ld4(c2, off);
                 float4 pc{0.f, 0.f, 0.f, 0.f};
-                if constexpr (TYPE == CIEDE2000) pc = cc[q];
+                if constexpr (TYPE == CIEDE2000) pc = ld4(cc, off);
                 const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, qc = cur.qc;
                 bool e0, e1, e2, e3;
                 const float v0 = pair_fast<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
