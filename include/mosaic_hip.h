@@ -128,6 +128,42 @@ mm_status mm_set_masks(mm_engine *e, const uint8_t *masks, int size);
  * f32 HWC [rows][cols][3].  Cells are gathered from it on the device. */
 mm_status mm_set_target(mm_engine *e, const float *image, int rows, int cols);
 
+/* ---- pre-processing and detail / size steps on the device ------------------
+ * (SURVEY 8f N2 / N3).  OpenCV is not part of the reference checkout, so the
+ * arithmetic of these steps is SPECIFIED in csrc/kernels.hpp (cell_pixel,
+ * preprocess_u8_kernel) and restated by the CPU checker of the test suite; only integer resize
+ * factors (detail 100/n %, even cell sizes per size step) are covered. */
+
+/* preprocessLibraryImages() (PhotomosaicGeneratorBase.cpp:255-290): u8 BGR
+ * [n_images][size][size][3] -> INTER_AREA shrink by `shrink` on the u8 images
+ * (detail cell size = size / shrink; 1 = none) -> f32 BGR (MM_RGB_EUCLIDEAN) or
+ * f32 Lab (MM_CIE76 / MM_CIEDE2000).  Replaces mm_set_library. */
+mm_status mm_set_library_u8(mm_engine *e, const uint8_t *bgr, int n_images, int size,
+                            int shrink, int diff_type);
+
+/* preprocessMainImage() (PhotomosaicGeneratorBase.cpp:223-252), colour scheme
+ * NONE: u8 BGR [rows][cols][3] -> f32 BGR or Lab.  Replaces mm_set_target. */
+mm_status mm_set_target_u8(mm_engine *e, const uint8_t *bgr, int rows, int cols, int diff_type);
+
+/* ImageUtility::batchResizeMat(lib) between size steps
+ * (CPUPhotomosaicGenerator.cpp:95-99): the resident f32 library is replaced by
+ * its INTER_AREA reduction by `factor` (2 per size step). */
+mm_status mm_shrink_library(mm_engine *e, int factor);
+
+/* Detail level 1/factor (getCellAt's resize of the cell to the detail size,
+ * PhotomosaicGeneratorBase.cpp:313-315): cell records keep x, y in image
+ * pixels of the NORMAL cell, bounds and masks are in detail pixels, and each
+ * detail pixel of a cell is the mean of a factor x factor block of the
+ * zero-filled normal cell.  1 (default) = detail 100 %. */
+mm_status mm_set_cell_scale(mm_engine *e, int factor);
+
+/* Read-back of the resident (pre-processed) inputs, for tests and for feeding a
+ * CPU generator the same arrays: library f32 [n_images][size][size][3] at its
+ * current size (mm_library_shape), main image f32 [rows][cols][3]. */
+mm_status mm_library_shape(mm_engine *e, int *n_images, int *size);
+mm_status mm_get_library(mm_engine *e, float *images_out);
+mm_status mm_get_target(mm_engine *e, float *image_out);
+
 /* ---- the hot path ------------------------------------------------------ */
 
 /* generateBestFits() for one size step.

@@ -50,6 +50,13 @@ SIGNATURES = {
     "mm_set_library": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
     "mm_set_masks": (ctypes.c_int, [_VP, _VP, ctypes.c_int]),
     "mm_set_target": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
+    "mm_set_library_u8": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mm_set_target_u8": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mm_shrink_library": (ctypes.c_int, [_VP, ctypes.c_int]),
+    "mm_set_cell_scale": (ctypes.c_int, [_VP, ctypes.c_int]),
+    "mm_library_shape": (ctypes.c_int, [_VP, c_int_p, c_int_p]),
+    "mm_get_library": (ctypes.c_int, [_VP, _VP]),
+    "mm_get_target": (ctypes.c_int, [_VP, _VP]),
     "mm_generate": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_int, _VP, _VP, _VP, _VP, _VP]),
     "mm_candidates_per_cell": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),

@@ -12,6 +12,8 @@ import struct
 
 import numpy as np
 
+from .imageutil import resize_area_u8
+
 MCS_MAGIC = 0x87AECFB1          # CellShape.h; header check CellShape.cpp:392-395
 MCS_VERSION = 8
 MCS_VERSION_ENCODED = 8         # images PNG-encoded from v8, raw before (CellShape.cpp:411-414)
@@ -23,25 +25,12 @@ def _threshold(mask):
 
 
 def _resize_area_u8(img, size):
-    """INTER_AREA shrink of a square u8 image (what resizeImage picks for a
-    factor < 1, Other/ImageUtility.cpp:50).  Area-weighted mean, rounded half
-    to even like cv::saturate_cast<uchar>.  For integer factors this is the
-    exact box mean; OpenCV's own arithmetic is not in the reference checkout,
-    so parity at this step is UNPINNED -- oracle and engine are
-    always given the same resized mask."""
-    n = img.shape[0]
-    if size > n:
+    """INTER_AREA shrink of a square u8 image (what resizeImage picks for a factor < 1,
+    Other/ImageUtility.cpp:50) -- imageutil.resize_area_u8, the restated OpenCV algorithm;
+    parity at this step is UNPINNED."""
+    if size > img.shape[0]:
         raise NotImplementedError("INTER_CUBIC enlargement is outside the hot path")
-    edges = np.linspace(0.0, n, size + 1)
-    w = np.zeros((size, n), dtype=np.float64)
-    for i in range(size):
-        lo, hi = edges[i], edges[i + 1]
-        j0, j1 = int(math.floor(lo)), int(math.ceil(hi))
-        for j in range(j0, min(j1, n)):
-            w[i, j] = max(0.0, min(hi, j + 1) - max(lo, j))
-        w[i] /= (hi - lo)
-    out = w @ img.astype(np.float64) @ w.T
-    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return resize_area_u8(img, size, size)
 
 
 class CellShape:
@@ -215,40 +204,68 @@ class CellShape:
 
 
 class CellGroup:
-    """Normal + detail cell shape for size step 0 (CellGroup.h:26-64).
+    """Normal + detail cell shapes per size step (CellGroup.h:26-64, CellGroup.cpp).
 
-    The engine covers detail 100 % and size steps 0 (all BASELINE configs);
-    other detail levels need OpenCV's resize of the cell pixels, which stays on
-    the reference host."""
+    The engine covers detail levels and size steps whose cell sizes divide evenly (detail
+    100/n %, cell size a multiple of 2^steps): the resizes are then whole-factor box means.
+    Other ratios need OpenCV's fractional INTER_AREA / INTER_CUBIC of cell pixels and stay
+    on the reference host."""
 
     def __init__(self, cellShape=None):
         self.detail = 1.0
         self.sizeSteps = 0
-        self._cell = cellShape if cellShape is not None else CellShape()
+        self._cells = [cellShape if cellShape is not None else CellShape()]
+        self._detailCells = [self._cells[0]]
+        if cellShape is not None:
+            self.setDetail(100, reset=True)
 
     def setCellShape(self, cellShape):
-        self._cell = cellShape
+        """CellGroup::setCellShape (CellGroup.cpp:29-56; edge cells are GUI-only)."""
+        self._cells[0] = cellShape
+        if not cellShape.empty():
+            self.setDetail(0, reset=True)
+        else:
+            self._cells, self._detailCells = [cellShape], [cellShape]
 
-    def setDetail(self, detail_percent=100):
-        if int(detail_percent) != 100:
-            raise NotImplementedError("detail != 100 % resizes cell pixels with OpenCV on the host")
-        self.detail = 1.0
+    def setDetail(self, detail_percent=100, reset=False):
+        """CellGroup::setDetail (CellGroup.cpp:65-87)."""
+        new = self.detail if reset else detail_percent / 100.0
+        if new != self.detail or reset:
+            self.detail = new
+            if not self._cells[0].empty():
+                size = max(int(self._cells[0].getSize() * self.detail), 1)
+                self._detailCells[0] = self._cells[0].resized(size)
+            self.setSizeSteps(self.sizeSteps, reset=True)
 
     def getDetail(self):
         return self.detail
 
-    def setSizeSteps(self, steps):
-        if int(steps) != 0:
-            raise NotImplementedError("size steps > 0 are outside the hot-path scope (SURVEY 8f N3)")
-        self.sizeSteps = 0
+    def setSizeSteps(self, steps, reset=False):
+        """CellGroup::setSizeSteps (CellGroup.cpp:96-128): each step halves the cell."""
+        steps = int(steps)
+        self._cells = (self._cells + [None] * steps)[:steps + 1]
+        self._detailCells = (self._detailCells + [None] * steps)[:steps + 1]
+        size = self._cells[0].getSize()
+        for step in range(1, steps + 1):
+            size //= 2
+            if reset or step > self.sizeSteps or self._cells[step] is None:
+                self._cells[step] = self._cells[step - 1].resized(size)
+                self._detailCells[step] = self._cells[step].resized(max(int(size * self.detail), 1))
+        self.sizeSteps = steps
 
     def getSizeSteps(self):
         return self.sizeSteps
 
     def getCell(self, sizeStep=0, detail=False):
-        if sizeStep != 0:
-            raise IndexError(sizeStep)
-        return self._cell
+        return (self._detailCells if detail else self._cells)[sizeStep]
 
     def getCellSize(self, sizeStep=0, detail=False):
         return self.getCell(sizeStep, detail).getSize()
+
+    def cellScale(self, sizeStep=0):
+        """Normal-cell pixels per detail pixel and axis at a step; raises unless whole."""
+        n, d = self.getCellSize(sizeStep), self.getCellSize(sizeStep, True)
+        if d <= 0 or n % d != 0:
+            raise NotImplementedError("cell size %d at detail size %d: only whole-number detail ratios "
+                                      "are covered (fractional INTER_AREA stays on the OpenCV host)" % (n, d))
+        return n // d

@@ -54,6 +54,8 @@ struct mm_engine {
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut;
     DevBuf row_map, spec_recs, deep, insufficient;
+    DevBuf stage_u8, srgb_lut, shrink_tmp;
+    int cell_scale = 1;          // mm_set_cell_scale: full-size cell pixels per detail pixel and axis
     int spec_k = 10;             // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
@@ -127,6 +129,8 @@ constexpr double kTieBand = 1e-9;
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+mm_status target_range(mm_engine* e);
+
 inline bool known_type(int t) { return t == MM_RGB_EUCLIDEAN || t == MM_CIE76 || t == MM_CIEDE2000; }
 
 mm_status check_ready(mm_engine* e)
@@ -152,8 +156,10 @@ mm_status check_cells(mm_engine* e, const mm_cell* cells, int n, int grid_w, int
             c.row_min >= 0 && c.row_min < c.row_max && c.row_max <= size &&
             c.col_min >= 0 && c.col_min < c.col_max && c.col_max <= size &&
             c.mask_id >= 0 && c.mask_id < 4 &&
-            (long long)c.y + c.row_min >= 0 && (long long)c.y + c.row_max <= e->rows &&
-            (long long)c.x + c.col_min >= 0 && (long long)c.x + c.col_max <= e->cols &&
+            (e->cell_scale > 1 ||      // the box mean zero-fills what lies outside the image
+             ((long long)c.y + c.row_min >= 0 && (long long)c.y + c.row_max <= e->rows &&
+              (long long)c.x + c.col_min >= 0 && (long long)c.x + c.col_max <= e->cols)) &&
+            (e->cell_scale == 1 || (std::abs((long long)c.x) < (1LL << 28) && std::abs((long long)c.y) < (1LL << 28))) &&
             (grid_w <= 0 || (c.grid_x >= 0 && c.grid_x < grid_w && c.grid_y >= 0 && c.grid_y < grid_h));
         if (!ok) {
             set_err(e, "cell %d: bound [%d,%d)x[%d,%d) at (%d,%d), mask %d, grid (%d,%d) does not fit "
@@ -346,7 +352,7 @@ mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_typ
     const mm::Variants var = variants_of(e);
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
-        recs_dev, (const float*)e->target.p, e->cols, (const uint8_t*)e->masks.p,
+        recs_dev, (const float*)e->target.p, e->rows, e->cols, e->cell_scale, (const uint8_t*)e->masks.p,
         (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
         (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p);
     HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
@@ -478,7 +484,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         }
 
         mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
-            recs_dev + done, (const float*)e->target.p, e->cols, (const uint8_t*)e->masks.p,
+            recs_dev + done, (const float*)e->target.p, e->rows, e->cols, e->cell_scale, (const uint8_t*)e->masks.p,
             (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
             (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p);
         HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
@@ -609,7 +615,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
     a.repeat_range = range; a.repeat_addition = addition; a.K = K;
     a.cand_index = cand_i_dev; a.cand_score = cand_s_dev;
     a.grid = (long long*)e->grid.p; a.best_score = (double*)e->best.p;
-    a.target = (const float*)e->target.p; a.rows = e->rows; a.cols = e->cols;
+    a.target = (const float*)e->target.p; a.rows = e->rows; a.cols = e->cols; a.cell_scale = e->cell_scale;
     a.masks = (const uint8_t*)e->masks.p; a.lib = (const float*)e->lib.p;
     a.lib_stride = (size_t)e->n_lib * 3 * ppad; a.inv_perm = (const int*)e->inv_perm.p;
     for (int i = 0; i < 4; ++i) a.var_of_mask[i] = e->var_of_mask[i];
@@ -779,7 +785,8 @@ void mm_destroy(mm_engine* e)
                        &e->dense_recs, &e->dense_i, &e->dense_s, &e->lib_means, &e->seeds,
                        &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
-                       &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum })
+                       &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
+                       &e->stage_u8, &e->srgb_lut, &e->shrink_tmp })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -839,16 +846,156 @@ mm_status mm_set_target(mm_engine* e, const float* image, int rows, int cols)
     mm_status st = ensure(e, e->target, bytes, "Failed to allocate main image");
     if (st) return st;
     HIP_TRY(e, hipMemcpy(e->target.p, image, bytes, hipMemcpyHostToDevice), "Failed to copy main image to device");
+    e->rows = rows;
+    e->cols = cols;
+    return target_range(e);
+}
+
+namespace {
+
+// sRGB decode table for preprocess_u8_kernel: c/255 -> linear, fp64 (the formulae of
+// synth.bgr_u8_to_lab_f32).
+mm_status ensure_srgb_lut(mm_engine* e)
+{
+    if (e->srgb_lut.p) return MM_OK;
+    double lut[256];
+    for (int i = 0; i < 256; ++i) {
+        const double c = (double)i / 255.0;
+        lut[i] = c > 0.04045 ? std::pow((c + 0.055) / 1.055, 2.4) : c / 12.92;
+    }
+    mm_status st = ensure(e, e->srgb_lut, sizeof lut, "Failed to allocate sRGB table");
+    if (st) return st;
+    HIP_TRY(e, hipMemcpy(e->srgb_lut.p, lut, sizeof lut, hipMemcpyHostToDevice), "Failed to copy sRGB table to device");
+    return MM_OK;
+}
+
+// u8 BGR images -> resident f32 (dst), optionally shrunk by `factor` first.
+mm_status preprocess_u8(mm_engine* e, const uint8_t* bgr, size_t n_images, int rows, int cols, int factor,
+                        int diff_type, DevBuf& dst)
+{
+    const size_t in_bytes = n_images * (size_t)rows * cols * 3;
+    const size_t out_px = n_images * (size_t)(rows / factor) * (cols / factor);
+    mm_status st;
+    if ((st = ensure_srgb_lut(e)) || (st = ensure(e, e->stage_u8, in_bytes, "Failed to allocate u8 staging")) ||
+        (st = ensure(e, dst, out_px * 3 * sizeof(float), "Failed to allocate preprocessed images")))
+        return st;
+    HIP_TRY(e, hipMemcpyAsync(e->stage_u8.p, bgr, in_bytes, hipMemcpyHostToDevice, e->stream), "Failed to copy u8 images to device");
+    const unsigned blocks = (unsigned)std::min<size_t>((out_px + mm::kBlock - 1) / mm::kBlock, 65536);
+    mm::preprocess_u8_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(
+        (const uint8_t*)e->stage_u8.p, (float*)dst.p, n_images, rows, cols, factor,
+        diff_type != MM_RGB_EUCLIDEAN, (const double*)e->srgb_lut.p);
+    HIP_TRY(e, hipGetLastError(), "Error during preprocessing kernel");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    return MM_OK;
+}
+
+mm_status target_range(mm_engine* e)
+{
+    mm_status st;
     if ((st = ensure(e, e->counter, 2 * sizeof(unsigned long long), "Failed to allocate counter"))) return st;
     HIP_TRY(e, hipMemsetAsync(e->counter.p, 0, sizeof(unsigned int), e->stream), "Failed to clear counter");
-    HIP_TRY(e, mm::launch_absmax_offset((const float*)e->target.p, (size_t)rows * cols, 3, 1, 50.0f,
+    HIP_TRY(e, mm::launch_absmax_offset((const float*)e->target.p, (size_t)e->rows * e->cols, 3, 1, 50.0f,
                                         (unsigned int*)e->counter.p, e->stream), "Error during range kernel");
     unsigned int bits = 0;
     HIP_TRY(e, hipMemcpyAsync(&bits, e->counter.p, sizeof bits, hipMemcpyDeviceToHost, e->stream), "range");
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
     memcpy(&e->target_dmax, &bits, sizeof bits);
+    return MM_OK;
+}
+
+}  // namespace
+
+mm_status mm_set_library_u8(mm_engine* e, const uint8_t* bgr, int n_images, int size, int shrink, int diff_type)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!bgr || n_images <= 0 || size <= 0 || size > 4096 || shrink < 1 || size % shrink != 0 || !known_type(diff_type)) {
+        set_err(e, "mm_set_library_u8: need n_images > 0, 0 < size <= 4096, shrink dividing size, a known type "
+                   "(got %d, %d, %d, %d)", n_images, size, shrink, diff_type);
+        return MM_INVALID_ARGUMENT;
+    }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    mm_status st = preprocess_u8(e, bgr, (size_t)n_images, size, size, shrink, diff_type, e->lib_hwc);
+    if (st) return st;
+    e->planes_dirty = true;
+    e->n_lib = n_images;
+    e->lib_size = size / shrink;
+    return MM_OK;
+}
+
+mm_status mm_set_target_u8(mm_engine* e, const uint8_t* bgr, int rows, int cols, int diff_type)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!bgr || rows <= 0 || cols <= 0 || !known_type(diff_type)) {
+        set_err(e, "mm_set_target_u8: need rows, cols > 0 and a known type (got %d, %d, %d)", rows, cols, diff_type);
+        return MM_INVALID_ARGUMENT;
+    }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    mm_status st = preprocess_u8(e, bgr, 1, rows, cols, 1, diff_type, e->target);
+    if (st) return st;
     e->rows = rows;
     e->cols = cols;
+    return target_range(e);
+}
+
+mm_status mm_shrink_library(mm_engine* e, int factor)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!e->lib_hwc.p || e->n_lib <= 0) { set_err(e, "mm_shrink_library: no library staged"); return MM_NOT_READY; }
+    if (factor < 1 || e->lib_size % factor != 0) {
+        set_err(e, "mm_shrink_library: factor %d does not divide the image size %d (only integer "
+                   "INTER_AREA factors are supported)", factor, e->lib_size);
+        return MM_INVALID_ARGUMENT;
+    }
+    if (factor == 1) return MM_OK;
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    const int so = e->lib_size / factor;
+    const size_t out_px = (size_t)e->n_lib * so * so;
+    mm_status st = ensure(e, e->shrink_tmp, out_px * 3 * sizeof(float), "Failed to allocate library images");
+    if (st) return st;
+    const unsigned blocks = (unsigned)std::min<size_t>((out_px + mm::kBlock - 1) / mm::kBlock, 65536);
+    mm::shrink_f32_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(
+        (const float*)e->lib_hwc.p, (float*)e->shrink_tmp.p, e->n_lib, e->lib_size, factor);
+    HIP_TRY(e, hipGetLastError(), "Error during library resize kernel");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    std::swap(e->lib_hwc, e->shrink_tmp);
+    e->lib_size = so;
+    e->planes_dirty = true;
+    return MM_OK;
+}
+
+mm_status mm_set_cell_scale(mm_engine* e, int factor)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (factor < 1 || factor > 64) { set_err(e, "mm_set_cell_scale: need 1 <= factor <= 64 (got %d)", factor); return MM_INVALID_ARGUMENT; }
+    e->cell_scale = factor;
+    return MM_OK;
+}
+
+mm_status mm_get_library(mm_engine* e, float* out)
+{
+    if (!e || !out) return MM_INVALID_ARGUMENT;
+    if (!e->lib_hwc.p || e->n_lib <= 0) { set_err(e, "mm_get_library: no library staged"); return MM_NOT_READY; }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, hipMemcpy(out, e->lib_hwc.p, (size_t)e->n_lib * e->lib_size * e->lib_size * 3 * sizeof(float),
+                         hipMemcpyDeviceToHost), "Error copying library to host");
+    return MM_OK;
+}
+
+mm_status mm_get_target(mm_engine* e, float* out)
+{
+    if (!e || !out) return MM_INVALID_ARGUMENT;
+    if (!e->target.p || e->rows <= 0) { set_err(e, "mm_get_target: no main image staged"); return MM_NOT_READY; }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, hipMemcpy(out, e->target.p, (size_t)e->rows * e->cols * 3 * sizeof(float), hipMemcpyDeviceToHost),
+            "Error copying main image to host");
+    return MM_OK;
+}
+
+mm_status mm_library_shape(mm_engine* e, int* n_images, int* size)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (n_images) *n_images = e->n_lib;
+    if (size) *size = e->lib_size;
     return MM_OK;
 }
 

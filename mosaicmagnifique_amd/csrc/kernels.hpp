@@ -103,13 +103,120 @@ hwc_to_planar_kernel(const float* __restrict__ hwc, float* __restrict__ planar,
     }
 }
 
-// getCellAt on the device (PhotomosaicGeneratorBase.cpp:293-329, detail 1):
+// The f32 pixel of a cell at detail position (r, c).  scale 1: the target pixel under the
+// cell.  scale n > 1 (detail level 1/n): the mean of the n x n block of the zero-filled
+// full-size cell -- getCellAt copies the visible part of the image into a zero cell and
+// resizes it to the detail size with cv::resize INTER_AREA (PhotomosaicGeneratorBase.cpp:
+// 305-315), which for an integer factor is the box mean.  Arithmetic SPECIFIED here (OpenCV
+// is not part of the reference checkout): float row sums left to right, rows added top to
+// bottom, one multiply by 1/(n n); for n = 2 that is ((a + b) + (c + d)) * 0.25f.
+__device__ __forceinline__ void cell_pixel(const float* __restrict__ target, int rows, int cols,
+                                           int y, int x, int r, int c, int n, float out[3])
+{
+    if (n == 1) {
+        const float* s = target + ((size_t)(y + r) * cols + (x + c)) * 3;
+        out[0] = s[0]; out[1] = s[1]; out[2] = s[2];
+        return;
+    }
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const int yy = y + r * n + i;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const int xx = x + c * n + j;
+            if (yy >= 0 && yy < rows && xx >= 0 && xx < cols) {
+                const float* s = target + ((size_t)yy * cols + xx) * 3;
+                r0 += s[0]; r1 += s[1]; r2 += s[2];
+            }
+        }
+        t0 += r0; t1 += r1; t2 += r2;
+    }
+    const float inv = 1.0f / (float)(n * n);
+    out[0] = t0 * inv; out[1] = t1 * inv; out[2] = t2 * inv;
+}
+
+// Library resize by an integer factor on f32 images, [n][S][S][3] -> [n][S/f][S/f][3]:
+// ImageUtility::batchResizeMat(lib) between size steps (CPUPhotomosaicGenerator.cpp:95-99,
+// Other/ImageUtility.cpp:91-101: cv::resize INTER_AREA to round(0.5 * size)).  Same box mean
+// as cell_pixel.
+__global__ void __launch_bounds__(kBlock)
+shrink_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_images, int size_in, int f)
+{
+    const int so = size_in / f;
+    const size_t total = (size_t)n_images * so * so;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const size_t img = t / ((size_t)so * so);
+        const int p = (int)(t - img * so * so);
+        const int r = p / so, c = p - r * so;
+        float px[3];
+        cell_pixel(src + img * (size_t)size_in * size_in * 3, size_in, size_in, 0, 0, r, c, f, px);
+        float* d = dst + t * 3;
+        d[0] = px[0]; d[1] = px[1]; d[2] = px[2];
+    }
+}
+
+// preprocessMainImage / preprocessLibraryImages on the device (PhotomosaicGeneratorBase.cpp:
+// 223-252, :255-290): u8 BGR -> [optional INTER_AREA shrink by f ON THE u8 IMAGE, as the
+// reference resizes the library before converting, :262-271] -> f32 BGR in [0,255]
+// (convertTo(CV_32F)) or f32 Lab (convertTo(CV_32F, 1/255) + cvtColor(BGR2Lab)).
+// Arithmetic SPECIFIED here, OpenCV being absent from the reference checkout:
+//   u8 shrink: f = 2: (a + b + c + d + 2) >> 2; f > 2: rint(float(sum) * (1.f / (f f)))
+//              (OpenCV 4 imgproc resize.cpp, ResizeAreaFastVec / ResizeAreaFast_);
+//   Lab: sRGB decode by a 256-entry fp64 table, the BGR2Lab matrix and D65 white of
+//        OpenCV's documentation, f(t) = cbrt(t) above 0.008856 else 7.787 t + 16/116, in
+//        fp64, rounded to f32 once -- the same formulae as synth.bgr_u8_to_lab_f32.
+__global__ void __launch_bounds__(kBlock)
+preprocess_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, size_t n_images,
+                     int rows_in, int cols_in, int f, int lab, const double* __restrict__ srgb)
+{
+    const int ro = rows_in / f, co = cols_in / f;
+    const size_t per = (size_t)ro * co, total = n_images * per;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const size_t img = t / per;
+        const size_t p = t - img * per;
+        const int r = (int)(p / co), c = (int)(p - (size_t)r * co);
+        const uint8_t* s = src + img * (size_t)rows_in * cols_in * 3;
+        int v[3];
+        if (f == 1) {
+            const uint8_t* q = s + ((size_t)r * cols_in + c) * 3;
+            v[0] = q[0]; v[1] = q[1]; v[2] = q[2];
+        } else {
+            int sum[3] = {0, 0, 0};
+            for (int i = 0; i < f; ++i)
+                for (int j = 0; j < f; ++j) {
+                    const uint8_t* q = s + ((size_t)(r * f + i) * cols_in + (c * f + j)) * 3;
+                    sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2];
+                }
+            const float scale = 1.0f / (float)(f * f);
+            for (int k = 0; k < 3; ++k)
+                v[k] = f == 2 ? (sum[k] + 2) >> 2 : min(255, max(0, __float2int_rn((float)sum[k] * scale)));
+        }
+        float* d = dst + t * 3;
+        if (!lab) {
+            d[0] = (float)v[0]; d[1] = (float)v[1]; d[2] = (float)v[2];
+            continue;
+        }
+        const double b = srgb[v[0]], g = srgb[v[1]], rr = srgb[v[2]];
+        const double x = (0.412453 * rr + 0.357580 * g + 0.180423 * b) / 0.950456;
+        const double y = 0.212671 * rr + 0.715160 * g + 0.072169 * b;
+        const double z = (0.019334 * rr + 0.119193 * g + 0.950227 * b) / 1.088754;
+        const double fx = x > 0.008856 ? cbrt(x) : 7.787 * x + 16.0 / 116.0;
+        const double fy = y > 0.008856 ? cbrt(y) : 7.787 * y + 16.0 / 116.0;
+        const double fz = z > 0.008856 ? cbrt(z) : 7.787 * z + 16.0 / 116.0;
+        const double l = y > 0.008856 ? 116.0 * fy - 16.0 : 903.3 * y;
+        d[0] = (float)l;
+        d[1] = (float)(500.0 * (fx - fy));
+        d[2] = (float)(200.0 * (fy - fz));
+    }
+}
+
+// getCellAt on the device (PhotomosaicGeneratorBase.cpp:293-329; detail 1/scale):
 // the visible part of the target under the cell rect, zero elsewhere, as planes;
 // and the per-cell active mask = mask variant AND local bound (the CUDA path's
 // imageDifferenceEdge target_area test, CUDA/PhotomosaicGenerator.cu:53-72).
 __global__ void __launch_bounds__(kBlock)
 gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ target,
-                    int cols, const uint8_t* __restrict__ masks,
+                    int rows, int cols, int scale, const uint8_t* __restrict__ masks,
                     float* __restrict__ cells, uint8_t* __restrict__ cmask,
                     int size, int P, int ppad, const int* __restrict__ perm, int4 var_of_mask,
                     uint8_t* __restrict__ cell_var, uint8_t* __restrict__ cell_full)
@@ -130,8 +237,9 @@ gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ 
     if (p >= 0) {
         const int row = p / size, col = p - row * size;
         if (row >= rec.row_min && row < rec.row_max && col >= rec.col_min && col < rec.col_max) {
-            const float* src = target + ((size_t)(rec.y + row) * cols + (rec.x + col)) * 3;
-            v0 = src[0]; v1 = src[1]; v2 = src[2];
+            float px[3];
+            cell_pixel(target, rows, cols, rec.y, rec.x, row, col, scale, px);
+            v0 = px[0]; v1 = px[1]; v2 = px[2];
             m = masks[(size_t)rec.mask_id * ppad + p] != 0;
         }
     }
@@ -469,6 +577,7 @@ struct ResolveArgs {
     double* best_score;         // [grid_h*grid_w], pre-filled with NaN
     // pixel data for the exact tie-break
     const float* target; int rows, cols;
+    int cell_scale;             // full-size cell pixels per detail pixel and axis (cell_pixel)
     const uint8_t* masks;
     const float* lib;           // [variants][L][3][ppad], permuted pixel order per variant
     size_t lib_stride;          // floats between two variants
@@ -532,7 +641,8 @@ __device__ double exact_total(const ResolveArgs& a, const mm_cell& rec, int cand
             double term = -1.0;                               // marker: not active
             if (mk[p] != 0 && row >= rec.row_min && row < rec.row_max &&
                 col >= rec.col_min && col < rec.col_max) {
-                const float* src = a.target + ((size_t)(rec.y + row) * a.cols + (rec.x + col)) * 3;
+                float src[3];
+                cell_pixel(a.target, a.rows, a.cols, rec.y, rec.x, row, col, a.cell_scale, src);
                 const int k = ip[p];
                 term = colour_diff<TYPE>(Px{src[0], src[1], src[2]},
                                          Px{l0[k], l0[a.ppad + k], l0[2 * (size_t)a.ppad + k]});
@@ -567,7 +677,8 @@ __device__ void dense_row(const ResolveArgs& a, const mm_cell& rec, double* row,
         for (int p = threadIdx.x; p < a.P; p += kBlock) {
             const int r = p / a.size, c = p - r * a.size;
             if (mk[p] != 0 && r >= rec.row_min && r < rec.row_max && c >= rec.col_min && c < rec.col_max) {
-                const float* src = a.target + ((size_t)(rec.y + r) * a.cols + (rec.x + c)) * 3;
+                float src[3];
+                cell_pixel(a.target, a.rows, a.cols, rec.y, rec.x, r, c, a.cell_scale, src);
                 const int k = ip[p];
                 acc += colour_diff<TYPE>(Px{src[0], src[1], src[2]},
                                          Px{l0[k], l0[a.ppad + k], l0[2 * (size_t)a.ppad + k]});
@@ -940,7 +1051,8 @@ __device__ double exact_total_wave(const ResolveArgs& a, const mm_cell& rec, int
             double term = -1.0;
             if (mk[p] != 0 && row >= rec.row_min && row < rec.row_max &&
                 col >= rec.col_min && col < rec.col_max) {
-                const float* src = a.target + ((size_t)(rec.y + row) * a.cols + (rec.x + col)) * 3;
+                float src[3];
+                cell_pixel(a.target, a.rows, a.cols, rec.y, rec.x, row, col, a.cell_scale, src);
                 const int k = ip[p];
                 term = colour_diff<TYPE>(Px{src[0], src[1], src[2]},
                                          Px{l0[k], l0[a.ppad + k], l0[2 * (size_t)a.ppad + k]});

@@ -84,6 +84,44 @@ class Engine:
             raise ValueError("target must be [rows][cols][3]")
         self._check(self._lib.mm_set_target(self._h, _lib.ptr(a), a.shape[0], a.shape[1]))
 
+    # -- pre-processing, detail and size steps on the device -------------------
+    def set_library_u8(self, images, diff_type, shrink=1):
+        """u8 BGR ``[n][size][size][3]`` as setLibrary receives it; resized to ``size / shrink``
+        and colour-converted on the device (preprocessLibraryImages)."""
+        a = np.ascontiguousarray(images, dtype=np.uint8)
+        if a.ndim != 4 or a.shape[1] != a.shape[2] or a.shape[3] != 3:
+            raise ValueError("library must be [n][size][size][3]")
+        self._check(self._lib.mm_set_library_u8(self._h, _lib.ptr(a), a.shape[0], a.shape[1], int(shrink), int(diff_type)))
+        self.n_library, self.size = a.shape[0], a.shape[1] // int(shrink)
+
+    def set_target_u8(self, image, diff_type):
+        """u8 BGR ``[rows][cols][3]``; colour-converted on the device (preprocessMainImage)."""
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("target must be [rows][cols][3]")
+        self._check(self._lib.mm_set_target_u8(self._h, _lib.ptr(a), a.shape[0], a.shape[1], int(diff_type)))
+
+    def shrink_library(self, factor=2):
+        """batchResizeMat between size steps: the resident library at 1/factor of its size."""
+        self._check(self._lib.mm_shrink_library(self._h, int(factor)))
+        self.size //= int(factor)
+
+    def set_cell_scale(self, factor):
+        """Detail level 1/factor: cells are box-averaged from factor x factor image pixels."""
+        self._check(self._lib.mm_set_cell_scale(self._h, int(factor)))
+
+    def get_library(self):
+        n, size = ctypes.c_int(), ctypes.c_int()
+        self._check(self._lib.mm_library_shape(self._h, ctypes.byref(n), ctypes.byref(size)))
+        out = np.empty((n.value, size.value, size.value, 3), dtype=np.float32)
+        self._check(self._lib.mm_get_library(self._h, _lib.ptr(out)))
+        return out
+
+    def get_target(self, rows, cols):
+        out = np.empty((rows, cols, 3), dtype=np.float32)
+        self._check(self._lib.mm_get_target(self._h, _lib.ptr(out)))
+        return out
+
     # -- hot path ------------------------------------------------------------
     def _callbacks(self, progress, cancel):
         cb = _lib.PROGRESS_CB(lambda done, _u: progress(done)) if progress else None

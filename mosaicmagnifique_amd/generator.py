@@ -42,6 +42,9 @@ class HIPPhotomosaicGenerator:
         self._progress_listeners = []
         self._staged = None          # what is resident on the device: (lib id, img id, type, mask id)
         self._staged_bgr = None
+        self._masks_key = None
+        self._lib_step = 0          # size step the resident library is at (it is halved per step)
+        self._rows = self._cols = 0
         self.lastError = ""
 
     # -- setters (PhotomosaicGeneratorBase.cpp:44-93) -------------------------
@@ -91,17 +94,45 @@ class HIPPhotomosaicGenerator:
         self.m_wasCanceled.value = 1
 
     # -- preprocessing (PhotomosaicGeneratorBase.cpp:223-290) -----------------
-    def preprocessMainImage(self):
+    def _stage(self):
+        """Inputs onto the device.  u8 BGR inputs are resized (library: to the detail cell
+        size, on the u8 image as the reference does, :262-271) and colour-converted there;
+        f32 inputs are taken as already preprocessed (library at the detail cell size)."""
+        t = self.m_colourDiffType
+        detail_size = self.m_cells.getCellSize(0, True)
+        if self.m_lib.dtype == np.uint8:
+            size = self.m_lib.shape[1]
+            if size % detail_size != 0:
+                raise NotImplementedError("library images of %d px at a detail cell of %d px: only whole-number "
+                                          "ratios are covered" % (size, detail_size))
+            self.m_engine.set_library_u8(self.m_lib, int(t), shrink=size // detail_size)
+        else:
+            if self.m_lib.shape[1] != detail_size:
+                raise ValueError("a preprocessed (f32) library must be at the detail cell size %d" % detail_size)
+            self.m_engine.set_library(np.ascontiguousarray(self.m_lib, dtype=np.float32))
         if self.m_img.dtype == np.uint8:
-            return synth.preprocess(self.m_img, self.m_colourDiffType)
-        return np.ascontiguousarray(self.m_img, dtype=np.float32)
+            self.m_engine.set_target_u8(self.m_img, int(t))
+        else:
+            self.m_engine.set_target(np.ascontiguousarray(self.m_img, dtype=np.float32))
+        self._rows, self._cols = self.m_img.shape[0], self.m_img.shape[1]
+
+    def preprocessMainImage(self):
+        """The main image as the engine holds it after preprocessMainImage (f32 BGR / Lab)."""
+        self._ensure_staged()
+        return self.m_engine.get_target(self._rows, self._cols)
 
     def preprocessLibraryImages(self):
-        if self.m_cells.getDetail() != 1:
-            raise NotImplementedError("detail != 100 %: library resize stays on the OpenCV host")
-        if self.m_lib.dtype == np.uint8:
-            return synth.preprocess(self.m_lib, self.m_colourDiffType)
-        return np.ascontiguousarray(self.m_lib, dtype=np.float32)
+        """The library as the engine holds it after preprocessLibraryImages: f32, at the detail
+        cell size of size step 0."""
+        self._ensure_staged(force=self._lib_step != 0)
+        return self.m_engine.get_library()
+
+    def _ensure_staged(self, force=False):
+        key = (id(self.m_lib), id(self.m_img), self.m_colourDiffType, id(self.m_cells.getCell(0, True)))
+        if force or key != self._staged:
+            self._stage()
+            self._staged = key
+            self._lib_step = 0
 
     # -- the hot path --------------------------------------------------------
     def generateBestFits(self):
@@ -119,43 +150,60 @@ class HIPPhotomosaicGenerator:
             return False
 
     def _generate(self):
-        if len(self.m_bestFits) != 1:
-            raise NotImplementedError("size steps > 0 are outside the hot-path scope (SURVEY 8f N3)")
-        detailShape = self.m_cells.getCell(0, True)
-        key = (id(self.m_lib), id(self.m_img), self.m_colourDiffType, id(detailShape))
-        if key != self._staged:
-            main = self.preprocessMainImage()
-            lib = self.preprocessLibraryImages()
-            self.m_engine.set_library(lib)
-            self.m_engine.set_masks(detailShape.masks4())
-            self.m_engine.set_target(main)
-            self._staged = key
-            self._rows, self._cols = main.shape[0], main.shape[1]
-
+        """The step loop of generateBestFits (CPUPhotomosaicGenerator.cpp:46-100): per size
+        step the step's cell shapes, the grid of that step, and a library halved once more."""
+        steps = len(self.m_bestFits)
+        if steps > self.m_cells.getSizeSteps() + 1:
+            raise ValueError("grid state has more size steps than the cell group")
+        self._ensure_staged(force=self._lib_step != 0)
         self.m_progress = 0
-        step = self.m_bestFits[0]
-        cells = GridUtility.cell_records(self.m_cells, step, self._rows, self._cols)
-        # Invalid cells still tick the progress bar in the reference; emit the
-        # total once the device batches are through.
-        def on_progress(done):
-            self.m_progress = done
-            for fn in self._progress_listeners:
-                fn(done)
+        listeners = self._progress_listeners
+        out_fits, out_scores = [], []
+        for step in range(steps):
+            if self.m_wasCanceled.value:
+                raise Cancelled(3, "cancelled")
+            if step > 0:                                # ImageUtility::batchResizeMat(lib), :95-99
+                if self.m_engine.size % 2 != 0:
+                    raise NotImplementedError("size step %d halves an odd library size %d" % (step, self.m_engine.size))
+                self.m_engine.shrink_library(2)
+                self._lib_step = step
+            detailShape = self.m_cells.getCell(step, True)
+            if detailShape.getSize() != self.m_engine.size:
+                raise NotImplementedError("detail cell of %d px against a %d px library at step %d"
+                                          % (detailShape.getSize(), self.m_engine.size, step))
+            if self._masks_key != id(detailShape):
+                self.m_engine.set_masks(detailShape.masks4())
+                self._masks_key = id(detailShape)
+            self.m_engine.set_cell_scale(self.m_cells.cellScale(step))
+            state = self.m_bestFits[step]
+            cells = GridUtility.cell_records(self.m_cells, state, self._rows, self._cols, step)
+            # progress counts every grid position, weighted 4^(steps-1-step) (:54,:85-88)
+            weight = int(4 ** (steps - 1 - step))
+            base = self.m_progress
 
-        best, score = self.m_engine.generate(
-            cells, step.shape[1], step.shape[0], int(self.m_colourDiffType),
-            self.m_repeatRange, self.m_repeatAddition, want_scores=True,
-            progress=on_progress if self._progress_listeners else None, cancel=self.m_wasCanceled)
+            def on_progress(done, base=base, weight=weight):
+                self.m_progress = base + done * weight
+                for fn in listeners:
+                    fn(self.m_progress)
 
-        # Write back only where the grid state has a value (CUDAPhotomosaicGenerator.cpp:310-324).
-        valid = step >= 0
-        out = step.copy()
-        out[valid] = best[valid]
-        # "Failed to find a best fit... The cell will be removed" (CPUPhotomosaicGenerator.cpp:173-177)
-        out[valid & (best >= self.m_engine.n_library)] = GridUtility.NULLOPT
-        self.m_bestFits = [out]
-        self.m_bestScores = [score]
-        for fn in self._progress_listeners:
+            best, score = self.m_engine.generate(
+                cells, state.shape[1], state.shape[0], int(self.m_colourDiffType),
+                self.m_repeatRange, self.m_repeatAddition, want_scores=True,
+                progress=on_progress if listeners else None, cancel=self.m_wasCanceled)
+            self.m_progress = base + state.size * weight
+
+            # Write back only where the grid state has a value (CUDAPhotomosaicGenerator.cpp:310-324).
+            valid = state >= 0
+            out = state.copy()
+            out[valid] = best[valid]
+            # "Failed to find a best fit... The cell will be removed" (CPUPhotomosaicGenerator.cpp:173-177)
+            out[valid & (best >= self.m_engine.n_library)] = GridUtility.NULLOPT
+            out_fits.append(out)
+            out_scores.append(score)
+        self.m_bestFits = out_fits
+        self.m_bestScores = out_scores
+        self.m_engine.set_cell_scale(1)
+        for fn in listeners:
             fn(self.getMaxProgress())
         return True
 
@@ -168,11 +216,13 @@ class HIPPhotomosaicGenerator:
         rows, cols = self.m_img.shape[0], self.m_img.shape[1]
         # every cell the grid names (with or without a value: the engine skips the latter)
         state = np.where(step >= 0, 0, GridUtility.NULLOPT)
-        cells = GridUtility.cell_records(self.m_cells, state, rows, cols)
+        plain = CellGroup(self.m_cells.getCell(0))           # painting uses the NORMAL cell at full size
+        cells = GridUtility.cell_records(plain, state, rows, cols)
         if self._staged_bgr is not self.m_lib:
             self.m_engine.set_library_bgr(self.m_lib)
-            self.m_engine.set_masks(self.m_cells.getCell(0).masks4())
             self._staged_bgr = self.m_lib
+        self.m_engine.set_masks(self.m_cells.getCell(0).masks4())
+        self._masks_key = None
         return self.m_engine.build_photomosaic(cells, step.shape[1], step.shape[0], step, rows, cols,
                                                backgroundColour)
 

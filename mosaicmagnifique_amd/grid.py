@@ -1,9 +1,9 @@
 """Grid geometry of the best-fit path (host side).
 
-Mirror of ``GridUtility`` (src/Grid/GridUtility.{h,cpp}) and of the part of
-``GridGenerator::getGridState`` that applies with size steps 0
-(src/Grid/GridGenerator.cpp:29-110,113-140,191-192), plus the marshalling of
-valid cells into the ``mm_cell`` records the C ABI takes.
+Mirror of ``GridUtility`` (src/Grid/GridUtility.{h,cpp}), ``GridBounds::mergeBounds``
+and ``GridGenerator::getGridState`` / ``findCellState`` with the entropy subdivision
+over size steps (src/Grid/GridGenerator.cpp:29-193), plus the marshalling of valid
+cells into the ``mm_cell`` records the C ABI takes.
 
 A ``StepBestFit`` is a 2-D ``int64`` array over the PADDED grid; ``NULLOPT``
 (-1) stands for ``std::nullopt``, 0 for the initial ``optional(0)``, and after
@@ -77,47 +77,152 @@ def getFlipStateAt(cellShape, x, y):
     return FlipState(h, v)
 
 
-def getGridState(cellGroup, imageRows, imageCols):
-    """GridGenerator::getGridState for size steps 0: ``[StepBestFit]`` with 0 where
-    the cell rect meets the image and NULLOPT where it does not
-    (GridGenerator.cpp:61-70 over :113-140)."""
-    shape = cellGroup.getCell(0)
-    if shape.empty():
+def mergeBounds(bounds):
+    """GridBounds::mergeBounds (Grid/GridBounds.cpp:36-107) on a list of Rect; returns the merged list."""
+    b = [Rect(*r) for r in bounds]
+
+    def union(p, q):
+        x0, y0 = min(p.x, q.x), min(p.y, q.y)
+        x1, y1 = max(p.x + p.width, q.x + q.width), max(p.y + p.height, q.y + q.height)
+        return Rect(x0, y0, x1 - x0, y1 - y0)
+
+    merged = True
+    while merged:
+        merged = False
+        i = 0
+        while i + 1 < len(b):
+            j = i + 1
+            while j < len(b) and i + 1 < len(b):
+                p, q = b[i], b[j]
+                merge = False
+                if p.x == q.x and p.width == q.width:
+                    d = q.y - p.y
+                    merge = d == 0 or (0 < d <= p.height) or (d < 0 and -d <= q.height)
+                elif p.y == q.y and p.height == q.height:
+                    d = q.x - p.x
+                    merge = d == 0 or (0 < d <= p.width) or (d < 0 and -d <= q.width)
+                else:
+                    u = union(p, q)
+                    merge = u == p or u == q
+                if merge:
+                    b[i] = union(p, q)
+                    del b[j]
+                    merged = True
+                else:
+                    j += 1
+            if i + 1 < len(b):
+                i += 1
+            else:
+                break
+    return b
+
+
+def _detail_bound(lx, ly, lw, lh, detail, size):
+    """The local bound at the detail size: int truncation + the min / max guards of
+    PhotomosaicGeneratorBase.cpp:318-326 (= GridGenerator.cpp:156-170).  Scalars or arrays."""
+    trunc = (lambda v: v.astype(np.int64)) if isinstance(lx, np.ndarray) else int
+    bx = np.minimum(size - 1, trunc(lx * detail))
+    by = np.minimum(size - 1, trunc(ly * detail))
+    bw = np.maximum(1, trunc(lw * detail))
+    bh = np.maximum(1, trunc(lh * detail))
+    return bx, by, np.minimum(size - bx, bw), np.minimum(size - by, bh)
+
+
+def findCellState(cellGroup, mainImage, x, y, bounds, step):
+    """GridGenerator::findCellState (GridGenerator.cpp:113-193) -> (state, entropy exceeded)."""
+    from .imageutil import MAX_ENTROPY, calculateEntropy, resize_area_u8
+    shape = cellGroup.getCell(step)
+    g = getRectAt(shape, x, y)
+    inside = False
+    for b in bounds:
+        y0, y1 = min(max(g.y, b.y), b.y + b.height), min(max(g.y + g.height, b.y), b.y + b.height)
+        x0, x1 = min(max(g.x, b.x), b.x + b.width), min(max(g.x + g.width, b.x), b.x + b.width)
+        if y0 != y1 and x0 != x1:
+            inside = True
+            break
+    if not inside:
+        return NULLOPT, False
+    if mainImage is not None and step < cellGroup.getSizeSteps():
+        rows, cols = mainImage.shape[0], mainImage.shape[1]
+        y0, y1 = min(max(g.y, 0), rows), min(max(g.y + g.height, 0), rows)
+        x0, x1 = min(max(g.x, 0), cols), min(max(g.x + g.width, 0), cols)
+        size = cellGroup.getCellSize(step, True)
+        bx, by, bw, bh = _detail_bound(x0 - g.x, y0 - g.y, x1 - x0, y1 - y0, cellGroup.getDetail(), size)
+        flip = getFlipStateAt(shape, x, y)
+        mask = cellGroup.getCell(step, True).getCellMask(flip.horizontal, flip.vertical)[by:by + bh, bx:bx + bw]
+        cell = mainImage[y0:y1, x0:x1]
+        if cell.shape[:2] != mask.shape:
+            cell = resize_area_u8(cell, mask.shape[0], mask.shape[1])      # resizeImage(EXACT), :180-181
+        if calculateEntropy(cell, mask) >= MAX_ENTROPY * 0.7:
+            return NULLOPT, True
+    return 0, False
+
+
+def getGridState(cellGroup, imageRows, imageCols, mainImage=None):
+    """GridGenerator::getGridState (GridGenerator.cpp:29-110): one StepBestFit per size step;
+    a cell whose masked grey-level entropy reaches 0.7 * MAX_ENTROPY is handed to the next
+    (half-size) step.  ``mainImage``: u8 BGR, needed only with size steps > 0; without it
+    (or with size steps 0) a cell is valid iff its rect meets the image."""
+    if cellGroup.getCell(0).empty():
         return []
-    gw, gh = calculateGridSize(shape, imageCols, imageRows)
-    gx, gy = np.meshgrid(np.arange(gw, dtype=np.int64) - PAD_GRID,
-                         np.arange(gh, dtype=np.int64) - PAD_GRID)
-    r = getRectAt(shape, gx, gy)
-    y0, y1 = np.clip(r.y, 0, imageRows), np.clip(r.y + r.height, 0, imageRows)
-    x0, x1 = np.clip(r.x, 0, imageCols), np.clip(r.x + r.width, 0, imageCols)
-    valid = (y0 != y1) & (x0 != x1)
-    return [np.where(valid, 0, NULLOPT).astype(np.int64)]
+    if mainImage is not None:
+        mainImage = np.asarray(mainImage)
+        imageRows, imageCols = mainImage.shape[0], mainImage.shape[1]
+    if cellGroup.getSizeSteps() == 0 or mainImage is None:
+        # fast path: whole-image bound, no entropy test (:113-140,:191-192)
+        shape = cellGroup.getCell(0)
+        gw, gh = calculateGridSize(shape, imageCols, imageRows)
+        gx, gy = np.meshgrid(np.arange(gw, dtype=np.int64) - PAD_GRID,
+                             np.arange(gh, dtype=np.int64) - PAD_GRID)
+        r = getRectAt(shape, gx, gy)
+        y0, y1 = np.clip(r.y, 0, imageRows), np.clip(r.y + r.height, 0, imageRows)
+        x0, x1 = np.clip(r.x, 0, imageCols), np.clip(r.x + r.width, 0, imageCols)
+        valid = (y0 != y1) & (x0 != x1)
+        return [np.where(valid, 0, NULLOPT).astype(np.int64)]
+
+    gridState = []
+    active = [Rect(0, 0, imageCols, imageRows)]
+    for step in range(cellGroup.getSizeSteps() + 1):
+        if not active:
+            break
+        shape = cellGroup.getCell(step)
+        gw, gh = calculateGridSize(shape, imageCols, imageRows)
+        state = np.full((gh, gw), NULLOPT, dtype=np.int64)
+        nxt = []
+        for y in range(-PAD_GRID, gh - PAD_GRID):
+            for x in range(-PAD_GRID, gw - PAD_GRID):
+                value, split = findCellState(cellGroup, mainImage, x, y, active, step)
+                state[y + PAD_GRID, x + PAD_GRID] = value
+                if split:
+                    g = getRectAt(shape, x, y)
+                    y0, y1 = min(max(g.y, 0), imageRows), min(max(g.y + g.height, 0), imageRows)
+                    x0, x1 = min(max(g.x, 0), imageCols), min(max(g.x + g.width, 0), imageCols)
+                    if y0 == y1 or x0 == x1:
+                        continue
+                    nxt.append(Rect(x0, y0, x1 - x0, y1 - y0))
+        gridState.append(state)
+        active = mergeBounds(nxt) if nxt else []
+    return gridState
 
 
-def cell_records(cellGroup, stepBestFit, imageRows, imageCols):
-    """One ``mm_cell`` per valid cell, in the reference's raster order
+def cell_records(cellGroup, stepBestFit, imageRows, imageCols, step=0):
+    """One ``mm_cell`` per valid cell of a size step, in the reference's raster order
     (CPUPhotomosaicGenerator.cpp:63-77).
 
-    Per cell: the global rect origin (getRectAt), the local bound at detail 1
-    with the truncation / min / max guards of getCellAt
-    (PhotomosaicGeneratorBase.cpp:299-326), the mask variant ``flipH + 2*flipV``
-    and the padded grid position."""
-    shape = cellGroup.getCell(0)
+    Per cell: the global rect origin of the NORMAL cell (getRectAt), the local bound at the
+    detail size with the truncation / min / max guards of getCellAt
+    (PhotomosaicGeneratorBase.cpp:299-326), the mask variant ``flipH + 2*flipV`` and the
+    padded grid position."""
+    shape = cellGroup.getCell(step)
     detail = cellGroup.getDetail()
-    size = cellGroup.getCell(0, True).getSize()
+    size = cellGroup.getCell(step, True).getSize()
     gy, gx = np.nonzero(np.asarray(stepBestFit) >= 0)      # row-major == raster order
     x = gx.astype(np.int64) - PAD_GRID
     y = gy.astype(np.int64) - PAD_GRID
     r = getRectAt(shape, x, y)
     y0, y1 = np.clip(r.y, 0, imageRows), np.clip(r.y + r.height, 0, imageRows)
     x0, x1 = np.clip(r.x, 0, imageCols), np.clip(r.x + r.width, 0, imageCols)
-    lx, ly, lw, lh = x0 - r.x, y0 - r.y, x1 - x0, y1 - y0
-    bx = np.minimum(size - 1, (lx * detail).astype(np.int64))
-    by = np.minimum(size - 1, (ly * detail).astype(np.int64))
-    bw = np.maximum(1, (lw * detail).astype(np.int64))
-    bh = np.maximum(1, (lh * detail).astype(np.int64))
-    bw = np.minimum(size - bx, bw)
-    bh = np.minimum(size - by, bh)
+    bx, by, bw, bh = _detail_bound(x0 - r.x, y0 - r.y, x1 - x0, y1 - y0, detail, size)
     flip = getFlipStateAt(shape, x, y)
 
     rec = np.zeros(len(x), dtype=CELL_DTYPE)

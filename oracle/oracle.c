@@ -258,6 +258,316 @@ orc_rect orc_cell_at(const orc_shape *s, int x, int y, const float *img,
 }
 
 /* ------------------------------------------------------------------------ */
+/* cv::resize INTER_AREA, cv::cvtColor BGR2GRAY (OpenCV 4.x imgproc -- absent   */
+/* from the reference checkout; restated from the library's published source:  */
+/* resize.cpp ResizeAreaFastVec / ResizeAreaFast_ / computeResizeAreaTab /      */
+/* ResizeArea_Invoker, color_yuv RGB2Gray<uchar>).  PARITY UNPINNED at these    */
+/* steps: no reference test holds a vector for them.                           */
+/* ------------------------------------------------------------------------ */
+
+/* INTER_AREA by an integer factor f on f32 HWC C3: box mean, float row sums left to
+ * right, rows top to bottom, times 1/(f f)  (f = 2: ((a + b) + (c + d)) * 0.25f). */
+void orc_shrink_f32(const float *src, int rows, int cols, int f, float *dst)
+{
+    const int ro = rows / f, co = cols / f;
+    const float inv = 1.0f / (float)(f * f);
+    for (int r = 0; r < ro; ++r)
+        for (int c = 0; c < co; ++c)
+            for (int ch = 0; ch < 3; ++ch) {
+                float total = 0.f;
+                for (int i = 0; i < f; ++i) {
+                    float row = 0.f;
+                    for (int j = 0; j < f; ++j)
+                        row += src[((size_t)(r * f + i) * cols + (c * f + j)) * 3u + ch];
+                    total += row;
+                }
+                dst[((size_t)r * co + c) * 3u + ch] = total * inv;
+            }
+}
+
+/* INTER_AREA by an integer factor f on u8 HWC with cn channels: f = 2: (sum + 2) >> 2
+ * (ResizeAreaFastVec<uchar>), otherwise cvRound(float(sum) * (1.f / (f f))). */
+void orc_shrink_u8(const uint8_t *src, int rows, int cols, int cn, int f, uint8_t *dst)
+{
+    const int ro = rows / f, co = cols / f;
+    const float scale = 1.0f / (float)(f * f);
+    for (int r = 0; r < ro; ++r)
+        for (int c = 0; c < co; ++c)
+            for (int ch = 0; ch < cn; ++ch) {
+                int sum = 0;
+                for (int i = 0; i < f; ++i)
+                    for (int j = 0; j < f; ++j)
+                        sum += src[((size_t)(r * f + i) * cols + (c * f + j)) * cn + ch];
+                int v = f == 2 ? (sum + 2) >> 2 : (int)lrintf((float)sum * scale);
+                dst[((size_t)r * co + c) * cn + ch] = (uint8_t)clampi(v, 0, 255);
+            }
+}
+
+typedef struct { int si, di; float alpha; } area_tab;
+
+/* computeResizeAreaTab: source cells (and their weights) under each destination cell. */
+static int area_table(int ssize, int dsize, double scale, area_tab *tab)
+{
+    int k = 0;
+    for (int dx = 0; dx < dsize; ++dx) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        if (sx2 > ssize - 1) sx2 = ssize - 1;
+        if (sx1 > sx2) sx1 = sx2;
+        if (sx1 - fsx1 > 1e-3) { tab[k].di = dx; tab[k].si = sx1 - 1; tab[k++].alpha = (float)((sx1 - fsx1) / cell); }
+        for (int sx = sx1; sx < sx2; ++sx) { tab[k].di = dx; tab[k].si = sx; tab[k++].alpha = (float)(1.0 / cell); }
+        if (fsx2 - sx2 > 1e-3) {
+            double w = fsx2 - sx2; if (w > 1.0) w = 1.0; if (w > cell) w = cell;
+            tab[k].di = dx; tab[k].si = sx2; tab[k++].alpha = (float)(w / cell);
+        }
+    }
+    return k;
+}
+
+/* cv::resize(src, dst, Size(dc, dr), 0, 0, INTER_AREA) for a SHRINK (dr <= sr, dc <= sc)
+ * of u8 HWC with cn channels: the integer-factor fast path when both scales are whole,
+ * else the weighted form (float accumulators, horizontal pass then vertical, cvRound). */
+void orc_resize_area_u8(const uint8_t *src, int sr, int sc, int cn, int dr, int dc, uint8_t *dst)
+{
+    if (sr == dr && sc == dc) { memcpy(dst, src, (size_t)sr * sc * cn); return; }
+    if (sr % dr == 0 && sc % dc == 0 && sr / dr == sc / dc) { orc_shrink_u8(src, sr, sc, cn, sr / dr, dst); return; }
+    const double scale_x = 1.0 / ((double)dc / sc), scale_y = 1.0 / ((double)dr / sr);
+    area_tab *xt = (area_tab *)malloc(sizeof(area_tab) * 2u * (size_t)sc);
+    area_tab *yt = (area_tab *)malloc(sizeof(area_tab) * 2u * (size_t)sr);
+    const int nx = area_table(sc, dc, scale_x, xt), ny = area_table(sr, dr, scale_y, yt);
+    float *buf = (float *)malloc(sizeof(float) * (size_t)dc * cn);
+    float *sum = (float *)calloc((size_t)dc * cn, sizeof(float));
+    int prev = yt[0].di;
+    for (int j = 0; j < ny; ++j) {
+        const float beta = yt[j].alpha;
+        const uint8_t *row = src + (size_t)yt[j].si * sc * cn;
+        for (int i = 0; i < dc * cn; ++i) buf[i] = 0.f;
+        for (int k = 0; k < nx; ++k)
+            for (int ch = 0; ch < cn; ++ch)
+                buf[xt[k].di * cn + ch] += (float)row[xt[k].si * cn + ch] * xt[k].alpha;
+        if (yt[j].di != prev) {
+            for (int i = 0; i < dc * cn; ++i) {
+                dst[(size_t)prev * dc * cn + i] = (uint8_t)clampi((int)lrintf(sum[i]), 0, 255);
+                sum[i] = beta * buf[i];
+            }
+            prev = yt[j].di;
+        } else {
+            for (int i = 0; i < dc * cn; ++i) sum[i] += beta * buf[i];
+        }
+    }
+    for (int i = 0; i < dc * cn; ++i) dst[(size_t)prev * dc * cn + i] = (uint8_t)clampi((int)lrintf(sum[i]), 0, 255);
+    free(xt); free(yt); free(buf); free(sum);
+}
+
+/* cv::cvtColor(BGR2GRAY) on u8: (B 1868 + G 9617 + R 4899 + 2^13) >> 14. */
+static uint8_t gray_of(const uint8_t *bgr)
+{
+    return (uint8_t)((bgr[0] * 1868 + bgr[1] * 9617 + bgr[2] * 4899 + (1 << 13)) >> 14);
+}
+
+/* ImageUtility::calculateEntropy, Other/ImageUtility.cpp:189-242: histogram of the grey
+ * values under the mask (mask may be NULL), entropy = -sum p log2 p. */
+double orc_entropy(const uint8_t *bgr, int rows, int cols, const uint8_t *mask, int mask_stride)
+{
+    size_t hist[256] = {0}, count = 0;
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c)
+            if (!mask || mask[(size_t)r * mask_stride + c] != 0) {
+                ++hist[gray_of(bgr + ((size_t)r * cols + c) * 3u)];
+                ++count;
+            }
+    double entropy = 0;
+    for (int i = 0; i < 256; ++i) {
+        const double p = hist[i] / (double)count;
+        if (p > 0) entropy -= p * log2(p);
+    }
+    return entropy;
+}
+
+/* PhotomosaicGeneratorBase::getCellAt, PhotomosaicGeneratorBase.cpp:293-329, at any
+ * detail whose cell-size ratio is a whole number: the visible part goes into a zero
+ * cell of the NORMAL size (:305-310), which is resized to the detail size (:313-315,
+ * INTER_AREA), and the local bound is scaled by `detail` with int truncation and the
+ * min / max guards (:318-326). */
+orc_rect orc_cell_at_detail(const orc_shape *s, int detail_size, double detail, int x, int y,
+                            const float *img, int rows, int cols, float *cell_out)
+{
+    const orc_rect g = orc_rect_at(s, x, y);
+    const int size = s->size;
+    const int y0 = clampi(g.y, 0, rows), y1 = clampi(g.y + g.h, 0, rows);
+    const int x0 = clampi(g.x, 0, cols), x1 = clampi(g.x + g.w, 0, cols);
+    const orc_rect local = { x0 - g.x, y0 - g.y, x1 - x0, y1 - y0 };
+
+    float *full = detail_size == size ? cell_out : (float *)malloc(sizeof(float) * 3u * (size_t)size * size);
+    memset(full, 0, sizeof(float) * 3u * (size_t)size * (size_t)size);
+    for (int r = 0; r < local.h; ++r) {
+        const float *src = img + ((size_t)(y0 + r) * cols + x0) * 3u;
+        float *dst = full + ((size_t)(local.y + r) * size + local.x) * 3u;
+        memcpy(dst, src, sizeof(float) * 3u * (size_t)local.w);
+    }
+    if (full != cell_out) {
+        orc_shrink_f32(full, size, size, size / detail_size, cell_out);
+        free(full);
+    }
+
+    const int ds = detail_size;
+    orc_rect b;
+    b.x = (int)(local.x * detail); if (b.x > ds - 1) b.x = ds - 1;
+    b.y = (int)(local.y * detail); if (b.y > ds - 1) b.y = ds - 1;
+    b.w = (int)(local.w * detail); if (b.w < 1) b.w = 1;
+    b.h = (int)(local.h * detail); if (b.h < 1) b.h = 1;
+    if (b.w > ds - b.x) b.w = ds - b.x;
+    if (b.h > ds - b.y) b.h = ds - b.y;
+    return b;
+}
+
+/* GridBounds::mergeBounds, Grid/GridBounds.cpp:36-107.  Returns the new count. */
+static orc_rect rect_union(orc_rect a, orc_rect b)
+{
+    const int x0 = a.x < b.x ? a.x : b.x, y0 = a.y < b.y ? a.y : b.y;
+    const int x1 = a.x + a.w > b.x + b.w ? a.x + a.w : b.x + b.w;
+    const int y1 = a.y + a.h > b.y + b.h ? a.y + a.h : b.y + b.h;
+    const orc_rect u = { x0, y0, x1 - x0, y1 - y0 };
+    return u;
+}
+static int rect_eq(orc_rect a, orc_rect b) { return a.x == b.x && a.y == b.y && a.w == b.w && a.h == b.h; }
+
+int orc_merge_bounds(orc_rect *b, int n)
+{
+    int merged = 1;
+    while (merged) {
+        merged = 0;
+        for (int i = 0; i + 1 < n;) {                      /* firstIt + 1 != end */
+            for (int j = i + 1; j < n && i + 1 < n;) {
+                int merge = 0;
+                if (b[i].x == b[j].x && b[i].w == b[j].w) {
+                    const int d = b[j].y - b[i].y;
+                    if (d == 0) merge = 1;
+                    else if (d > 0 && d <= b[i].h) merge = 1;
+                    else if (d < 0 && -d <= b[j].h) merge = 1;
+                } else if (b[i].y == b[j].y && b[i].h == b[j].h) {
+                    const int d = b[j].x - b[i].x;
+                    if (d == 0) merge = 1;
+                    else if (d > 0 && d <= b[i].w) merge = 1;
+                    else if (d < 0 && -d <= b[j].w) merge = 1;
+                } else {
+                    const orc_rect u = rect_union(b[i], b[j]);
+                    if (rect_eq(u, b[i]) || rect_eq(u, b[j])) merge = 1;
+                }
+                if (merge) {
+                    b[i] = rect_union(b[i], b[j]);
+                    memmove(b + j, b + j + 1, sizeof(orc_rect) * (size_t)(n - j - 1));
+                    --n;
+                    merged = 1;
+                } else {
+                    ++j;
+                }
+            }
+            if (i + 1 < n) ++i; else break;
+        }
+    }
+    return n;
+}
+
+/* GridGenerator::findCellState, Grid/GridGenerator.cpp:113-193.  Returns the state
+ * (0 = optional(0), -1 = nullopt) and sets *split when the entropy threshold is met. */
+static int64_t cell_state(const orc_shape *s, int detail_size, double detail, const uint8_t *masks,
+                          const uint8_t *img, int rows, int cols, int x, int y,
+                          const orc_rect *bounds, int n_bounds, int not_last_step, int *split)
+{
+    const orc_rect g = orc_rect_at(s, x, y);
+    *split = 0;
+    int in_bounds = 0;
+    for (int i = 0; i < n_bounds && !in_bounds; ++i) {
+        const orc_rect *b = &bounds[i];
+        const int y0 = clampi(g.y, b->y, b->y + b->h), y1 = clampi(g.y + g.h, b->y, b->y + b->h);
+        const int x0 = clampi(g.x, b->x, b->x + b->w), x1 = clampi(g.x + g.w, b->x, b->x + b->w);
+        if (y0 != y1 && x0 != x1) in_bounds = 1;
+    }
+    if (!in_bounds) return -1;
+
+    if (img && not_last_step) {
+        const int y0 = clampi(g.y, 0, rows), y1 = clampi(g.y + g.h, 0, rows);
+        const int x0 = clampi(g.x, 0, cols), x1 = clampi(g.x + g.w, 0, cols);
+        const orc_rect local = { x0 - g.x, y0 - g.y, x1 - x0, y1 - y0 };
+        int fh, fv;
+        orc_flip_state_at(s, x, y, &fh, &fv);
+        const int ds = detail_size;
+        orc_rect b;
+        b.x = (int)(local.x * detail); if (b.x > ds - 1) b.x = ds - 1;
+        b.y = (int)(local.y * detail); if (b.y > ds - 1) b.y = ds - 1;
+        b.w = (int)(local.w * detail); if (b.w < 1) b.w = 1;
+        b.h = (int)(local.h * detail); if (b.h < 1) b.h = 1;
+        if (b.w > ds - b.x) b.w = ds - b.x;
+        if (b.h > ds - b.y) b.h = ds - b.y;
+        /* visible part of the image, resized to the bounded mask's size (:153,:180-181) */
+        const int vr = y1 - y0, vc = x1 - x0;
+        uint8_t *vis = (uint8_t *)malloc((size_t)vr * vc * 3u);
+        for (int r = 0; r < vr; ++r)
+            memcpy(vis + (size_t)r * vc * 3u, img + ((size_t)(y0 + r) * cols + x0) * 3u, (size_t)vc * 3u);
+        uint8_t *cell = vis;
+        if (vr != b.h || vc != b.w) {
+            /* resizeImage EXACT (Other/ImageUtility.cpp:34-61): INTER_AREA when the factor
+             * (by height, or by width when the height matches) is < 1; a visible part
+             * SMALLER than the mask (INTER_CUBIC) cannot happen for detail <= 1. */
+            cell = (uint8_t *)malloc((size_t)b.h * b.w * 3u);
+            orc_resize_area_u8(vis, vr, vc, 3, b.h, b.w, cell);
+        }
+        const uint8_t *mask = masks + (size_t)(fh + 2 * fv) * ds * ds + (size_t)b.y * ds + b.x;
+        const double e = orc_entropy(cell, b.h, b.w, mask, ds);
+        if (cell != vis) free(cell);
+        free(vis);
+        if (e >= 8.0 * 0.7) { *split = 1; return -1; }      /* MAX_ENTROPY * 0.7, ImageUtility.h:69 */
+    }
+    return 0;
+}
+
+/* GridGenerator::getGridState, Grid/GridGenerator.cpp:29-110, all size steps.
+ * shapes[step] / detail_sizes[step] / masks[step] (4 detail masks each); img u8 BGR or
+ * NULL (no image: every cell valid at step 0, no entropy).  states[step] must hold
+ * grid_w[step] * grid_h[step] entries (orc_grid_size).  Returns the number of steps
+ * produced (the loop stops when a step leaves no bounds). */
+int orc_grid_state_steps(const orc_shape *shapes, const int *detail_sizes, const uint8_t *const *masks,
+                         int size_steps, double detail, const uint8_t *img, int rows, int cols,
+                         int64_t *const *states, const int *grid_w, const int *grid_h)
+{
+    int cap = 16, n_active = 1, n_next = 0, produced = 0;
+    orc_rect *active = (orc_rect *)malloc(sizeof(orc_rect) * (size_t)cap);
+    orc_rect *next = (orc_rect *)malloc(sizeof(orc_rect) * (size_t)cap);
+    active[0].x = 0; active[0].y = 0; active[0].w = cols; active[0].h = rows;
+    for (int step = 0; step <= size_steps && n_active > 0; ++step) {
+        const orc_shape *s = &shapes[step];
+        n_next = 0;
+        for (int y = -ORC_PAD_GRID; y < grid_h[step] - ORC_PAD_GRID; ++y)
+            for (int x = -ORC_PAD_GRID; x < grid_w[step] - ORC_PAD_GRID; ++x) {
+                int split;
+                states[step][(size_t)(y + ORC_PAD_GRID) * grid_w[step] + (x + ORC_PAD_GRID)] =
+                    cell_state(s, detail_sizes[step], detail, masks[step], img, rows, cols, x, y,
+                               active, n_active, step < size_steps, &split);
+                if (!split) continue;
+                const orc_rect g = orc_rect_at(s, x, y);
+                const int y0 = clampi(g.y, 0, rows), y1 = clampi(g.y + g.h, 0, rows);
+                const int x0 = clampi(g.x, 0, cols), x1 = clampi(g.x + g.w, 0, cols);
+                if (y0 == y1 || x0 == x1) continue;
+                if (n_next == cap) {
+                    cap *= 2;
+                    active = (orc_rect *)realloc(active, sizeof(orc_rect) * (size_t)cap);
+                    next = (orc_rect *)realloc(next, sizeof(orc_rect) * (size_t)cap);
+                }
+                next[n_next].x = x0; next[n_next].y = y0; next[n_next].w = x1 - x0; next[n_next].h = y1 - y0;
+                ++n_next;
+            }
+        ++produced;
+        orc_rect *t = active; active = next; next = t;
+        n_active = n_next;
+        if (n_active > 0) n_active = orc_merge_bounds(active, n_active);
+    }
+    free(active); free(next);
+    return produced;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Repeats, best fit, driver                                                 */
 /* ------------------------------------------------------------------------ */
 
@@ -339,13 +649,14 @@ int64_t orc_find_cell_best_fit(int type, const float *cell, orc_rect bounds,
  * one size step: strictly sequential raster order over the padded grid
  * (:63,:70); each valid cell sees the already-chosen neighbours through
  * calculateRepeats. */
-int orc_generate_best_fits(const orc_shape *s, const float *img, int rows, int cols,
-                           const float *lib, int64_t n_lib, const uint8_t *masks,
-                           int type, int repeat_range, int repeat_addition,
-                           int grid_w, int grid_h, int64_t *grid, double *scores,
-                           int max_cells, int early_exit)
+int orc_generate_step(const orc_shape *s, int detail_size, double detail,
+                      const float *img, int rows, int cols,
+                      const float *lib, int64_t n_lib, const uint8_t *masks,
+                      int type, int repeat_range, int repeat_addition,
+                      int grid_w, int grid_h, int64_t *grid, double *scores,
+                      int max_cells, int early_exit)
 {
-    const int size = s->size;
+    const int size = detail_size;
     const size_t px = (size_t)size * size;
     float *cell = (float *)malloc(sizeof(float) * 3u * px);
     const int rep_cap = repeat_range * (2 * repeat_range + 1) + repeat_range + 1;
@@ -364,7 +675,7 @@ int orc_generate_best_fits(const orc_shape *s, const float *img, int rows, int c
             if (max_cells >= 0 && done >= max_cells)
                 goto out;
 
-            const orc_rect bounds = orc_cell_at(s, x, y, img, rows, cols, cell);
+            const orc_rect bounds = orc_cell_at_detail(s, detail_size, detail, x, y, img, rows, cols, cell);
             int fh, fv;
             orc_flip_state_at(s, x, y, &fh, &fv);
             const uint8_t *mask = masks + (size_t)(fh + 2 * fv) * px;
@@ -383,6 +694,17 @@ out:
     free(rep_keys);
     free(rep_vals);
     return done;
+}
+
+int orc_generate_best_fits(const orc_shape *s, const float *img, int rows, int cols,
+                           const float *lib, int64_t n_lib, const uint8_t *masks,
+                           int type, int repeat_range, int repeat_addition,
+                           int grid_w, int grid_h, int64_t *grid, double *scores,
+                           int max_cells, int early_exit)
+{
+    return orc_generate_step(s, s->size, 1.0, img, rows, cols, lib, n_lib, masks, type,
+                             repeat_range, repeat_addition, grid_w, grid_h, grid, scores,
+                             max_cells, early_exit);
 }
 
 /* PhotomosaicGeneratorBase::buildPhotomosaic, PhotomosaicGeneratorBase.cpp:110-207,

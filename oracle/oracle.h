@@ -106,6 +106,37 @@ int orc_generate_best_fits(const orc_shape *s, const float *img, int rows, int c
                            int grid_w, int grid_h, int64_t *grid, double *scores,
                            int max_cells, int early_exit);
 
+/* ---- detail levels and size steps ------------------------
+ * OpenCV (cv::resize, cv::cvtColor) is a third-party dependency absent from the
+ * reference checkout (the project links a system OpenCV 4.x; no version is pinned in
+ * the repository).  These functions restate its published algorithms for the cases
+ * the path needs; parity at these steps is UNPINNED (no reference test holds vectors
+ * for them) -- engine, host and oracle share this one specification. */
+void orc_shrink_f32(const float *src, int rows, int cols, int f, float *dst);
+void orc_shrink_u8(const uint8_t *src, int rows, int cols, int cn, int f, uint8_t *dst);
+void orc_resize_area_u8(const uint8_t *src, int sr, int sc, int cn, int dr, int dc, uint8_t *dst);
+/* ImageUtility::calculateEntropy (Other/ImageUtility.cpp:189-242); mask may be NULL. */
+double orc_entropy(const uint8_t *bgr, int rows, int cols, const uint8_t *mask, int mask_stride);
+/* getCellAt at detail = detail_size / s->size (whole-number ratio); cell_out holds
+ * detail_size^2 * 3 floats. */
+orc_rect orc_cell_at_detail(const orc_shape *s, int detail_size, double detail, int x, int y,
+                            const float *img, int rows, int cols, float *cell_out);
+/* One size step of generateBestFits at any such detail: s = the step's NORMAL cell
+ * shape, lib / masks at the step's DETAIL size. */
+int orc_generate_step(const orc_shape *s, int detail_size, double detail,
+                      const float *img, int rows, int cols,
+                      const float *lib, int64_t n_lib, const uint8_t *masks,
+                      int type, int repeat_range, int repeat_addition,
+                      int grid_w, int grid_h, int64_t *grid, double *scores,
+                      int max_cells, int early_exit);
+/* GridBounds::mergeBounds (Grid/GridBounds.cpp:36-107); returns the new count. */
+int orc_merge_bounds(orc_rect *bounds, int n);
+/* GridGenerator::getGridState over all size steps with the entropy subdivision
+ * (Grid/GridGenerator.cpp:29-193). */
+int orc_grid_state_steps(const orc_shape *shapes, const int *detail_sizes, const uint8_t *const *masks,
+                         int size_steps, double detail, const uint8_t *img, int rows, int cols,
+                         int64_t *const *states, const int *grid_w, const int *grid_h);
+
 /* PhotomosaicGeneratorBase::buildPhotomosaic for one size step
  * (Photomosaic/PhotomosaicGeneratorBase.cpp:110-207).  lib_bgr: the library as
  * setLibrary received it, u8 BGR [n][size][size][3]; masks: 4 masks of the NORMAL

@@ -71,6 +71,23 @@ class Oracle:
         lib.orc_find_cell_best_fit.argtypes = [i, vp, Rect, vp, i, vp, ctypes.c_int64, vp, vp, i, i, dp]
         lib.orc_build_photomosaic.restype = None
         lib.orc_build_photomosaic.argtypes = [ctypes.POINTER(Shape), i, i, vp, vp, i, i, vp, vp, vp]
+        lib.orc_shrink_f32.restype = None
+        lib.orc_shrink_f32.argtypes = [vp, i, i, i, vp]
+        lib.orc_shrink_u8.restype = None
+        lib.orc_shrink_u8.argtypes = [vp, i, i, i, i, vp]
+        lib.orc_resize_area_u8.restype = None
+        lib.orc_resize_area_u8.argtypes = [vp, i, i, i, i, i, vp]
+        lib.orc_entropy.restype = d
+        lib.orc_entropy.argtypes = [vp, i, i, vp, i]
+        lib.orc_cell_at_detail.restype = Rect
+        lib.orc_cell_at_detail.argtypes = [ctypes.POINTER(Shape), i, d, i, i, vp, i, i, vp]
+        lib.orc_generate_step.restype = i
+        lib.orc_generate_step.argtypes = [ctypes.POINTER(Shape), i, d, vp, i, i, vp, ctypes.c_int64, vp,
+                                          i, i, i, i, i, vp, vp, i, i]
+        lib.orc_merge_bounds.restype = i
+        lib.orc_merge_bounds.argtypes = [vp, i]
+        lib.orc_grid_state_steps.restype = i
+        lib.orc_grid_state_steps.argtypes = [vp, vp, vp, i, d, vp, i, i, vp, vp, vp]
         lib.orc_generate_best_fits.restype = i
         lib.orc_generate_best_fits.argtypes = [ctypes.POINTER(Shape), vp, i, i, vp, ctypes.c_int64, vp,
                                                i, i, i, i, i, vp, vp, i, i]
@@ -143,6 +160,80 @@ class Oracle:
             1 if early_exit else 0)
         return grid, scores, done
 
+
+    # -- detail levels and size steps ------------------------------------------
+    def shrink_f32(self, img, f):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        out = np.empty((img.shape[0] // f, img.shape[1] // f, 3), dtype=np.float32)
+        self.lib.orc_shrink_f32(img.ctypes.data, img.shape[0], img.shape[1], int(f), out.ctypes.data)
+        return out
+
+    def shrink_library_f32(self, lib_images, f):
+        return np.stack([self.shrink_f32(im, f) for im in lib_images])
+
+    def resize_area_u8(self, img, rows, cols):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty((rows, cols) if img.ndim == 2 else (rows, cols, cn), dtype=np.uint8)
+        self.lib.orc_resize_area_u8(img.ctypes.data, img.shape[0], img.shape[1], cn, rows, cols, out.ctypes.data)
+        return out
+
+    def entropy(self, bgr, mask=None):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        return self.lib.orc_entropy(bgr.ctypes.data, bgr.shape[0], bgr.shape[1],
+                                    mask.ctypes.data if mask is not None else None,
+                                    mask.shape[1] if mask is not None else 0)
+
+    def cell_at_detail(self, shape, detail_size, detail, x, y, img):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        cell = np.empty((detail_size, detail_size, 3), dtype=np.float32)
+        r = self.lib.orc_cell_at_detail(ctypes.byref(shape), int(detail_size), float(detail), x, y,
+                                        img.ctypes.data, img.shape[0], img.shape[1], cell.ctypes.data)
+        return cell, (r.x, r.y, r.w, r.h)
+
+    def merge_bounds(self, rects):
+        arr = (Rect * max(len(rects), 1))(*[Rect(*r) for r in rects])
+        n = self.lib.orc_merge_bounds(ctypes.addressof(arr), len(rects))
+        return [(arr[k].x, arr[k].y, arr[k].w, arr[k].h) for k in range(n)]
+
+    def grid_state_steps(self, shapes, detail_sizes, masks_per_step, detail, img_u8, rows, cols):
+        """shapes: orc_shape per step; masks_per_step: [4][d][d] u8 per step; img_u8 BGR or None.
+        Returns the list of state arrays (one per produced step)."""
+        n = len(shapes)
+        sh = (Shape * n)(*shapes)
+        ds = (ctypes.c_int * n)(*[int(v) for v in detail_sizes])
+        mk = [np.ascontiguousarray(m, dtype=np.uint8) for m in masks_per_step]
+        mp = (ctypes.c_void_p * n)(*[m.ctypes.data for m in mk])
+        sizes = [self.grid_size(shapes[k], cols, rows) for k in range(n)]
+        states = [np.full((gh, gw), -1, dtype=np.int64) for gw, gh in sizes]
+        sp = (ctypes.c_void_p * n)(*[a.ctypes.data for a in states])
+        gw = (ctypes.c_int * n)(*[v[0] for v in sizes])
+        gh = (ctypes.c_int * n)(*[v[1] for v in sizes])
+        img = None if img_u8 is None else np.ascontiguousarray(img_u8, dtype=np.uint8)
+        produced = self.lib.orc_grid_state_steps(
+            ctypes.addressof(sh), ctypes.addressof(ds), ctypes.addressof(mp), n - 1, float(detail),
+            img.ctypes.data if img is not None else None, rows, cols,
+            ctypes.addressof(sp), ctypes.addressof(gw), ctypes.addressof(gh))
+        return states[:produced]
+
+    def generate_step(self, shape, detail_size, detail, img, lib_images, masks, type_id, repeat_range=0,
+                      repeat_addition=0, state=None, max_cells=-1, early_exit=True):
+        """One size step at any whole-ratio detail: shape = the step's NORMAL cell shape,
+        lib_images / masks at the step's detail size.  Same returns as generate_best_fits."""
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        lib_images = np.ascontiguousarray(lib_images, dtype=np.float32)
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        assert lib_images.shape[1] == detail_size and masks.shape[1] == detail_size
+        grid = np.ascontiguousarray(state, dtype=np.int64).copy()
+        scores = np.empty(grid.shape, dtype=np.float64)
+        done = self.lib.orc_generate_step(
+            ctypes.byref(shape), int(detail_size), float(detail), img.ctypes.data, img.shape[0], img.shape[1],
+            lib_images.ctypes.data, lib_images.shape[0], masks.ctypes.data, int(type_id), int(repeat_range),
+            int(repeat_addition), grid.shape[1], grid.shape[0], grid.ctypes.data, scores.ctypes.data,
+            int(max_cells), 1 if early_exit else 0)
+        return grid, scores, done
 
     def build_photomosaic(self, shape, rows, cols, lib_bgr, masks, grid, background=(0, 0, 0, 0)):
         lib_bgr = np.ascontiguousarray(lib_bgr, dtype=np.uint8)
