@@ -240,6 +240,15 @@ mm_status mm_set_library_bgr(mm_engine *e, const uint8_t *images, int n_images, 
 mm_status mm_build_photomosaic(mm_engine *e, const mm_cell *cells, int n_cells, int grid_w, int grid_h,
                                const int64_t *best_fit, const uint8_t background[4], int rows, int cols,
                                uint8_t *mosaic_out);
+/* The same for size step `step_index` of several (:123-202): step 0 starts a new mosaic;
+ * a later step paints only the pixels no earlier step's cell masks cover (:189-196).
+ * Between the steps the caller stages the step's NORMAL masks (mm_set_masks) and halves the
+ * u8 library (mm_shrink_library_bgr, ImageUtility::batchResizeMat, :126-127).  The engine
+ * keeps the mosaic; mosaic_out may be NULL for all but the last step. */
+mm_status mm_build_photomosaic_step(mm_engine *e, const mm_cell *cells, int n_cells, int grid_w, int grid_h,
+                                    const int64_t *best_fit, const uint8_t background[4], int rows, int cols,
+                                    int step_index, uint8_t *mosaic_out);
+mm_status mm_shrink_library_bgr(mm_engine *e, int factor);
 
 /* Engine options.  "filter" (default 1): two-tier scoring -- an fp32 filter pass over
  * every (cell, candidate), then the fp64 reference-form score of each cell's

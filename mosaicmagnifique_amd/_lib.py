@@ -73,6 +73,9 @@ SIGNATURES = {
     "mm_set_library_bgr": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
     "mm_build_photomosaic": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP,
                                             ctypes.c_int, ctypes.c_int, _VP]),
+    "mm_build_photomosaic_step": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),
+    "mm_shrink_library_bgr": (ctypes.c_int, [_VP, ctypes.c_int]),
     "mm_set_option": (ctypes.c_int, [_VP, ctypes.c_char_p, ctypes.c_int]),
     "mm_get_timing": (ctypes.c_int, [_VP, ctypes.POINTER(MMTiming)]),
     "mm_colour_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),

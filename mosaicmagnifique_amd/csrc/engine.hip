@@ -54,7 +54,8 @@ struct mm_engine {
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut;
     DevBuf row_map, spec_recs, deep, insufficient;
-    DevBuf stage_u8, srgb_lut, shrink_tmp;
+    DevBuf stage_u8, srgb_lut, shrink_tmp, covered;
+    int mosaic_rows = 0, mosaic_cols = 0;       // the mosaic kept between mm_build_photomosaic_step calls
     int cell_scale = 1;          // mm_set_cell_scale: full-size cell pixels per detail pixel and axis
     int spec_k = 10;             // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
@@ -786,7 +787,7 @@ void mm_destroy(mm_engine* e)
                        &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
-                       &e->stage_u8, &e->srgb_lut, &e->shrink_tmp })
+                       &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1240,15 +1241,51 @@ mm_status mm_set_library_bgr(mm_engine* e, const uint8_t* images, int n_images, 
     return MM_OK;
 }
 
+mm_status mm_shrink_library_bgr(mm_engine* e, int factor)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!e->lib_bgr.p || e->n_lib_bgr <= 0) { set_err(e, "mm_shrink_library_bgr: no u8 library staged"); return MM_NOT_READY; }
+    if (factor < 1 || e->lib_bgr_size % factor != 0) {
+        set_err(e, "mm_shrink_library_bgr: factor %d does not divide the image size %d", factor, e->lib_bgr_size);
+        return MM_INVALID_ARGUMENT;
+    }
+    if (factor == 1) return MM_OK;
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    const int so = e->lib_bgr_size / factor;
+    const size_t out_px = (size_t)e->n_lib_bgr * so * so;
+    mm_status st = ensure(e, e->stage_u8, out_px * 3, "Failed to allocate library images");
+    if (st) return st;
+    const unsigned blocks = (unsigned)std::min<size_t>((out_px + mm::kBlock - 1) / mm::kBlock, 65536);
+    mm::shrink_u8_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(
+        (const uint8_t*)e->lib_bgr.p, (uint8_t*)e->stage_u8.p, e->n_lib_bgr, e->lib_bgr_size, factor);
+    HIP_TRY(e, hipGetLastError(), "Error during library resize kernel");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    std::swap(e->lib_bgr, e->stage_u8);
+    e->lib_bgr_size = so;
+    return MM_OK;
+}
+
 mm_status mm_build_photomosaic(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w, int grid_h,
                                const int64_t* best_fit, const uint8_t background[4], int rows, int cols,
                                uint8_t* mosaic_out)
 {
+    if (!mosaic_out) { set_err(e, "mm_build_photomosaic: bad arguments"); return e ? MM_INVALID_ARGUMENT : MM_INVALID_ARGUMENT; }
+    return mm_build_photomosaic_step(e, cells, n_cells, grid_w, grid_h, best_fit, background, rows, cols, 0, mosaic_out);
+}
+
+mm_status mm_build_photomosaic_step(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w, int grid_h,
+                                    const int64_t* best_fit, const uint8_t background[4], int rows, int cols,
+                                    int step_index, uint8_t* mosaic_out)
+{
     if (!e) return MM_INVALID_ARGUMENT;
     if (n_cells < 0 || (n_cells > 0 && !cells) || grid_w <= 0 || grid_h <= 0 || !best_fit || !background ||
-        rows <= 0 || cols <= 0 || !mosaic_out) {
+        rows <= 0 || cols <= 0 || step_index < 0) {
         set_err(e, "mm_build_photomosaic: bad arguments");
         return MM_INVALID_ARGUMENT;
+    }
+    if (step_index > 0 && (!e->covered.p || e->mosaic_rows != rows || e->mosaic_cols != cols)) {
+        set_err(e, "mm_build_photomosaic_step: step %d without a step 0 of the same %dx%d mosaic", step_index, cols, rows);
+        return MM_NOT_READY;
     }
     if (!e->lib_bgr.p || !e->masks.p) {
         set_err(e, "u8 library (mm_set_library_bgr) and masks must be staged before building the photomosaic");
@@ -1274,8 +1311,11 @@ mm_status mm_build_photomosaic(mm_engine* e, const mm_cell* cells, int n_cells, 
     if ((st = ensure(e, e->recs, (size_t)std::max(n_cells, 1) * sizeof(mm_cell), "Failed to allocate cell records")) ||
         (st = ensure(e, e->grid, grid_cells * sizeof(long long), "Failed to allocate best fits")) ||
         (st = ensure(e, e->owner, n_pixels * sizeof(unsigned int), "Failed to allocate owner map")) ||
-        (st = ensure(e, e->mosaic, n_pixels * sizeof(uint32_t), "Failed to allocate photomosaic")))
+        (st = ensure(e, e->mosaic, n_pixels * sizeof(uint32_t), "Failed to allocate photomosaic")) ||
+        (st = ensure(e, e->covered, n_pixels, "Failed to allocate photomosaic mask")))
         return st;
+    e->mosaic_rows = rows;
+    e->mosaic_cols = cols;
     HIP_TRY(e, hipEventRecord(e->ev[6], e->stream), "event");
     HIP_TRY(e, hipMemcpyAsync(e->recs.p, cells, (size_t)n_cells * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
             "Failed to copy cell records to device");
@@ -1294,11 +1334,13 @@ mm_status mm_build_photomosaic(mm_engine* e, const mm_cell* cells, int n_cells, 
     const unsigned blocks = (unsigned)std::min<size_t>((n_pixels + mm::kBlock - 1) / mm::kBlock, 16384);
     mm::mosaic_compose_kernel<<<blocks, mm::kBlock, 0, e->stream>>>(
         (const unsigned int*)e->owner.p, (const mm_cell*)e->recs.p, (const long long*)e->grid.p, grid_w,
-        (const uint8_t*)e->lib_bgr.p, size, cols, n_pixels, bg, (uint32_t*)e->mosaic.p);
+        (const uint8_t*)e->lib_bgr.p, size, cols, n_pixels, bg, (uint32_t*)e->mosaic.p,
+        (uint8_t*)e->covered.p, step_index == 0);
     HIP_TRY(e, hipGetLastError(), "Error during photomosaic compose kernel");
     HIP_TRY(e, hipEventRecord(e->ev[5], e->stream), "event");
-    HIP_TRY(e, hipMemcpyAsync(mosaic_out, e->mosaic.p, n_pixels * 4, hipMemcpyDeviceToHost, e->stream),
-            "Error copying photomosaic to host");
+    if (mosaic_out)
+        HIP_TRY(e, hipMemcpyAsync(mosaic_out, e->mosaic.p, n_pixels * 4, hipMemcpyDeviceToHost, e->stream),
+                "Error copying photomosaic to host");
     HIP_TRY(e, hipEventRecord(e->ev[7], e->stream), "event");
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
     e->timing = mm_timing{};

@@ -1267,13 +1267,18 @@ mosaic_owner_kernel(const mm_cell* __restrict__ recs, const long long* __restric
     atomicMax(&owner[(size_t)(rec.y + row) * cols + (rec.x + col)], (unsigned int)blockIdx.y + 1u);
 }
 
+// covered: u8 per pixel, 1 = a cell mask of this or an earlier size step holds the pixel
+// (mosaicMask, PhotomosaicGeneratorBase.cpp:115,182-184).  first != 0: size step 0, every pixel
+// is written (:197-201); otherwise only pixels no earlier step covers (:189-196).
 __global__ void __launch_bounds__(kBlock)
 mosaic_compose_kernel(const unsigned int* __restrict__ owner, const mm_cell* __restrict__ recs,
                       const long long* __restrict__ best_fit, int grid_w,
                       const uint8_t* __restrict__ lib_bgr, int size, int cols, size_t n_pixels,
-                      uint32_t background, uint32_t* __restrict__ mosaic)
+                      uint32_t background, uint32_t* __restrict__ mosaic,
+                      uint8_t* __restrict__ covered, int first)
 {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_pixels; i += (size_t)gridDim.x * kBlock) {
+        if (!first && covered[i]) continue;
         const unsigned int o = owner[i];
         uint32_t px = background;
         if (o != 0) {
@@ -1284,6 +1289,32 @@ mosaic_compose_kernel(const unsigned int* __restrict__ owner, const mm_cell* __r
             px = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | 0xff000000u;
         }
         mosaic[i] = px;
+        covered[i] = o != 0;
+    }
+}
+
+// ImageUtility::batchResizeMat on the u8 library between the size steps of buildPhotomosaic
+// (PhotomosaicGeneratorBase.cpp:126-127): INTER_AREA by a whole factor, the u8 rule of
+// preprocess_u8_kernel (the alpha plane the reference carries is a constant 255).
+__global__ void __launch_bounds__(kBlock)
+shrink_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n_images, int size_in, int f)
+{
+    const int so = size_in / f;
+    const size_t total = (size_t)n_images * so * so;
+    const float scale = 1.0f / (float)(f * f);
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const size_t img = t / ((size_t)so * so);
+        const int p = (int)(t - img * so * so);
+        const int r = p / so, c = p - r * so;
+        const uint8_t* s = src + img * (size_t)size_in * size_in * 3;
+        int sum[3] = {0, 0, 0};
+        for (int i = 0; i < f; ++i)
+            for (int j = 0; j < f; ++j) {
+                const uint8_t* q = s + ((size_t)(r * f + i) * size_in + (c * f + j)) * 3;
+                sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2];
+            }
+        for (int k = 0; k < 3; ++k)
+            dst[t * 3 + k] = (uint8_t)(f == 2 ? (sum[k] + 2) >> 2 : min(255, max(0, __float2int_rn((float)sum[k] * scale))));
     }
 }
 

@@ -202,16 +202,23 @@ class Engine:
             raise ValueError("library must be [n][size][size][3]")
         self._check(self._lib.mm_set_library_bgr(self._h, _lib.ptr(a), a.shape[0], a.shape[1]))
 
-    def build_photomosaic(self, cells, grid_w, grid_h, best_fit, rows, cols, background=(0, 0, 0, 0)):
-        """mm_build_photomosaic -> u8 BGRA [rows][cols][4]."""
+    def build_photomosaic(self, cells, grid_w, grid_h, best_fit, rows, cols, background=(0, 0, 0, 0),
+                          step_index=0, want_output=True):
+        """mm_build_photomosaic[_step] -> u8 BGRA [rows][cols][4] (None if not wanted).
+        step_index > 0 continues the mosaic of the earlier steps."""
         rec = _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
         fit = np.ascontiguousarray(best_fit, dtype=np.int64)
         assert fit.shape == (grid_h, grid_w)
         bg = np.array(background, dtype=np.uint8)
-        out = np.empty((rows, cols, 4), dtype=np.uint8)
-        self._check(self._lib.mm_build_photomosaic(self._h, _lib.ptr(rec), len(rec), grid_w, grid_h, _lib.ptr(fit),
-                                                   _lib.ptr(bg), rows, cols, _lib.ptr(out)))
+        out = np.empty((rows, cols, 4), dtype=np.uint8) if want_output else None
+        self._check(self._lib.mm_build_photomosaic_step(
+            self._h, _lib.ptr(rec), len(rec), grid_w, grid_h, _lib.ptr(fit), _lib.ptr(bg), rows, cols,
+            int(step_index), _lib.ptr(out) if want_output else None))
         return out
+
+    def shrink_library_bgr(self, factor=2):
+        """batchResizeMat on the u8 library between the size steps of buildPhotomosaic."""
+        self._check(self._lib.mm_shrink_library_bgr(self._h, int(factor)))
 
     def set_option(self, name, value):
         """mm_set_option: "filter" 1 (default, two-tier fp32 filter + fp64 re-score) or 0 (fp64 only)."""

@@ -209,22 +209,29 @@ class HIPPhotomosaicGenerator:
 
     def buildPhotomosaic(self, backgroundColour=(0, 0, 0, 0)):
         """PhotomosaicGeneratorBase::buildPhotomosaic (PhotomosaicGeneratorBase.cpp:110-207) on the
-        device: u8 BGRA ``[rows][cols][4]``.  Needs the library as u8 BGR (what setLibrary got)."""
+        device: u8 BGRA ``[rows][cols][4]``.  Needs the library as u8 BGR (what setLibrary got), at
+        the NORMAL cell size of step 0.  Size steps: each step's cells are painted with the library
+        halved once more, only where no earlier step's cell masks cover the pixel (:189-196)."""
         if self.m_lib is None or self.m_lib.dtype != np.uint8:
             raise ValueError("buildPhotomosaic needs the u8 BGR library given to setLibrary")
-        step = self.m_bestFits[0]
+        if self.m_lib.shape[1] != self.m_cells.getCellSize(0):
+            raise ValueError("buildPhotomosaic needs the library at the cell size %d" % self.m_cells.getCellSize(0))
         rows, cols = self.m_img.shape[0], self.m_img.shape[1]
-        # every cell the grid names (with or without a value: the engine skips the latter)
-        state = np.where(step >= 0, 0, GridUtility.NULLOPT)
-        plain = CellGroup(self.m_cells.getCell(0))           # painting uses the NORMAL cell at full size
-        cells = GridUtility.cell_records(plain, state, rows, cols)
-        if self._staged_bgr is not self.m_lib:
-            self.m_engine.set_library_bgr(self.m_lib)
-            self._staged_bgr = self.m_lib
-        self.m_engine.set_masks(self.m_cells.getCell(0).masks4())
+        self.m_engine.set_library_bgr(self.m_lib)
         self._masks_key = None
-        return self.m_engine.build_photomosaic(cells, step.shape[1], step.shape[0], step, rows, cols,
-                                               backgroundColour)
+        out = None
+        for index, step in enumerate(self.m_bestFits):
+            if index > 0:
+                self.m_engine.shrink_library_bgr(2)
+            shape = self.m_cells.getCell(index)
+            self.m_engine.set_masks(shape.masks4())
+            # every cell the grid names (with or without a value: the engine skips the latter)
+            state = np.where(step >= 0, 0, GridUtility.NULLOPT)
+            cells = GridUtility.cell_records(CellGroup(shape), state, rows, cols)   # NORMAL cell, full size
+            out = self.m_engine.build_photomosaic(cells, step.shape[1], step.shape[0], step, rows, cols,
+                                                  backgroundColour, step_index=index,
+                                                  want_output=index == len(self.m_bestFits) - 1)
+        return out
 
     def getBestFits(self):
         return [s.copy() for s in self.m_bestFits]

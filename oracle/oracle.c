@@ -746,3 +746,56 @@ void orc_build_photomosaic(const orc_shape *s, int rows, int cols, const uint8_t
         }
     }
 }
+
+/* PhotomosaicGeneratorBase::buildPhotomosaic over size steps (PhotomosaicGeneratorBase.cpp:
+ * 110-207): shapes[step] = the NORMAL cell shapes, masks[step] their 4 masks, grids[step] the
+ * best fits; the u8 library (at shapes[0].size) is halved before every later step (:126-127,
+ * orc_shrink_u8) and a later step fills only what no earlier step's masks cover (:189-196). */
+void orc_build_photomosaic_steps(const orc_shape *shapes, int n_steps, int rows, int cols,
+                                 const uint8_t *lib_bgr, int64_t n_lib, const uint8_t *const *masks,
+                                 const int *grid_w, const int *grid_h, const int64_t *const *grids,
+                                 const uint8_t background[4], uint8_t *mosaic_out)
+{
+    const size_t n_px = (size_t)rows * cols;
+    uint8_t *step_img = (uint8_t *)malloc(n_px * 4u);
+    uint8_t *covered = (uint8_t *)calloc(n_px, 1), *step_mask = (uint8_t *)malloc(n_px);
+    int size = shapes[0].size;
+    uint8_t *lib = (uint8_t *)malloc((size_t)n_lib * size * size * 3u);
+    memcpy(lib, lib_bgr, (size_t)n_lib * size * size * 3u);
+    for (int step = 0; step < n_steps; ++step) {
+        if (step != 0) {
+            const int half = size / 2;
+            uint8_t *next = (uint8_t *)malloc((size_t)n_lib * half * half * 3u);
+            for (int64_t i = 0; i < n_lib; ++i)
+                orc_shrink_u8(lib + (size_t)i * size * size * 3u, size, size, 3, 2, next + (size_t)i * half * half * 3u);
+            free(lib);
+            lib = next;
+            size = half;
+        }
+        const orc_shape *s = &shapes[step];
+        const size_t px = (size_t)size * size;
+        orc_build_photomosaic(s, rows, cols, lib, masks[step], grid_w[step], grid_h[step], grids[step],
+                              background, step_img);
+        /* mosaicMaskStep: union of the painted cells' bounded masks (:182-184) */
+        memset(step_mask, 0, n_px);
+        for (int y = -ORC_PAD_GRID; y < grid_h[step] - ORC_PAD_GRID; ++y)
+            for (int x = -ORC_PAD_GRID; x < grid_w[step] - ORC_PAD_GRID; ++x) {
+                if (grids[step][(size_t)(y + ORC_PAD_GRID) * grid_w[step] + (x + ORC_PAD_GRID)] < 0) continue;
+                const orc_rect g = orc_rect_at(s, x, y);
+                const int y0 = clampi(g.y, 0, rows), y1 = clampi(g.y + g.h, 0, rows);
+                const int x0 = clampi(g.x, 0, cols), x1 = clampi(g.x + g.w, 0, cols);
+                int fh, fv;
+                orc_flip_state_at(s, x, y, &fh, &fv);
+                const uint8_t *mask = masks[step] + (size_t)(fh + 2 * fv) * px;
+                for (int r = y0; r < y1; ++r)
+                    for (int c = x0; c < x1; ++c)
+                        step_mask[(size_t)r * cols + c] |= mask[(size_t)(r - g.y) * size + (c - g.x)];
+            }
+        for (size_t i = 0; i < n_px; ++i)
+            if (step == 0 || !covered[i]) {
+                memcpy(mosaic_out + 4 * i, step_img + 4 * i, 4);
+                covered[i] = step_mask[i];
+            }
+    }
+    free(step_img); free(covered); free(step_mask); free(lib);
+}

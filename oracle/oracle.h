@@ -148,6 +148,12 @@ void orc_build_photomosaic(const orc_shape *s, int rows, int cols, const uint8_t
                            const uint8_t *masks, int grid_w, int grid_h, const int64_t *grid,
                            const uint8_t background[4], uint8_t *mosaic_out);
 
+/* buildPhotomosaic over size steps (PhotomosaicGeneratorBase.cpp:110-207). */
+void orc_build_photomosaic_steps(const orc_shape *shapes, int n_steps, int rows, int cols,
+                                 const uint8_t *lib_bgr, int64_t n_lib, const uint8_t *const *masks,
+                                 const int *grid_w, const int *grid_h, const int64_t *const *grids,
+                                 const uint8_t background[4], uint8_t *mosaic_out);
+
 #ifdef __cplusplus
 }
 #endif

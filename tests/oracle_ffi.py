@@ -88,6 +88,8 @@ class Oracle:
         lib.orc_merge_bounds.argtypes = [vp, i]
         lib.orc_grid_state_steps.restype = i
         lib.orc_grid_state_steps.argtypes = [vp, vp, vp, i, d, vp, i, i, vp, vp, vp]
+        lib.orc_build_photomosaic_steps.restype = None
+        lib.orc_build_photomosaic_steps.argtypes = [vp, i, i, i, vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp]
         lib.orc_generate_best_fits.restype = i
         lib.orc_generate_best_fits.argtypes = [ctypes.POINTER(Shape), vp, i, i, vp, ctypes.c_int64, vp,
                                                i, i, i, i, i, vp, vp, i, i]
@@ -244,6 +246,25 @@ class Oracle:
         self.lib.orc_build_photomosaic(ctypes.byref(shape), rows, cols, lib_bgr.ctypes.data, masks.ctypes.data,
                                        grid.shape[1], grid.shape[0], grid.ctypes.data, bg.ctypes.data,
                                        out.ctypes.data)
+        return out
+
+
+    def build_photomosaic_steps(self, shapes, rows, cols, lib_bgr, masks_per_step, grids, background=(0, 0, 0, 0)):
+        n = len(shapes)
+        sh = (Shape * n)(*shapes)
+        lib_bgr = np.ascontiguousarray(lib_bgr, dtype=np.uint8)
+        mk = [np.ascontiguousarray(m, dtype=np.uint8) for m in masks_per_step]
+        gr = [np.ascontiguousarray(g, dtype=np.int64) for g in grids]
+        mp = (ctypes.c_void_p * n)(*[m.ctypes.data for m in mk])
+        gp = (ctypes.c_void_p * n)(*[g.ctypes.data for g in gr])
+        gw = (ctypes.c_int * n)(*[g.shape[1] for g in gr])
+        gh = (ctypes.c_int * n)(*[g.shape[0] for g in gr])
+        bg = np.array(background, dtype=np.uint8)
+        out = np.empty((rows, cols, 4), dtype=np.uint8)
+        self.lib.orc_build_photomosaic_steps(ctypes.addressof(sh), n, rows, cols, lib_bgr.ctypes.data,
+                                             lib_bgr.shape[0], ctypes.addressof(mp), ctypes.addressof(gw),
+                                             ctypes.addressof(gh), ctypes.addressof(gp), bg.ctypes.data,
+                                             out.ctypes.data)
         return out
 
 

@@ -131,6 +131,30 @@ def test_size_steps(oracle, t, detail):
     assert (state[0] < 0).sum() > (G.getGridState(CellGroup(cases.square_shape(32)), 200, 264)[0] < 0).sum()
 
 
+def test_build_photomosaic_over_size_steps(oracle):
+    """buildPhotomosaic with size steps: the half-size cells of step 1 fill only what step 0 left."""
+    img = synth.target_u8(200, 264, lattice=64)
+    noise = (synth.mix(0x77, np.arange(200)[:, None], np.arange(132)[None, :]) % np.uint32(200)).astype(np.int16) - 100
+    img[:, 132:] = np.clip(img[:, 132:].astype(np.int16) + noise[..., None], 0, 255).astype(np.uint8)
+    lib = synth.library_u8(100, 32)
+    for shape in (cases.square_shape(32), cases.hexagon_shape().resized(32)):
+        lib_s = synth.library_u8(100, shape.getSize())
+        gen, state = run_steps(oracle, shape, img, lib_s, Type.CIE76, 50, 1, (1, 200))
+        assert len(state) == 2
+        group = gen.getCellGroup()
+        fits = gen.getBestFits()
+        bg = (10, 20, 30, 0)
+        got = gen.buildPhotomosaic(bg)
+        want = oracle.build_photomosaic_steps([shape_of(group.getCell(s)) for s in range(2)], 200, 264, lib_s,
+                                              [group.getCell(s).masks4() for s in range(2)], fits, bg)
+        assert np.array_equal(got, want)
+        assert (got[..., 3] == 255).any() and got.shape == (200, 264, 4)
+        # generating again after building (masks and library were re-staged for painting) still works
+        gen.setGridState(state)
+        assert gen.generateBestFits(), gen.lastError
+        assert all(np.array_equal(a, b) for a, b in zip(gen.getBestFits(), fits))
+
+
 def test_unsupported_ratios_are_refused():
     group = CellGroup(cases.square_shape(30))
     group.setDetail(40)                       # 30 -> 12: ratio 2.5
