@@ -26,6 +26,143 @@ const std::vector<uint8_t>& CellShape::getCellMask(bool flippedHorizontal, bool 
     return m_masks[(flippedHorizontal ? 1 : 0) + (flippedVertical ? 2 : 0)];
 }
 
+CellShape CellShape::resized(int size) const
+{
+    if (m_size == 0 || size == m_size) return *this;
+    CellShape out(size, ImageUtility::resizeArea(m_masks[0], m_size, m_size, 1, size, size));
+    const double ratio = (double)size / m_size;
+    out.rowSpacing = std::max((int)std::floor(rowSpacing * ratio), 1);
+    out.colSpacing = std::max((int)std::floor(colSpacing * ratio), 1);
+    out.alternateRowSpacing = std::max((int)std::floor(alternateRowSpacing * ratio), 1);
+    out.alternateColSpacing = std::max((int)std::floor(alternateColSpacing * ratio), 1);
+    out.alternateRowOffset = (int)std::floor(alternateRowOffset * ratio);
+    out.alternateColOffset = (int)std::floor(alternateColOffset * ratio);
+    out.alternateColFlipHorizontal = alternateColFlipHorizontal;
+    out.alternateColFlipVertical = alternateColFlipVertical;
+    out.alternateRowFlipHorizontal = alternateRowFlipHorizontal;
+    out.alternateRowFlipVertical = alternateRowFlipVertical;
+    return out;
+}
+
+// ---------------------------------------------------------------------------- CellGroup
+void CellGroup::setCellShape(const CellShape& shape)
+{
+    m_cells.at(0) = shape;
+    if (!shape.empty()) setDetail(0, true);
+    else { m_cells.resize(1); m_detailCells.assign(1, shape); }
+}
+
+void CellGroup::setDetail(int detailPercent, bool reset)
+{
+    const double newDetail = reset ? m_detail : detailPercent / 100.0;
+    if (newDetail != m_detail || reset) {
+        m_detail = newDetail;
+        if (!m_cells.at(0).empty())
+            m_detailCells.at(0) = m_cells.at(0).resized(std::max((int)(m_cells.at(0).getSize() * m_detail), 1));
+        setSizeSteps(m_sizeSteps, true);
+    }
+}
+
+void CellGroup::setSizeSteps(size_t steps, bool reset)
+{
+    m_cells.resize(steps + 1);
+    m_detailCells.resize(steps + 1);
+    int cellSize = m_cells.at(0).getSize();
+    for (size_t step = 1; step <= steps; ++step) {
+        cellSize /= 2;
+        if (reset || step > m_sizeSteps) {
+            m_cells.at(step) = m_cells.at(step - 1).resized(cellSize);
+            m_detailCells.at(step) = m_cells.at(step).resized(std::max((int)(cellSize * m_detail), 1));
+        }
+    }
+    m_sizeSteps = steps;
+}
+
+// ---------------------------------------------------------------------------- ImageUtility
+namespace ImageUtility {
+
+namespace {
+struct AreaEntry { int di, si; float alpha; };
+
+// computeResizeAreaTab (OpenCV imgproc resize.cpp)
+std::vector<AreaEntry> areaTable(int ssize, int dsize, double scale)
+{
+    std::vector<AreaEntry> tab;
+    for (int dx = 0; dx < dsize; ++dx) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) tab.push_back({dx, sx1 - 1, (float)((sx1 - fsx1) / cell)});
+        for (int sx = sx1; sx < sx2; ++sx) tab.push_back({dx, sx, (float)(1.0 / cell)});
+        if (fsx2 - sx2 > 1e-3) tab.push_back({dx, sx2, (float)(std::min(std::min(fsx2 - sx2, 1.0), cell) / cell)});
+    }
+    return tab;
+}
+
+uint8_t roundToU8(float v) { return (uint8_t)std::clamp((int)std::lrintf(v), 0, 255); }
+}  // namespace
+
+std::vector<uint8_t> resizeArea(const std::vector<uint8_t>& src, int rows, int cols, int cn, int outRows, int outCols)
+{
+    if (rows == outRows && cols == outCols) return src;
+    if (outRows > rows || outCols > cols) throw std::invalid_argument("INTER_CUBIC enlargement is outside the hot path");
+    std::vector<uint8_t> dst((size_t)outRows * outCols * cn);
+    if (rows % outRows == 0 && cols % outCols == 0 && rows / outRows == cols / outCols) {
+        const int f = rows / outRows;                       // whole factor: ResizeAreaFast
+        const float scale = 1.0f / (float)(f * f);
+        for (int r = 0; r < outRows; ++r)
+            for (int c = 0; c < outCols; ++c)
+                for (int ch = 0; ch < cn; ++ch) {
+                    int sum = 0;
+                    for (int i = 0; i < f; ++i)
+                        for (int j = 0; j < f; ++j) sum += src[((size_t)(r * f + i) * cols + (c * f + j)) * cn + ch];
+                    dst[((size_t)r * outCols + c) * cn + ch] = f == 2 ? (uint8_t)((sum + 2) >> 2) : roundToU8((float)sum * scale);
+                }
+        return dst;
+    }
+    const auto xt = areaTable(cols, outCols, 1.0 / ((double)outCols / cols));
+    const auto yt = areaTable(rows, outRows, 1.0 / ((double)outRows / rows));
+    std::vector<float> buf((size_t)outCols * cn), sum((size_t)outCols * cn, 0.f);
+    int prev = yt.front().di;
+    for (const AreaEntry& y : yt) {
+        std::fill(buf.begin(), buf.end(), 0.f);
+        const uint8_t* row = src.data() + (size_t)y.si * cols * cn;
+        for (const AreaEntry& x : xt)
+            for (int ch = 0; ch < cn; ++ch) buf[(size_t)x.di * cn + ch] += (float)row[(size_t)x.si * cn + ch] * x.alpha;
+        if (y.di != prev) {
+            for (size_t i = 0; i < sum.size(); ++i) { dst[(size_t)prev * outCols * cn + i] = roundToU8(sum[i]); sum[i] = y.alpha * buf[i]; }
+            prev = y.di;
+        } else {
+            for (size_t i = 0; i < sum.size(); ++i) sum[i] += y.alpha * buf[i];
+        }
+    }
+    for (size_t i = 0; i < sum.size(); ++i) dst[(size_t)prev * outCols * cn + i] = roundToU8(sum[i]);
+    return dst;
+}
+
+double calculateEntropy(const uint8_t* bgr, int rows, int cols, const uint8_t* mask, int maskStride)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    size_t histogram[256] = {0}, pixelCount = 0;
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c)
+            if (!mask || mask[(size_t)r * maskStride + c] != 0) {
+                const uint8_t* p = bgr + ((size_t)r * cols + c) * 3;
+                ++histogram[(p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14];    // BGR2GRAY
+                ++pixelCount;
+            }
+    double entropy = 0;
+    for (size_t value : histogram) {
+        const double probability = value / (double)pixelCount;
+        if (probability > 0) entropy -= probability * std::log2(probability);
+    }
+    return entropy;
+}
+
+}  // namespace ImageUtility
+
 // ---------------------------------------------------------------------------- GridUtility
 namespace GridUtility {
 
@@ -66,21 +203,106 @@ FlipState getFlipStateAt(const CellShape& s, int x, int y)         // GridUtilit
     return f;
 }
 
-MosaicBestFit getGridState(const CellGroup& cells, int imageRows, int imageCols)
+void mergeBounds(std::vector<Rect>& b)
 {
-    const CellShape& shape = cells.getCell(0);
-    MosaicBestFit state;
-    if (shape.getSize() == 0) return state;
-    const Point g = calculateGridSize(shape, imageCols, imageRows, PAD_GRID);
-    state.emplace_back((size_t)g.y, std::vector<CellBestFit>((size_t)g.x));
-    for (int y = -PAD_GRID; y < g.y - PAD_GRID; ++y)
-        for (int x = -PAD_GRID; x < g.x - PAD_GRID; ++x) {
-            const Rect r = getRectAt(shape, x, y);
-            const int y0 = std::clamp(r.y, 0, imageRows), y1 = std::clamp(r.y + r.height, 0, imageRows);
-            const int x0 = std::clamp(r.x, 0, imageCols), x1 = std::clamp(r.x + r.width, 0, imageCols);
-            if (y0 != y1 && x0 != x1) state[0][(size_t)(y + PAD_GRID)][(size_t)(x + PAD_GRID)] = 0;
+    auto unite = [](const Rect& p, const Rect& q) {
+        const int x0 = std::min(p.x, q.x), y0 = std::min(p.y, q.y);
+        const int x1 = std::max(p.x + p.width, q.x + q.width), y1 = std::max(p.y + p.height, q.y + q.height);
+        return Rect{x0, y0, x1 - x0, y1 - y0};
+    };
+    auto same = [](const Rect& p, const Rect& q) { return p.x == q.x && p.y == q.y && p.width == q.width && p.height == q.height; };
+    bool boundWasMerged = true;
+    while (boundWasMerged) {
+        boundWasMerged = false;
+        for (size_t i = 0; i + 1 < b.size();) {
+            for (size_t j = i + 1; j < b.size() && i + 1 < b.size();) {
+                bool merge = false;
+                if (b[i].x == b[j].x && b[i].width == b[j].width) {
+                    const int d = b[j].y - b[i].y;
+                    merge = d == 0 || (d > 0 && d <= b[i].height) || (d < 0 && -d <= b[j].height);
+                } else if (b[i].y == b[j].y && b[i].height == b[j].height) {
+                    const int d = b[j].x - b[i].x;
+                    merge = d == 0 || (d > 0 && d <= b[i].width) || (d < 0 && -d <= b[j].width);
+                } else {
+                    const Rect u = unite(b[i], b[j]);
+                    merge = same(u, b[i]) || same(u, b[j]);
+                }
+                if (merge) { b[i] = unite(b[i], b[j]); b.erase(b.begin() + (long)j); boundWasMerged = true; }
+                else ++j;
+            }
+            if (i + 1 < b.size()) ++i; else break;
         }
-    return state;
+    }
+}
+
+// The local bound at the detail size (PhotomosaicGeneratorBase.cpp:318-326 = GridGenerator.cpp:156-170).
+Rect detailBound(const Rect& local, double detail, int size)
+{
+    Rect b{ std::min(size - 1, (int)(local.x * detail)), std::min(size - 1, (int)(local.y * detail)),
+            std::max(1, (int)(local.width * detail)), std::max(1, (int)(local.height * detail)) };
+    b.width = std::min(size - b.x, b.width);
+    b.height = std::min(size - b.y, b.height);
+    return b;
+}
+
+// GridGenerator::findCellState (GridGenerator.cpp:113-193)
+static std::pair<CellBestFit, bool> findCellState(const CellGroup& cells, const Image8* mainImage, int x, int y,
+                                                  const std::vector<Rect>& bounds, size_t step)
+{
+    const Rect g = getRectAt(cells.getCell(step), x, y);
+    bool inBounds = false;
+    for (const Rect& it : bounds) {
+        const int yStart = std::clamp(g.y, it.y, it.y + it.height), yEnd = std::clamp(g.y + g.height, it.y, it.y + it.height);
+        const int xStart = std::clamp(g.x, it.x, it.x + it.width), xEnd = std::clamp(g.x + g.width, it.x, it.x + it.width);
+        if (yStart != yEnd && xStart != xEnd) { inBounds = true; break; }
+    }
+    if (!inBounds) return {std::nullopt, false};
+    if (mainImage && step < cells.getSizeSteps()) {
+        const int yStart = std::clamp(g.y, 0, mainImage->rows), yEnd = std::clamp(g.y + g.height, 0, mainImage->rows);
+        const int xStart = std::clamp(g.x, 0, mainImage->cols), xEnd = std::clamp(g.x + g.width, 0, mainImage->cols);
+        const int size = cells.getCellSize(step, true);
+        const Rect b = detailBound(Rect{xStart - g.x, yStart - g.y, xEnd - xStart, yEnd - yStart}, cells.getDetail(), size);
+        const FlipState flip = getFlipStateAt(cells.getCell(step), x, y);
+        std::vector<uint8_t> cell((size_t)(yEnd - yStart) * (xEnd - xStart) * 3);
+        for (int r = yStart; r < yEnd; ++r)
+            std::copy_n(mainImage->data.data() + ((size_t)r * mainImage->cols + xStart) * 3, (size_t)(xEnd - xStart) * 3,
+                        cell.data() + (size_t)(r - yStart) * (xEnd - xStart) * 3);
+        if (yEnd - yStart != b.height || xEnd - xStart != b.width)          // resizeImage(EXACT), :180-181
+            cell = ImageUtility::resizeArea(cell, yEnd - yStart, xEnd - xStart, 3, b.height, b.width);
+        const uint8_t* mask = cells.getCell(step, true).getCellMask(flip.horizontal, flip.vertical).data() + (size_t)b.y * size + b.x;
+        if (ImageUtility::calculateEntropy(cell.data(), b.height, b.width, mask, size) >= ImageUtility::MAX_ENTROPY * 0.7)
+            return {std::nullopt, true};
+    }
+    return {0, false};
+}
+
+MosaicBestFit getGridState(const CellGroup& cells, const Image8* mainImage, int imageRows, int imageCols)
+{
+    MosaicBestFit gridState;
+    if (cells.getCell(0).empty()) return gridState;
+    const int gridHeight = mainImage ? mainImage->rows : imageRows, gridWidth = mainImage ? mainImage->cols : imageCols;
+    std::vector<Rect> bounds[2];
+    int active = 0;
+    bounds[active].push_back(Rect{0, 0, gridWidth, gridHeight});
+    for (size_t step = 0; step <= cells.getSizeSteps() && !bounds[active].empty(); ++step) {
+        const Point g = calculateGridSize(cells.getCell(step), gridWidth, gridHeight, PAD_GRID);
+        gridState.emplace_back((size_t)g.y, std::vector<CellBestFit>((size_t)g.x));
+        bounds[!active].clear();
+        for (int y = -PAD_GRID; y < g.y - PAD_GRID; ++y)
+            for (int x = -PAD_GRID; x < g.x - PAD_GRID; ++x) {
+                const auto [bestFit, entropy] = findCellState(cells, mainImage, x, y, bounds[active], step);
+                gridState[step][(size_t)(y + PAD_GRID)][(size_t)(x + PAD_GRID)] = bestFit;
+                if (!entropy) continue;
+                const Rect r = getRectAt(cells.getCell(step), x, y);
+                const int y0 = std::clamp(r.y, 0, gridHeight), y1 = std::clamp(r.y + r.height, 0, gridHeight);
+                const int x0 = std::clamp(r.x, 0, gridWidth), x1 = std::clamp(r.x + r.width, 0, gridWidth);
+                if (y0 == y1 || x0 == x1) continue;
+                bounds[!active].push_back(Rect{x0, y0, x1 - x0, y1 - y0});
+            }
+        active = !active;
+        if (!bounds[active].empty()) mergeBounds(bounds[active]);
+    }
+    return gridState;
 }
 
 }  // namespace GridUtility
@@ -94,8 +316,16 @@ HIPPhotomosaicGenerator::HIPPhotomosaicGenerator(int device)
 
 HIPPhotomosaicGenerator::~HIPPhotomosaicGenerator() { mm_destroy(m_engine); }
 
-void HIPPhotomosaicGenerator::setMainImage(const Image& img) { m_img = img; m_staleInputs = true; }
-void HIPPhotomosaicGenerator::setLibrary(const std::vector<Image>& lib) { m_lib = lib; m_staleInputs = true; }
+void HIPPhotomosaicGenerator::setMainImage(const Image& img) { m_img = img; m_img8 = Image8{}; m_rows = img.rows; m_cols = img.cols; m_staleInputs = true; }
+void HIPPhotomosaicGenerator::setLibrary(const std::vector<Image>& lib) { m_lib = lib; m_lib8.clear(); m_libCount = lib.size(); m_staleInputs = true; }
+void HIPPhotomosaicGenerator::setMainImage(const Image8& img) { m_img8 = img; m_img = Image{}; m_rows = img.rows; m_cols = img.cols; m_staleInputs = true; }
+void HIPPhotomosaicGenerator::setLibrary(const std::vector<Image8>& lib)
+{
+    m_lib8 = lib; m_lib.clear(); m_libCount = lib.size(); m_staleInputs = true;
+    m_libBgr.clear();
+    for (const Image8& im : lib) m_libBgr.push_back(im.data);      // buildPhotomosaic paints with the same images
+    m_staleBgr = true;
+}
 void HIPPhotomosaicGenerator::setCellGroup(const CellGroup& cellGroup) { m_cells = cellGroup; m_staleInputs = true; }
 void HIPPhotomosaicGenerator::setGridState(const GridUtility::MosaicBestFit& gridState) { m_bestFits = gridState; }
 void HIPPhotomosaicGenerator::setRepeat(int repeatRange, int repeatAddition) { m_repeatRange = repeatRange; m_repeatAddition = repeatAddition; }
@@ -119,75 +349,128 @@ mm_timing HIPPhotomosaicGenerator::timing() const
     return t;
 }
 
-// One record per valid cell, raster order (CPUPhotomosaicGenerator.cpp:63-77); the bound
-// is getCellAt's at detail 1 (PhotomosaicGeneratorBase.cpp:299-326).
-std::vector<mm_cell> HIPPhotomosaicGenerator::cellRecords(bool onlyWithValue) const
+// One record per cell of a size step, raster order (CPUPhotomosaicGenerator.cpp:63-77).
+// painting = false: cells with a value, bound at the detail size (getCellAt,
+// PhotomosaicGeneratorBase.cpp:299-326); painting = true: the same cells with the bound of the
+// NORMAL cell at full size (buildPhotomosaic, :152-164).
+std::vector<mm_cell> HIPPhotomosaicGenerator::cellRecords(size_t step, bool painting) const
 {
-    const CellShape& normal = m_cells.getCell(0);
-    const CellShape& detail = m_cells.getCell(0, true);
+    const CellShape& normal = m_cells.getCell(step);
+    const CellShape& detail = painting ? normal : m_cells.getCell(step, true);
     const int size = detail.getSize();
-    const GridUtility::StepBestFit& grid = m_bestFits[0];
+    const double d = painting ? 1.0 : m_cells.getDetail();
+    const GridUtility::StepBestFit& grid = m_bestFits[step];
     const int gridH = (int)grid.size(), gridW = (int)grid.at(0).size();
     std::vector<mm_cell> cells;
     for (int y = -GridUtility::PAD_GRID; y < gridH - GridUtility::PAD_GRID; ++y)
         for (int x = -GridUtility::PAD_GRID; x < gridW - GridUtility::PAD_GRID; ++x) {
-            if (onlyWithValue && !grid[(size_t)(y + GridUtility::PAD_GRID)][(size_t)(x + GridUtility::PAD_GRID)].has_value()) continue;
+            if (!grid[(size_t)(y + GridUtility::PAD_GRID)][(size_t)(x + GridUtility::PAD_GRID)].has_value()) continue;
             const GridUtility::Rect r = GridUtility::getRectAt(normal, x, y);
-            const int y0 = std::clamp(r.y, 0, m_img.rows), y1 = std::clamp(r.y + r.height, 0, m_img.rows);
-            const int x0 = std::clamp(r.x, 0, m_img.cols), x1 = std::clamp(r.x + r.width, 0, m_img.cols);
+            const int y0 = std::clamp(r.y, 0, m_rows), y1 = std::clamp(r.y + r.height, 0, m_rows);
+            const int x0 = std::clamp(r.x, 0, m_cols), x1 = std::clamp(r.x + r.width, 0, m_cols);
             if (y0 == y1 || x0 == x1) continue;                  // rect misses the image (never has a value)
-            const double d = m_cells.getDetail();
-            int bx = std::min(size - 1, (int)((x0 - r.x) * d)), by = std::min(size - 1, (int)((y0 - r.y) * d));
-            int bw = std::max(1, (int)((x1 - x0) * d)), bh = std::max(1, (int)((y1 - y0) * d));
-            bw = std::min(size - bx, bw);
-            bh = std::min(size - by, bh);
+            const GridUtility::Rect b = GridUtility::detailBound(GridUtility::Rect{x0 - r.x, y0 - r.y, x1 - x0, y1 - y0}, d, size);
             const GridUtility::FlipState f = GridUtility::getFlipStateAt(detail, x, y);
-            cells.push_back(mm_cell{ r.x, r.y, by, by + bh, bx, bx + bw, (f.horizontal ? 1 : 0) + (f.vertical ? 2 : 0),
+            cells.push_back(mm_cell{ r.x, r.y, b.y, b.y + b.height, b.x, b.x + b.width, (f.horizontal ? 1 : 0) + (f.vertical ? 2 : 0),
                                      x + GridUtility::PAD_GRID, y + GridUtility::PAD_GRID });
         }
     return cells;
 }
 
+static std::vector<uint8_t> masks4(const CellShape& shape)
+{
+    std::vector<uint8_t> masks;
+    for (int id = 0; id < 4; ++id) {                                  // order of CUDAPhotomosaicGenerator.cpp:122-134
+        const auto& m = shape.getCellMask(id & 1, id & 2);
+        masks.insert(masks.end(), m.begin(), m.end());
+    }
+    return masks;
+}
+
+static std::vector<int64_t> flatGrid(const GridUtility::StepBestFit& grid)
+{
+    const size_t gridH = grid.size(), gridW = grid.at(0).size();
+    std::vector<int64_t> fits(gridW * gridH, -1);
+    for (size_t gy = 0; gy < gridH; ++gy)
+        for (size_t gx = 0; gx < gridW; ++gx)
+            if (grid[gy][gx].has_value()) fits[gy * gridW + gx] = (int64_t)grid[gy][gx].value();
+    return fits;
+}
+
+// PhotomosaicGeneratorBase::buildPhotomosaic (:110-207): per size step the NORMAL masks, the u8
+// library halved once more (:126-127), and only the pixels no earlier step covers (:189-196).
 std::vector<uint8_t> HIPPhotomosaicGenerator::buildPhotomosaic(const uint8_t backgroundColour[4])
 {
     m_lastError.clear();
-    if (m_bestFits.size() != 1 || m_libBgr.empty()) { m_lastError = "buildPhotomosaic needs one size step and the u8 library"; return {}; }
-    const CellShape& normal = m_cells.getCell(0);
-    const int size = normal.getSize();
-    mm_status st;
-    if (m_staleBgr) {
-        std::vector<uint8_t> flat;
-        flat.reserve(m_libBgr.size() * (size_t)size * size * 3);
-        for (const auto& im : m_libBgr) {
-            if (im.size() != (size_t)size * size * 3) { m_lastError = "library image size != cell size"; return {}; }
-            flat.insert(flat.end(), im.begin(), im.end());
-        }
-        std::vector<uint8_t> masks;
-        for (int id = 0; id < 4; ++id) { const auto& m = normal.getCellMask(id & 1, id & 2); masks.insert(masks.end(), m.begin(), m.end()); }
-        if ((st = mm_set_library_bgr(m_engine, flat.data(), (int)m_libBgr.size(), size)) != MM_OK ||
-            (st = mm_set_masks(m_engine, masks.data(), size)) != MM_OK) { m_lastError = mm_last_error(m_engine); return {}; }
-        m_staleBgr = false;
+    if (m_bestFits.empty() || m_libBgr.empty()) { m_lastError = "buildPhotomosaic needs best fits and the u8 library"; return {}; }
+    const int size = m_cells.getCellSize(0);
+    std::vector<uint8_t> flat;
+    flat.reserve(m_libBgr.size() * (size_t)size * size * 3);
+    for (const auto& im : m_libBgr) {
+        if (im.size() != (size_t)size * size * 3) { m_lastError = "library image size != cell size"; return {}; }
+        flat.insert(flat.end(), im.begin(), im.end());
     }
-    const GridUtility::StepBestFit& grid = m_bestFits[0];
-    const int gridH = (int)grid.size(), gridW = (int)grid.at(0).size();
-    std::vector<int64_t> fits((size_t)gridW * gridH, -1);
-    for (int gy = 0; gy < gridH; ++gy)
-        for (int gx = 0; gx < gridW; ++gx)
-            if (grid[(size_t)gy][(size_t)gx].has_value()) fits[(size_t)gy * gridW + gx] = (int64_t)grid[(size_t)gy][(size_t)gx].value();
-    const std::vector<mm_cell> cells = cellRecords(true);
-    std::vector<uint8_t> mosaic((size_t)m_img.rows * m_img.cols * 4);
-    st = mm_build_photomosaic(m_engine, cells.data(), (int)cells.size(), gridW, gridH, fits.data(), backgroundColour,
-                              m_img.rows, m_img.cols, mosaic.data());
-    if (st != MM_OK) { m_lastError = mm_last_error(m_engine); return {}; }
+    mm_status st;
+    if ((st = mm_set_library_bgr(m_engine, flat.data(), (int)m_libBgr.size(), size)) != MM_OK) { m_lastError = mm_last_error(m_engine); return {}; }
+    m_staleInputs = true;               // the masks staged for generating are replaced below
+    std::vector<uint8_t> mosaic((size_t)m_rows * m_cols * 4);
+    for (size_t step = 0; step < m_bestFits.size(); ++step) {
+        const std::vector<uint8_t> masks = masks4(m_cells.getCell(step));
+        if ((step != 0 && (st = mm_shrink_library_bgr(m_engine, 2)) != MM_OK) ||
+            (st = mm_set_masks(m_engine, masks.data(), m_cells.getCellSize(step))) != MM_OK) { m_lastError = mm_last_error(m_engine); return {}; }
+        const GridUtility::StepBestFit& grid = m_bestFits[step];
+        const std::vector<int64_t> fits = flatGrid(grid);
+        const std::vector<mm_cell> cells = cellRecords(step, true);
+        st = mm_build_photomosaic_step(m_engine, cells.data(), (int)cells.size(), (int)grid.at(0).size(), (int)grid.size(),
+                                       fits.data(), backgroundColour, m_rows, m_cols, (int)step,
+                                       step + 1 == m_bestFits.size() ? mosaic.data() : nullptr);
+        if (st != MM_OK) { m_lastError = mm_last_error(m_engine); return {}; }
+    }
     return mosaic;
 }
 
-static void onProgress(int done, void* user)
+namespace {
+struct ProgressScope { HIPPhotomosaicGenerator* self; int base, weight; };
+void onProgress(int done, void* user)
 {
-    auto* self = static_cast<HIPPhotomosaicGenerator*>(user);
-    if (self->progress) self->progress(done);
+    auto* scope = static_cast<ProgressScope*>(user);
+    if (scope->self->progress) scope->self->progress(scope->base + done * scope->weight);
+}
+}  // namespace
+
+// preprocessMainImage / preprocessLibraryImages (PhotomosaicGeneratorBase.cpp:223-290) -> device.
+bool HIPPhotomosaicGenerator::stageInputs()
+{
+    const int detailSize = m_cells.getCellSize(0, true);
+    const int type = (int)m_colourDiffType;
+    mm_status st = MM_OK;
+    if (!m_lib8.empty()) {
+        const int size = m_lib8.front().rows;
+        if (size % detailSize != 0) { m_lastError = "library image size is not a whole multiple of the detail cell size"; return false; }
+        std::vector<uint8_t> flat;
+        flat.reserve(m_lib8.size() * (size_t)size * size * 3);
+        for (const Image8& im : m_lib8) {
+            if (im.rows != size || im.cols != size) { m_lastError = "library images differ in size"; return false; }
+            flat.insert(flat.end(), im.data.begin(), im.data.end());
+        }
+        st = mm_set_library_u8(m_engine, flat.data(), (int)m_lib8.size(), size, size / detailSize, type);
+    } else if (!m_lib.empty()) {
+        std::vector<float> flat((size_t)m_lib.size() * detailSize * detailSize * 3);
+        for (size_t i = 0; i < m_lib.size(); ++i) {
+            if (m_lib[i].rows != detailSize || m_lib[i].cols != detailSize) { m_lastError = "library image size != detail cell size"; return false; }
+            std::copy(m_lib[i].data.begin(), m_lib[i].data.end(), flat.begin() + i * (size_t)detailSize * detailSize * 3);
+        }
+        st = mm_set_library(m_engine, flat.data(), (int)m_lib.size(), detailSize);
+    } else { m_lastError = "no library"; return false; }
+    if (st != MM_OK) { m_lastError = mm_last_error(m_engine); return false; }
+    if (!m_img8.data.empty()) st = mm_set_target_u8(m_engine, m_img8.data.data(), m_img8.rows, m_img8.cols, type);
+    else if (!m_img.data.empty()) st = mm_set_target(m_engine, m_img.data.data(), m_img.rows, m_img.cols);
+    else { m_lastError = "no main image"; return false; }
+    if (st != MM_OK) { m_lastError = mm_last_error(m_engine); return false; }
+    return true;
 }
 
+// The step loop of generateBestFits (CPUPhotomosaicGenerator.cpp:46-100).
 bool HIPPhotomosaicGenerator::generateBestFits()
 {
     m_lastError.clear();
@@ -195,49 +478,47 @@ bool HIPPhotomosaicGenerator::generateBestFits()
         if (st != MM_CANCELLED) m_lastError = mm_last_error(m_engine);   // the reference shows a message box + LogCritical
         return false;
     };
-    if (m_bestFits.size() != 1) { m_lastError = "size steps > 0 are outside the hot-path scope"; return false; }
-    const CellShape& normal = m_cells.getCell(0);
-    const CellShape& detail = m_cells.getCell(0, true);
-    const int size = detail.getSize();
-
-    if (m_staleInputs) {        // staged once; later generateBestFits() calls reuse the resident copies
-        if (m_lib.empty() || m_img.data.empty()) { m_lastError = "no main image / library"; return false; }
-        std::vector<float> lib((size_t)m_lib.size() * size * size * 3);
-        for (size_t i = 0; i < m_lib.size(); ++i) {
-            if (m_lib[i].rows != size || m_lib[i].cols != size) { m_lastError = "library image size != cell size"; return false; }
-            std::copy(m_lib[i].data.begin(), m_lib[i].data.end(), lib.begin() + i * (size_t)size * size * 3);
-        }
-        std::vector<uint8_t> masks;
-        for (int id = 0; id < 4; ++id) {
-            const auto& m = detail.getCellMask(id & 1, id & 2);           // order of CUDAPhotomosaicGenerator.cpp:122-134
-            masks.insert(masks.end(), m.begin(), m.end());
-        }
-        mm_status st;
-        if ((st = mm_set_library(m_engine, lib.data(), (int)m_lib.size(), size)) != MM_OK) return fail(st);
-        if ((st = mm_set_masks(m_engine, masks.data(), size)) != MM_OK) return fail(st);
-        if ((st = mm_set_target(m_engine, m_img.data.data(), m_img.rows, m_img.cols)) != MM_OK) return fail(st);
-        m_staleInputs = false;
+    const size_t steps = m_bestFits.size();
+    if (steps == 0 || steps > m_cells.getSizeSteps() + 1) { m_lastError = "grid state does not match the cell group's size steps"; return false; }
+    // the resident library is halved per step, so several steps re-stage it every time
+    if (m_staleInputs || steps > 1) {
+        if (!stageInputs()) return false;
+        m_staleInputs = steps > 1;
     }
+    int progressBase = 0;
+    for (size_t step = 0; step < steps; ++step) {
+        if (m_wasCanceled) return false;
+        const CellShape& normal = m_cells.getCell(step);
+        const CellShape& detail = m_cells.getCell(step, true);
+        if (detail.getSize() <= 0 || normal.getSize() % detail.getSize() != 0) { m_lastError = "only whole-number detail ratios are covered"; return false; }
+        mm_status st;
+        if (step > 0 && (st = mm_shrink_library(m_engine, 2)) != MM_OK) return fail(st);       // batchResizeMat, :95-99
+        const std::vector<uint8_t> masks = masks4(detail);
+        if ((st = mm_set_masks(m_engine, masks.data(), detail.getSize())) != MM_OK) return fail(st);
+        if ((st = mm_set_cell_scale(m_engine, normal.getSize() / detail.getSize())) != MM_OK) return fail(st);
 
-    GridUtility::StepBestFit& grid = m_bestFits[0];
-    const int gridH = (int)grid.size(), gridW = (int)grid.at(0).size();
-    const std::vector<mm_cell> cells = cellRecords(true);
+        GridUtility::StepBestFit& grid = m_bestFits[step];
+        const int gridH = (int)grid.size(), gridW = (int)grid.at(0).size();
+        const std::vector<mm_cell> cells = cellRecords(step, false);
+        std::vector<int64_t> bestFit((size_t)gridW * gridH);
+        ProgressScope scope{this, progressBase, (int)std::pow(4, (steps - 1) - step)};        // progressStep, :54
+        st = mm_generate(m_engine, cells.data(), (int)cells.size(), gridW, gridH, (int)m_colourDiffType,
+                         m_repeatRange, m_repeatAddition, bestFit.data(), nullptr,
+                         progress ? onProgress : nullptr, &scope, &m_wasCanceled);
+        if (st != MM_OK) return fail(st);
+        progressBase += gridW * gridH * scope.weight;
 
-    std::vector<int64_t> bestFit((size_t)gridW * gridH);
-    const mm_status st = mm_generate(m_engine, cells.data(), (int)cells.size(), gridW, gridH, (int)m_colourDiffType,
-                                     m_repeatRange, m_repeatAddition, bestFit.data(), nullptr,
-                                     progress ? onProgress : nullptr, this, &m_wasCanceled);
-    if (st != MM_OK) return fail(st);
-
-    // Write back where the grid state has a value (CUDAPhotomosaicGenerator.cpp:310-324);
-    // the sentinel ("Failed to find a best fit", CPUPhotomosaicGenerator.cpp:173-177) removes the cell.
-    for (int gy = 0; gy < gridH; ++gy)
-        for (int gx = 0; gx < gridW; ++gx) {
-            auto& cell = grid[(size_t)gy][(size_t)gx];
-            if (!cell.has_value()) continue;
-            const int64_t v = bestFit[(size_t)gy * gridW + gx];
-            if (v >= 0 && v < (int64_t)m_lib.size()) cell = (size_t)v; else cell = std::nullopt;
-        }
+        // Write back where the grid state has a value (CUDAPhotomosaicGenerator.cpp:310-324);
+        // the sentinel ("Failed to find a best fit", CPUPhotomosaicGenerator.cpp:173-177) removes the cell.
+        for (int gy = 0; gy < gridH; ++gy)
+            for (int gx = 0; gx < gridW; ++gx) {
+                auto& cell = grid[(size_t)gy][(size_t)gx];
+                if (!cell.has_value()) continue;
+                const int64_t v = bestFit[(size_t)gy * gridW + gx];
+                if (v >= 0 && v < (int64_t)m_libCount) cell = (size_t)v; else cell = std::nullopt;
+            }
+    }
+    mm_set_cell_scale(m_engine, 1);
     if (progress) progress(getMaxProgress());
     return true;
 }

@@ -39,11 +39,27 @@ struct Point { int x, y; };
 struct FlipState { bool horizontal = false, vertical = false; };
 }  // namespace GridUtility
 
-// f32 HWC, 3 channels.
+// f32 HWC, 3 channels (already colour-converted), and u8 BGR HWC as cv::imread delivers it.
 struct Image {
     int rows = 0, cols = 0;
     std::vector<float> data;
 };
+struct Image8 {
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> data;
+};
+
+// Other/ImageUtility.{h,cpp} as far as the grid needs it.  OpenCV is not available here:
+// INTER_AREA and BGR2GRAY restate the library's published algorithms (see
+// mosaicmagnifique_amd/imageutil.py for the references); the tests hold this file, the
+// Python host and the CPU checker to the same values.
+namespace ImageUtility {
+constexpr double MAX_ENTROPY = 8.0;                                           // ImageUtility.h:69
+// cv::resize(..., INTER_AREA) for a shrink of a u8 image with cn interleaved channels.
+std::vector<uint8_t> resizeArea(const std::vector<uint8_t>& src, int rows, int cols, int cn, int outRows, int outCols);
+// calculateEntropy (ImageUtility.cpp:189-242): bgr [rows][cols][3]; mask (may be null) with row stride maskStride.
+double calculateEntropy(const uint8_t* bgr, int rows, int cols, const uint8_t* mask, int maskStride);
+}  // namespace ImageUtility
 
 // The part of CellShape (CellShape/CellShape.h:25-113) the path reads.
 class CellShape {
@@ -52,6 +68,10 @@ public:
     CellShape(int size, std::vector<uint8_t> mask);     // thresholded > 127 like setCellMask
     const std::vector<uint8_t>& getCellMask(bool flippedHorizontal, bool flippedVertical) const;
     int getSize() const { return m_size; }
+    bool empty() const { return m_size == 0; }
+    // CellShape::resized (CellShape.cpp:281-312): mask resized + re-thresholded, spacings
+    // floored (never < 1), offsets floored, flip flags copied.
+    CellShape resized(int size) const;
     int rowSpacing = 0, colSpacing = 0, alternateRowSpacing = 0, alternateColSpacing = 0;
     int alternateRowOffset = 0, alternateColOffset = 0;
     bool alternateColFlipHorizontal = false, alternateColFlipVertical = false;
@@ -62,24 +82,36 @@ private:
     std::vector<uint8_t> m_masks[4];      // index flipH + 2*flipV
 };
 
-// CellGroup (CellShape/CellGroup.h:26-64) at detail 100 %, size steps 0.
+// CellGroup (CellShape/CellGroup.h:26-64, CellGroup.cpp): normal + detail cell shape per size
+// step.  The engine covers detail levels and steps whose cell sizes divide evenly.
 class CellGroup {
 public:
-    void setCellShape(const CellShape& shape) { m_cell = shape; }
-    const CellShape& getCell(size_t sizeStep, bool detail = false) const { (void)sizeStep; (void)detail; return m_cell; }
-    double getDetail() const { return 1.0; }
-    size_t getSizeSteps() const { return 0; }
+    void setCellShape(const CellShape& shape);
+    void setDetail(int detailPercent = 100, bool reset = false);      // CellGroup.cpp:65-87
+    void setSizeSteps(size_t steps, bool reset = false);              // CellGroup.cpp:96-128
+    const CellShape& getCell(size_t sizeStep, bool detail = false) const { return (detail ? m_detailCells : m_cells).at(sizeStep); }
+    int getCellSize(size_t sizeStep, bool detail = false) const { return getCell(sizeStep, detail).getSize(); }
+    double getDetail() const { return m_detail; }
+    size_t getSizeSteps() const { return m_sizeSteps; }
 
 private:
-    CellShape m_cell;
+    std::vector<CellShape> m_cells{1}, m_detailCells{1};
+    double m_detail = 1.0;
+    size_t m_sizeSteps = 0;
 };
 
 namespace GridUtility {
 Point calculateGridSize(const CellShape& cellShape, int imageWidth, int imageHeight, int pad);
 Rect getRectAt(const CellShape& cellShape, int x, int y);
 FlipState getFlipStateAt(const CellShape& cellShape, int x, int y);
-// GridGenerator::getGridState for size steps 0 (Grid/GridGenerator.cpp:29-110).
-MosaicBestFit getGridState(const CellGroup& cells, int imageRows, int imageCols);
+// The local bound of a cell at the detail size (PhotomosaicGeneratorBase.cpp:318-326).
+Rect detailBound(const Rect& local, double detail, int size);
+// GridBounds::mergeBounds (Grid/GridBounds.cpp:36-107).
+void mergeBounds(std::vector<Rect>& bounds);
+// GridGenerator::getGridState (Grid/GridGenerator.cpp:29-193).  mainImage (u8 BGR, may be null)
+// drives the entropy subdivision over size steps; without it every cell meeting the image is valid.
+MosaicBestFit getGridState(const CellGroup& cells, const Image8* mainImage, int imageRows, int imageCols);
+inline MosaicBestFit getGridState(const CellGroup& cells, int imageRows, int imageCols) { return getGridState(cells, nullptr, imageRows, imageCols); }
 }  // namespace GridUtility
 
 class HIPPhotomosaicGenerator {
@@ -89,8 +121,11 @@ public:
     HIPPhotomosaicGenerator(const HIPPhotomosaicGenerator&) = delete;
     HIPPhotomosaicGenerator& operator=(const HIPPhotomosaicGenerator&) = delete;
 
-    void setMainImage(const Image& img);
-    void setLibrary(const std::vector<Image>& lib);
+    void setMainImage(const Image& img);                       // already preprocessed (f32 BGR / Lab)
+    void setLibrary(const std::vector<Image>& lib);            // already preprocessed, at the detail cell size
+    // u8 BGR as the reference's setters receive them: resized (library) and colour-converted on the device.
+    void setMainImage(const Image8& img);
+    void setLibrary(const std::vector<Image8>& lib);
     // The library as u8 BGR (what the reference's setLibrary receives before preprocessing);
     // only buildPhotomosaic needs it.
     void setLibraryBGR(const std::vector<std::vector<uint8_t>>& libBgr) { m_libBgr = libBgr; m_staleBgr = true; }
@@ -116,9 +151,14 @@ private:
     mm_engine* m_engine = nullptr;
     Image m_img;
     std::vector<Image> m_lib;
+    Image8 m_img8;
+    std::vector<Image8> m_lib8;
+    int m_rows = 0, m_cols = 0;
+    size_t m_libCount = 0;
+    bool stageInputs();
     std::vector<std::vector<uint8_t>> m_libBgr;
     bool m_staleInputs = true, m_staleBgr = true;
-    std::vector<mm_cell> cellRecords(bool onlyWithValue) const;
+    std::vector<mm_cell> cellRecords(size_t step, bool painting) const;
     ColourDifference::Type m_colourDiffType = ColourDifference::Type::RGB_EUCLIDEAN;
     CellGroup m_cells;
     GridUtility::MosaicBestFit m_bestFits;

@@ -18,7 +18,7 @@ HOST = os.path.join(ROOT, "mosaicmagnifique_amd", "csrc", "host")
 
 def build_runner(out):
     lib_dir = os.path.dirname(_build.build())
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", out,
+    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-Wall", "-Wextra", "-o", out,
            os.path.join(ROOT, "tests", "host_cpp_runner.cpp"),
            os.path.join(HOST, "HIPPhotomosaicGenerator.cpp"),
            "-L" + lib_dir, "-lmosaic_hip", "-Wl,-rpath," + lib_dir]
@@ -31,6 +31,30 @@ def test_host_cpp_compiles(tmp_path):
     assert os.path.exists(build_runner(str(tmp_path / "runner")))
 
 
+def header_of(shape, rows, cols, n_lib, t, rep, detail=100, steps=0, u8=False):
+    return np.array([rows, cols, shape.getSize(), n_lib, int(t), rep[0], rep[1],
+                     shape.rowSpacing, shape.colSpacing, shape.alternateRowSpacing, shape.alternateColSpacing,
+                     shape.alternateRowOffset, shape.alternateColOffset,
+                     shape.alternateColFlipHorizontal, shape.alternateColFlipVertical,
+                     shape.alternateRowFlipHorizontal, shape.alternateRowFlipVertical,
+                     detail, steps, int(u8)], dtype=np.int32)
+
+
+def read_result(path, rows, cols):
+    raw = np.fromfile(path, dtype=np.uint8)
+    steps = int(np.frombuffer(raw[:4], dtype=np.int32)[0])
+    pos, grids = 4, []
+    for _ in range(steps):
+        gh, gw = (int(v) for v in np.frombuffer(raw[pos:pos + 8], dtype=np.int32))
+        pos += 8
+        grids.append(np.frombuffer(raw[pos:pos + 8 * gh * gw], dtype=np.int64).reshape(gh, gw))
+        pos += 8 * gh * gw
+    return grids, raw[pos:].reshape(rows, cols, 4)
+
+
+SHAPES = {"square": lambda: cases.square_shape(16), "hexagon": cases.hexagon_shape, "flippy": cases.flippy_shape}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape_name,t,rep", [
     ("square", Type.RGB_EUCLIDEAN, (0, 0)),
@@ -38,31 +62,65 @@ def test_host_cpp_compiles(tmp_path):
     ("flippy", Type.CIE76, (1, 50)),
 ])
 def test_host_cpp_matches_oracle(oracle, tmp_path, shape_name, t, rep):
-    shape = {"square": lambda: cases.square_shape(16), "hexagon": cases.hexagon_shape,
-             "flippy": cases.flippy_shape}[shape_name]()
+    shape = SHAPES[shape_name]()
     size = shape.getSize()
     rows, cols, n_lib = 4 * size + 5, 5 * size + 9, 40
     from mosaicmagnifique_amd import synth
     lib_u8 = synth.library_u8(n_lib, size)
     img = synth.preprocess(synth.target_u8(rows, cols, lattice=max(size, 8)), t)
     lib = synth.preprocess(lib_u8, t)
-    header = np.array([rows, cols, size, n_lib, int(t), rep[0], rep[1],
-                       shape.rowSpacing, shape.colSpacing, shape.alternateRowSpacing, shape.alternateColSpacing,
-                       shape.alternateRowOffset, shape.alternateColOffset,
-                       shape.alternateColFlipHorizontal, shape.alternateColFlipVertical,
-                       shape.alternateRowFlipHorizontal, shape.alternateRowFlipVertical], dtype=np.int32)
     scenario, result = tmp_path / "scenario.bin", tmp_path / "result.bin"
     with open(scenario, "wb") as f:
-        f.write(header.tobytes()); f.write(img.tobytes()); f.write(lib.tobytes())
+        f.write(header_of(shape, rows, cols, n_lib, t, rep).tobytes()); f.write(img.tobytes()); f.write(lib.tobytes())
         f.write(shape.getCellMask(False, False).tobytes())
         f.write(lib_u8.tobytes())
     runner = build_runner(str(tmp_path / "runner"))
     subprocess.run([runner, str(scenario), str(result)], check=True, timeout=300)
-    raw = np.fromfile(result, dtype=np.uint8)
-    gh, gw = np.frombuffer(raw[:8], dtype=np.int32)
-    got = np.frombuffer(raw[8:8 + 8 * gh * gw], dtype=np.int64).reshape(gh, gw)
+    (got,), mosaic = read_result(result, rows, cols)
     want, _, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), *rep)
     assert np.array_equal(got, want)
-    mosaic = raw[8 + 8 * gh * gw:].reshape(rows, cols, 4)
     want_mosaic = oracle.build_photomosaic(shape_of(shape), rows, cols, lib_u8, shape.masks4(), want, (7, 8, 9, 10))
     assert np.array_equal(mosaic, want_mosaic)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape_name,t,rep,detail,steps", [
+    ("square32", Type.CIE76, (2, 300), 50, 1),          # CreateCellGroup(size, 1, 50), tst_CUDAGenerator.h
+    ("hexagon", Type.CIEDE2000, (1, 200), 50, 2),
+    ("square32", Type.RGB_EUCLIDEAN, (0, 0), 25, 0),
+])
+def test_host_cpp_u8_inputs_detail_and_size_steps(oracle, tmp_path, shape_name, t, rep, detail, steps):
+    """The C++ host fed like the reference's fixtures (u8 BGR image and library, detail 50 %, size
+    steps) against the Python host run the same way -- which test_gpu_detail_steps.py holds to the
+    oracle -- grid for grid and pixel for pixel."""
+    from mosaicmagnifique_amd import GridUtility as G
+    from mosaicmagnifique_amd import HIPPhotomosaicGenerator, synth
+    from mosaicmagnifique_amd.cellshape import CellGroup
+    shape = cases.square_shape(32) if shape_name == "square32" else SHAPES[shape_name]()
+    size = shape.getSize()
+    rows, cols, n_lib = 5 * size + 7, 6 * size + 3, 60
+    img = synth.target_u8(rows, cols, lattice=2 * size)
+    rng = np.random.default_rng(11)
+    img[:, cols // 2:] = rng.integers(0, 256, (rows, cols - cols // 2, 3), dtype=np.uint8)     # busy half: splits
+    lib = synth.library_u8(n_lib, size)
+    scenario, result = tmp_path / "scenario.bin", tmp_path / "result.bin"
+    with open(scenario, "wb") as f:
+        f.write(header_of(shape, rows, cols, n_lib, t, rep, detail, steps, u8=True).tobytes())
+        f.write(img.tobytes()); f.write(lib.tobytes()); f.write(shape.getCellMask(False, False).tobytes())
+    runner = build_runner(str(tmp_path / "runner"))
+    subprocess.run([runner, str(scenario), str(result)], check=True, timeout=300)
+    grids, mosaic = read_result(result, rows, cols)
+
+    group = CellGroup(shape)
+    group.setSizeSteps(steps)
+    group.setDetail(detail)
+    state = G.getGridState(group, rows, cols, mainImage=img)
+    gen = HIPPhotomosaicGenerator(0)
+    gen.setMainImage(img); gen.setLibrary(lib); gen.setColourDifference(t); gen.setCellGroup(group)
+    gen.setGridState(state); gen.setRepeat(*rep)
+    assert gen.generateBestFits(), gen.lastError
+    want = gen.getBestFits()
+    assert len(grids) == len(want) and (steps == 0 or len(want) > 1)
+    for a, b in zip(grids, want):
+        assert np.array_equal(a, b)
+    assert np.array_equal(mosaic, gen.buildPhotomosaic((7, 8, 9, 10)))
