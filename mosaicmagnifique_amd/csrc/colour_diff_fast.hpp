@@ -40,7 +40,7 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 __device__ __forceinline__ float euclidean_fast(const PxF& p, const PxF& q)
 {
     const float d0 = p.c0 - q.c0, d1 = p.c1 - q.c1, d2 = p.c2 - q.c2;
-    return fsqrt(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
+    return fsqrt(fmaxf(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)), 0.0f));      // max(NaN, 0) = 0: inactive pixel
 }
 
 // (x/25)^7 / ((x/25)^7 + 1) under a square root, as x7 * rsq(x7 * (x7 + 1)).
@@ -133,7 +133,7 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     const float inv_d = frcp(big_d);
     const float t_l = d_l * frcp(s_l);
     const float xx = fmaf(t_l, t_l, num * (inv_d * inv_d));
-    return fsqrt(fmaxf(xx, 0.0f));
+    return fsqrt(fmaxf(xx, 0.0f));          // also max(NaN, 0) = 0: an inactive pixel (c0 = NaN) adds nothing
 }
 
 __device__ __forceinline__ float chroma_of(float a, float b) { return fsqrt(fmaf(a, a, b * b)); }

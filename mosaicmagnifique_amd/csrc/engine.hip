@@ -54,7 +54,7 @@ struct mm_engine {
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut;
     DevBuf row_map, spec_recs, deep, insufficient;
-    DevBuf stage_u8, srgb_lut, shrink_tmp, covered;
+    DevBuf stage_u8, srgb_lut, shrink_tmp, covered, cells_f0;
     int mosaic_rows = 0, mosaic_cols = 0;       // the mosaic kept between mm_build_photomosaic_step calls
     int cell_scale = 1;          // mm_set_cell_scale: full-size cell pixels per detail pixel and axis
     int spec_k = 10;             // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
@@ -355,7 +355,7 @@ mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_typ
     mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
         recs_dev, (const float*)e->target.p, e->rows, e->cols, e->cell_scale, (const uint8_t*)e->masks.p,
         (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
-        (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p);
+        (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, nullptr);
     HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
     if (after_gather) HIP_TRY(e, hipEventRecord(after_gather, e->stream), "event");
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
@@ -436,11 +436,13 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     const int ftype = diff_type == MM_CIEDE2000 ? mm::CIEDE2000 : mm::RGB_EUCLIDEAN;
     if (two_tier) {
         if ((st = ensure_hue_lut(e)) ||
-            (st = ensure(e, e->cell_chroma, (size_t)batch * ppad * sizeof(float), "Failed to allocate cell chroma planes")))
+            (st = ensure(e, e->cell_chroma, (size_t)batch * ppad * sizeof(float), "Failed to allocate cell chroma planes")) ||
+            (st = ensure(e, e->cells_f0, (size_t)batch * ppad * sizeof(float), "Failed to allocate cell planes")))
             return st;
     }
     mm::FilterInputs fin{};
     fin.cells = (const float*)e->cells.p; fin.cmask = (const uint8_t*)e->cmask.p;
+    fin.cells_f0 = (const float*)e->cells_f0.p;
     fin.cell_chroma = (const float*)e->cell_chroma.p; fin.lib = (const float*)e->lib.p;
     fin.lib_chroma = (const float*)e->lib_chroma.p; fin.hue_lut = (const float4*)e->hue_lut.p;
     fin.var = variants_of(e);
@@ -487,7 +489,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
             recs_dev + done, (const float*)e->target.p, e->rows, e->cols, e->cell_scale, (const uint8_t*)e->masks.p,
             (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
-            (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p);
+            (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, (float*)e->cells_f0.p);
         HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
         if (diff_type == MM_CIEDE2000) {
             HIP_TRY(e, mm::launch_chroma_planes((const float*)e->cells.p, (float*)e->cell_chroma.p, (size_t)b, ppad, e->stream),
@@ -787,7 +789,7 @@ void mm_destroy(mm_engine* e)
                        &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
-                       &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered })
+                       &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0 })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);

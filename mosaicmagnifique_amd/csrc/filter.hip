@@ -101,7 +101,7 @@ __device__ __forceinline__ LibGroup load_lib_group(const float4* b0, const float
 // one cell; cells fastest within a group so resident workgroups share library tiles.
 template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
-filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
+filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
               const float* __restrict__ cell_chroma, const float* __restrict__ lib,
               const float* __restrict__ lib_chroma, float* __restrict__ scores,
               int n_cells, int L, int ppad, int cand_per_block, int cell_group,
@@ -128,10 +128,11 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
     const int groups = var.groups[v];                    // only the variant's active pixels
     lib += (size_t)v * var.lib_stride;
     lib_chroma += (size_t)v * var.chroma_stride;
-    const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
-    const float4* c1 = c0 + ppad / 4;
+    // channel 0 from the plane that holds NaN at inactive pixels: their terms come out as
+    // max(NaN, 0) = 0 (colour_diff_fast.hpp), so there is no mask to load or test here
+    const float4* c0 = reinterpret_cast<const float4*>(cells_f0 + (size_t)cell * ppad);
+    const float4* c1 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad) + ppad / 4;
     const float4* c2 = c1 + ppad / 4;
-    const uint32_t* mk = reinterpret_cast<const uint32_t*>(cmask + (size_t)cell * ppad);
     const float4* cc = reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
 
     // Early exit, the device form of the reference's `variant < bestVariant` loop guards
@@ -207,11 +208,9 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
                 }
                 const int q = lane + kWave * j;
                 const unsigned int off = (unsigned int)q * 16u;
-                const uint32_t m = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(mk) + off / 4u);
 #ifdef MM_COUNT_VISITS
                 visited += 1;
 #endif
-                if (m == 0) return false;
                 const float4 p0 = ld4(c0, off), p1 = ld4(c1, off), p2 = ld4(c2, off);
                 float4 pc{0.f, 0.f, 0.f, 0.f};
                 if constexpr (TYPE == CIEDE2000) pc = ld4(cc, off);
@@ -221,23 +220,25 @@ filter_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask
                 const float v1 = pair_fast<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
                 const float v2 = pair_fast<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
                 const float v3 = pair_fast<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
-                const bool a0 = m & 0x000000ffu, a1 = m & 0x0000ff00u, a2 = m & 0x00ff0000u, a3 = m & 0xff000000u;
                 if constexpr (TYPE == CIEDE2000) {
-                    acc += ((a0 && !e0) ? v0 : 0.0f) + ((a1 && !e1) ? v1 : 0.0f)
-                         + ((a2 && !e2) ? v2 : 0.0f) + ((a3 && !e3) ? v3 : 0.0f);
-                    const uint32_t em = (e0 ? 0x000000ffu : 0u) | (e1 ? 0x0000ff00u : 0u) |
-                                       (e2 ? 0x00ff0000u : 0u) | (e3 ? 0xff000000u : 0u);
-                    if (em & m) {                               // rare: ~1e-5 of pairs
-                        acc_edge += ((a0 && e0) ? v0 : 0.0f) + ((a1 && e1) ? v1 : 0.0f)
-                                  + ((a2 && e2) ? v2 : 0.0f) + ((a3 && e3) ? v3 : 0.0f);
+                    // discontinuity pairs are rare (~1e-5): one wave-wide test, then the slow branch
+                    const bool a0 = p0.x == p0.x, a1 = p0.y == p0.y, a2 = p0.z == p0.z, a3 = p0.w == p0.w;   // not NaN = active
+                    if (__builtin_amdgcn_ballot_w64((e0 && a0) || (e1 && a1) || (e2 && a2) || (e3 && a3)) != 0) {
+                        acc += ((e0 && a0) ? 0.0f : v0) + ((e1 && a1) ? 0.0f : v1)
+                             + ((e2 && a2) ? 0.0f : v2) + ((e3 && a3) ? 0.0f : v3);
+                        acc_edge += ((e0 && a0) ? v0 : 0.0f) + ((e1 && a1) ? v1 : 0.0f)
+                                  + ((e2 && a2) ? v2 : 0.0f) + ((e3 && a3) ? v3 : 0.0f);
+                        const bool ea[4] = {e0 && a0, e1 && a1, e2 && a2, e3 && a3};
                         for (int k = 0; k < 4; ++k)
-                            if ((em & m) >> (8 * k) & 0xffu) {
+                            if (ea[k]) {
                                 const unsigned int slot = atomicAdd(edge_count, 1u);
                                 if (slot < edge_cap) edges[slot] = EdgeEntry{cell, l, 4 * q + k};
                             }
+                    } else {
+                        acc += (v0 + v1) + (v2 + v3);
                     }
                 } else {
-                    acc += (a0 ? v0 : 0.0f) + (a1 ? v1 : 0.0f) + (a2 ? v2 : 0.0f) + (a3 ? v3 : 0.0f);
+                    acc += (v0 + v1) + (v2 + v3);
                 }
                 return false;
             };
@@ -273,7 +274,7 @@ constexpr int kLdsBlock = 1024;
 
 template <int TYPE>
 __global__ void __launch_bounds__(kLdsBlock)
-filter_lds_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
+filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
                   const float* __restrict__ cell_chroma, const float* __restrict__ lib,
                   const float* __restrict__ lib_chroma, float* __restrict__ scores,
                   int n_cells, int L, int ppad, int cand_per_block, int cell_group,
@@ -288,7 +289,6 @@ filter_lds_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
     float4* s1 = s0 + pq;
     float4* s2 = s1 + pq;
     float4* sc = s2 + pq;
-    uint32_t* sm = reinterpret_cast<uint32_t*>(sc + (TYPE == CIEDE2000 ? pq : 0));
 
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long bid = blockIdx.x;
@@ -310,15 +310,14 @@ filter_lds_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
         for (int i = threadIdx.x; i <= kHueLutSize; i += kLdsBlock) lut[i] = hue_lut[i];
     {
         const float4* g0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
+        const float4* gf = reinterpret_cast<const float4*>(cells_f0 + (size_t)cell * ppad);     // NaN = inactive
         const float4* gc = reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
-        const uint32_t* gm = reinterpret_cast<const uint32_t*>(cmask + (size_t)cell * ppad);
         const int nq = groups * kWave;
         for (int q = threadIdx.x; q < nq; q += kLdsBlock) {
-            s0[q] = g0[q];
+            s0[q] = gf[q];
             s1[q] = g0[pq + q];
             s2[q] = g0[2 * pq + q];
             if constexpr (TYPE == CIEDE2000) sc[q] = gc[q];
-            sm[q] = gm[q];
         }
     }
     __syncthreads();
@@ -340,8 +339,6 @@ filter_lds_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
                 const int q = lane + kWave * j;
                 const LibGroup cur = nxt;
                 if (j + 1 < groups) nxt = load_lib_group<TYPE>(b0, b1, b2, bc, q + kWave);   // one group ahead
-                const uint32_t m = sm[q];
-                if (m == 0) continue;
                 const float4 p0 = s0[q], p1 = s1[q], p2 = s2[q];
                 float4 pc{0.f, 0.f, 0.f, 0.f};
                 if constexpr (TYPE == CIEDE2000) pc = sc[q];
@@ -351,23 +348,24 @@ filter_lds_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
                 const float v1 = pair_fast<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
                 const float v2 = pair_fast<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
                 const float v3 = pair_fast<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
-                const bool a0 = m & 0x000000ffu, a1 = m & 0x0000ff00u, a2 = m & 0x00ff0000u, a3 = m & 0xff000000u;
                 if constexpr (TYPE == CIEDE2000) {
-                    acc += ((a0 && !e0) ? v0 : 0.0f) + ((a1 && !e1) ? v1 : 0.0f)
-                         + ((a2 && !e2) ? v2 : 0.0f) + ((a3 && !e3) ? v3 : 0.0f);
-                    const uint32_t em = (e0 ? 0x000000ffu : 0u) | (e1 ? 0x0000ff00u : 0u) |
-                                       (e2 ? 0x00ff0000u : 0u) | (e3 ? 0xff000000u : 0u);
-                    if (em & m) {
-                        acc_edge += ((a0 && e0) ? v0 : 0.0f) + ((a1 && e1) ? v1 : 0.0f)
-                                  + ((a2 && e2) ? v2 : 0.0f) + ((a3 && e3) ? v3 : 0.0f);
+                    const bool a0 = p0.x == p0.x, a1 = p0.y == p0.y, a2 = p0.z == p0.z, a3 = p0.w == p0.w;
+                    if (__builtin_amdgcn_ballot_w64((e0 && a0) || (e1 && a1) || (e2 && a2) || (e3 && a3)) != 0) {
+                        acc += ((e0 && a0) ? 0.0f : v0) + ((e1 && a1) ? 0.0f : v1)
+                             + ((e2 && a2) ? 0.0f : v2) + ((e3 && a3) ? 0.0f : v3);
+                        acc_edge += ((e0 && a0) ? v0 : 0.0f) + ((e1 && a1) ? v1 : 0.0f)
+                                  + ((e2 && a2) ? v2 : 0.0f) + ((e3 && a3) ? v3 : 0.0f);
+                        const bool ea[4] = {e0 && a0, e1 && a1, e2 && a2, e3 && a3};
                         for (int k = 0; k < 4; ++k)
-                            if ((em & m) >> (8 * k) & 0xffu) {
+                            if (ea[k]) {
                                 const unsigned int slot = atomicAdd(edge_count, 1u);
                                 if (slot < edge_cap) edges[slot] = EdgeEntry{cell, l, 4 * q + k};
                             }
+                    } else {
+                        acc += (v0 + v1) + (v2 + v3);
                     }
                 } else {
-                    acc += (a0 ? v0 : 0.0f) + (a1 ? v1 : 0.0f) + (a2 ? v2 : 0.0f) + (a3 ? v3 : 0.0f);
+                    acc += (v0 + v1) + (v2 + v3);
                 }
             }
         }
@@ -675,8 +673,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     hipError_t code = hipMemsetAsync(edge_count, 0, 8 * sizeof(unsigned int), stream);   // + diagnostics counters
     if (code != hipSuccess) return code;
     // LDS-resident form when the cell (4 planes + mask) fits beside the hue table
-    const size_t lds_bytes = (type == CIEDE2000 ? (size_t)(kHueLutSize + 1) * 16 + (size_t)ppad * 16 : (size_t)ppad * 12) +
-                             (size_t)ppad;
+    const size_t lds_bytes = type == CIEDE2000 ? (size_t)(kHueLutSize + 1) * 16 + (size_t)ppad * 16 : (size_t)ppad * 12;
     if (in.use_lds_form && lds_bytes <= 156 * 1024) {
         const int cpb = 64;
         const long long tiles = (L + cpb - 1) / cpb;
@@ -687,7 +684,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes)) != hipSuccess) return code;
             kern<<<dim3((unsigned)nblk), kLdsBlock, lds_bytes, stream>>>(
-                in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
+                in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
                 edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, in.lb_scale);
             if ((code = hipGetLastError()) != hipSuccess) return code;
             edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
@@ -697,21 +694,21 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes)) != hipSuccess) return code;
             kern<<<dim3((unsigned)nblk), kLdsBlock, lds_bytes, stream>>>(
-                in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
+                in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
                 edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, in.lb_scale);
         }
         return hipGetLastError();
     }
     if (type == CIEDE2000) {
         filter_kernel<CIEDE2000><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
-            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
+            in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
     } else {
         filter_kernel<RGB_EUCLIDEAN><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
-            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
+            in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale);
     }
     return hipGetLastError();

@@ -219,7 +219,8 @@ gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ 
                     int rows, int cols, int scale, const uint8_t* __restrict__ masks,
                     float* __restrict__ cells, uint8_t* __restrict__ cmask,
                     int size, int P, int ppad, const int* __restrict__ perm, int4 var_of_mask,
-                    uint8_t* __restrict__ cell_var, uint8_t* __restrict__ cell_full)
+                    uint8_t* __restrict__ cell_var, uint8_t* __restrict__ cell_full,
+                    float* __restrict__ cells_f0)
 {
     const mm_cell rec = recs[blockIdx.y];
     const int vm[4] = {var_of_mask.x, var_of_mask.y, var_of_mask.z, var_of_mask.w};
@@ -248,6 +249,10 @@ gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ 
     dst[ppad] = v1;
     dst[2 * (size_t)ppad] = v2;
     cmask[(size_t)blockIdx.y * ppad + k] = m;
+    // Channel 0 once more for the fp32 filter pass, with a quiet NaN where the pixel is not
+    // active: every filter term of such a pixel comes out as max(NaN, 0) = 0, so the filter
+    // kernels need no mask (filter.hip).
+    if (cells_f0) cells_f0[(size_t)blockIdx.y * ppad + k] = m ? v0 : __builtin_nanf("");
 }
 
 // ---------------------------------------------------------------------------

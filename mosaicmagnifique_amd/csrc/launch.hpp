@@ -34,6 +34,7 @@ struct FilterInputs {
     Variants var;
     const float* cells;         // f32 planar [B][3][ppad]
     const uint8_t* cmask;       // u8 [B][ppad]
+    const float* cells_f0;      // f32 [B][ppad]  channel 0 with NaN at inactive pixels (what the filter kernels read)
     const float* cell_chroma;   // f32 [B][ppad]  sqrt(a^2+b^2) per cell pixel (CIEDE2000 only)
     const float* lib;           // f32 planar [L][3][ppad]
     const float* lib_chroma;    // f32 [L][ppad]
