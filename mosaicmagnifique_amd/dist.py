@@ -65,7 +65,8 @@ class ShardedBestFit:
         import torch
         key = (per, k)
         if self._bufs is None or self._bufs[0] != key:
-            dev = torch.device("cuda", self.engine.device)
+            # a stand-in engine of the CPU tests names its own device; the real one is a GPU
+            dev = getattr(self.engine, "torch_device", None) or torch.device("cuda", self.engine.device)
             self._bufs = (key,
                           torch.full((max(per, 1), k), -1, dtype=torch.int32, device=dev),
                           torch.full((max(per, 1), k), float("inf"), dtype=torch.float64, device=dev))
@@ -96,7 +97,8 @@ class ShardedBestFit:
         deep = np.zeros(n, dtype=np.uint8) if speculate else None
         while True:
             idx_all, score_all = allgather_candidates(idx[:per], score[:per], n, self.world, self.group)
-            torch.cuda.synchronize(idx.device)      # the engine runs on its own stream
+            if idx.device.type == "cuda":
+                torch.cuda.synchronize(idx.device)  # the engine runs on its own stream
             out = self.engine.resolve(cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, k,
                                       idx_all.data_ptr(), score_all.data_ptr(), on_device=True, deep=deep, k_fill=ks)
             if not speculate:
