@@ -410,3 +410,26 @@ def test_split_api_speculation_matches_generate(oracle, engine):
         deep[todo] = 1
     assert rounds >= 2 and deep.sum() > 0
     assert np.array_equal(best, whole) and np.array_equal(score[state >= 0], whole_score[state >= 0])
+
+
+@pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIE76, Type.CIEDE2000])
+@pytest.mark.parametrize("rep", [(0, 0), (3, 700)], ids=["norepeat", "repeats"])
+def test_consistency_over_iterations(t, rep):
+    """CUDAGeneratorFixture CONSISTENCY_* (test/tst_CUDAGenerator.h:62-85, :226-330): the same
+    generator run ITERATIONS times from a fresh grid state returns the same best fits every time
+    (atomics, dynamic work pulls and the speculative path must not leak run-to-run variation)."""
+    shape = cases.hexagon_shape()
+    group = cases.group_of(shape)
+    img, lib = cases.inputs(300, 410, 64, 90, t, lattice=96)
+    gen = HIPPhotomosaicGenerator(0)
+    gen.setMainImage(img); gen.setLibrary(lib); gen.setColourDifference(t); gen.setCellGroup(group)
+    gen.setRepeat(*rep)
+    last = None
+    for _ in range(5):
+        gen.setGridState(G.getGridState(group, img.shape[0], img.shape[1]))
+        assert gen.generateBestFits(), gen.lastError
+        fits, scores = gen.getBestFits()[0], gen.getBestScores()[0]
+        if last is not None:
+            assert np.array_equal(fits, last[0])
+            assert np.array_equal(scores, last[1], equal_nan=True)         # bit-identical, not just close
+        last = (fits, scores)
