@@ -93,6 +93,7 @@ typedef struct mm_timing {
     double build_ms;          /* mm_build_photomosaic: owner map + compose kernels */
     int64_t spec_rounds;      /* resolve passes of the speculate-and-verify loop (1 = no cell needed deepening) */
     int64_t deepened_cells;   /* cells whose short candidate list had to be extended to the full length */
+    int64_t resolve_sweeps;   /* parallel sweeps the repeat-penalty resolve took to reach its fix point */
 } mm_timing;
 
 /* Progress: called on the calling thread between device batches with

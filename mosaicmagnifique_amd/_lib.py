@@ -27,7 +27,8 @@ class MMTiming(ctypes.Structure):
                 ("dense_rows", ctypes.c_int64), ("rescore_ms", ctypes.c_double),
                 ("dense_cells", ctypes.c_int64), ("edge_pairs", ctypes.c_int64),
                 ("seed_ms", ctypes.c_double), ("build_ms", ctypes.c_double),
-                ("spec_rounds", ctypes.c_int64), ("deepened_cells", ctypes.c_int64)]
+                ("spec_rounds", ctypes.c_int64), ("deepened_cells", ctypes.c_int64),
+                ("resolve_sweeps", ctypes.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

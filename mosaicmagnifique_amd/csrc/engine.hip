@@ -53,7 +53,7 @@ struct mm_engine {
     DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s;
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut;
-    DevBuf row_map, spec_recs, deep, insufficient;
+    DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
     DevBuf stage_u8, srgb_lut, shrink_tmp, covered, cells_f0;
     int mosaic_rows = 0, mosaic_cols = 0;       // the mosaic kept between mm_build_photomosaic_step calls
     int cell_scale = 1;          // mm_set_cell_scale: full-size cell pixels per detail pixel and axis
@@ -67,6 +67,8 @@ struct mm_engine {
     float lib_dmax = 50.0f, target_dmax = 50.0f;    // max |c0 - 50| over the library / the target
     int n_var = 0, var_of_mask[4] = {0, 0, 0, 0}, var_groups[4] = {0, 0, 0, 0};
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
+    int use_sweep_resolve = 1;   // mm_set_option("sweep_resolve", 0): raster-order chain instead of parallel sweeps
+    int max_sweeps = 48;         // mm_set_option("max_sweeps", n): sweeps before falling back to the chain
     int use_lds_filter = -1;     // mm_set_option("lds_filter", 0/1); -1 = auto (Euclid only: it is the L2-bound one)
     int extra_seeds = 22;        // mm_set_option("seeds", n): proxy-chosen seeds beyond the list length
     int tile_candidates = 0;     // mm_set_option("tile", n): candidates per filter workgroup (0 = default)
@@ -655,10 +657,63 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
             });
             HIP_TRY(e, hipGetLastError(), "Error during dense rows kernel");
         }
+        // Repeat penalty as parallel sweeps to the raster-order fix point (resolve_wave_kernel,
+        // mode 2): launched a few at a time, each with its own change counter; the first sweep
+        // that changed nothing proves the state final.  Past max_sweeps (long collision chains,
+        // e.g. a flat target) the grid is reset and the sequential forms below take over.
+        bool swept = false;
+        if (sequential && e->use_sweep_resolve != 0) {
+            const int max_sweeps = e->max_sweeps, batch = 6;
+            // per sweep: [max_sweeps] exact re-sum counters (u64), then [max_sweeps] change counters (u32)
+            const size_t counts_bytes = (size_t)max_sweeps * (sizeof(unsigned long long) + sizeof(unsigned int));
+            if ((st = ensure(e, e->sweep_counts, counts_bytes, "Failed to allocate sweep counters"))) return st;
+            unsigned long long* exacts = (unsigned long long*)e->sweep_counts.p;
+            unsigned int* counts = (unsigned int*)(exacts + max_sweeps);
+            HIP_TRY(e, hipMemsetAsync(e->sweep_counts.p, 0, counts_bytes, e->stream), "Failed to clear sweep counters");
+            const int blocks = std::max(1, std::min(n, 8192));
+            std::vector<unsigned int> host_counts(batch);
+            unsigned long long* const exact_total_count = a.exact_count;
+            int launched = 0;
+            while (!swept && launched < max_sweeps) {
+                const int now = std::min(batch, max_sweeps - launched);
+                for (int i = 0; i < now; ++i) {
+                    a.sweep_changes = counts + launched + i;
+                    a.exact_count = exacts + launched + i;
+                    by_type(diff_type, [&](auto T) {
+                        mm::resolve_wave_kernel<decltype(T)::value><<<blocks, mm::kWave, 0, e->stream>>>(a, 2);
+                        return MM_OK;
+                    });
+                }
+                HIP_TRY(e, hipGetLastError(), "Error during calculate repeats / find lowest kernel");
+                HIP_TRY(e, hipMemcpyAsync(host_counts.data(), counts + launched, (size_t)now * sizeof(unsigned int),
+                                          hipMemcpyDeviceToHost, e->stream), "sweep counters");
+                HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+                for (int i = 0; i < now && !swept; ++i)
+                    if (host_counts[i] == 0) {
+                        swept = true;
+                        e->timing.resolve_sweeps += launched + i + 1;
+                        // the re-sums of the final state = those of the sweep that changed nothing
+                        HIP_TRY(e, hipMemcpyAsync(exact_total_count, exacts + launched + i, sizeof(unsigned long long),
+                                                  hipMemcpyDeviceToDevice, e->stream), "exact counter");
+                    }
+                launched += now;
+            }
+            a.exact_count = exact_total_count;
+            if (!swept) {                       // not converged: start the chain from a clean grid
+                e->timing.resolve_sweeps += launched;
+                HIP_TRY(e, hipMemcpyAsync(e->grid.p, init.data(), cells_total * sizeof(long long), hipMemcpyHostToDevice, e->stream),
+                        "Failed to copy max best fit from host to device");
+                HIP_TRY(e, hipMemcpyAsync(e->best.p, nan_init.data(), cells_total * sizeof(double), hipMemcpyHostToDevice, e->stream),
+                        "Failed to reset lowest variant");
+                HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+            }
+        }
         // whole grid + progress counters + per-wave exact buffers in LDS?
         const size_t rows_lds = (((size_t)grid_w * grid_h + grid_h + 2) & ~(size_t)1) * sizeof(int) +
                                 (size_t)mm::kRowWaves * mm::kRowExactChunk * sizeof(double);
-        if (sequential && e->use_row_pipeline != 0 && rows_lds <= 158 * 1024) {
+        if (swept) {
+            // final state reached by the sweeps
+        } else if (sequential && e->use_row_pipeline != 0 && rows_lds <= 158 * 1024) {
             if ((st = ensure(e, e->row_index, ((size_t)2 * grid_h + 1) * sizeof(int), "Failed to allocate row index")))
                 return st;
             int* row_first = (int*)e->row_index.p;
@@ -1369,6 +1424,8 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "prune") == 0) { e->use_prune = value != 0; return MM_OK; }
     if (strcmp(name, "wave_resolve") == 0) { e->use_wave_resolve = value != 0; return MM_OK; }
     if (strcmp(name, "row_pipeline") == 0) { e->use_row_pipeline = value != 0; return MM_OK; }
+    if (strcmp(name, "sweep_resolve") == 0) { e->use_sweep_resolve = value != 0; return MM_OK; }
+    if (strcmp(name, "max_sweeps") == 0) { if (value < 1 || value > 4096) return MM_INVALID_ARGUMENT; e->max_sweeps = value; return MM_OK; }
     if (strcmp(name, "lds_filter") == 0) { e->use_lds_filter = value < 0 ? -1 : (value != 0); return MM_OK; }
     if (strcmp(name, "spec_k") == 0) { e->spec_k = std::max(0, value); return MM_OK; }
     if (strcmp(name, "seeds") == 0) { e->extra_seeds = std::max(0, value); return MM_OK; }

@@ -600,6 +600,8 @@ struct ResolveArgs {
     uint8_t* insufficient;      // [n_cells] out: 1 = the pick of a non-deep cell could not be verified
     const int* row_slot;        // [n_cells] slot in `rows`, -1 = list is complete
     const double* dense_rows;   // [marked][L]
+    // sweep resolve (resolve_wave_kernel mode 2): picks changed by this sweep
+    unsigned int* sweep_changes;
 };
 
 // Repeat value of library image `cand` at padded cell (px, py):
@@ -837,7 +839,7 @@ dense_rows_kernel(ResolveArgs a, double* __restrict__ rows)
     if (threadIdx.x == 0) atomicAdd(a.dense_count, 1ull);
 }
 
-// sequential != 0: ONE wave walks the cells in raster order; the chosen indices of the
+// sequential == 1: ONE wave walks the cells in raster order; the chosen indices of the
 // last R+1 grid rows live in an LDS ring (the only state calculateRepeats reads,
 // CPUPhotomosaicGenerator.cpp:189-224).  Lane k holds candidate k; the <= R(2R+1)+R
 // neighbour picks are fetched once into lanes and matched against every lane's
@@ -845,18 +847,31 @@ dense_rows_kernel(ResolveArgs a, double* __restrict__ rows)
 // for the near-tie test finish the cell.  The next cell's record and candidates are
 // loaded while the current one is processed.  sequential == 0: waves take cells
 // independently (no penalty, no ring).
+//
+// sequential == 2, the SWEEP form of the raster-order dependency: every cell is
+// re-decided in parallel from the picks currently in a.grid (in place), and the number
+// of cells whose pick changed is counted.  The reference's result is the unique fix
+// point of "cell = f(picks of the cells before it in raster order)" (induction over the
+// raster order), and a sweep that changes nothing saw one constant state, i.e. that
+// fix point.  Cells only read cells earlier in raster order, so after s sweeps every
+// cell whose dependency chain is shorter than s is final: the host launches sweeps
+// until one reports no change (a handful when collisions are local) and falls back to
+// the sequential forms if a bound is passed.  Time no longer grows with the grid height,
+// which is what the multi-GPU step needs: its resolve covers the cells of ALL ranks.
 template <int TYPE>
 __global__ void __launch_bounds__(kWave)
 resolve_wave_kernel(ResolveArgs a, int sequential)
 {
-    extern __shared__ int ring[];              // [(R+1)][grid_w], sequential mode only
+    extern __shared__ int ring[];              // [(R+1)][grid_w], sequential == 1 only
     __shared__ double buf[kExactChunk];
     __shared__ double bcast;
     const int lane = threadIdx.x;
+    const bool sweep = sequential == 2;
     const bool penalise = sequential && a.repeat_range > 0 && a.repeat_addition != 0;
     const int R = a.repeat_range, ring_rows = R + 1, gw = a.grid_w;
     const int sentinel = a.L;
-    if (penalise) {
+    if (sweep) sequential = 0;                 // cells are taken independently
+    if (penalise && !sweep) {
         for (int i = lane; i < ring_rows * gw; i += kWave) ring[i] = sentinel;
         __syncthreads();
     }
@@ -884,7 +899,7 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
         const int px = rec.grid_x, py = rec.grid_y;
         int n_above = 0, wrow = 0, sx = 0, sy = 0, nn = 0;
         if (penalise) {
-            if (py != cur_row) {                // entering a grid row: recycle the ring rows it needs
+            if (!sweep && py != cur_row) {      // entering a grid row: recycle the ring rows it needs
                 for (int r = max(cur_row + 1, py - R); r <= py; ++r)
                     for (int x = lane; x < gw; x += kWave) ring[(r % ring_rows) * gw + x] = sentinel;
                 cur_row = py;
@@ -921,7 +936,8 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
                     int ry, rx;
                     if (t < n_above) { const int q = t / wrow; ry = sy + q; rx = sx + (t - q * wrow); }
                     else { ry = py; rx = sx + (t - n_above); }
-                    nbv = ring[(ry % ring_rows) * gw + rx];
+                    nbv = sweep ? (int)__atomic_load_n(&a.grid[(size_t)ry * gw + rx], __ATOMIC_RELAXED)
+                                : ring[(ry % ring_rows) * gw + rx];
                 }
                 const int cnt = min(kWave, nn - t0);
                 for (int j = 0; j < cnt; ++j)
@@ -999,11 +1015,16 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
         }
         if (lane == 0) {
             const size_t pos = (size_t)py * gw + px;
-            a.grid[pos] = chosen;
+            if (sweep) {
+                if (__atomic_load_n(&a.grid[pos], __ATOMIC_RELAXED) != chosen) atomicAdd(a.sweep_changes, 1u);
+                __atomic_store_n(&a.grid[pos], chosen, __ATOMIC_RELAXED);
+            } else {
+                a.grid[pos] = chosen;
+            }
             a.best_score[pos] = chosen_total;
-            if (penalise) ring[(py % ring_rows) * gw + px] = (int)chosen;
+            if (penalise && !sweep) ring[(py % ring_rows) * gw + px] = (int)chosen;
         }
-        if (penalise) __syncthreads();          // single wave: orders the LDS write before the next reads
+        if (penalise && !sweep) __syncthreads();    // single wave: orders the LDS write before the next reads
 
         rec = nrec;
         my_ci = nci;

@@ -26,15 +26,20 @@ SHAPES = {
 REL_TOL = {0: 1e-12, 1: 1e-12, 2: 1e-4}
 
 
-RESOLVE_MODES = {"rows": (1, 1), "wave": (1, 0), "workgroup": (0, 0)}     # (wave_resolve, row_pipeline)
+# (wave_resolve, row_pipeline, sweep_resolve): the parallel sweeps (default), the row-pipelined
+# chain, the single-wave chain, the workgroup-per-cell chain
+RESOLVE_MODES = {"sweep": (1, 1, 1), "rows": (1, 1, 0), "wave": (1, 0, 0), "workgroup": (0, 0, 0)}
 
 
-def generate(shape, img, lib, t, rep=(0, 0), device=0, use_filter=1, wave_resolve="rows"):
+def generate(shape, img, lib, t, rep=(0, 0), device=0, use_filter=1, wave_resolve="sweep", options=()):
     group = cases.group_of(shape)
     gen = HIPPhotomosaicGenerator(device)
     gen.m_engine.set_option("filter", use_filter)
     gen.m_engine.set_option("wave_resolve", RESOLVE_MODES[wave_resolve][0])
     gen.m_engine.set_option("row_pipeline", RESOLVE_MODES[wave_resolve][1])
+    gen.m_engine.set_option("sweep_resolve", RESOLVE_MODES[wave_resolve][2])
+    for name, value in options:
+        gen.m_engine.set_option(name, value)
     gen.setMainImage(img)
     gen.setLibrary(lib)
     gen.setColourDifference(t)
@@ -45,8 +50,8 @@ def generate(shape, img, lib, t, rep=(0, 0), device=0, use_filter=1, wave_resolv
     return gen
 
 
-def compare(oracle, shape, img, lib, t, rep=(0, 0), use_filter=1, wave_resolve="rows"):
-    gen = generate(shape, img, lib, t, rep, use_filter=use_filter, wave_resolve=wave_resolve)
+def compare(oracle, shape, img, lib, t, rep=(0, 0), use_filter=1, wave_resolve="sweep", options=()):
+    gen = generate(shape, img, lib, t, rep, use_filter=use_filter, wave_resolve=wave_resolve, options=options)
     got, score = gen.getBestFits()[0], gen.getBestScores()[0]
     want, want_score, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), *rep)
     assert got.shape == want.shape
@@ -77,6 +82,27 @@ def test_compare_matrix(oracle, t, shape_name, rep, use_filter):
     gen = compare(oracle, shape, img, lib, t, rep, use_filter)
     tm = gen.timing()
     assert (tm["rescore_ms"] > 0) == bool(use_filter and gen.m_engine.speculative_candidates(*rep) < n_lib)
+
+
+@pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIEDE2000])
+def test_sweep_resolve_reaches_the_raster_order_result(oracle, t):
+    """The repeat penalty as parallel sweeps to the fix point (resolve_wave_kernel mode 2):
+    on a nearly flat target every cell wants the same few images, so picks keep displacing
+    each other along the raster order -- the longest dependency chains the path can see.
+    Same grid and scores as the oracle's sequential scan with (a) enough sweeps, (b) a
+    sweep budget too small to converge (falls back to the chain), (c) sweeps off."""
+    size = 16
+    shape = cases.square_shape(size)
+    img, lib = cases.inputs(12 * size, 14 * size, size, 90, t, lattice=64 * size)   # one lattice cell: smooth, near-flat
+    sweeps = {}
+    for name, options in (("free", (("max_sweeps", 512),)), ("starved", (("max_sweeps", 2),)), ("off", (("sweep_resolve", 0),))):
+        for rep in ((3, 250), (4, 100000), (2, -40)):
+            gen = compare(oracle, shape, img, lib, t, rep=rep, options=options)
+            sweeps[name, rep] = gen.timing()["resolve_sweeps"]
+    assert all(sweeps["off", rep] == 0 for rep in ((3, 250), (4, 100000), (2, -40)))
+    assert all(sweeps["starved", rep] >= 2 for rep in ((3, 250), (4, 100000), (2, -40)))     # 2 per resolve pass, then the chain
+    assert all(2 <= sweeps["free", rep] <= 512 for rep in ((3, 250), (4, 100000), (2, -40))), sweeps
+    assert max(sweeps["free", rep] for rep in ((3, 250), (4, 100000))) > 3, sweeps           # the chains were really long
 
 
 @pytest.mark.parametrize("wave_resolve", list(RESOLVE_MODES))
