@@ -110,6 +110,52 @@ def cpu_baseline(w):
     return grid, scores, done, dt
 
 
+def host_cores(cap=16):
+    """Threads for the all-cores leg: the affinity mask, cut by the cgroup CPU quota when there
+    is one, and by `cap` (a one-GPU box's CPU share is 16 cores whatever the mask says)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline_all_cores(w, per_thread=2):
+    """the same port on every host core of this process's CPU share -- one
+    thread per core, each scoring its own `per_thread` valid cells (no repeat penalty: base
+    scores are what parallelises; the penalty resolve is negligible on the CPU too).
+    ctypes releases the GIL inside the oracle call."""
+    import threading
+
+    import oracle_ffi
+    o = oracle_ffi.load()
+    cores = host_cores()
+    state = w["state_single"]
+    valid = np.argwhere(state >= 0)
+    cores = max(1, min(cores, len(valid) // per_thread))
+    shape = oracle_ffi.shape_of(w["shape"])
+    masks = w["shape"].masks4()
+    done = [0] * cores
+
+    def work(k):
+        mine = np.full(state.shape, -1, dtype=np.int64)
+        for gy, gx in valid[k * per_thread:(k + 1) * per_thread]:
+            mine[gy, gx] = state[gy, gx]
+        done[k] = o.generate_best_fits(shape, w["img"], w["lib"], masks, w["t"], 0, 0, state=mine)[2]
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt = time.perf_counter() - t0
+    return sum(done), cores, dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +297,11 @@ def main():
         "last_step_device_ms": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
     }
 
+    if world == 1:
+        # what a plain coalesced read stream reaches on this device (4 GiB, past the Infinity Cache)
+        measured = engine.stream_read_gbs(4 << 30, 5)
+        out["roofline"]["peak_measured"] = measured
+        out["roofline"]["frac_of_measured"] = achieved / measured if measured > 0 else None
     if world == 1 and not args.no_cpu:
         grid, cscore, done, dt = cpu_baseline(w)
         recs = my_cells[:done]
@@ -264,6 +315,13 @@ def main():
         }
         out["parity_on_cpu_sample"] = {"indices_equal": bool(same), "max_rel_score_err": rel}
         out["speedup_vs_cpu"] = value / (done / dt)
+        n_all, cores, dt_all = cpu_baseline_all_cores(w)
+        out["cpu_baseline_all_cores"] = {
+            "value": n_all / dt_all, "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": "%d valid cells, %d per thread, one thread per host core of this process, base scores "
+                      "only (oracle/oracle.c, early exit on, %.1f s)" % (n_all, n_all // max(cores, 1), dt_all),
+        }
+        out["speedup_vs_cpu_all_cores"] = value / (n_all / dt_all)
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -146,6 +146,16 @@ mm_status mm_set_library_u8(mm_engine *e, const uint8_t *bgr, int n_images, int 
  * NONE: u8 BGR [rows][cols][3] -> f32 BGR or Lab.  Replaces mm_set_target. */
 mm_status mm_set_target_u8(mm_engine *e, const uint8_t *bgr, int rows, int cols, int diff_type);
 
+/* One variant of ColourScheme::getColourScheme{Complementary,Triadic,Compound,Tetradic,
+ * Analagous} (ColourScheme.cpp:44-177): the u8 BGR image with its hue rotated by `degrees`
+ * (u8 -> f32 -> BGR2HSV_FULL -> H = fmod(H + degrees, 360) -> HSV2BGR_FULL -> u8), written to
+ * the caller's `out` [rows][cols][3].  The host builds the variant list of a scheme from it
+ * (the rotations are 180 | 120,240 | 150,210 | 90,180,270 | 30,60,90) and stages the variant it
+ * compares against with mm_set_target_u8.  OpenCV's cvtColor is a third-party dependency absent
+ * from the reference checkout: the arithmetic is specified in csrc/kernels.hpp (hue_rotate_px). */
+mm_status mm_hue_rotate_u8(mm_engine *e, const uint8_t *bgr, int rows, int cols, float degrees,
+                           uint8_t *out);
+
 /* ImageUtility::batchResizeMat(lib) between size steps
  * (CPUPhotomosaicGenerator.cpp:95-99): the resident f32 library is replaced by
  * its INTER_AREA reduction by `factor` (2 per size step). */
@@ -286,6 +296,11 @@ mm_status mm_filter_diff_batch(mm_engine *e, int diff_type,
  * candidates dropped outright by the lightness bound} of the last batch.  Only builds
  * with -DMM_COUNT_VISITS count; otherwise zeros. */
 mm_status mm_debug_visit_counters(mm_engine *e, unsigned long long out[3]);
+
+/* Calibration: GB/s a plain coalesced float4 read stream over `bytes` of device memory reaches
+ * (best of `repeats` launches); bench.py quotes the roofline fraction against it as well as
+ * against the 8 TB/s specification. */
+mm_status mm_debug_stream_read(mm_engine *e, size_t bytes, int repeats, double *gb_per_s);
 
 #ifdef __cplusplus
 }

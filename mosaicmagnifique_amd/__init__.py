@@ -7,10 +7,11 @@ Importing the package does not load the library; the first engine does, and it
 raises if the library is not built (there is no CPU fallback).
 """
 from . import colourdifference as ColourDifference  # noqa: F401
+from . import colourscheme as ColourScheme  # noqa: F401
 from . import grid as GridUtility  # noqa: F401
 from .cellshape import CellGroup, CellShape  # noqa: F401
 
-__all__ = ["ColourDifference", "GridUtility", "CellShape", "CellGroup",
+__all__ = ["ColourDifference", "ColourScheme", "GridUtility", "CellShape", "CellGroup",
            "HIPPhotomosaicGenerator", "Engine"]
 
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mm_set_target": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
     "mm_set_library_u8": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mm_set_target_u8": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mm_hue_rotate_u8": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_float, _VP]),
     "mm_shrink_library": (ctypes.c_int, [_VP, ctypes.c_int]),
     "mm_set_cell_scale": (ctypes.c_int, [_VP, ctypes.c_int]),
     "mm_library_shape": (ctypes.c_int, [_VP, c_int_p, c_int_p]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "mm_colour_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),
     "mm_filter_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),
     "mm_debug_visit_counters": (ctypes.c_int, [_VP, _VP]),
+    "mm_debug_stream_read": (ctypes.c_int, [_VP, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None

@@ -995,6 +995,28 @@ mm_status mm_set_target_u8(mm_engine* e, const uint8_t* bgr, int rows, int cols,
     return target_range(e);
 }
 
+mm_status mm_hue_rotate_u8(mm_engine* e, const uint8_t* bgr, int rows, int cols, float degrees, uint8_t* out)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!bgr || !out || rows <= 0 || cols <= 0 || !(degrees >= 0.0f && degrees < 360.0f)) {
+        set_err(e, "mm_hue_rotate_u8: need rows, cols > 0 and 0 <= degrees < 360 (got %d, %d, %g)", rows, cols, (double)degrees);
+        return MM_INVALID_ARGUMENT;
+    }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    const size_t n_px = (size_t)rows * cols, bytes = n_px * 3;
+    mm_status st;
+    if ((st = ensure(e, e->stage_u8, 2 * bytes, "Failed to allocate u8 staging"))) return st;
+    uint8_t* src = (uint8_t*)e->stage_u8.p;
+    uint8_t* dst = src + bytes;
+    HIP_TRY(e, hipMemcpyAsync(src, bgr, bytes, hipMemcpyHostToDevice, e->stream), "Failed to copy u8 image to device");
+    const unsigned blocks = (unsigned)std::min<size_t>((n_px + mm::kBlock - 1) / mm::kBlock, 65536);
+    mm::hue_rotate_u8_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(src, dst, n_px, degrees);
+    HIP_TRY(e, hipGetLastError(), "Error during hue rotation kernel");
+    HIP_TRY(e, hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, e->stream), "Failed to copy variant to host");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    return MM_OK;
+}
+
 mm_status mm_shrink_library(mm_engine* e, int factor)
 {
     if (!e) return MM_INVALID_ARGUMENT;
@@ -1414,6 +1436,37 @@ mm_status mm_debug_visit_counters(mm_engine* e, unsigned long long out[3])
     unsigned int raw[8] = {0};
     HIP_TRY(e, hipMemcpy(raw, e->edge_count.p, sizeof raw, hipMemcpyDeviceToHost), "counters");
     memcpy(out, raw + 2, 3 * sizeof(unsigned long long));
+    return MM_OK;
+}
+
+// Calibration: GB/s of a coalesced float4 read stream over `bytes` of device memory (larger than
+// the 256 MiB Infinity Cache to see HBM), best of `repeats` launches timed with HIP events.
+mm_status mm_debug_stream_read(mm_engine* e, size_t bytes, int repeats, double* gb_per_s)
+{
+    if (!e || !gb_per_s || bytes < (1u << 20) || repeats < 1) return MM_INVALID_ARGUMENT;
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    const size_t n_vec = bytes / 16;
+    const int blocks = 256 * 16;                                  // 16 workgroups of 4 waves per CU
+    DevBuf src, sink;
+    mm_status st;
+    if ((st = ensure(e, src, n_vec * 16, "Failed to allocate stream buffer")) ||
+        (st = ensure(e, sink, (size_t)blocks * mm::kBlock * sizeof(float), "Failed to allocate stream sink"))) {
+        release(src); release(sink);
+        return st;
+    }
+    hipError_t code = hipMemsetAsync(src.p, 0, n_vec * 16, e->stream);
+    double best_ms = 1e30;
+    for (int r = 0; r <= repeats && code == hipSuccess; ++r) {     // launch 0 warms up
+        if ((code = hipEventRecord(e->ev[4], e->stream)) != hipSuccess) break;
+        mm::stream_read_kernel<<<blocks, mm::kBlock, 0, e->stream>>>((const float4*)src.p, n_vec, (float*)sink.p);
+        if ((code = hipGetLastError()) != hipSuccess) break;
+        if ((code = hipEventRecord(e->ev[5], e->stream)) != hipSuccess) break;
+        if ((code = hipStreamSynchronize(e->stream)) != hipSuccess) break;
+        if (r > 0) best_ms = std::min(best_ms, (double)elapsed(e->ev[4], e->ev[5]));
+    }
+    release(src); release(sink);
+    if (code != hipSuccess) return hip_fail(e, code, "Error during stream read calibration", __FILE__, __LINE__);
+    *gb_per_s = (double)(n_vec * 16) / (best_ms * 1e-3) / 1e9;
     return MM_OK;
 }
 

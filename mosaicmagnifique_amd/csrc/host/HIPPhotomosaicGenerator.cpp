@@ -337,6 +337,42 @@ void HIPPhotomosaicGenerator::setColourDifference(ColourDifference::Type type)
     m_colourDiffType = type;
 }
 
+std::vector<float> ColourScheme::rotations(Type type)
+{
+    switch (type) {
+    case Type::NONE: return {};
+    case Type::COMPLEMENTARY: return {180.0f};                 // ColourScheme.cpp:44-60
+    case Type::TRIADIC: return {120.0f, 240.0f};               // :66-87
+    case Type::COMPOUND: return {150.0f, 210.0f};              // :93-114
+    case Type::TETRADIC: return {90.0f, 180.0f, 270.0f};       // :121-146
+    case Type::ANALAGOUS: return {30.0f, 60.0f, 90.0f};        // :153-177
+    default: throw std::invalid_argument("No function for given type");      // ColourScheme.cpp:31
+    }
+}
+
+void HIPPhotomosaicGenerator::setColourScheme(ColourScheme::Type type)
+{
+    ColourScheme::rotations(type);          // throws on MAX
+    m_colourSchemeType = type;
+    m_staleInputs = true;
+}
+
+std::vector<Image8> HIPPhotomosaicGenerator::mainImageVariants()
+{
+    std::vector<Image8> out;
+    if (m_img8.data.empty()) { m_lastError = "colour-scheme variants need the u8 BGR main image"; return out; }
+    out.push_back(m_img8);
+    for (float degrees : ColourScheme::rotations(m_colourSchemeType)) {
+        Image8 v{m_img8.rows, m_img8.cols, std::vector<uint8_t>(m_img8.data.size())};
+        if (mm_hue_rotate_u8(m_engine, m_img8.data.data(), m_img8.rows, m_img8.cols, degrees, v.data.data()) != MM_OK) {
+            m_lastError = mm_last_error(m_engine);
+            return {};
+        }
+        out.push_back(std::move(v));
+    }
+    return out;
+}
+
 int HIPPhotomosaicGenerator::getMaxProgress() const                     // PhotomosaicGeneratorBase.cpp:210-214
 {
     return (int)(std::pow(4, m_bestFits.size() - 1) * m_bestFits.size() * m_bestFits.at(0).at(0).size() * m_bestFits.at(0).size());
@@ -463,7 +499,13 @@ bool HIPPhotomosaicGenerator::stageInputs()
         st = mm_set_library(m_engine, flat.data(), (int)m_lib.size(), detailSize);
     } else { m_lastError = "no library"; return false; }
     if (st != MM_OK) { m_lastError = mm_last_error(m_engine); return false; }
-    if (!m_img8.data.empty()) st = mm_set_target_u8(m_engine, m_img8.data.data(), m_img8.rows, m_img8.cols, type);
+    if (m_colourSchemeType != ColourScheme::Type::NONE) {
+        // every variant's cell aliases the last variant (setColourScheme): compare against that one
+        const std::vector<Image8> variants = mainImageVariants();
+        if (variants.empty()) return false;
+        st = mm_set_target_u8(m_engine, variants.back().data.data(), m_img8.rows, m_img8.cols, type);
+    }
+    else if (!m_img8.data.empty()) st = mm_set_target_u8(m_engine, m_img8.data.data(), m_img8.rows, m_img8.cols, type);
     else if (!m_img.data.empty()) st = mm_set_target(m_engine, m_img.data.data(), m_img.rows, m_img.cols);
     else { m_lastError = "no main image"; return false; }
     if (st != MM_OK) { m_lastError = mm_last_error(m_engine); return false; }

@@ -29,6 +29,12 @@ namespace ColourDifference {
 enum class Type { RGB_EUCLIDEAN = 0, CIE76 = 1, CIEDE2000 = 2, MAX = 3 };   // ColourDifference.h:13-19
 }
 
+namespace ColourScheme {
+enum class Type { NONE = 0, COMPLEMENTARY, TRIADIC, COMPOUND, TETRADIC, ANALAGOUS, MAX };   // ColourScheme.h:13-22
+// Hue rotations (degrees) of the variants that follow the original image, ColourScheme.cpp:44-177.
+std::vector<float> rotations(Type type);                                                  // throws std::invalid_argument on MAX
+}
+
 namespace GridUtility {
 using CellBestFit = std::optional<size_t>;
 using StepBestFit = std::vector<std::vector<CellBestFit>>;
@@ -130,6 +136,13 @@ public:
     // only buildPhotomosaic needs it.
     void setLibraryBGR(const std::vector<std::vector<uint8_t>>& libBgr) { m_libBgr = libBgr; m_staleBgr = true; }
     void setColourDifference(ColourDifference::Type type);      // throws std::invalid_argument on MAX
+    // PhotomosaicGeneratorBase::setColourScheme (PhotomosaicGeneratorBase.cpp:64-69).  getCellAt
+    // builds the V variant cells as copies of ONE cv::Mat header (:310), so they share a buffer and
+    // every cell the best-fit scan sees holds the LAST variant (:311-312): the reference's result
+    // with a scheme equals its result with the last variant as the main image.  That variant is
+    // what gets staged (u8 main image required); mainImageVariants() returns the whole list.
+    void setColourScheme(ColourScheme::Type type = ColourScheme::Type::NONE);
+    std::vector<Image8> mainImageVariants();                      // m_colourSchemeFunc(m_img), :231-232; empty on error
     void setCellGroup(const CellGroup& cellGroup);
     const CellGroup& getCellGroup() const { return m_cells; }
     void setGridState(const GridUtility::MosaicBestFit& gridState);
@@ -160,6 +173,7 @@ private:
     bool m_staleInputs = true, m_staleBgr = true;
     std::vector<mm_cell> cellRecords(size_t step, bool painting) const;
     ColourDifference::Type m_colourDiffType = ColourDifference::Type::RGB_EUCLIDEAN;
+    ColourScheme::Type m_colourSchemeType = ColourScheme::Type::NONE;
     CellGroup m_cells;
     GridUtility::MosaicBestFit m_bestFits;
     int m_repeatRange = 0, m_repeatAddition = 0;

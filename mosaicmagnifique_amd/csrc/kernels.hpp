@@ -210,6 +210,62 @@ preprocess_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, s
     }
 }
 
+// One hue-rotated variant of a u8 BGR image: ColourScheme::getColourScheme* (ColourScheme.cpp:
+// 44-177) builds every variant as  u8 -> f32 (values stay 0..255) -> cvtColor(BGR2HSV_FULL) ->
+// H = fmod(H + degrees, 360) -> cvtColor(HSV2BGR_FULL) -> convertTo(u8).  The two cvtColor calls
+// are OpenCV (4.5.2, absent from the checkout; no reference test holds vectors for them), so the
+// arithmetic is SPECIFIED here, after OpenCV's documented f32 formulas, in f32, this order:
+//   V = max(B,G,R); m = min(B,G,R); d = V - m; S = d / (|V| + FLT_EPSILON); k = 60 / (d + FLT_EPSILON)
+//   H = (G-B) k          if V == R
+//       (B-R) k + 120    else if V == G
+//       (R-G) k + 240    else;            H += 360 if H < 0
+//   back: S == 0 -> B = G = R = V; else h = fmod(H * (6/360), 6), i = floor(h), f = h - i
+//   (i outside 0..5 -> i = 0, f = 0), tab = {V, V(1-S), V(1-S f), V(1-S(1-f))},
+//   (B,G,R) = tab[{1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}][i]
+//   u8 = saturate(round-half-even) -- cv::saturate_cast<uchar>(float).
+// Built without fp contraction (engine.hip), so the oracle and the numpy restatement
+// (colourscheme.py) agree with it bit for bit.  Parity unpinned at this step, as for Lab.
+__device__ __forceinline__ void hue_rotate_px(const uint8_t* q, float degrees, uint8_t* out)
+{
+    const float b = (float)q[0], g = (float)q[1], r = (float)q[2];
+    float v = r, vmin = r;
+    if (v < g) v = g;
+    if (v < b) v = b;
+    if (vmin > g) vmin = g;
+    if (vmin > b) vmin = b;
+    float diff = v - vmin;
+    const float s = diff / (fabsf(v) + 1.1920928955078125e-07f);
+    diff = 60.0f / (diff + 1.1920928955078125e-07f);
+    float h;
+    if (v == r) h = (g - b) * diff;
+    else if (v == g) h = (b - r) * diff + 120.0f;
+    else h = (r - g) * diff + 240.0f;
+    if (h < 0.0f) h += 360.0f;
+    h = fmodf(h + degrees, 360.0f);                       // ColourScheme.cpp:52,69-70,...
+    float ob, og, orr;
+    if (s == 0.0f) {
+        ob = og = orr = v;
+    } else {
+        float hh = fmodf(h * (6.0f / 360.0f), 6.0f);
+        int sector = (int)floorf(hh);
+        hh -= (float)sector;
+        if ((unsigned)sector >= 6u) { sector = 0; hh = 0.0f; }
+        const float tab[4] = {v, v * (1.0f - s), v * (1.0f - s * hh), v * (1.0f - s * (1.0f - hh))};
+        constexpr int kSector[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+        ob = tab[kSector[sector][0]]; og = tab[kSector[sector][1]]; orr = tab[kSector[sector][2]];
+    }
+    out[0] = (uint8_t)min(255, max(0, __float2int_rn(ob)));
+    out[1] = (uint8_t)min(255, max(0, __float2int_rn(og)));
+    out[2] = (uint8_t)min(255, max(0, __float2int_rn(orr)));
+}
+
+__global__ void __launch_bounds__(kBlock)
+hue_rotate_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n_pixels, float degrees)
+{
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n_pixels; t += (size_t)gridDim.x * kBlock)
+        hue_rotate_px(src + t * 3, degrees, dst + t * 3);
+}
+
 // getCellAt on the device (PhotomosaicGeneratorBase.cpp:293-329; detail 1/scale):
 // the visible part of the target under the cell rect, zero elsewhere, as planes;
 // and the per-cell active mask = mask variant AND local bound (the CUDA path's
@@ -1342,6 +1398,27 @@ shrink_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int
         for (int k = 0; k < 3; ++k)
             dst[t * 3 + k] = (uint8_t)(f == 2 ? (sum[k] + 2) >> 2 : min(255, max(0, __float2int_rn((float)sum[k] * scale))));
     }
+}
+
+// ---------------------------------------------------------------------------
+// calibration: what a plain coalesced read stream reaches on this device
+// ---------------------------------------------------------------------------
+
+// Every lane sums float4 loads of a grid-stride stream (1 KiB per wave-instruction, the
+// access pattern of the filter kernels' plane loads); one store per thread keeps the loads.
+__global__ void __launch_bounds__(kBlock)
+stream_read_kernel(const float4* __restrict__ src, size_t n_vec, float* __restrict__ sink)
+{
+    float4 acc{0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 3 * stride < n_vec; i += 4 * stride) {            // four loads in flight per lane
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
+        acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; i < n_vec; i += stride) { const float4 a = src[i]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+    sink[(size_t)blockIdx.x * kBlock + threadIdx.x] = (acc.x + acc.y) + (acc.z + acc.w);
 }
 
 // ---------------------------------------------------------------------------

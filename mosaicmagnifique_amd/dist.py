@@ -7,7 +7,8 @@ dependencies of the path: base scores of different cells are independent, so
 valid cells (raster order) are cut into ``world`` contiguous blocks; library,
 masks and target are replicated (<= ~1.1 GB even for config E, trivial against
 288 GB of HBM).  The only exchange is ONE all-gather of the per-cell candidate
-lists (K x 12 bytes per cell: a few KB to a few MB), after which every rank runs
+lists (K x 12 bytes per cell: a few KB to a few MB; indices and scores travel in one
+packed byte buffer), after which every rank runs
 the same deterministic resolve, so all ranks end with the identical best-fit grid.
 The payload is latency-bound, far below the size where the 7 x ~153 GB/s xGMI
 links matter: a single collective on one stream, no bucketing, no overlap games.
@@ -27,11 +28,22 @@ def padded_len(n_cells, world):
     return -(-n_cells // world) if n_cells else 0
 
 
-def allgather_candidates(idx_local, score_local, n_cells, world, group=None):
-    """All-gather of the shards' candidate lists.
+def pack_layout(per, k):
+    """Byte layout of one rank's candidate lists inside the single all-gather buffer:
+    ``[per][k]`` int32 indices, padded to 8 bytes, then ``[per][k]`` float64 scores."""
+    idx_bytes = per * k * 4
+    score_off = (idx_bytes + 7) // 8 * 8
+    return score_off, score_off + per * k * 8
+
+
+def allgather_candidates(idx_local, score_local, n_cells, world, group=None, packed=None):
+    """ONE all-gather of the shards' candidate lists.
 
     idx_local  int32  [per][k]   (torch tensor, rows past the shard's own count are padding)
     score_local f64   [per][k]
+    packed: optional uint8 tensor [pack_layout(per, k)[1]] whose first bytes ARE idx_local and
+    whose tail IS score_local (ShardedBestFit allocates them as views of it); without it the
+    two are copied into a fresh buffer first.
     Returns (idx [n_cells][k], score [n_cells][k]) identical on every rank.
     Works on CUDA tensors (nccl/RCCL) and CPU tensors (gloo).
     """
@@ -39,14 +51,18 @@ def allgather_candidates(idx_local, score_local, n_cells, world, group=None):
     import torch.distributed as dist
     per, k = idx_local.shape
     assert per == padded_len(n_cells, world) and score_local.shape == (per, k)
-    idx_all = torch.empty((world * per, k), dtype=idx_local.dtype, device=idx_local.device)
-    score_all = torch.empty((world * per, k), dtype=score_local.dtype, device=score_local.device)
+    score_off, total = pack_layout(per, k)
+    if packed is None:
+        packed = torch.zeros(total, dtype=torch.uint8, device=idx_local.device)
+        packed[:per * k * 4].view(torch.int32).view(per, k).copy_(idx_local)
+        packed[score_off:].view(torch.float64).view(per, k).copy_(score_local)
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
-        idx_all.copy_(idx_local)
-        score_all.copy_(score_local)
+        gathered = packed.view(1, total)
     else:
-        dist.all_gather_into_tensor(idx_all, idx_local.contiguous(), group=group)
-        dist.all_gather_into_tensor(score_all, score_local.contiguous(), group=group)
+        gathered = torch.empty((world, total), dtype=torch.uint8, device=packed.device)
+        dist.all_gather_into_tensor(gathered.view(-1), packed, group=group)
+    idx_all = gathered[:, :per * k * 4].contiguous().view(torch.int32).view(world * per, k)
+    score_all = gathered[:, score_off:].contiguous().view(torch.float64).view(world * per, k)
     # shards are contiguous blocks of `per`, so trimming the tail removes exactly the padding
     return idx_all[:n_cells], score_all[:n_cells]
 
@@ -67,10 +83,15 @@ class ShardedBestFit:
         if self._bufs is None or self._bufs[0] != key:
             # a stand-in engine of the CPU tests names its own device; the real one is a GPU
             dev = getattr(self.engine, "torch_device", None) or torch.device("cuda", self.engine.device)
-            self._bufs = (key,
-                          torch.full((max(per, 1), k), -1, dtype=torch.int32, device=dev),
-                          torch.full((max(per, 1), k), float("inf"), dtype=torch.float64, device=dev))
-        return self._bufs[1], self._bufs[2]
+            rows = max(per, 1)
+            score_off, total = pack_layout(rows, k)
+            packed = torch.zeros(total, dtype=torch.uint8, device=dev)      # what the one all-gather sends
+            idx = packed[:rows * k * 4].view(torch.int32).view(rows, k)
+            score = packed[score_off:].view(torch.float64).view(rows, k)
+            idx.fill_(-1)
+            score.fill_(float("inf"))
+            self._bufs = (key, idx, score, packed)
+        return self._bufs[1], self._bufs[2], self._bufs[3]
 
     def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0, spec_k=10):
         """cells: ALL valid cells in raster order (every rank passes the same array).
@@ -87,7 +108,7 @@ class ShardedBestFit:
         speculate = ks < k and n > 0
         per = padded_len(n, self.world)
         lo, hi = shard_range(n, self.world, self.rank)
-        idx, score = self._buffers(per, k)
+        idx, score, packed = self._buffers(per, k)
         if hi - lo < per:                       # short last shard: keep the padding rows inert
             idx[hi - lo:] = -1
             score[hi - lo:] = float("inf")
@@ -96,7 +117,8 @@ class ShardedBestFit:
                                     out_score=score.data_ptr(), on_device=True, k_fill=ks)
         deep = np.zeros(n, dtype=np.uint8) if speculate else None
         while True:
-            idx_all, score_all = allgather_candidates(idx[:per], score[:per], n, self.world, self.group)
+            idx_all, score_all = allgather_candidates(idx[:per], score[:per], n, self.world, self.group,
+                                                      packed=packed if per >= 1 else None)
             if idx.device.type == "cuda":
                 torch.cuda.synchronize(idx.device)  # the engine runs on its own stream
             out = self.engine.resolve(cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, k,

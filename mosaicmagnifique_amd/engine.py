@@ -101,6 +101,16 @@ class Engine:
             raise ValueError("target must be [rows][cols][3]")
         self._check(self._lib.mm_set_target_u8(self._h, _lib.ptr(a), a.shape[0], a.shape[1], int(diff_type)))
 
+    def hue_rotate_u8(self, image, degrees):
+        """One colour-scheme variant (ColourScheme.cpp:44-177): the u8 BGR image with its hue
+        rotated by ``degrees`` through f32 HSV_FULL, on the device."""
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("image must be [rows][cols][3]")
+        out = np.empty_like(a)
+        self._check(self._lib.mm_hue_rotate_u8(self._h, _lib.ptr(a), a.shape[0], a.shape[1], float(degrees), _lib.ptr(out)))
+        return out
+
     def shrink_library(self, factor=2):
         """batchResizeMat between size steps: the resident library at 1/factor of its size."""
         self._check(self._lib.mm_shrink_library(self._h, int(factor)))
@@ -223,6 +233,12 @@ class Engine:
     def set_option(self, name, value):
         """mm_set_option: "filter" 1 (default, two-tier fp32 filter + fp64 re-score) or 0 (fp64 only)."""
         self._check(self._lib.mm_set_option(self._h, name.encode(), int(value)))
+
+    def stream_read_gbs(self, nbytes=4 << 30, repeats=5):
+        """Calibration: GB/s of a coalesced float4 read stream over ``nbytes`` of device memory."""
+        out = ctypes.c_double(0.0)
+        self._check(self._lib.mm_debug_stream_read(self._h, int(nbytes), int(repeats), ctypes.byref(out)))
+        return out.value
 
     def timing(self):
         t = _lib.MMTiming()

@@ -18,6 +18,7 @@ import logging
 import numpy as np
 
 from . import colourdifference as ColourDifference
+from . import colourscheme as ColourScheme
 from . import grid as GridUtility
 from . import synth
 from .cellshape import CellGroup
@@ -32,6 +33,7 @@ class HIPPhotomosaicGenerator:
         self.m_img = None
         self.m_lib = None
         self.m_colourDiffType = ColourDifference.Type.RGB_EUCLIDEAN
+        self.m_colourSchemeType = ColourScheme.Type.NONE
         self.m_cells = CellGroup()
         self.m_bestFits = []
         self.m_repeatRange = 0
@@ -63,9 +65,23 @@ class HIPPhotomosaicGenerator:
             raise ValueError("No function for given type")     # ColourDifference.cpp:23
         self.m_colourDiffType = t
 
-    def setColourScheme(self, t=0):
-        if int(t) != 0:
-            raise NotImplementedError("colour-scheme variants are outside the hot-path scope (SURVEY 8f N3)")
+    def setColourScheme(self, t=ColourScheme.Type.NONE):
+        """PhotomosaicGeneratorBase::setColourScheme (PhotomosaicGeneratorBase.cpp:64-69).
+
+        preprocessMainImage builds one main image per variant of the scheme (:231-232), and
+        findCellBestFit scans every variant's cell per library image (CPUPhotomosaicGenerator.cpp:
+        139).  But getCellAt creates the V cells as V copies of ONE ``cv::Mat`` header
+        (``std::vector<cv::Mat> cells(n, cv::Mat(...))``, PhotomosaicGeneratorBase.cpp:310), so
+        they share one pixel buffer and each ``copyTo`` overwrites the previous variant (:311-312;
+        a later resize copies that same content): every cell the scan sees holds the LAST
+        variant.  The reference's result with a colour scheme is therefore exactly its result
+        with the last variant as the main image -- on the CPU and on the CUDA path alike -- and
+        that is what this generator computes (identical indices; tests/test_gpu_colour_scheme.py).
+        The variant list itself is available from ``mainImageVariants``."""
+        t = ColourScheme.Type(t)
+        if t == ColourScheme.Type.MAX:
+            raise ValueError("No function for given type")      # ColourScheme.cpp:31
+        self.m_colourSchemeType = t
 
     def setCellGroup(self, cellGroup):
         self.m_cells = cellGroup
@@ -79,6 +95,13 @@ class HIPPhotomosaicGenerator:
     def setRepeat(self, repeatRange=0, repeatAddition=0):
         self.m_repeatRange = int(repeatRange)
         self.m_repeatAddition = int(repeatAddition)
+
+    def mainImageVariants(self):
+        """m_colourSchemeFunc(m_img) (PhotomosaicGeneratorBase.cpp:231-232): the u8 main image
+        followed by its hue-rotated variants, rotated on the device."""
+        if self.m_img is None or self.m_img.dtype != np.uint8:
+            raise ValueError("colour-scheme variants need the u8 BGR main image")
+        return ColourScheme.getFunction(self.m_colourSchemeType)(self.m_img, rotate=self.m_engine.hue_rotate_u8)
 
     # -- progress / cancel ---------------------------------------------------
     def connectProgress(self, fn):
@@ -110,7 +133,10 @@ class HIPPhotomosaicGenerator:
             if self.m_lib.shape[1] != detail_size:
                 raise ValueError("a preprocessed (f32) library must be at the detail cell size %d" % detail_size)
             self.m_engine.set_library(np.ascontiguousarray(self.m_lib, dtype=np.float32))
-        if self.m_img.dtype == np.uint8:
+        if self.m_colourSchemeType != ColourScheme.Type.NONE:
+            # every variant's cell aliases the last variant (setColourScheme): compare against that one
+            self.m_engine.set_target_u8(self.mainImageVariants()[-1], int(t))
+        elif self.m_img.dtype == np.uint8:
             self.m_engine.set_target_u8(self.m_img, int(t))
         else:
             self.m_engine.set_target(np.ascontiguousarray(self.m_img, dtype=np.float32))
@@ -128,7 +154,8 @@ class HIPPhotomosaicGenerator:
         return self.m_engine.get_library()
 
     def _ensure_staged(self, force=False):
-        key = (id(self.m_lib), id(self.m_img), self.m_colourDiffType, id(self.m_cells.getCell(0, True)))
+        key = (id(self.m_lib), id(self.m_img), self.m_colourDiffType, self.m_colourSchemeType,
+               id(self.m_cells.getCell(0, True)))
         if force or key != self._staged:
             self._stage()
             self._staged = key

@@ -10,6 +10,7 @@
  */
 #include "oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -301,6 +302,43 @@ void orc_shrink_u8(const uint8_t *src, int rows, int cols, int cn, int f, uint8_
                 int v = f == 2 ? (sum + 2) >> 2 : (int)lrintf((float)sum * scale);
                 dst[((size_t)r * co + c) * cn + ch] = (uint8_t)clampi(v, 0, 255);
             }
+}
+
+/* One hue-rotated colour-scheme variant (ColourScheme.cpp:44-177): u8 BGR -> f32 ->
+ * BGR2HSV_FULL -> H = fmod(H + degrees, 360) -> HSV2BGR_FULL -> u8, in f32, following
+ * OpenCV 4.5.2's documented float formulas (RGB2HSV_f / HSV2RGB_native); OpenCV is absent
+ * from the checkout and no reference test holds vectors: parity unpinned at this step. */
+void orc_hue_rotate_u8(const uint8_t *src, size_t n_pixels, float degrees, uint8_t *dst)
+{
+    static const int sector_data[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    for (size_t t = 0; t < n_pixels; ++t) {
+        const float b = (float)src[3 * t], g = (float)src[3 * t + 1], r = (float)src[3 * t + 2];
+        float v = r, vmin = r, diff, s, h;
+        if (v < g) v = g;
+        if (v < b) v = b;
+        if (vmin > g) vmin = g;
+        if (vmin > b) vmin = b;
+        diff = v - vmin;
+        s = diff / (fabsf(v) + FLT_EPSILON);
+        diff = 60.0f / (diff + FLT_EPSILON);
+        if (v == r) h = (g - b) * diff;
+        else if (v == g) h = (b - r) * diff + 120.0f;
+        else h = (r - g) * diff + 240.0f;
+        if (h < 0.0f) h += 360.0f;
+        h = fmodf(h + degrees, 360.0f);              /* ColourScheme.cpp:52 */
+        float o[3];
+        if (s == 0.0f) {
+            o[0] = o[1] = o[2] = v;
+        } else {
+            float hh = fmodf(h * (6.0f / 360.0f), 6.0f);
+            int sector = (int)floorf(hh);
+            hh -= (float)sector;
+            if ((unsigned)sector >= 6u) { sector = 0; hh = 0.0f; }
+            const float tab[4] = {v, v * (1.0f - s), v * (1.0f - s * hh), v * (1.0f - s * (1.0f - hh))};
+            o[0] = tab[sector_data[sector][0]]; o[1] = tab[sector_data[sector][1]]; o[2] = tab[sector_data[sector][2]];
+        }
+        for (int k = 0; k < 3; ++k) dst[3 * t + k] = (uint8_t)clampi((int)lrintf(o[k]), 0, 255);
+    }
 }
 
 typedef struct { int si, di; float alpha; } area_tab;

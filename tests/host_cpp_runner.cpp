@@ -3,7 +3,7 @@
 // (test/tst_CUDAGenerator.h:20-41,163-212: CreateCellGroup(size, steps, detail), setters,
 // GridGenerator::getGridState, generateBestFits), writes the best-fit grids and the mosaic.
 //   scenario.bin: int32 header {rows, cols, size, L, type, range, addition, 6 spacings/offsets,
-//                 4 flips, detail percent, size steps, inputs are u8}
+//                 4 flips, detail percent, size steps, (inputs are u8) | colour scheme << 1}
 //                 u8 inputs:  u8 BGR image, u8 BGR library (L x size x size x 3), u8 mask (size*size)
 //                 f32 inputs: f32 image, f32 library, u8 mask, then the u8 BGR library for buildPhotomosaic
 //   result.bin:   int32 steps, per step int32 gridH, gridW + int64 grid (-1 = nullopt), then the BGRA mosaic
@@ -24,7 +24,8 @@ int main(int argc, char** argv)
     int32_t h[20];
     if (fread(h, sizeof h, 1, f) != 1) return 2;
     const int rows = h[0], cols = h[1], size = h[2], L = h[3];
-    const bool u8 = h[19] != 0;
+    const bool u8 = (h[19] & 1) != 0;
+    const int scheme = h[19] >> 1;
 
     HIPPhotomosaicGenerator generator(0);
     Image8 img8{rows, cols, {}};
@@ -62,6 +63,7 @@ int main(int argc, char** argv)
     group.setDetail(h[17]);
 
     generator.setColourDifference(static_cast<ColourDifference::Type>(h[4]));
+    generator.setColourScheme(static_cast<ColourScheme::Type>(scheme));
     generator.setCellGroup(group);
     generator.setGridState(GridUtility::getGridState(group, u8 ? &img8 : nullptr, rows, cols));
     generator.setRepeat(h[5], h[6]);

@@ -77,6 +77,8 @@ class Oracle:
         lib.orc_shrink_u8.argtypes = [vp, i, i, i, i, vp]
         lib.orc_resize_area_u8.restype = None
         lib.orc_resize_area_u8.argtypes = [vp, i, i, i, i, i, vp]
+        lib.orc_hue_rotate_u8.restype = None
+        lib.orc_hue_rotate_u8.argtypes = [vp, ctypes.c_size_t, ctypes.c_float, vp]
         lib.orc_entropy.restype = d
         lib.orc_entropy.argtypes = [vp, i, i, vp, i]
         lib.orc_cell_at_detail.restype = Rect
@@ -178,6 +180,12 @@ class Oracle:
         cn = 1 if img.ndim == 2 else img.shape[2]
         out = np.empty((rows, cols) if img.ndim == 2 else (rows, cols, cn), dtype=np.uint8)
         self.lib.orc_resize_area_u8(img.ctypes.data, img.shape[0], img.shape[1], cn, rows, cols, out.ctypes.data)
+        return out
+
+    def hue_rotate_u8(self, bgr, degrees):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        out = np.empty_like(bgr)
+        self.lib.orc_hue_rotate_u8(bgr.ctypes.data, bgr.size // 3, float(degrees), out.ctypes.data)
         return out
 
     def entropy(self, bgr, mask=None):

@@ -31,13 +31,13 @@ def test_host_cpp_compiles(tmp_path):
     assert os.path.exists(build_runner(str(tmp_path / "runner")))
 
 
-def header_of(shape, rows, cols, n_lib, t, rep, detail=100, steps=0, u8=False):
+def header_of(shape, rows, cols, n_lib, t, rep, detail=100, steps=0, u8=False, scheme=0):
     return np.array([rows, cols, shape.getSize(), n_lib, int(t), rep[0], rep[1],
                      shape.rowSpacing, shape.colSpacing, shape.alternateRowSpacing, shape.alternateColSpacing,
                      shape.alternateRowOffset, shape.alternateColOffset,
                      shape.alternateColFlipHorizontal, shape.alternateColFlipVertical,
                      shape.alternateRowFlipHorizontal, shape.alternateRowFlipVertical,
-                     detail, steps, int(u8)], dtype=np.int32)
+                     detail, steps, int(u8) | (int(scheme) << 1)], dtype=np.int32)
 
 
 def read_result(path, rows, cols):
@@ -124,3 +124,29 @@ def test_host_cpp_u8_inputs_detail_and_size_steps(oracle, tmp_path, shape_name, 
     for a, b in zip(grids, want):
         assert np.array_equal(a, b)
     assert np.array_equal(mosaic, gen.buildPhotomosaic((7, 8, 9, 10)))
+
+
+@pytest.mark.gpu
+def test_host_cpp_colour_scheme(oracle, tmp_path):
+    """setColourScheme through the C++ host: the grid equals the oracle's on the scheme's last
+    variant (the reference's variant cells all alias that one, PhotomosaicGeneratorBase.cpp:310)."""
+    from mosaicmagnifique_amd import synth
+    from mosaicmagnifique_amd.colourscheme import Type as Scheme
+    shape, t, rep = cases.square_shape(16), Type.CIEDE2000, (1, 150)
+    size, rows, cols, n_lib = 16, 70, 90, 50
+    img = synth.target_u8(rows, cols, lattice=16)
+    lib = synth.library_u8(n_lib, size)
+    scenario, result = tmp_path / "scenario.bin", tmp_path / "result.bin"
+    with open(scenario, "wb") as f:
+        f.write(header_of(shape, rows, cols, n_lib, t, rep, u8=True, scheme=Scheme.TRIADIC).tobytes())
+        f.write(img.tobytes()); f.write(lib.tobytes()); f.write(shape.getCellMask(False, False).tobytes())
+    runner = build_runner(str(tmp_path / "runner"))
+    subprocess.run([runner, str(scenario), str(result)], check=True, timeout=300)
+    (got,), _ = read_result(result, rows, cols)
+    last = oracle.hue_rotate_u8(img, 240.0)
+    want, _, _ = oracle.generate_best_fits(shape_of(shape), synth.preprocess(last, t), synth.preprocess(lib, t),
+                                           shape.masks4(), int(t), *rep)
+    assert np.array_equal(got, want)
+    plain, _, _ = oracle.generate_best_fits(shape_of(shape), synth.preprocess(img, t), synth.preprocess(lib, t),
+                                            shape.masks4(), int(t), *rep)
+    assert not np.array_equal(got, plain)          # the scheme really changed the picture
