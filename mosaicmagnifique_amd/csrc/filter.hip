@@ -143,8 +143,9 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     //
     // CIEDE2000 exits earlier still, through a lower bound on the pixels NOT yet visited:
     //   dE00^2 = tL^2 + (tC^2 + tH^2 + R_T tC tH) >= tL^2      (|R_T| < 2, :145,:153-157)
-    //   tL = dL / S_L,  S_L <= S_L(max |L - 50| over library and target) =: S_max
-    // so dE00 >= |dL| / S_max, and for a 256-pixel group g of the plane order
+    //   tL = dL / S_L,  S_L <= S_max(g) := S_L((max_g |L_cell - 50| + max_g |L_lib - 50|) / 2)
+    //   (the pair's mean lightness cannot be further from 50 than that; maxima over group g: ldev planes)
+    // so dE00 >= |dL| / S_max(g), and for a 256-pixel group g of the plane order
     //   sum_{p in g} |L_cell - L_lib|  >=  | sum_{p in g} L_cell  -  sum_{p in g} L_lib |,
     // which needs only ONE precomputed number per image and group (lsum planes) -- no pass
     // over the pixels.  Lane g holds group g's bound; a suffix scan turns it into "bound
@@ -156,10 +157,14 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // never enter the exit test: only terms with a proven error bound may prune.
     const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
     bool use_lb = false;
-    float cell_ls = 0.0f;
+    float cell_ls = 0.0f, cell_ld = 0.0f;
+    (void)lb_scale;
     if constexpr (TYPE == CIEDE2000) {
         use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;
-        if (use_lb && lane < groups) cell_ls = var.cell_lsum[(size_t)cell * var.lsum_stride + lane];
+        if (use_lb && lane < groups) {
+            cell_ls = var.cell_lsum[(size_t)cell * var.lsum_stride + lane];
+            cell_ld = var.cell_ldev[(size_t)cell * var.lsum_stride + lane];
+        }
     }
 
     const int l_base = tile * cand_per_block;
@@ -181,9 +186,16 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             if (use_lb) {
                 float d = 0.0f;
                 if (lane < groups) {
-                    const float ls = var.lib_lsum[((size_t)v * L + l) * var.lsum_stride + lane];
-                    // 1e-2: fp32 rounding of two 256-term sums of values <= ~100, with margin
-                    d = fmaxf(fabsf(cell_ls - ls) - 1e-2f, 0.0f) * lb_scale;
+                    const size_t at = ((size_t)v * L + l) * var.lsum_stride + lane;
+                    const float ls = var.lib_lsum[at];
+                    // S_L of every pair of the group: |L_bar - 50| <= (max|L_cell - 50| + max|L_lib - 50|) / 2
+                    // over the group's active pixels, and S_L grows with it (:138-139)
+                    const float x = 0.5f * (cell_ld + var.lib_ldev[at]);
+                    const float x2 = x * x;
+                    const float s_l = fmaf(0.015f * x2, frsq(20.0f + x2), 1.0f);
+                    // 1e-2: fp32 rounding of two 256-term sums of values <= ~100, with margin;
+                    // 0.9999: v_rsq / v_rcp are good to ~1 ulp
+                    d = fmaxf(fabsf(cell_ls - ls) - 1e-2f, 0.0f) * (0.9999f * frcp(s_l));
                 }
                 // inclusive suffix scan over lanes (lane j <- sum of lanes >= j)
                 for (int off = 1; off < kWave; off <<= 1) {
@@ -476,7 +488,8 @@ chroma_planes_kernel(const float* __restrict__ planar, float* __restrict__ chrom
 // One wave per (image, group).  Feeds the lightness bound of filter_kernel.
 __global__ void __launch_bounds__(kBlock)
 group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ mask, size_t mask_stride,
-                  float* __restrict__ lsum, size_t n_images, int n_groups, int lsum_stride, int ppad)
+                  float* __restrict__ lsum, float* __restrict__ ldev, size_t n_images, int n_groups,
+                  int lsum_stride, int ppad)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t w = (size_t)blockIdx.x * (kBlock / kWave) + wave;
@@ -489,7 +502,11 @@ group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ 
     float s = ((m & 0x000000ffu) ? x.x : 0.0f) + ((m & 0x0000ff00u) ? x.y : 0.0f)
             + ((m & 0x00ff0000u) ? x.z : 0.0f) + ((m & 0xff000000u) ? x.w : 0.0f);
     s = wave_sum_f(s);
-    if (lane == 0) lsum[img * lsum_stride + g] = s;
+    // ldev[img][g] = max over the same positions of |x - 50| (how far the group's lightness strays from 50)
+    float d = fmaxf(fmaxf((m & 0x000000ffu) ? fabsf(x.x - 50.0f) : 0.0f, (m & 0x0000ff00u) ? fabsf(x.y - 50.0f) : 0.0f),
+                    fmaxf((m & 0x00ff0000u) ? fabsf(x.z - 50.0f) : 0.0f, (m & 0xff000000u) ? fabsf(x.w - 50.0f) : 0.0f));
+    for (int off = 32; off > 0; off >>= 1) d = fmaxf(d, __shfl_xor(d, off, kWave));
+    if (lane == 0) { lsum[img * lsum_stride + g] = s; ldev[img * lsum_stride + g] = d; }
 }
 
 // Mean colour of every library image (over all pixels), f32 [L][3]: a proxy used only
@@ -714,12 +731,12 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     return hipGetLastError();
 }
 
-hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* lsum,
+hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* lsum, float* ldev,
                              size_t n_images, int n_groups, int lsum_stride, int ppad, hipStream_t stream)
 {
     const size_t waves = n_images * (size_t)n_groups;
     if (waves == 0) return hipSuccess;
-    group_sums_kernel<<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, lsum, n_images,
+    group_sums_kernel<<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, lsum, ldev, n_images,
                                                                         n_groups, lsum_stride, ppad);
     return hipGetLastError();
 }

@@ -25,6 +25,9 @@ struct Variants {
     // 256-position group, over the mask's active positions
     const float* lib_lsum;      // [V][L][lsum_stride]
     const float* cell_lsum;     // [B][lsum_stride]
+    // ... and max |first channel - 50| over the same positions (bounds S_L group by group)
+    const float* lib_ldev;      // [V][L][lsum_stride]
+    const float* cell_ldev;     // [B][lsum_stride]
     const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask (not clipped)
     int lsum_stride;
 };
@@ -53,8 +56,9 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream);
 
-// lsum[img][g] = masked sum of channel 0 over plane positions [256 g, 256 g + 256).
-hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* lsum,
+// lsum[img][g] = masked sum of channel 0 over plane positions [256 g, 256 g + 256);
+// ldev[img][g] = masked max of |channel 0 - 50| over the same positions.
+hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* lsum, float* ldev,
                              size_t n_images, int n_groups, int lsum_stride, int ppad, hipStream_t stream);
 
 // max |x - offset| over a strided set, written with atomicMax as float bits into *out_bits
