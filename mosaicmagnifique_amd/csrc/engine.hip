@@ -230,7 +230,7 @@ mm_status prepare_planes(mm_engine* e)
         (st = ensure(e, e->lib_chroma, (size_t)n_var * L * ppad * sizeof(float), "Failed to allocate library chroma planes")) ||
         (st = ensure(e, e->lib_means, (size_t)L * 3 * sizeof(float), "Failed to allocate library means")) ||
         (st = ensure(e, e->pos_mask, pos_mask.size(), "Failed to allocate position masks")) ||
-        (st = ensure(e, e->lib_lsum, (size_t)2 * n_var * L * (ppad / 256) * sizeof(float), "Failed to allocate group sums")))
+        (st = ensure(e, e->lib_lsum, (size_t)5 * n_var * L * (ppad / 256) * sizeof(float), "Failed to allocate group statistics")))
         return st;
     HIP_TRY(e, hipMemcpyAsync(e->pos_mask.p, pos_mask.data(), pos_mask.size(), hipMemcpyHostToDevice, e->stream),
             "Failed to copy position masks to device");
@@ -247,7 +247,7 @@ mm_status prepare_planes(mm_engine* e)
         HIP_TRY(e, mm::launch_group_sums((const float*)e->lib.p + (size_t)v * L * 3 * ppad,
                                          (const uint8_t*)e->pos_mask.p + (size_t)v * ppad, 0,
                                          (float*)e->lib_lsum.p + (size_t)v * L * (ppad / 256),
-                                         (float*)e->lib_lsum.p + (size_t)(n_var + v) * L * (ppad / 256), (size_t)L, ppad / 256,
+                                         (size_t)n_var * L * (ppad / 256), (size_t)L, ppad / 256,
                                          ppad / 256, ppad, e->stream),
                 "Error during library group-sum kernel");
     }
@@ -276,10 +276,10 @@ mm::Variants variants_of(const mm_engine* e)
     v.lib_stride = (size_t)e->n_lib * 3 * ppad;
     v.chroma_stride = (size_t)e->n_lib * ppad;
     for (int i = 0; i < 4; ++i) v.groups[i] = e->var_groups[i];
-    v.lib_lsum = (const float*)e->lib_lsum.p;
-    v.cell_lsum = (const float*)e->cell_lsum.p;
-    v.lib_ldev = v.lib_lsum + (size_t)e->n_var * e->n_lib * (ppad / 256);         // second half of each buffer
-    v.cell_ldev = v.cell_lsum ? v.cell_lsum + e->cell_lsum.bytes / sizeof(float) / 2 : nullptr;
+    v.lib_stats = (const float*)e->lib_lsum.p;
+    v.cell_stats = (const float*)e->cell_lsum.p;
+    v.lib_stats_stride = (size_t)e->n_var * e->n_lib * (ppad / 256);
+    v.cell_stats_stride = e->cell_lsum.bytes / sizeof(float) / 5;
     v.cell_full = (const uint8_t*)e->cell_full.p;
     v.lsum_stride = ppad / 256;
     return v;
@@ -420,7 +420,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     mm_status st;
     if ((st = ensure(e, e->cell_var, (size_t)batch, "Failed to allocate cell variants")) ||
         (st = ensure(e, e->cell_full, (size_t)batch, "Failed to allocate cell flags")) ||
-        (st = ensure(e, e->cell_lsum, (size_t)2 * batch * (ppad / 256) * sizeof(float), "Failed to allocate group sums")) ||
+        (st = ensure(e, e->cell_lsum, (size_t)5 * batch * (ppad / 256) * sizeof(float), "Failed to allocate group statistics")) ||
         (st = ensure(e, e->cells, (size_t)batch * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
         (st = ensure(e, e->cmask, (size_t)batch * ppad, "Failed to allocate cell masks")) ||
         (st = ensure(e, e->scores, (size_t)batch * L * sizeof(double), "Failed to allocate variants")))
@@ -500,7 +500,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             HIP_TRY(e, mm::launch_chroma_planes((const float*)e->cells.p, (float*)e->cell_chroma.p, (size_t)b, ppad, e->stream),
                     "Error during cell chroma kernel");
             HIP_TRY(e, mm::launch_group_sums((const float*)e->cells.p, (const uint8_t*)e->cmask.p, (size_t)ppad,
-                                             (float*)e->cell_lsum.p, (float*)e->cell_lsum.p + e->cell_lsum.bytes / sizeof(float) / 2,
+                                             (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 5,
                                              (size_t)b, ppad / 256, ppad / 256, ppad, e->stream),
                     "Error during cell group-sum kernel");
         }

@@ -111,6 +111,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
 {
     __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
+    __shared__ float cell_st[TYPE == CIEDE2000 ? 5 : 1][kWave];     // group statistics of the cell (early-exit bound)
     if (threadIdx.x == 0) next_candidate = kBlock / kWave;
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut); else __syncthreads();
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
@@ -142,12 +143,17 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // The test is wave-uniform: one wave owns the whole candidate.
     //
     // CIEDE2000 exits earlier still, through a lower bound on the pixels NOT yet visited:
-    //   dE00^2 = tL^2 + (tC^2 + tH^2 + R_T tC tH) >= tL^2      (|R_T| < 2, :145,:153-157)
-    //   tL = dL / S_L,  S_L <= S_max(g) := S_L((max_g |L_cell - 50| + max_g |L_lib - 50|) / 2)
-    //   (the pair's mean lightness cannot be further from 50 than that; maxima over group g: ldev planes)
-    // so dE00 >= |dL| / S_max(g), and for a 256-pixel group g of the plane order
-    //   sum_{p in g} |L_cell - L_lib|  >=  | sum_{p in g} L_cell  -  sum_{p in g} L_lib |,
-    // which needs only ONE precomputed number per image and group (lsum planes) -- no pass
+    //   dE00^2 = tL^2 + tC^2 + tH^2 + R_T tC tH >= tL^2 + (1 - |R_T|/2) (tC^2 + tH^2)        (:153-157)
+    //   tC^2 + tH^2 >= (dC'^2 + dH'^2) / S_C^2            (S_H = 1 + 0.015 C' T <= S_C = 1 + 0.045 C', T < 1.93)
+    //   dC'^2 + dH'^2 = |(a1', b1) - (a2', b2)|^2 >= da^2 + db^2                         (a' = (1 + G) a, G >= 0)
+    // so per pair  dE00 >= sqrt( (dL / S_L)^2 + rho (da^2 + db^2) / S_C^2 ),  rho = 1 - |R_T| / 2, and with the
+    // worst constants of a 256-pixel group g of the plane order in place of the per-pair ones:
+    //   S_L <= S_L((max_g |L_cell - 50| + max_g |L_lib - 50|) / 2)         (the pair's mean lightness lies within; :138-139)
+    //   C_bar' <= g(C_bar) = (1.5 - 0.5 sqrt(C_bar^7 / (C_bar^7 + 25^7))) C_bar, increasing, C_bar <= (max_g C_cell + max_g C_lib) / 2
+    //   S_C <= 1 + 0.045 g(.),   |R_T| <= sin(60 deg) * 2 sqrt(g^7 / (g^7 + 25^7))            (d_theta <= 30 deg; :132-136,:145)
+    // and, by the triangle inequality of the Euclidean norm over the group's pixels,
+    //   sum_{p in g} dE00 >= sqrt( (sum|dL|)^2 / S_L^2 + rho ((sum|da|)^2 + (sum|db|)^2) / S_C^2 ),  sum_p |dX| >= |sum_p X_cell - sum_p X_lib|,
+    // which needs FIVE precomputed numbers per image and group (group_sums_kernel) -- no pass
     // over the pixels.  Lane g holds group g's bound; a suffix scan turns it into "bound
     // of groups >= j".  The candidate is dropped once
     //   (trusted partial sum of groups < j) + (bound of groups >= j) > limit.
@@ -157,13 +163,15 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // never enter the exit test: only terms with a proven error bound may prune.
     const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
     bool use_lb = false;
-    float cell_ls = 0.0f, cell_ld = 0.0f;
     (void)lb_scale;
     if constexpr (TYPE == CIEDE2000) {
-        use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;
-        if (use_lb && lane < groups) {
-            cell_ls = var.cell_lsum[(size_t)cell * var.lsum_stride + lane];
-            cell_ld = var.cell_ldev[(size_t)cell * var.lsum_stride + lane];
+        use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;     // workgroup-uniform
+        if (use_lb) {
+            // the cell's five numbers per group (group_sums_kernel) wait in LDS: read per candidate, no registers held
+            if (wave == 0 && lane < groups)
+                for (int k = 0; k < 5; ++k)
+                    cell_st[k][lane] = var.cell_stats[(size_t)k * var.cell_stats_stride + (size_t)cell * var.lsum_stride + lane];
+            __syncthreads();
         }
     }
 
@@ -186,16 +194,25 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             if (use_lb) {
                 float d = 0.0f;
                 if (lane < groups) {
-                    const size_t at = ((size_t)v * L + l) * var.lsum_stride + lane;
-                    const float ls = var.lib_lsum[at];
+                    const float* st = var.lib_stats + ((size_t)v * L + l) * var.lsum_stride + lane;
+                    const size_t bs = var.lib_stats_stride;
                     // S_L of every pair of the group: |L_bar - 50| <= (max|L_cell - 50| + max|L_lib - 50|) / 2
                     // over the group's active pixels, and S_L grows with it (:138-139)
-                    const float x = 0.5f * (cell_ld + var.lib_ldev[at]);
+                    const float x = 0.5f * (cell_st[1][lane] + st[bs]);
                     const float x2 = x * x;
                     const float s_l = fmaf(0.015f * x2, frsq(20.0f + x2), 1.0f);
-                    // 1e-2: fp32 rounding of two 256-term sums of values <= ~100, with margin;
-                    // 0.9999: v_rsq / v_rcp are good to ~1 ulp
-                    d = fmaxf(fabsf(cell_ls - ls) - 1e-2f, 0.0f) * (0.9999f * frcp(s_l));
+                    // S_C and R_T likewise from the largest chroma of the two groups (see above)
+                    const float cbar = 0.5f * (cell_st[4][lane] + st[4 * bs]);
+                    const float gc = (1.5f - 0.5f * sqrt_ratio7(cbar)) * cbar;         // >= C_bar' of every pair
+                    const float s_c = fmaf(0.045f, gc, 1.0f);
+                    const float rho = 1.0f - 0.86603f * sqrt_ratio7(gc);               // <= 1 - |R_T| / 2
+                    // 1e-2: fp32 rounding of two 256-term sums of values <= ~128, with margin
+                    const float t_l = fmaxf(fabsf(cell_st[0][lane] - st[0]) - 1e-2f, 0.0f) * frcp(s_l);
+                    const float da = fmaxf(fabsf(cell_st[2][lane] - st[2 * bs]) - 1e-2f, 0.0f);
+                    const float db = fmaxf(fabsf(cell_st[3][lane] - st[3 * bs]) - 1e-2f, 0.0f);
+                    const float inv_c = frcp(s_c);
+                    // 0.9999: v_rsq / v_rcp / v_sqrt are good to ~1 ulp
+                    d = 0.9999f * fsqrt(fmaf(t_l, t_l, rho * fmaf(da, da, db * db) * (inv_c * inv_c)));
                 }
                 // inclusive suffix scan over lanes (lane j <- sum of lanes >= j)
                 for (int off = 1; off < kWave; off <<= 1) {
@@ -482,13 +499,15 @@ chroma_planes_kernel(const float* __restrict__ planar, float* __restrict__ chrom
     }
 }
 
-// First-channel sums over each 256-position group of the plane order, counting only the
-// positions flagged in `mask` (per image if mask_stride != 0, else shared):
-//   lsum[img][g] = sum_{k in [256 g, 256 g + 256), mask[k] != 0} planar[img][0][k]
-// One wave per (image, group).  Feeds the lightness bound of filter_kernel.
+// Per-image statistics over each 256-position group of the plane order, counting only the
+// positions flagged in `mask` (per image if mask_stride != 0, else shared).  Five blocks of
+// [n_images][lsum_stride] floats, `block_stride` floats apart:
+//   0: sum of channel 0              1: max |channel 0 - 50|
+//   2: sum of channel 1              3: sum of channel 2        4: max sqrt(ch1^2 + ch2^2)
+// One wave per (image, group).  Feeds the lower bound of filter_kernel's early exit.
 __global__ void __launch_bounds__(kBlock)
 group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ mask, size_t mask_stride,
-                  float* __restrict__ lsum, float* __restrict__ ldev, size_t n_images, int n_groups,
+                  float* __restrict__ stats, size_t block_stride, size_t n_images, int n_groups,
                   int lsum_stride, int ppad)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -497,16 +516,27 @@ group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ 
     const size_t img = w / n_groups;
     const int g = (int)(w - img * n_groups);
     const int q = g * kWave + lane;
-    const float4 x = reinterpret_cast<const float4*>(planar + img * 3 * (size_t)ppad)[q];
+    const float4* base = reinterpret_cast<const float4*>(planar + img * 3 * (size_t)ppad);
+    const float4 x = base[q], a = base[ppad / 4 + q], b = base[2 * (size_t)(ppad / 4) + q];
     const uint32_t m = reinterpret_cast<const uint32_t*>(mask + img * mask_stride)[q];
-    float s = ((m & 0x000000ffu) ? x.x : 0.0f) + ((m & 0x0000ff00u) ? x.y : 0.0f)
-            + ((m & 0x00ff0000u) ? x.z : 0.0f) + ((m & 0xff000000u) ? x.w : 0.0f);
-    s = wave_sum_f(s);
-    // ldev[img][g] = max over the same positions of |x - 50| (how far the group's lightness strays from 50)
-    float d = fmaxf(fmaxf((m & 0x000000ffu) ? fabsf(x.x - 50.0f) : 0.0f, (m & 0x0000ff00u) ? fabsf(x.y - 50.0f) : 0.0f),
-                    fmaxf((m & 0x00ff0000u) ? fabsf(x.z - 50.0f) : 0.0f, (m & 0xff000000u) ? fabsf(x.w - 50.0f) : 0.0f));
-    for (int off = 32; off > 0; off >>= 1) d = fmaxf(d, __shfl_xor(d, off, kWave));
-    if (lane == 0) { lsum[img * lsum_stride + g] = s; ldev[img * lsum_stride + g] = d; }
+    const bool on[4] = {(m & 0x000000ffu) != 0, (m & 0x0000ff00u) != 0, (m & 0x00ff0000u) != 0, (m & 0xff000000u) != 0};
+    const float xs[4] = {x.x, x.y, x.z, x.w}, as[4] = {a.x, a.y, a.z, a.w}, bs[4] = {b.x, b.y, b.z, b.w};
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, dev = 0.f, cmax = 0.f;
+    for (int k = 0; k < 4; ++k)
+        if (on[k]) {
+            s0 += xs[k]; s1 += as[k]; s2 += bs[k];
+            dev = fmaxf(dev, fabsf(xs[k] - 50.0f));
+            cmax = fmaxf(cmax, chroma_of(as[k], bs[k]));
+        }
+    s0 = wave_sum_f(s0); s1 = wave_sum_f(s1); s2 = wave_sum_f(s2);
+    for (int off = 32; off > 0; off >>= 1) {
+        dev = fmaxf(dev, __shfl_xor(dev, off, kWave));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, off, kWave));
+    }
+    if (lane == 0) {
+        float* o = stats + img * lsum_stride + g;
+        o[0] = s0; o[block_stride] = dev; o[2 * block_stride] = s1; o[3 * block_stride] = s2; o[4 * block_stride] = cmax;
+    }
 }
 
 // Mean colour of every library image (over all pixels), f32 [L][3]: a proxy used only
@@ -731,13 +761,14 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     return hipGetLastError();
 }
 
-hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* lsum, float* ldev,
-                             size_t n_images, int n_groups, int lsum_stride, int ppad, hipStream_t stream)
+hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
+                             size_t block_stride, size_t n_images, int n_groups, int lsum_stride, int ppad,
+                             hipStream_t stream)
 {
     const size_t waves = n_images * (size_t)n_groups;
     if (waves == 0) return hipSuccess;
-    group_sums_kernel<<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, lsum, ldev, n_images,
-                                                                        n_groups, lsum_stride, ppad);
+    group_sums_kernel<<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, stats, block_stride,
+                                                                        n_images, n_groups, lsum_stride, ppad);
     return hipGetLastError();
 }
 

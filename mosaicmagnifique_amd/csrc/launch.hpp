@@ -21,13 +21,11 @@ struct Variants {
     size_t lib_stride;          // floats between the planar libraries of two variants (L*3*ppad)
     size_t chroma_stride;       // floats between their chroma planes (L*ppad)
     int groups[4];
-    // lightness bound of the filter's early exit (filter.hip): first-channel sums per
-    // 256-position group, over the mask's active positions
-    const float* lib_lsum;      // [V][L][lsum_stride]
-    const float* cell_lsum;     // [B][lsum_stride]
-    // ... and max |first channel - 50| over the same positions (bounds S_L group by group)
-    const float* lib_ldev;      // [V][L][lsum_stride]
-    const float* cell_ldev;     // [B][lsum_stride]
+    // lower bound of the filter's early exit (filter.hip): five statistics per image and
+    // 256-position group over the mask's active positions (group_sums_kernel), as five blocks
+    const float* lib_stats;     // 5 x [V][L][lsum_stride], lib_stats_stride floats apart
+    const float* cell_stats;    // 5 x [B][lsum_stride], cell_stats_stride floats apart
+    size_t lib_stats_stride, cell_stats_stride;
     const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask (not clipped)
     int lsum_stride;
 };
@@ -56,10 +54,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream);
 
-// lsum[img][g] = masked sum of channel 0 over plane positions [256 g, 256 g + 256);
-// ldev[img][g] = masked max of |channel 0 - 50| over the same positions.
-hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* lsum, float* ldev,
-                             size_t n_images, int n_groups, int lsum_stride, int ppad, hipStream_t stream);
+// stats block k (block_stride floats apart), [img][g] over plane positions [256 g, 256 g + 256):
+// masked sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma.
+hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
+                             size_t block_stride, size_t n_images, int n_groups, int lsum_stride, int ppad, hipStream_t stream);
 
 // max |x - offset| over a strided set, written with atomicMax as float bits into *out_bits
 // (zero it first).

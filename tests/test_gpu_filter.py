@@ -137,3 +137,28 @@ def test_too_many_contenders_fall_back_to_fp64(oracle, engine, t):
     img[:16, :16] = base                                   # cell (0,0) matches the cluster
     tm = run_both(oracle, engine, cases.square_shape(16), img, lib, t)
     assert tm["dense_cells"] >= 1
+
+
+@pytest.mark.parametrize("kind", ["blue", "mixed-chroma"])
+def test_early_exit_bound_keeps_every_contender(oracle, engine, kind):
+    """64 x 64 cells (16 groups: the chroma-augmented bound of the early exit at work) on content
+    where its constants are tightest against the truth: saturated blue-violet patches (R_T at its
+    largest) and a mix of grey and colourful patches.  Pruned == unpruned == fp64-only == oracle."""
+    rng = np.random.default_rng(12 if kind == "blue" else 13)
+    size, n_lib, rows, cols = 64, 120, 128, 192
+
+    def patches(shape_hw, n):
+        if kind == "blue":
+            th = np.deg2rad(rng.uniform(250, 300, (n, 1, 1)) + rng.normal(0, 3, (n,) + shape_hw))
+            r = rng.uniform(25, 110, (n, 1, 1)) + rng.normal(0, 4, (n,) + shape_hw)
+        else:
+            th = rng.uniform(0, 2 * np.pi, (n, 1, 1)) + rng.normal(0, 0.1, (n,) + shape_hw)
+            r = np.where(rng.uniform(size=(n, 1, 1)) < 0.4, 2.0, rng.uniform(5, 90, (n, 1, 1))) + np.abs(rng.normal(0, 2, (n,) + shape_hw))
+        light = rng.uniform(15, 85, (n, 1, 1)) + rng.normal(0, 3, (n,) + shape_hw)
+        return np.stack([light, r * np.cos(th), r * np.sin(th)], -1).astype(np.float32)
+
+    lib = patches((size, size), n_lib)
+    tiles = patches((size, size), (rows // size) * (cols // size))
+    img = tiles.reshape(rows // size, cols // size, size, size, 3).transpose(0, 2, 1, 3, 4).reshape(rows, cols, 3).copy()
+    tm = run_both(oracle, engine, cases.square_shape(size), img, lib, Type.CIEDE2000, rep=(1, 300))
+    assert tm["dense_cells"] == 0
