@@ -190,7 +190,7 @@ mm_status by_type(int diff_type, F&& f)
 }
 
 // De-duplicates the 4 mask variants, builds each distinct variant's pixel permutation
-// (active pixels first, row-major among themselves, then the inactive ones) and re-planes
+// (active pixels first, in a tile-major walk among themselves, then the inactive ones) and re-planes
 // the library in that order: [V][L][3][ppad] + chroma planes [V][L][ppad] + means.
 mm_status prepare_planes(mm_engine* e)
 {
@@ -212,13 +212,30 @@ mm_status prepare_planes(mm_engine* e)
     }
     std::vector<int> perm((size_t)n_var * ppad, -1), inv((size_t)n_var * P, 0);
     std::vector<uint8_t> pos_mask((size_t)n_var * ppad, 0);     // 1 on the plane positions holding active pixels
+    // Pixel walk: 16 x 16 tiles in raster order, inside a tile its four 8 x 8 quarters, raster inside a
+    // quarter.  A 256-position group of the planes is then a compact 16 x 16 patch of the image (for a
+    // full mask) and a 64-position block a compact 8 x 8 one, which is what makes the block means of
+    // the filter's early-exit bound (filter.hip) tell neighbouring images apart.
+    std::vector<int> walk(P);
+    {
+        std::vector<std::pair<unsigned, int>> keyed(P);
+        for (int p = 0; p < P; ++p) {
+            const unsigned y = (unsigned)(p / size), x = (unsigned)(p % size);
+            const unsigned tiles_x = ((unsigned)size + 15u) / 16u;
+            const unsigned key = ((((y / 16u) * tiles_x + x / 16u) * 4u + ((y % 16u) / 8u) * 2u + (x % 16u) / 8u) * 64u)
+                               + (y % 8u) * 8u + x % 8u;
+            keyed[p] = {key, p};
+        }
+        std::sort(keyed.begin(), keyed.end());
+        for (int p = 0; p < P; ++p) walk[p] = keyed[p].second;
+    }
     for (int v = 0; v < n_var; ++v) {
         const uint8_t* mk = e->masks_host.data() + (size_t)first_mask_of_var[v] * P;
         int k = 0;
-        for (int p = 0; p < P; ++p) if (mk[p] != 0) { perm[(size_t)v * ppad + k] = p; inv[(size_t)v * P + p] = k; ++k; }
+        for (int p : walk) if (mk[p] != 0) { perm[(size_t)v * ppad + k] = p; inv[(size_t)v * P + p] = k; ++k; }
         for (int a = 0; a < k; ++a) pos_mask[(size_t)v * ppad + a] = 1;
         e->var_groups[v] = (k + 255) / 256;
-        for (int p = 0; p < P; ++p) if (mk[p] == 0) { perm[(size_t)v * ppad + k] = p; inv[(size_t)v * P + p] = k; ++k; }
+        for (int p : walk) if (mk[p] == 0) { perm[(size_t)v * ppad + k] = p; inv[(size_t)v * P + p] = k; ++k; }
     }
     for (int v = n_var; v < 4; ++v) e->var_groups[v] = 0;
     e->n_var = n_var;
@@ -230,7 +247,7 @@ mm_status prepare_planes(mm_engine* e)
         (st = ensure(e, e->lib_chroma, (size_t)n_var * L * ppad * sizeof(float), "Failed to allocate library chroma planes")) ||
         (st = ensure(e, e->lib_means, (size_t)L * 3 * sizeof(float), "Failed to allocate library means")) ||
         (st = ensure(e, e->pos_mask, pos_mask.size(), "Failed to allocate position masks")) ||
-        (st = ensure(e, e->lib_lsum, (size_t)5 * n_var * L * (ppad / 256) * sizeof(float), "Failed to allocate group statistics")))
+        (st = ensure(e, e->lib_lsum, (size_t)5 * n_var * L * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")))
         return st;
     HIP_TRY(e, hipMemcpyAsync(e->pos_mask.p, pos_mask.data(), pos_mask.size(), hipMemcpyHostToDevice, e->stream),
             "Failed to copy position masks to device");
@@ -246,9 +263,8 @@ mm_status prepare_planes(mm_engine* e)
         HIP_TRY(e, hipGetLastError(), "Error during library plane kernel");
         HIP_TRY(e, mm::launch_group_sums((const float*)e->lib.p + (size_t)v * L * 3 * ppad,
                                          (const uint8_t*)e->pos_mask.p + (size_t)v * ppad, 0,
-                                         (float*)e->lib_lsum.p + (size_t)v * L * (ppad / 256),
-                                         (size_t)n_var * L * (ppad / 256), (size_t)L, ppad / 256,
-                                         ppad / 256, ppad, e->stream),
+                                         (float*)e->lib_lsum.p + (size_t)v * L * (ppad / 64),
+                                         (size_t)n_var * L * (ppad / 64), (size_t)L, ppad, e->stream),
                 "Error during library group-sum kernel");
     }
     HIP_TRY(e, mm::launch_chroma_planes((const float*)e->lib.p, (float*)e->lib_chroma.p, (size_t)n_var * L, ppad, e->stream),
@@ -278,10 +294,10 @@ mm::Variants variants_of(const mm_engine* e)
     for (int i = 0; i < 4; ++i) v.groups[i] = e->var_groups[i];
     v.lib_stats = (const float*)e->lib_lsum.p;
     v.cell_stats = (const float*)e->cell_lsum.p;
-    v.lib_stats_stride = (size_t)e->n_var * e->n_lib * (ppad / 256);
+    v.lib_stats_stride = (size_t)e->n_var * e->n_lib * (ppad / 64);
     v.cell_stats_stride = e->cell_lsum.bytes / sizeof(float) / 5;
+    v.n_blocks = ppad / 64;
     v.cell_full = (const uint8_t*)e->cell_full.p;
-    v.lsum_stride = ppad / 256;
     return v;
 }
 
@@ -420,7 +436,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     mm_status st;
     if ((st = ensure(e, e->cell_var, (size_t)batch, "Failed to allocate cell variants")) ||
         (st = ensure(e, e->cell_full, (size_t)batch, "Failed to allocate cell flags")) ||
-        (st = ensure(e, e->cell_lsum, (size_t)5 * batch * (ppad / 256) * sizeof(float), "Failed to allocate group statistics")) ||
+        (st = ensure(e, e->cell_lsum, (size_t)5 * batch * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
         (st = ensure(e, e->cells, (size_t)batch * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
         (st = ensure(e, e->cmask, (size_t)batch * ppad, "Failed to allocate cell masks")) ||
         (st = ensure(e, e->scores, (size_t)batch * L * sizeof(double), "Failed to allocate variants")))
@@ -501,7 +517,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                     "Error during cell chroma kernel");
             HIP_TRY(e, mm::launch_group_sums((const float*)e->cells.p, (const uint8_t*)e->cmask.p, (size_t)ppad,
                                              (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 5,
-                                             (size_t)b, ppad / 256, ppad / 256, ppad, e->stream),
+                                             (size_t)b, ppad, e->stream),
                     "Error during cell group-sum kernel");
         }
         HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");

@@ -111,7 +111,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
 {
     __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
-    __shared__ float cell_st[TYPE == CIEDE2000 ? 5 : 1][kWave];     // group statistics of the cell (early-exit bound)
+    // block statistics of the cell (early-exit bound), up to 4 blocks per lane
+    __shared__ float cell_st[TYPE == CIEDE2000 ? 5 : 1][TYPE == CIEDE2000 ? 4 * kWave : 1];
     if (threadIdx.x == 0) next_candidate = kBlock / kWave;
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut); else __syncthreads();
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
@@ -167,14 +168,16 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     if constexpr (TYPE == CIEDE2000) {
         use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;     // workgroup-uniform
         if (use_lb) {
-            // the cell's five numbers per group (group_sums_kernel) wait in LDS: read per candidate, no registers held
-            if (wave == 0 && lane < groups)
+            // the cell's five numbers per block (group_sums_kernel) wait in LDS: read per candidate, no registers held
+            for (int t = threadIdx.x; t < 4 * groups; t += kBlock)
                 for (int k = 0; k < 5; ++k)
-                    cell_st[k][lane] = var.cell_stats[(size_t)k * var.cell_stats_stride + (size_t)cell * var.lsum_stride + lane];
+                    cell_st[k][t] = var.cell_stats[(size_t)k * var.cell_stats_stride + (size_t)cell * var.n_blocks + t];
             __syncthreads();
         }
     }
 
+    // blocks per lane in the bound's prelude: 1, 2 or 4 (a power of two, so groups start on lane boundaries)
+    const int lane_shift = groups <= 16 ? 0 : (groups <= 32 ? 1 : 2), per_lane = 1 << lane_shift;
     const int l_base = tile * cand_per_block;
     const int n_here = min(cand_per_block, L - l_base);
     for (int idx = wave; idx < n_here;) {
@@ -192,27 +195,32 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         float rest = 0.0f;                 // lane j: lightness bound of groups >= j
         if constexpr (TYPE == CIEDE2000) {
             if (use_lb) {
+                // Lane k takes blocks k*m .. k*m+m-1 (m = blocks per lane: 1 up to 64 x 64 cells, so a lane
+                // is a quarter of a group; 4 at 128 x 128: a lane is a group).
+                const int n_blk = 4 * groups;
                 float d = 0.0f;
-                if (lane < groups) {
-                    const float* st = var.lib_stats + ((size_t)v * L + l) * var.lsum_stride + lane;
+                for (int i = 0; i < per_lane; ++i) {
+                    const int blk = lane * per_lane + i;
+                    if (blk >= n_blk) break;
+                    const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + blk;
                     const size_t bs = var.lib_stats_stride;
-                    // S_L of every pair of the group: |L_bar - 50| <= (max|L_cell - 50| + max|L_lib - 50|) / 2
-                    // over the group's active pixels, and S_L grows with it (:138-139)
-                    const float x = 0.5f * (cell_st[1][lane] + st[bs]);
+                    // S_L of every pair of the block: |L_bar - 50| <= (max|L_cell - 50| + max|L_lib - 50|) / 2
+                    // over the block's active pixels, and S_L grows with it (:138-139)
+                    const float x = 0.5f * (cell_st[1][blk] + st[bs]);
                     const float x2 = x * x;
                     const float s_l = fmaf(0.015f * x2, frsq(20.0f + x2), 1.0f);
-                    // S_C and R_T likewise from the largest chroma of the two groups (see above)
-                    const float cbar = 0.5f * (cell_st[4][lane] + st[4 * bs]);
+                    // S_C and R_T likewise from the largest chroma of the two blocks (see above)
+                    const float cbar = 0.5f * (cell_st[4][blk] + st[4 * bs]);
                     const float gc = (1.5f - 0.5f * sqrt_ratio7(cbar)) * cbar;         // >= C_bar' of every pair
                     const float s_c = fmaf(0.045f, gc, 1.0f);
                     const float rho = 1.0f - 0.86603f * sqrt_ratio7(gc);               // <= 1 - |R_T| / 2
-                    // 1e-2: fp32 rounding of two 256-term sums of values <= ~128, with margin
-                    const float t_l = fmaxf(fabsf(cell_st[0][lane] - st[0]) - 1e-2f, 0.0f) * frcp(s_l);
-                    const float da = fmaxf(fabsf(cell_st[2][lane] - st[2 * bs]) - 1e-2f, 0.0f);
-                    const float db = fmaxf(fabsf(cell_st[3][lane] - st[3 * bs]) - 1e-2f, 0.0f);
+                    // 1e-2: fp32 rounding of two 64-term sums of values <= ~128, with margin
+                    const float t_l = fmaxf(fabsf(cell_st[0][blk] - st[0]) - 1e-2f, 0.0f) * frcp(s_l);
+                    const float da = fmaxf(fabsf(cell_st[2][blk] - st[2 * bs]) - 1e-2f, 0.0f);
+                    const float db = fmaxf(fabsf(cell_st[3][blk] - st[3 * bs]) - 1e-2f, 0.0f);
                     const float inv_c = frcp(s_c);
                     // 0.9999: v_rsq / v_rcp / v_sqrt are good to ~1 ulp
-                    d = 0.9999f * fsqrt(fmaf(t_l, t_l, rho * fmaf(da, da, db * db) * (inv_c * inv_c)));
+                    d += 0.9999f * fsqrt(fmaf(t_l, t_l, rho * fmaf(da, da, db * db) * (inv_c * inv_c)));
                 }
                 // inclusive suffix scan over lanes (lane j <- sum of lanes >= j)
                 for (int off = 1; off < kWave; off <<= 1) {
@@ -232,7 +240,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             // One 256-pixel group of the candidate against the cell; true = candidate dropped.
             auto visit = [&](const LibGroup& cur, int j) -> bool {
                 if (j != 0 && j % check_every == 0) {
-                    const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), j)) : 0.0f;
+                    // group j starts at block 4 j = the first block of lane (4 j) >> lane_shift
+                    const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), (4 * j) >> lane_shift)) : 0.0f;
                     if (wave_sum_dpp(acc) + rest_j > limit) return true;
                 }
                 const int q = lane + kWave * j;
@@ -499,16 +508,18 @@ chroma_planes_kernel(const float* __restrict__ planar, float* __restrict__ chrom
     }
 }
 
-// Per-image statistics over each 256-position group of the plane order, counting only the
-// positions flagged in `mask` (per image if mask_stride != 0, else shared).  Five blocks of
-// [n_images][lsum_stride] floats, `block_stride` floats apart:
+// Per-image statistics over each 64-position BLOCK of the plane order (four blocks make one of
+// the filter's 256-position groups; the plane order is tile-major, engine.hip prepare_planes, so
+// a block is a compact patch of the image), counting only the positions flagged in `mask`
+// (per image if mask_stride != 0, else shared).  Five arrays of [n_images][n_blocks] floats,
+// `block_stride` floats apart:
 //   0: sum of channel 0              1: max |channel 0 - 50|
 //   2: sum of channel 1              3: sum of channel 2        4: max sqrt(ch1^2 + ch2^2)
-// One wave per (image, group).  Feeds the lower bound of filter_kernel's early exit.
+// One wave per (image, group): 16 lanes per block.  Feeds the lower bound of filter_kernel's early exit.
 __global__ void __launch_bounds__(kBlock)
 group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ mask, size_t mask_stride,
                   float* __restrict__ stats, size_t block_stride, size_t n_images, int n_groups,
-                  int lsum_stride, int ppad)
+                  int n_blocks, int ppad)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t w = (size_t)blockIdx.x * (kBlock / kWave) + wave;
@@ -528,13 +539,13 @@ group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ 
             dev = fmaxf(dev, fabsf(xs[k] - 50.0f));
             cmax = fmaxf(cmax, chroma_of(as[k], bs[k]));
         }
-    s0 = wave_sum_f(s0); s1 = wave_sum_f(s1); s2 = wave_sum_f(s2);
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 8; off > 0; off >>= 1) {              // within the block's 16 lanes
+        s0 += __shfl_xor(s0, off, kWave); s1 += __shfl_xor(s1, off, kWave); s2 += __shfl_xor(s2, off, kWave);
         dev = fmaxf(dev, __shfl_xor(dev, off, kWave));
         cmax = fmaxf(cmax, __shfl_xor(cmax, off, kWave));
     }
-    if (lane == 0) {
-        float* o = stats + img * lsum_stride + g;
+    if ((lane & 15) == 0) {
+        float* o = stats + img * n_blocks + 4 * g + (lane >> 4);
         o[0] = s0; o[block_stride] = dev; o[2 * block_stride] = s1; o[3 * block_stride] = s2; o[4 * block_stride] = cmax;
     }
 }
@@ -762,13 +773,13 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
 }
 
 hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
-                             size_t block_stride, size_t n_images, int n_groups, int lsum_stride, int ppad,
-                             hipStream_t stream)
+                             size_t block_stride, size_t n_images, int ppad, hipStream_t stream)
 {
+    const int n_groups = ppad / 256, n_blocks = ppad / 64;
     const size_t waves = n_images * (size_t)n_groups;
     if (waves == 0) return hipSuccess;
     group_sums_kernel<<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, stats, block_stride,
-                                                                        n_images, n_groups, lsum_stride, ppad);
+                                                                        n_images, n_groups, n_blocks, ppad);
     return hipGetLastError();
 }
 

@@ -22,12 +22,12 @@ struct Variants {
     size_t chroma_stride;       // floats between their chroma planes (L*ppad)
     int groups[4];
     // lower bound of the filter's early exit (filter.hip): five statistics per image and
-    // 256-position group over the mask's active positions (group_sums_kernel), as five blocks
-    const float* lib_stats;     // 5 x [V][L][lsum_stride], lib_stats_stride floats apart
-    const float* cell_stats;    // 5 x [B][lsum_stride], cell_stats_stride floats apart
+    // 64-position block over the mask's active positions (group_sums_kernel), as five arrays
+    const float* lib_stats;     // 5 x [V][L][n_blocks], lib_stats_stride floats apart
+    const float* cell_stats;    // 5 x [B][n_blocks], cell_stats_stride floats apart
     size_t lib_stats_stride, cell_stats_stride;
+    int n_blocks;               // ppad / 64
     const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask (not clipped)
-    int lsum_stride;
 };
 
 // Device inputs of the fp32 filter kernels.
@@ -54,10 +54,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream);
 
-// stats block k (block_stride floats apart), [img][g] over plane positions [256 g, 256 g + 256):
+// stats array k (block_stride floats apart), [img][ppad / 64] over plane positions [64 b, 64 b + 64):
 // masked sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma.
 hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
-                             size_t block_stride, size_t n_images, int n_groups, int lsum_stride, int ppad, hipStream_t stream);
+                             size_t block_stride, size_t n_images, int ppad, hipStream_t stream);
 
 // max |x - offset| over a strided set, written with atomicMax as float bits into *out_bits
 // (zero it first).
