@@ -265,9 +265,11 @@ mm_status mm_shrink_library_bgr(mm_engine *e, int factor);
  * every (cell, candidate), then the fp64 reference-form score of each cell's
  * contenders only; 0 scores everything in fp64.  "prune" (default 1): the filter pass
  * abandons a candidate once its running sum passes a per-cell upper bound (the device
- * form of the reference's early exit).  "wave_resolve" / "row_pipeline" (default 1): the
- * single-wave and the row-pipelined forms of the resolve.  "max_batch" (default 0 = sized
- * from free device memory): cap on the cells scored per device batch.  "spec_k" (default 10):
+ * form of the reference's early exit).  "sweep_resolve" (default 1): the repeat
+ * penalty as parallel sweeps to the raster-order fix point ("max_sweeps", default 48, before the
+ * chain takes over); "wave_resolve" / "row_pipeline" (default 1): the single-wave and the
+ * row-pipelined forms of the chain.  "max_batch" (default 0 = sized
+ * from free device memory): cap on the cells scored per device batch.  "spec_k" (default 6):
  * length of mm_generate's speculative short lists, 0 = always the full length.  Results are
  * identical whatever the options. */
 mm_status mm_set_option(mm_engine *e, const char *name, int value);

@@ -57,7 +57,7 @@ struct mm_engine {
     DevBuf stage_u8, srgb_lut, shrink_tmp, covered, cells_f0;
     int mosaic_rows = 0, mosaic_cols = 0;       // the mosaic kept between mm_build_photomosaic_step calls
     int cell_scale = 1;          // mm_set_cell_scale: full-size cell pixels per detail pixel and axis
-    int spec_k = 10;             // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
+    int spec_k = 6;              // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
     // per distinct mask in that mask's active-pixels-first order whenever either changes
