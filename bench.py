@@ -167,6 +167,17 @@ def main():
                     help="engine tuning option (mm_set_option), for experiments")
     args = ap.parse_args()
 
+    # Only the JSON line may reach stdout: RCCL prints a version banner there when it initialises,
+    # so everything else written to fd 1 during the run is sent to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(line, flush=True)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -322,8 +333,9 @@ def main():
                       "only (oracle/oracle.c, early exit on, %.1f s)" % (n_all, n_all // max(cores, 1), dt_all),
         }
         out["speedup_vs_cpu_all_cores"] = value / (n_all / dt_all)
-    print(json.dumps(out))
+    emit(json.dumps(out))
     if use_dist:
+        os.dup2(2, 1)
         dist.destroy_process_group()
 
 

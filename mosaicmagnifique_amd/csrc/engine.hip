@@ -71,6 +71,7 @@ struct mm_engine {
     int max_sweeps = 48;         // mm_set_option("max_sweeps", n): sweeps before falling back to the chain
     int use_lds_filter = -1;     // mm_set_option("lds_filter", 0/1); -1 = auto (Euclid only: it is the L2-bound one)
     int extra_seeds = 22;        // mm_set_option("seeds", n): proxy-chosen seeds beyond the list length
+    int lds_pad_kb = 0;          // mm_set_option("lds_pad_kb", n): diagnostics -- extra LDS per filter workgroup (lowers occupancy)
     int tile_candidates = 0;     // mm_set_option("tile", n): candidates per filter workgroup (0 = default)
     int max_batch_cells = 0;     // mm_set_option("max_batch", n): cap on cells per device batch (0 = from memory)
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
@@ -468,6 +469,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.lib_chroma = (const float*)e->lib_chroma.p; fin.hue_lut = (const float4*)e->hue_lut.p;
     fin.var = variants_of(e);
     fin.tile_candidates = e->tile_candidates;
+    fin.lds_pad_bytes = (size_t)e->lds_pad_kb * 1024;
     fin.use_lds_form = e->use_lds_filter < 0 ? (diff_type != MM_CIEDE2000) : e->use_lds_filter;
     {   // dE00 >= |dL| / S_L(max |L - 50|): S_L = 1 + 0.015 d^2 / sqrt(20 + d^2) grows with d (:138-139)
         const double d = std::max(50.0, (double)std::max(e->lib_dmax, e->target_dmax));
@@ -1502,6 +1504,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "lds_filter") == 0) { e->use_lds_filter = value < 0 ? -1 : (value != 0); return MM_OK; }
     if (strcmp(name, "spec_k") == 0) { e->spec_k = std::max(0, value); return MM_OK; }
     if (strcmp(name, "seeds") == 0) { e->extra_seeds = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "lds_pad_kb") == 0) { e->lds_pad_kb = std::min(120, std::max(0, value)); return MM_OK; }
     if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }
     if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);

@@ -758,7 +758,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         return hipGetLastError();
     }
     if (type == CIEDE2000) {
-        filter_kernel<CIEDE2000><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
+        if (in.lds_pad_bytes > 0 &&
+            (code = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel<CIEDE2000>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)in.lds_pad_bytes)) != hipSuccess) return code;
+        filter_kernel<CIEDE2000><<<dim3((unsigned)blocks), kBlock, in.lds_pad_bytes, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale);
         if ((code = hipGetLastError()) != hipSuccess) return code;

@@ -43,6 +43,7 @@ struct FilterInputs {
     float lb_scale;             // slightly under 1 / S_L,max: dE00 >= |dL| * lb_scale (filter.hip)
     int use_lds_form;           // 1: cell tile staged in LDS by 1024-thread workgroups when it fits
     int tile_candidates;        // candidates per workgroup of filter_kernel (0 = default)
+    size_t lds_pad_bytes;       // diagnostics: unused dynamic LDS per filter workgroup (lowers the occupancy)
 };
 
 // Tier-1 filter scores f32 [n_cells][L] (see filter.hip).  Pairs on the discontinuity
