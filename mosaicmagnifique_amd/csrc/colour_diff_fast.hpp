@@ -44,9 +44,12 @@ __device__ __forceinline__ float euclidean_fast(const PxF& p, const PxF& q)
 }
 
 // (x/25)^7 / ((x/25)^7 + 1) under a square root, as x7 * rsq(x7 * (x7 + 1)).
-__device__ __forceinline__ float sqrt_ratio7(float x)
+__device__ __forceinline__ float sqrt_ratio7_scaled(float s);
+__device__ __forceinline__ float sqrt_ratio7(float x) { return sqrt_ratio7_scaled(x * 0.04f); }
+// The same for a MEAN given as the sum of its two terms: (x1 + x2) / 2 / 25 = (x1 + x2) * 0.02, one multiply.
+__device__ __forceinline__ float sqrt_ratio7_of_sum(float x_sum) { return sqrt_ratio7_scaled(x_sum * 0.02f); }
+__device__ __forceinline__ float sqrt_ratio7_scaled(float s)
 {
-    const float s = x * 0.04f;
     const float s2 = s * s, s4 = s2 * s2;
     const float z = fmaf(s4 * s2, s, 1e-30f);       // > 0: no 0 * inf below
     return z * frsq(fmaf(z, z, z));
@@ -56,7 +59,8 @@ __device__ __forceinline__ float sqrt_ratio7(float x)
 // on the mean hue angle ALONE, so both are tabulated over the circle and interpolated
 // linearly.  The index is the "diamond angle" of the mean-hue unit vector (hc, hs):
 //   t = 2 - copysign(1 + hc / (|hc| + |hs|), hs)   in [0, 4),  monotone in the angle,
-// which needs one v_rcp_f32 and no inverse trig.  Entry i holds {T, dT, G, dG} at
+// which needs one v_rcp_f32 and no inverse trig.  Entry i holds {T, dT, G, dG}, G = -2 sin(2 d_theta)
+// (so that R_T = G R_C / 2 is one multiply, :136,:145), at
 // t_i = 4 i / kHueLutSize with d* the difference to entry i+1 (kHueLutSize + 1 entries;
 // the last repeats the first).  Built in fp64 on the host (engine.hip build_hue_lut).
 // Interpolation error at 2048 entries: < 2e-5 on T, < 2e-5 on G.
@@ -72,7 +76,7 @@ constexpr int kHueLutSize = 2048;
 //   dH' = 2 sqrt(P) sin(dh/2)  (:102)  and  sin^2(dh/2) = (1 - cos dh)/2, so
 //     |dh| <= 90:  dH'^2 = 2 (P - dot) = 2 cross^2 / (P + dot)      (no cancellation)
 //     |dh| >  90:  dH'^2 = 2 (P + |dot|)
-//   i.e. with e = P + |dot|, r = rsq(2 e):  dH' = 2 cross r   or   sign(cross) 2 e r.
+//   i.e. with e = P + |dot|, r = rsq(e / 2) = 2 rsq(2 e):  dH' = cross r   or   sign(cross) e r.
 //   mean hue direction (:104-122, "h1 plus half the wrapped difference"), any positive
 //   scale (the table index is scale-free): with s = C2 v1, t = C1 v2 (equal lengths)
 //     |dh| <= 90:  s + t                       (bisector, length >= sqrt(2) P)
@@ -85,7 +89,7 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
                                                 const float4* __restrict__ lut, bool* needs_exact)
 {
     // G, a', C' (:50-59)
-    const float one_g = 1.5f - 0.5f * sqrt_ratio7(0.5f * (c1 + c2));     // 1 + G
+    const float one_g = 1.5f - 0.5f * sqrt_ratio7_of_sum(c1 + c2);       // 1 + G
     const float a1 = one_g * p.c1, a2 = one_g * q.c1;
     const float b1 = p.c2, b2 = q.c2;
     // + 1e-36: C' >= 1e-18 > 0 (rsq stays finite, a grey colour keeps a direction below)
@@ -99,23 +103,23 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     *needs_exact = !acute && fabsf(cross) < 3e-5f * pp;
 
     const float e = pp + fabsf(dot);
-    const float r = frsq(e + e);                                            // e >= P >= 1e-36
-    const float half_dh = acute ? cross * r : copysignf(e * r, cross);      // dH' / 2  (:102)
+    const float r = frsq(0.5f * e);                                         // = 2 rsq(2 e);  e >= P >= 1e-36
+    const float d_h = acute ? cross * r : copysignf(e * r, cross);          // dH'  (:102): 2 cross rsq(2e) | sign 2e rsq(2e)
 
     // mean hue direction -> table index -> T and sin(2 d_theta)
     const float sx = a1 * c2p, sy = b1 * c2p, tx = a2 * c1p, ty = b2 * c1p;
     const float hx = acute ? sx + tx : copysignf(1.0f, cross) * (ty - sy);
     const float hy = acute ? sy + ty : copysignf(1.0f, cross) * (sx - tx);
     const float qd = hx * frcp(fmaxf(fabsf(hx) + fabsf(hy), 1e-36f));
-    const float x = (2.0f - copysignf(1.0f + qd, hy)) * (float)(kHueLutSize / 4);
-    const int idx = min(max((int)x, 0), kHueLutSize - 1);      // x >= 0: truncation = floor
-    const float fr = x - (float)idx;                            // x == N (angle 2 pi) -> entry N-1, fr = 1
+    const float x = fmaf(-(float)(kHueLutSize / 4), copysignf(1.0f + qd, hy), (float)(kHueLutSize / 2));   // (2 - c) N/4
+    const int idx = min(max((int)x, 0), kHueLutSize);          // x in [0, N]: truncation = floor; entry N repeats entry 0
+    const float fr = __builtin_amdgcn_fractf(x);                // x - floor(x), one instruction
     const float4 en = lut[idx];
     const float t = fmaf(fr, en.y, en.x);
     const float s2 = fmaf(fr, en.w, en.z);
 
     const float csum = c1p + c2p;                           // 2 * mean C'
-    const float r_t = -s2 * 2.0f * sqrt_ratio7(0.5f * csum);    // :136,:145
+    const float r_t = s2 * sqrt_ratio7_of_sum(csum);            // :136,:145; the table holds -2 sin(2 d_theta)
     const float lb = 0.5f * (p.c0 + q.c0) - 50.0f;
     const float l2 = lb * lb;
     const float s_l = fmaf(0.015f * l2, frsq(20.0f + l2), 1.0f);
@@ -128,7 +132,7 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     const float d_c = c2p - c1p;
     const float big_d = s_c * s_h;
     const float ta = d_c * s_h;
-    const float tb = (half_dh + half_dh) * s_c;
+    const float tb = d_h * s_c;
     const float num = fmaf(ta, ta, fmaf(tb, tb, (r_t * ta) * tb));
     const float inv_d = frcp(big_d);
     const float t_l = d_l * frcp(s_l);

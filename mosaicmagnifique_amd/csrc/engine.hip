@@ -303,7 +303,7 @@ mm::Variants variants_of(const mm_engine* e)
 }
 
 // The hue table of colour_diff_fast.hpp, in fp64 from the reference formulas: entry i is the
-// mean hue whose diamond angle is t_i = 4 i / N; {T, dT, G, dG} with G = sin(2 d_theta),
+// mean hue whose diamond angle is t_i = 4 i / N; {T, dT, G, dG} with G = -2 sin(2 d_theta),
 // d_theta = rad(30) exp(-((h - rad(275)) / rad(25))^2) and h in [0, 2 pi) NOT wrapped around
 // 275 degrees (ColourDifference.cpp:124-133,145).
 std::vector<float> build_hue_lut()
@@ -323,7 +323,7 @@ std::vector<float> build_hue_lut()
         T[i] = 1.0 - 0.17 * std::cos(h - rad(30.0)) + 0.24 * std::cos(2.0 * h) +
                0.32 * std::cos(3.0 * h + rad(6.0)) - 0.20 * std::cos(4.0 * h - rad(63.0));
         const double z = (h - rad(275.0)) / rad(25.0);
-        G[i] = std::sin(2.0 * rad(30.0) * std::exp(-z * z));
+        G[i] = -2.0 * std::sin(2.0 * rad(30.0) * std::exp(-z * z));      // R_T = G * sqrt(C^7 / (C^7 + 25^7)), :136,:145
     }
     std::vector<float> lut((size_t)(N + 1) * 4);
     for (int i = 0; i <= N; ++i) {
