@@ -90,6 +90,8 @@ class ShardedBestFit:
             score = packed[score_off:].view(torch.float64).view(rows, k)
             idx.fill_(-1)
             score.fill_(float("inf"))
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)     # the engine writes these on its own stream
             self._bufs = (key, idx, score, packed)
         return self._bufs[1], self._bufs[2], self._bufs[3]
 
@@ -112,6 +114,8 @@ class ShardedBestFit:
         if hi - lo < per:                       # short last shard: keep the padding rows inert
             idx[hi - lo:] = -1
             score[hi - lo:] = float("inf")
+            if idx.device.type == "cuda":
+                torch.cuda.synchronize(idx.device)
         if hi > lo:
             self.engine.score_cells(cells[lo:hi], diff_type, k, out_index=idx.data_ptr(),
                                     out_score=score.data_ptr(), on_device=True, k_fill=ks)
