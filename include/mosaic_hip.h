@@ -141,6 +141,11 @@ mm_status mm_set_target(mm_engine *e, const float *image, int rows, int cols);
  * f32 Lab (MM_CIE76 / MM_CIEDE2000).  Replaces mm_set_library. */
 mm_status mm_set_library_u8(mm_engine *e, const uint8_t *bgr, int n_images, int size,
                             int shrink, int diff_type);
+/* The same for ANY detail cell size <= size (a detail level like 75 %): where size / detail_size
+ * is not whole the shrink is cv::resize's general INTER_AREA (computeResizeAreaTab +
+ * ResizeArea_Invoker, f32 accumulators, table order; csrc/kernels.hpp resize_area_u8_kernel). */
+mm_status mm_set_library_u8_sized(mm_engine *e, const uint8_t *bgr, int n_images, int size,
+                                  int detail_size, int diff_type);
 
 /* preprocessMainImage() (PhotomosaicGeneratorBase.cpp:223-252), colour scheme
  * NONE: u8 BGR [rows][cols][3] -> f32 BGR or Lab.  Replaces mm_set_target. */
@@ -167,6 +172,12 @@ mm_status mm_shrink_library(mm_engine *e, int factor);
  * detail pixel of a cell is the mean of a factor x factor block of the
  * zero-filled normal cell.  1 (default) = detail 100 %. */
 mm_status mm_set_cell_scale(mm_engine *e, int factor);
+/* Any detail level: the normal cell of normal_size pixels is resized to detail_size (= the
+ * library's current size).  A whole ratio is mm_set_cell_scale(normal_size / detail_size); otherwise
+ * each detail pixel is cv::resize's general INTER_AREA of the zero-filled normal cell
+ * (computeResizeAreaTab + ResizeArea_Invoker<float, float>: f32, table order, no fused
+ * multiply-adds; csrc/kernels.hpp cell_pixel). */
+mm_status mm_set_cell_resize(mm_engine *e, int normal_size, int detail_size);
 
 /* Read-back of the resident (pre-processed) inputs, for tests and for feeding a
  * CPU generator the same arrays: library f32 [n_images][size][size][3] at its

@@ -53,6 +53,8 @@ SIGNATURES = {
     "mm_set_target": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
     "mm_set_library_u8": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mm_set_target_u8": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mm_set_library_u8_sized": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mm_set_cell_resize": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int]),
     "mm_hue_rotate_u8": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_float, _VP]),
     "mm_shrink_library": (ctypes.c_int, [_VP, ctypes.c_int]),
     "mm_set_cell_scale": (ctypes.c_int, [_VP, ctypes.c_int]),

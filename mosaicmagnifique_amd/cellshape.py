@@ -263,9 +263,7 @@ class CellGroup:
         return self.getCell(sizeStep, detail).getSize()
 
     def cellScale(self, sizeStep=0):
-        """Normal-cell pixels per detail pixel and axis at a step; raises unless whole."""
+        """Normal-cell pixels per detail pixel and axis at a step when that is a whole number,
+        else 0 (the engine then uses the general INTER_AREA tables, mm_set_cell_resize)."""
         n, d = self.getCellSize(sizeStep), self.getCellSize(sizeStep, True)
-        if d <= 0 or n % d != 0:
-            raise NotImplementedError("cell size %d at detail size %d: only whole-number detail ratios "
-                                      "are covered (fractional INTER_AREA stays on the OpenCV host)" % (n, d))
-        return n // d
+        return n // d if d > 0 and n % d == 0 else 0

@@ -56,7 +56,11 @@ struct mm_engine {
     DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
     DevBuf stage_u8, srgb_lut, shrink_tmp, covered, cells_f0;
     int mosaic_rows = 0, mosaic_cols = 0;       // the mosaic kept between mm_build_photomosaic_step calls
-    int cell_scale = 1;          // mm_set_cell_scale: full-size cell pixels per detail pixel and axis
+    int cell_scale = 1;          // mm_set_cell_scale / mm_set_cell_resize: normal-cell pixels per detail pixel and
+                                 // axis when that is a whole number, 0 = any ratio (area table in `area_tab`)
+    int cell_normal = 0;         // normal cell size the area table was built for
+    DevBuf area_tab;             // [detail + 1] first | [entries] src | [entries] alpha (kernels.hpp CellResize)
+    int area_entries = 0;
     int spec_k = 6;              // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
@@ -160,7 +164,7 @@ mm_status check_cells(mm_engine* e, const mm_cell* cells, int n, int grid_w, int
             c.row_min >= 0 && c.row_min < c.row_max && c.row_max <= size &&
             c.col_min >= 0 && c.col_min < c.col_max && c.col_max <= size &&
             c.mask_id >= 0 && c.mask_id < 4 &&
-            (e->cell_scale > 1 ||      // the box mean zero-fills what lies outside the image
+            (e->cell_scale != 1 ||     // the resize zero-fills what lies outside the image
              ((long long)c.y + c.row_min >= 0 && (long long)c.y + c.row_max <= e->rows &&
               (long long)c.x + c.col_min >= 0 && (long long)c.x + c.col_max <= e->cols)) &&
             (e->cell_scale == 1 || (std::abs((long long)c.x) < (1LL << 28) && std::abs((long long)c.y) < (1LL << 28))) &&
@@ -174,6 +178,19 @@ mm_status check_cells(mm_engine* e, const mm_cell* cells, int n, int grid_w, int
         }
     }
     return MM_OK;
+}
+
+// How the kernels make a detail pixel (kernels.hpp CellResize) from the engine's state.
+mm::CellResize cell_resize_of(const mm_engine* e)
+{
+    mm::CellResize r{e->cell_scale, nullptr, nullptr, nullptr};
+    if (e->cell_scale == 0) {
+        const int* base = (const int*)e->area_tab.p;
+        r.first = base;
+        r.src = base + (e->lib_size + 1);
+        r.alpha = (const float*)(base + (e->lib_size + 1) + e->area_entries);
+    }
+    return r;
 }
 
 float elapsed(hipEvent_t a, hipEvent_t b)
@@ -375,7 +392,7 @@ mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_typ
     const mm::Variants var = variants_of(e);
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
-        recs_dev, (const float*)e->target.p, e->rows, e->cols, e->cell_scale, (const uint8_t*)e->masks.p,
+        recs_dev, (const float*)e->target.p, e->rows, e->cols, cell_resize_of(e), (const uint8_t*)e->masks.p,
         (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
         (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, nullptr);
     HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
@@ -510,7 +527,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         }
 
         mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
-            recs_dev + done, (const float*)e->target.p, e->rows, e->cols, e->cell_scale, (const uint8_t*)e->masks.p,
+            recs_dev + done, (const float*)e->target.p, e->rows, e->cols, cell_resize_of(e), (const uint8_t*)e->masks.p,
             (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
             (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, (float*)e->cells_f0.p);
         HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
@@ -642,7 +659,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
     a.repeat_range = range; a.repeat_addition = addition; a.K = K;
     a.cand_index = cand_i_dev; a.cand_score = cand_s_dev;
     a.grid = (long long*)e->grid.p; a.best_score = (double*)e->best.p;
-    a.target = (const float*)e->target.p; a.rows = e->rows; a.cols = e->cols; a.cell_scale = e->cell_scale;
+    a.target = (const float*)e->target.p; a.rows = e->rows; a.cols = e->cols; a.cell_scale = cell_resize_of(e);
     a.masks = (const uint8_t*)e->masks.p; a.lib = (const float*)e->lib.p;
     a.lib_stride = (size_t)e->n_lib * 3 * ppad; a.inv_perm = (const int*)e->inv_perm.p;
     for (int i = 0; i < 4; ++i) a.var_of_mask[i] = e->var_of_mask[i];
@@ -866,7 +883,8 @@ void mm_destroy(mm_engine* e)
                        &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
-                       &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0 })
+                       &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0, &e->area_tab,
+                       &e->sweep_counts })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -950,6 +968,27 @@ mm_status ensure_srgb_lut(mm_engine* e)
 }
 
 // u8 BGR images -> resident f32 (dst), optionally shrunk by `factor` first.
+// computeResizeAreaTab (OpenCV 4 imgproc resize.cpp) for one axis: the source indices and
+// weights under each destination index, scale = 1 / (dsize / ssize) as cv::resize computes it.
+void build_area_table(int ssize, int dsize, std::vector<int>& first, std::vector<int>& src, std::vector<float>& alpha)
+{
+    const double scale = 1.0 / ((double)dsize / ssize);
+    first.assign(dsize + 1, 0);
+    src.clear(); alpha.clear();
+    for (int dx = 0; dx < dsize; ++dx) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        first[dx] = (int)src.size();
+        if (sx1 - fsx1 > 1e-3) { src.push_back(sx1 - 1); alpha.push_back((float)((sx1 - fsx1) / cell)); }
+        for (int sx = sx1; sx < sx2; ++sx) { src.push_back(sx); alpha.push_back((float)(1.0 / cell)); }
+        if (fsx2 - sx2 > 1e-3) { src.push_back(sx2); alpha.push_back((float)(std::min(std::min(fsx2 - sx2, 1.0), cell) / cell)); }
+    }
+    first[dsize] = (int)src.size();
+}
+
 mm_status preprocess_u8(mm_engine* e, const uint8_t* bgr, size_t n_images, int rows, int cols, int factor,
                         int diff_type, DevBuf& dst)
 {
@@ -999,6 +1038,59 @@ mm_status mm_set_library_u8(mm_engine* e, const uint8_t* bgr, int n_images, int 
     e->planes_dirty = true;
     e->n_lib = n_images;
     e->lib_size = size / shrink;
+    return MM_OK;
+}
+
+mm_status mm_set_library_u8_sized(mm_engine* e, const uint8_t* bgr, int n_images, int size, int detail_size, int diff_type)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!bgr || n_images <= 0 || size <= 0 || size > 4096 || detail_size < 1 || detail_size > size || !known_type(diff_type)) {
+        set_err(e, "mm_set_library_u8_sized: need n_images > 0, 0 < detail size <= size <= 4096, a known type "
+                   "(got %d, %d, %d, %d)", n_images, size, detail_size, diff_type);
+        return MM_INVALID_ARGUMENT;
+    }
+    if (size % detail_size == 0) return mm_set_library_u8(e, bgr, n_images, size, size / detail_size, diff_type);
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    // INTER_AREA by a ratio that is not whole, on the u8 images (the reference resizes before it
+    // converts, PhotomosaicGeneratorBase.cpp:262-271), then the usual colour conversion
+    std::vector<int> first, src;
+    std::vector<float> alpha;
+    build_area_table(size, detail_size, first, src, alpha);
+    const size_t n = src.size(), in_bytes = (size_t)n_images * size * size * 3;
+    const size_t out_px = (size_t)n_images * detail_size * detail_size;
+    DevBuf tab, small;
+    mm_status st;
+    if ((st = ensure_srgb_lut(e)) || (st = ensure(e, e->stage_u8, in_bytes, "Failed to allocate u8 staging")) ||
+        (st = ensure(e, tab, ((size_t)detail_size + 1 + 2 * n) * sizeof(int), "Failed to allocate resize table")) ||
+        (st = ensure(e, small, out_px * 3, "Failed to allocate resized images")) ||
+        (st = ensure(e, e->lib_hwc, out_px * 3 * sizeof(float), "Failed to allocate preprocessed images"))) {
+        release(tab); release(small);
+        return st;
+    }
+    int* base = (int*)tab.p;
+    hipError_t code = hipMemcpyAsync(e->stage_u8.p, bgr, in_bytes, hipMemcpyHostToDevice, e->stream);
+    if (code == hipSuccess) code = hipMemcpyAsync(base, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, e->stream);
+    if (code == hipSuccess) code = hipMemcpyAsync(base + detail_size + 1, src.data(), n * sizeof(int), hipMemcpyHostToDevice, e->stream);
+    if (code == hipSuccess) code = hipMemcpyAsync(base + detail_size + 1 + n, alpha.data(), n * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    if (code == hipSuccess) {
+        const mm::CellResize rs{0, base, base + detail_size + 1, (const float*)(base + detail_size + 1 + n)};
+        const unsigned blocks = (unsigned)std::min<size_t>((out_px + mm::kBlock - 1) / mm::kBlock, 65536);
+        mm::resize_area_u8_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(
+            (const uint8_t*)e->stage_u8.p, (uint8_t*)small.p, (size_t)n_images, size, detail_size, rs);
+        code = hipGetLastError();
+        if (code == hipSuccess) {
+            mm::preprocess_u8_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(
+                (const uint8_t*)small.p, (float*)e->lib_hwc.p, (size_t)n_images, detail_size, detail_size, 1,
+                diff_type != MM_RGB_EUCLIDEAN, (const double*)e->srgb_lut.p);
+            code = hipGetLastError();
+        }
+    }
+    if (code == hipSuccess) code = hipStreamSynchronize(e->stream);      // host vectors and temporaries go out of scope
+    release(tab); release(small);
+    if (code != hipSuccess) return hip_fail(e, code, "Error during library resize", __FILE__, __LINE__);
+    e->planes_dirty = true;
+    e->n_lib = n_images;
+    e->lib_size = detail_size;
     return MM_OK;
 }
 
@@ -1062,6 +1154,35 @@ mm_status mm_shrink_library(mm_engine* e, int factor)
     std::swap(e->lib_hwc, e->shrink_tmp);
     e->lib_size = so;
     e->planes_dirty = true;
+    return MM_OK;
+}
+
+mm_status mm_set_cell_resize(mm_engine* e, int normal_size, int detail_size)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (detail_size < 1 || normal_size < detail_size || normal_size > 64 * detail_size || normal_size > 8192) {
+        set_err(e, "mm_set_cell_resize: need 1 <= detail size <= normal size <= 64 x detail size (got %d, %d)", normal_size, detail_size);
+        return MM_INVALID_ARGUMENT;
+    }
+    if (normal_size % detail_size == 0) { e->cell_scale = normal_size / detail_size; return MM_OK; }
+    if (detail_size != e->lib_size) {
+        set_err(e, "mm_set_cell_resize: detail size %d differs from the library's %d", detail_size, e->lib_size);
+        return MM_INVALID_ARGUMENT;
+    }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    std::vector<int> first, src;
+    std::vector<float> alpha;
+    build_area_table(normal_size, detail_size, first, src, alpha);
+    const size_t n = src.size();
+    mm_status st = ensure(e, e->area_tab, ((size_t)detail_size + 1 + 2 * n) * sizeof(int), "Failed to allocate resize table");
+    if (st) return st;
+    int* base = (int*)e->area_tab.p;
+    HIP_TRY(e, hipMemcpy(base, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice), "Failed to copy resize table");
+    HIP_TRY(e, hipMemcpy(base + detail_size + 1, src.data(), n * sizeof(int), hipMemcpyHostToDevice), "Failed to copy resize table");
+    HIP_TRY(e, hipMemcpy(base + detail_size + 1 + n, alpha.data(), n * sizeof(float), hipMemcpyHostToDevice), "Failed to copy resize table");
+    e->area_entries = (int)n;
+    e->cell_normal = normal_size;
+    e->cell_scale = 0;
     return MM_OK;
 }
 

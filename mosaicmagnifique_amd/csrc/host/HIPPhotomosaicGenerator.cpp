@@ -482,14 +482,14 @@ bool HIPPhotomosaicGenerator::stageInputs()
     mm_status st = MM_OK;
     if (!m_lib8.empty()) {
         const int size = m_lib8.front().rows;
-        if (size % detailSize != 0) { m_lastError = "library image size is not a whole multiple of the detail cell size"; return false; }
+        if (size < detailSize) { m_lastError = "library images smaller than the detail cell (INTER_CUBIC enlargement is outside the hot path)"; return false; }
         std::vector<uint8_t> flat;
         flat.reserve(m_lib8.size() * (size_t)size * size * 3);
         for (const Image8& im : m_lib8) {
             if (im.rows != size || im.cols != size) { m_lastError = "library images differ in size"; return false; }
             flat.insert(flat.end(), im.data.begin(), im.data.end());
         }
-        st = mm_set_library_u8(m_engine, flat.data(), (int)m_lib8.size(), size, size / detailSize, type);
+        st = mm_set_library_u8_sized(m_engine, flat.data(), (int)m_lib8.size(), size, detailSize, type);
     } else if (!m_lib.empty()) {
         std::vector<float> flat((size_t)m_lib.size() * detailSize * detailSize * 3);
         for (size_t i = 0; i < m_lib.size(); ++i) {
@@ -532,12 +532,12 @@ bool HIPPhotomosaicGenerator::generateBestFits()
         if (m_wasCanceled) return false;
         const CellShape& normal = m_cells.getCell(step);
         const CellShape& detail = m_cells.getCell(step, true);
-        if (detail.getSize() <= 0 || normal.getSize() % detail.getSize() != 0) { m_lastError = "only whole-number detail ratios are covered"; return false; }
+        if (detail.getSize() <= 0 || detail.getSize() > normal.getSize()) { m_lastError = "detail cell larger than the cell"; return false; }
         mm_status st;
         if (step > 0 && (st = mm_shrink_library(m_engine, 2)) != MM_OK) return fail(st);       // batchResizeMat, :95-99
         const std::vector<uint8_t> masks = masks4(detail);
         if ((st = mm_set_masks(m_engine, masks.data(), detail.getSize())) != MM_OK) return fail(st);
-        if ((st = mm_set_cell_scale(m_engine, normal.getSize() / detail.getSize())) != MM_OK) return fail(st);
+        if ((st = mm_set_cell_resize(m_engine, normal.getSize(), detail.getSize())) != MM_OK) return fail(st);   // getCellAt's resize, :313-315
 
         GridUtility::StepBestFit& grid = m_bestFits[step];
         const int gridH = (int)grid.size(), gridW = (int)grid.at(0).size();

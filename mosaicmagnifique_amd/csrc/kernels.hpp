@@ -110,12 +110,51 @@ hwc_to_planar_kernel(const float* __restrict__ hwc, float* __restrict__ planar,
 // 305-315), which for an integer factor is the box mean.  Arithmetic SPECIFIED here (OpenCV
 // is not part of the reference checkout): float row sums left to right, rows added top to
 // bottom, one multiply by 1/(n n); for n = 2 that is ((a + b) + (c + d)) * 0.25f.
+// How a detail pixel is made from the normal-size cell.  scale >= 1: whole ratio, box mean (above).
+// scale == 0: any ratio -- cv::resize(..., INTER_AREA) for a shrink that is not a whole number is
+// computeResizeAreaTab + ResizeArea_Invoker<float, float> (OpenCV 4 imgproc resize.cpp): per axis a
+// table of (source index, weight) entries per destination index; a destination row is
+//   buf = ((0 + S[sx0] a0) + S[sx1] a1) + ...   for every contributing source row, in table order,
+//   sum = b0 * buf0;  sum += b1 * buf1; ...       down the contributing rows,
+// in f32 without fused multiply-adds.  Cells are square, so one table serves both axes:
+// entries [first[d], first[d + 1]) belong to destination index d (engine.hip build_area_table).
+struct CellResize {
+    int scale;
+    const int* first;       // [detail_size + 1]
+    const int* src;         // [entries] source row / column inside the normal-size cell
+    const float* alpha;     // [entries]
+};
+
 __device__ __forceinline__ void cell_pixel(const float* __restrict__ target, int rows, int cols,
-                                           int y, int x, int r, int c, int n, float out[3])
+                                           int y, int x, int r, int c, const CellResize& rs, float out[3])
 {
+    const int n = rs.scale;
     if (n == 1) {
         const float* s = target + ((size_t)(y + r) * cols + (x + c)) * 3;
         out[0] = s[0]; out[1] = s[1]; out[2] = s[2];
+        return;
+    }
+    if (n == 0) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        const int ky0 = rs.first[r], ky1 = rs.first[r + 1], kx0 = rs.first[c], kx1 = rs.first[c + 1];
+        for (int ky = ky0; ky < ky1; ++ky) {
+            const int yy = y + rs.src[ky];
+            const float beta = rs.alpha[ky];
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            for (int kx = kx0; kx < kx1; ++kx) {
+                const int xx = x + rs.src[kx];
+                const float al = rs.alpha[kx];
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;                  // the cell is zero outside the image
+                if (yy >= 0 && yy < rows && xx >= 0 && xx < cols) {
+                    const float* s = target + ((size_t)yy * cols + xx) * 3;
+                    s0 = s[0]; s1 = s[1]; s2 = s[2];
+                }
+                b0 = b0 + s0 * al; b1 = b1 + s1 * al; b2 = b2 + s2 * al;
+            }
+            if (ky == ky0) { t0 = beta * b0; t1 = beta * b1; t2 = beta * b2; }
+            else { t0 = t0 + beta * b0; t1 = t1 + beta * b1; t2 = t2 + beta * b2; }
+        }
+        out[0] = t0; out[1] = t1; out[2] = t2;
         return;
     }
     float t0 = 0.f, t1 = 0.f, t2 = 0.f;
@@ -149,7 +188,7 @@ shrink_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_
         const int p = (int)(t - img * so * so);
         const int r = p / so, c = p - r * so;
         float px[3];
-        cell_pixel(src + img * (size_t)size_in * size_in * 3, size_in, size_in, 0, 0, r, c, f, px);
+        cell_pixel(src + img * (size_t)size_in * size_in * 3, size_in, size_in, 0, 0, r, c, CellResize{f, nullptr, nullptr, nullptr}, px);
         float* d = dst + t * 3;
         d[0] = px[0]; d[1] = px[1]; d[2] = px[2];
     }
@@ -266,13 +305,47 @@ hue_rotate_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
         hue_rotate_px(src + t * 3, degrees, dst + t * 3);
 }
 
+// cv::resize(..., INTER_AREA) of square u8 BGR images by a ratio that is not a whole number
+// (the library at a detail level like 75 %, PhotomosaicGeneratorBase.cpp:262-271): the same
+// tables and accumulation order as cell_pixel's scale == 0 form, rounded half-to-even and
+// saturated at the end (ResizeArea_Invoker<uchar, float>, cv::saturate_cast<uchar>).
+__global__ void __launch_bounds__(kBlock)
+resize_area_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n_images,
+                      int size_in, int size_out, CellResize rs)
+{
+    const size_t per = (size_t)size_out * size_out, total = n_images * per;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const size_t img = t / per;
+        const size_t p = t - img * per;
+        const int r = (int)(p / size_out), c = (int)(p - (size_t)r * size_out);
+        const uint8_t* s = src + img * (size_t)size_in * size_in * 3;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        const int ky0 = rs.first[r], ky1 = rs.first[r + 1], kx0 = rs.first[c], kx1 = rs.first[c + 1];
+        for (int ky = ky0; ky < ky1; ++ky) {
+            const uint8_t* row = s + (size_t)rs.src[ky] * size_in * 3;
+            const float beta = rs.alpha[ky];
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            for (int kx = kx0; kx < kx1; ++kx) {
+                const uint8_t* q = row + (size_t)rs.src[kx] * 3;
+                const float al = rs.alpha[kx];
+                b0 = b0 + (float)q[0] * al; b1 = b1 + (float)q[1] * al; b2 = b2 + (float)q[2] * al;
+            }
+            if (ky == ky0) { t0 = beta * b0; t1 = beta * b1; t2 = beta * b2; }
+            else { t0 = t0 + beta * b0; t1 = t1 + beta * b1; t2 = t2 + beta * b2; }
+        }
+        dst[t * 3 + 0] = (uint8_t)min(255, max(0, __float2int_rn(t0)));
+        dst[t * 3 + 1] = (uint8_t)min(255, max(0, __float2int_rn(t1)));
+        dst[t * 3 + 2] = (uint8_t)min(255, max(0, __float2int_rn(t2)));
+    }
+}
+
 // getCellAt on the device (PhotomosaicGeneratorBase.cpp:293-329; detail 1/scale):
 // the visible part of the target under the cell rect, zero elsewhere, as planes;
 // and the per-cell active mask = mask variant AND local bound (the CUDA path's
 // imageDifferenceEdge target_area test, CUDA/PhotomosaicGenerator.cu:53-72).
 __global__ void __launch_bounds__(kBlock)
 gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ target,
-                    int rows, int cols, int scale, const uint8_t* __restrict__ masks,
+                    int rows, int cols, CellResize scale, const uint8_t* __restrict__ masks,
                     float* __restrict__ cells, uint8_t* __restrict__ cmask,
                     int size, int P, int ppad, const int* __restrict__ perm, int4 var_of_mask,
                     uint8_t* __restrict__ cell_var, uint8_t* __restrict__ cell_full,
@@ -638,7 +711,7 @@ struct ResolveArgs {
     double* best_score;         // [grid_h*grid_w], pre-filled with NaN
     // pixel data for the exact tie-break
     const float* target; int rows, cols;
-    int cell_scale;             // full-size cell pixels per detail pixel and axis (cell_pixel)
+    CellResize cell_scale;      // how a detail pixel is made from the normal-size cell (cell_pixel)
     const uint8_t* masks;
     const float* lib;           // [variants][L][3][ppad], permuted pixel order per variant
     size_t lib_stride;          // floats between two variants

@@ -116,6 +116,19 @@ class Engine:
         self._check(self._lib.mm_shrink_library(self._h, int(factor)))
         self.size //= int(factor)
 
+    def set_library_u8_sized(self, images, diff_type, detail_size):
+        """u8 BGR library resized on the device to ANY detail cell size <= its own (general
+        INTER_AREA where the ratio is not whole) and colour-converted (preprocessLibraryImages)."""
+        a = np.ascontiguousarray(images, dtype=np.uint8)
+        if a.ndim != 4 or a.shape[1] != a.shape[2] or a.shape[3] != 3:
+            raise ValueError("library must be [n][size][size][3]")
+        self._check(self._lib.mm_set_library_u8_sized(self._h, _lib.ptr(a), a.shape[0], a.shape[1], int(detail_size), int(diff_type)))
+        self.n_library, self.size = a.shape[0], int(detail_size)
+
+    def set_cell_resize(self, normal_size, detail_size):
+        """Any detail level: cells of ``normal_size`` pixels are resized to ``detail_size`` (INTER_AREA)."""
+        self._check(self._lib.mm_set_cell_resize(self._h, int(normal_size), int(detail_size)))
+
     def set_cell_scale(self, factor):
         """Detail level 1/factor: cells are box-averaged from factor x factor image pixels."""
         self._check(self._lib.mm_set_cell_scale(self._h, int(factor)))

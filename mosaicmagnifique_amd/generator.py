@@ -124,11 +124,10 @@ class HIPPhotomosaicGenerator:
         t = self.m_colourDiffType
         detail_size = self.m_cells.getCellSize(0, True)
         if self.m_lib.dtype == np.uint8:
-            size = self.m_lib.shape[1]
-            if size % detail_size != 0:
-                raise NotImplementedError("library images of %d px at a detail cell of %d px: only whole-number "
-                                          "ratios are covered" % (size, detail_size))
-            self.m_engine.set_library_u8(self.m_lib, int(t), shrink=size // detail_size)
+            if self.m_lib.shape[1] < detail_size:
+                raise NotImplementedError("library images of %d px below the detail cell of %d px: INTER_CUBIC "
+                                          "enlargement is outside the hot path" % (self.m_lib.shape[1], detail_size))
+            self.m_engine.set_library_u8_sized(self.m_lib, int(t), detail_size)
         else:
             if self.m_lib.shape[1] != detail_size:
                 raise ValueError("a preprocessed (f32) library must be at the detail cell size %d" % detail_size)
@@ -201,7 +200,7 @@ class HIPPhotomosaicGenerator:
             if self._masks_key != id(detailShape):
                 self.m_engine.set_masks(detailShape.masks4())
                 self._masks_key = id(detailShape)
-            self.m_engine.set_cell_scale(self.m_cells.cellScale(step))
+            self.m_engine.set_cell_resize(self.m_cells.getCellSize(step), detailShape.getSize())
             state = self.m_bestFits[step]
             cells = GridUtility.cell_records(self.m_cells, state, self._rows, self._cols, step)
             # progress counts every grid position, weighted 4^(steps-1-step) (:54,:85-88)

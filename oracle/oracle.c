@@ -423,8 +423,41 @@ double orc_entropy(const uint8_t *bgr, int rows, int cols, const uint8_t *mask, 
     return entropy;
 }
 
+/* cv::resize(src, dst, Size(dc, dr), 0, 0, INTER_AREA) for a shrink of f32 HWC with cn channels
+ * by a ratio that is not whole: computeResizeAreaTab + ResizeArea_Invoker<float, float>
+ * (float accumulators, horizontal pass in table order, then down the contributing rows). */
+void orc_resize_area_f32(const float *src, int sr, int sc, int cn, int dr, int dc, float *dst)
+{
+    const double scale_x = 1.0 / ((double)dc / sc), scale_y = 1.0 / ((double)dr / sr);
+    area_tab *xt = (area_tab *)malloc(sizeof(area_tab) * 2u * (size_t)sc);
+    area_tab *yt = (area_tab *)malloc(sizeof(area_tab) * 2u * (size_t)sr);
+    const int nx = area_table(sc, dc, scale_x, xt), ny = area_table(sr, dr, scale_y, yt);
+    float *buf = (float *)malloc(sizeof(float) * (size_t)dc * cn);
+    float *sum = (float *)calloc((size_t)dc * cn, sizeof(float));
+    int prev = yt[0].di;
+    for (int j = 0; j < ny; ++j) {
+        const float beta = yt[j].alpha;
+        const float *row = src + (size_t)yt[j].si * sc * cn;
+        for (int i = 0; i < dc * cn; ++i) buf[i] = 0.f;
+        for (int k = 0; k < nx; ++k)
+            for (int ch = 0; ch < cn; ++ch)
+                buf[xt[k].di * cn + ch] += row[xt[k].si * cn + ch] * xt[k].alpha;
+        if (yt[j].di != prev) {
+            for (int i = 0; i < dc * cn; ++i) {
+                dst[(size_t)prev * dc * cn + i] = sum[i];
+                sum[i] = beta * buf[i];
+            }
+            prev = yt[j].di;
+        } else {
+            for (int i = 0; i < dc * cn; ++i) sum[i] += beta * buf[i];
+        }
+    }
+    for (int i = 0; i < dc * cn; ++i) dst[(size_t)prev * dc * cn + i] = sum[i];
+    free(xt); free(yt); free(buf); free(sum);
+}
+
 /* PhotomosaicGeneratorBase::getCellAt, PhotomosaicGeneratorBase.cpp:293-329, at any
- * detail whose cell-size ratio is a whole number: the visible part goes into a zero
+ * detail (a whole cell-size ratio is the box mean, any other the general INTER_AREA): the visible part goes into a zero
  * cell of the NORMAL size (:305-310), which is resized to the detail size (:313-315,
  * INTER_AREA), and the local bound is scaled by `detail` with int truncation and the
  * min / max guards (:318-326). */
@@ -445,7 +478,8 @@ orc_rect orc_cell_at_detail(const orc_shape *s, int detail_size, double detail, 
         memcpy(dst, src, sizeof(float) * 3u * (size_t)local.w);
     }
     if (full != cell_out) {
-        orc_shrink_f32(full, size, size, size / detail_size, cell_out);
+        if (size % detail_size == 0) orc_shrink_f32(full, size, size, size / detail_size, cell_out);
+        else orc_resize_area_f32(full, size, size, 3, detail_size, detail_size, cell_out);
         free(full);
     }
 

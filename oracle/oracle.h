@@ -116,6 +116,7 @@ void orc_shrink_f32(const float *src, int rows, int cols, int f, float *dst);
 void orc_shrink_u8(const uint8_t *src, int rows, int cols, int cn, int f, uint8_t *dst);
 /* colour-scheme variant: hue rotated by `degrees` through f32 HSV_FULL (ColourScheme.cpp:44-177) */
 void orc_hue_rotate_u8(const uint8_t *src, size_t n_pixels, float degrees, uint8_t *dst);
+void orc_resize_area_f32(const float *src, int sr, int sc, int cn, int dr, int dc, float *dst);
 void orc_resize_area_u8(const uint8_t *src, int sr, int sc, int cn, int dr, int dc, uint8_t *dst);
 /* ImageUtility::calculateEntropy (Other/ImageUtility.cpp:189-242); mask may be NULL. */
 double orc_entropy(const uint8_t *bgr, int rows, int cols, const uint8_t *mask, int mask_stride);

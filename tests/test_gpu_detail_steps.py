@@ -155,8 +155,64 @@ def test_build_photomosaic_over_size_steps(oracle):
         assert all(np.array_equal(a, b) for a, b in zip(gen.getBestFits(), fits))
 
 
-def test_unsupported_ratios_are_refused():
+def test_what_is_still_refused(engine):
     group = CellGroup(cases.square_shape(30))
-    group.setDetail(40)                       # 30 -> 12: ratio 2.5
-    with pytest.raises(NotImplementedError):
-        group.cellScale(0)
+    group.setDetail(40)                       # 30 -> 12: ratio 2.5, the general resize
+    assert group.cellScale(0) == 0
+    group.setDetail(50)
+    assert group.cellScale(0) == 2
+    from mosaicmagnifique_amd.engine import EngineError
+    with pytest.raises(EngineError):           # a detail cell larger than the cell: INTER_CUBIC, not on the path
+        engine.set_cell_resize(16, 24)
+    engine.set_library(synth.preprocess(synth.library_u8(4, 15), Type.RGB_EUCLIDEAN))
+    with pytest.raises(EngineError):           # halving an odd library size between size steps
+        engine.shrink_library(2)
+
+
+@pytest.mark.parametrize("detail_size", [23, 18, 17, 7, 1])
+def test_library_u8_general_resize_then_convert(oracle, engine, detail_size):
+    """A detail level whose cell-size ratio is not whole (24 -> 23 / 18 / 17 / 7 / 1 px): cv::resize's
+    general INTER_AREA on the u8 images (computeResizeAreaTab + ResizeArea_Invoker), then the
+    colour conversion.  Device == oracle == numpy restatement, byte for byte before conversion."""
+    lib = synth.library_u8(40, 24)
+    small = np.stack([oracle.resize_area_u8(im, detail_size, detail_size) for im in lib])
+    assert np.array_equal(small, np.stack([imageutil.resize_area_u8(im, detail_size, detail_size) for im in lib]))
+    for t in (Type.RGB_EUCLIDEAN, Type.CIE76):
+        engine.set_library_u8_sized(lib, int(t), detail_size)
+        got = engine.get_library()
+        want = synth.preprocess(small, t)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= (0 if t == Type.RGB_EUCLIDEAN else 1e-5)
+
+
+@pytest.mark.parametrize("shape_name,detail,t,rep", [
+    ("square32", 75, Type.RGB_EUCLIDEAN, (0, 0)),        # 32 -> 24: ratio 4/3
+    ("square32", 60, Type.CIEDE2000, (2, 400)),           # 32 -> 19
+    ("square32", 30, Type.CIE76, (1, 100)),               # 32 -> 9
+    ("hexagon", 75, Type.CIEDE2000, (2, 300)),            # 64 -> 48, overlapping rows, clipped x = -1 / y = -1 cells
+    ("flippy", 70, Type.CIE76, (1, 50)),                  # 24 -> 16 (int(16.8)), all four mask variants differ
+    ("square32", 97, Type.RGB_EUCLIDEAN, (0, 0)),         # 32 -> 31: almost every detail pixel straddles two
+])
+def test_fractional_detail(oracle, shape_name, detail, t, rep):
+    """Detail levels whose cell-size ratio is not a whole number: getCellAt's resize of the zero-filled
+    cell is the general INTER_AREA (f32, table order), the bound is scaled with int truncation, the
+    mask comes from CellShape::resized.  Indices bit-exact and scores within tolerance against the
+    oracle fed the same pre-processed arrays; ragged image sizes so clipped cells are resized too."""
+    shape = {"square32": lambda: cases.square_shape(32), "hexagon": cases.hexagon_shape,
+             "flippy": lambda: cases.flippy_shape(24)}[shape_name]()
+    size = shape.getSize()
+    img = synth.target_u8(4 * size + size // 3, 5 * size + size // 2, lattice=2 * size)
+    lib = synth.library_u8(70, size)
+    gen, _ = run_steps(oracle, shape, img, lib, t, detail, 0, rep)
+    assert gen.m_engine.size == max(int(size * detail / 100.0), 1)
+
+
+def test_fractional_detail_with_a_size_step(oracle):
+    """Detail 75 % with one size step where the sizes stay consistent (32 -> 24, 16 -> 12; the library
+    halves 24 -> 12): both steps use the general resize of the cell."""
+    img = synth.target_u8(150, 200, lattice=64)
+    noise = (synth.mix(0x91, np.arange(150)[:, None], np.arange(100)[None, :]) % np.uint32(200)).astype(np.int16) - 100
+    img[:, 100:] = np.clip(img[:, 100:].astype(np.int16) + noise[..., None], 0, 255).astype(np.uint8)
+    lib = synth.library_u8(60, 32)
+    gen, state = run_steps(oracle, cases.square_shape(32), img, lib, Type.CIEDE2000, 75, 1, (1, 200))
+    assert len(state) == 2 and (state[1] >= 0).any()

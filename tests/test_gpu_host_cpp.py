@@ -88,6 +88,8 @@ def test_host_cpp_matches_oracle(oracle, tmp_path, shape_name, t, rep):
     ("square32", Type.CIE76, (2, 300), 50, 1),          # CreateCellGroup(size, 1, 50), tst_CUDAGenerator.h
     ("hexagon", Type.CIEDE2000, (1, 200), 50, 2),
     ("square32", Type.RGB_EUCLIDEAN, (0, 0), 25, 0),
+    ("square32", Type.CIE76, (1, 100), 75, 1),          # ratio 4/3: the general INTER_AREA of cells and library
+    ("hexagon", Type.CIEDE2000, (0, 0), 40, 0),          # 64 -> 25
 ])
 def test_host_cpp_u8_inputs_detail_and_size_steps(oracle, tmp_path, shape_name, t, rep, detail, steps):
     """The C++ host fed like the reference's fixtures (u8 BGR image and library, detail 50 %, size
