@@ -807,6 +807,19 @@ __device__ void dense_row(const ResolveArgs& a, const mm_cell& rec, double* row,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int v = a.var_of_mask[rec.mask_id];
     const int* ip = a.inv_perm + (size_t)v * a.P;
+    {   // A cell with no active pixel (a sliver of an offset shape whose bound misses the mask) scores 0
+        // against every image: the commonest reason for a whole row, and it needs no pixel pass.
+        int any = 0;
+        for (int p = threadIdx.x; p < a.P && !any; p += kBlock) {
+            const int r = p / a.size, c = p - r * a.size;
+            any = mk[p] != 0 && r >= rec.row_min && r < rec.row_max && c >= rec.col_min && c < rec.col_max;
+        }
+        if (!__syncthreads_or(any)) {
+            for (int l = threadIdx.x; l < a.L; l += kBlock) row[l] = 0.0;
+            __syncthreads();
+            return;
+        }
+    }
     for (int l = 0; l < a.L; ++l) {
         const float* l0 = a.lib + (size_t)v * a.lib_stride + (size_t)l * 3 * a.ppad;
         double acc = 0.0;
