@@ -531,9 +531,10 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
             (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, (float*)e->cells_f0.p);
         HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
-        if (diff_type == MM_CIEDE2000) {
+        if (diff_type == MM_CIEDE2000)
             HIP_TRY(e, mm::launch_chroma_planes((const float*)e->cells.p, (float*)e->cell_chroma.p, (size_t)b, ppad, e->stream),
                     "Error during cell chroma kernel");
+        {
             HIP_TRY(e, mm::launch_group_sums((const float*)e->cells.p, (const uint8_t*)e->cmask.p, (size_t)ppad,
                                              (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 5,
                                              (size_t)b, ppad, e->stream),

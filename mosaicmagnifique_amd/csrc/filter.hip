@@ -362,6 +362,15 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
+    // Euclidean differences: the lower bound on the unvisited pixels needs no constants at all --
+    // by the triangle inequality of the Euclidean norm over a block's pixels
+    //   sum_block sqrt(d0^2 + d1^2 + d2^2) >= sqrt((sum d0)^2 + (sum d1)^2 + (sum d2)^2),
+    // from the three channel sums per image and 64-position block (group_sums_kernel).  Same
+    // prelude as filter_kernel: lane k takes blocks k*m .., suffix scan, group j reads lane (4 j) >> shift.
+    // Only for unclipped cells (the library's sums are over the mask's pixels).
+    bool use_lb = false;
+    if constexpr (TYPE != CIEDE2000) use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;
+    const int lane_shift = groups <= 16 ? 0 : (groups <= 32 ? 1 : 2), per_lane = 1 << lane_shift;
     const int l_end = min((tile + 1) * cand_per_block, L);
     for (int l = tile * cand_per_block + wave; l < l_end; l += kLdsBlock / kWave) {
         const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
@@ -369,11 +378,37 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
         const float4* b2 = b1 + pq;
         const float4* bc = reinterpret_cast<const float4*>(lib_chroma + (size_t)l * ppad);
         bool pruned = false;
+        float rest = 0.0f;                 // lane k: bound of everything from lane k's first block on
+        if (use_lb) {
+            const int n_blk = 4 * groups;
+            float d = 0.0f;
+            for (int i = 0; i < per_lane; ++i) {
+                const int blk = lane * per_lane + i;
+                if (blk >= n_blk) break;
+                const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + blk;
+                const float* ct = var.cell_stats + (size_t)cell * var.n_blocks + blk;
+                const size_t bs = var.lib_stats_stride, cs = var.cell_stats_stride;
+                // 2e-2: fp32 rounding of two 64-term sums of values <= 255, with margin
+                const float d0 = fmaxf(fabsf(ct[0] - st[0]) - 2e-2f, 0.0f);
+                const float d1 = fmaxf(fabsf(ct[2 * cs] - st[2 * bs]) - 2e-2f, 0.0f);
+                const float d2 = fmaxf(fabsf(ct[3 * cs] - st[3 * bs]) - 2e-2f, 0.0f);
+                d += 0.9999f * fsqrt(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
+            }
+            for (int off = 1; off < kWave; off <<= 1) {       // inclusive suffix scan over lanes
+                const float up = __shfl_down(d, off, kWave);
+                if (lane + off < kWave) d += up;
+            }
+            rest = d;
+            pruned = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), 0)) > limit;
+        }
         float acc = 0.0f, acc_edge = 0.0f;
-        if (groups > 0) {
+        if (!pruned && groups > 0) {
             LibGroup nxt = load_lib_group<TYPE>(b0, b1, b2, bc, lane);
             for (int j = 0; j < groups; ++j) {
-                if (j != 0 && wave_sum_dpp(acc) > limit) { pruned = true; break; }
+                if (j != 0) {
+                    const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), (4 * j) >> lane_shift)) : 0.0f;
+                    if (wave_sum_dpp(acc) + rest_j > limit) { pruned = true; break; }
+                }
                 const int q = lane + kWave * j;
                 const LibGroup cur = nxt;
                 if (j + 1 < groups) nxt = load_lib_group<TYPE>(b0, b1, b2, bc, q + kWave);   // one group ahead

@@ -83,3 +83,20 @@ def test_the_constants_are_worst_cases(oracle):
     h = np.deg2rad(np.linspace(0, 360, 360001))
     t = 1 - 0.17 * np.cos(h - np.deg2rad(30)) + 0.24 * np.cos(2 * h) + 0.32 * np.cos(3 * h + np.deg2rad(6)) - 0.20 * np.cos(4 * h - np.deg2rad(63))
     assert 0 < t.min() and t.max() < 1.93 and 0.015 * t.max() < 0.045
+
+
+@pytest.mark.parametrize("type_id,kind", [(0, "uniform"), (0, "patches"), (1, "close-patches"), (1, "blue")])
+def test_euclid_block_bound_never_exceeds_the_true_sum(oracle, type_id, kind):
+    """RGB-Euclidean / CIE76: sum_block |x_p - y_p| >= |sum_block x_p - sum_block y_p| (triangle
+    inequality of the Euclidean norm), the bound of filter_lds_kernel's early exit -- no constants."""
+    rng = np.random.default_rng(7 + sum(map(ord, kind)))
+    cell, lib = groups(rng, kind, 2000, n=64)
+    if type_id == 0:                                       # what RGB inputs look like: integer-valued 0..255
+        cell = np.clip(np.rint(cell * 2.0 + 60), 0, 255); lib = np.clip(np.rint(lib * 2.0 + 60), 0, 255)
+    cell, lib = cell.astype(np.float32), lib.astype(np.float32)
+    true = oracle.colour_diff_batch(type_id, cell.reshape(-1, 3), lib.reshape(-1, 3)).reshape(cell.shape[:2]).sum(1)
+    d = np.abs(cell.astype(np.float64).sum(1) - lib.astype(np.float64).sum(1))
+    bound = np.sqrt((d ** 2).sum(1))
+    assert (bound <= true * (1 + 1e-12) + 1e-9).all()
+    if kind == "patches":
+        assert np.median(bound / true) > 0.5

@@ -162,3 +162,15 @@ def test_early_exit_bound_keeps_every_contender(oracle, engine, kind):
     img = tiles.reshape(rows // size, cols // size, size, size, 3).transpose(0, 2, 1, 3, 4).reshape(rows, cols, 3).copy()
     tm = run_both(oracle, engine, cases.square_shape(size), img, lib, Type.CIEDE2000, rep=(1, 300))
     assert tm["dense_cells"] == 0
+
+
+@pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIE76])
+@pytest.mark.parametrize("size", [64, 48, 16])
+def test_euclid_early_exit_bound_keeps_every_contender(oracle, engine, t, size):
+    """The block-mean bound of the LDS filter kernel (Euclidean differences) at 16 / 9 / 1 groups per
+    cell, clipped cells included (they take the plain partial-sum exit): pruned == unpruned ==
+    fp64-only == oracle, with and without repeats."""
+    rows, cols = 3 * size + size // 2, 4 * size + size // 3
+    img, lib = cases.inputs(rows, cols, size, 150, t, lattice=size)
+    run_both(oracle, engine, cases.square_shape(size), img, lib, t)
+    run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(2, 3000))
