@@ -467,7 +467,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             (st = ensure(e, e->cont_f, (size_t)batch * Kc * sizeof(float), "Failed to allocate contenders")) ||
             (st = ensure(e, e->cont_s, (size_t)batch * Kc * sizeof(double), "Failed to allocate contenders")) ||
             (st = ensure(e, e->flags, (size_t)batch, "Failed to allocate cell flags")) ||
-            (st = ensure(e, e->edge_count, 8 * sizeof(unsigned int), "Failed to allocate edge counter")) ||
+            (st = ensure(e, e->edge_count, 16 * sizeof(unsigned int), "Failed to allocate edge counter")) ||
             (st = ensure(e, e->edges, (size_t)edge_cap * sizeof(mm::EdgeEntry), "Failed to allocate edge list")))
             return st;
     }

@@ -100,36 +100,52 @@ __device__ __forceinline__ LibGroup load_lib_group(const float4* b0, const float
 // (cell, candidate), lanes over float4 pixel groups, 4 waves = 4 candidates of
 // one cell; cells fastest within a group so resident workgroups share library tiles.
 template <int TYPE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
               const float* __restrict__ cell_chroma, const float* __restrict__ lib,
               const float* __restrict__ lib_chroma, float* __restrict__ scores,
               int n_cells, int L, int ppad, int cand_per_block, int cell_group,
               EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
               unsigned int edge_cap, const float* __restrict__ prune_above, int check_every,
-              const float4* __restrict__ hue_lut, Variants var, float lb_scale)
+              const float4* __restrict__ hue_lut, Variants var, float lb_scale, long long total_items)
 {
     __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
+    __shared__ unsigned int next_item;      // ... and workgroups pull (cell, tile) items: the hue table is loaded once
     // block statistics of the cell (early-exit bound), up to 4 blocks per lane
     __shared__ float cell_st[TYPE == CIEDE2000 ? 5 : 1][TYPE == CIEDE2000 ? 4 * kWave : 1];
-    if (threadIdx.x == 0) next_candidate = kBlock / kWave;
-    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut); else __syncthreads();
+    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
-    const long long bid = blockIdx.x;
     const long long per_group = (long long)cell_group * n_tiles;
+    const float* const lib_base = lib;
+    const float* const lib_chroma_base = lib_chroma;
+    // Persistent workgroups: as many as the device holds at once, each taking the next item of the
+    // launch order (cells fastest inside a group of cells, so the workgroups resident together share
+    // a few candidate tiles in L2) from a global counter.  A 33 KB table per 32-candidate tile was
+    // three times the HBM traffic of the launch in L2 -> LDS copies, and its latency idled the waves
+    // at every workgroup start.
+    for (;;) {
+    __syncthreads();                        // the previous item is done with next_candidate / cell_st
+    if (threadIdx.x == 0) {
+        next_item = atomicAdd(edge_count + 8, 1u);
+        next_candidate = kBlock / kWave;
+    }
+    __syncthreads();
+    // read back as a scalar: everything derived from it (cell, tile, plane addresses) stays in SGPRs
+    const long long bid = (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)next_item);
+    if (bid >= total_items) break;
     const int group = (int)(bid / per_group);
     const long long rem = bid - (long long)group * per_group;
     const int cells_here = min(cell_group, n_cells - group * cell_group);
     const int tile = (int)(rem / cells_here);
     const int cell = group * cell_group + (int)(rem - (long long)tile * cells_here);
-    if (tile >= n_tiles || cell >= n_cells) return;
+    if (tile >= n_tiles || cell >= n_cells) continue;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int v = var.cell_var[cell];
     const int groups = var.groups[v];                    // only the variant's active pixels
-    lib += (size_t)v * var.lib_stride;
-    lib_chroma += (size_t)v * var.chroma_stride;
+    lib = lib_base + (size_t)v * var.lib_stride;
+    lib_chroma = lib_chroma_base + (size_t)v * var.chroma_stride;
     // channel 0 from the plane that holds NaN at inactive pixels: their terms come out as
     // max(NaN, 0) = 0 (colour_diff_fast.hpp), so there is no mask to load or test here
     const float4* c0 = reinterpret_cast<const float4*>(cells_f0 + (size_t)cell * ppad);
@@ -299,6 +315,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         acc = wave_sum_f(acc + acc_edge);
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }
+    }   // next item
 }
 
 // LDS-resident form of filter_kernel: a 1024-thread workgroup (16 waves) stages ONE cell
@@ -758,12 +775,21 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                          const float* prune_above, hipStream_t stream)
 {
     const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : 32, cell_group = 512;
+    // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited), times two
+    // so a finishing workgroup's slot refills at once
+    auto persistent_grid = [&](const void* kern, long long items) -> unsigned {
+        int dev = 0, cus = 256, per_cu = 4;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, in.lds_pad_bytes) != hipSuccess || per_cu < 1) per_cu = 4;
+        (void)hipGetLastError();
+        return (unsigned)std::min<long long>(items, (long long)cus * per_cu * 2);
+    };
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long blocks = (long long)n_cells * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
     const int check_every = groups > 16 ? groups / 16 : 1;
-    hipError_t code = hipMemsetAsync(edge_count, 0, 8 * sizeof(unsigned int), stream);   // + diagnostics counters
+    hipError_t code = hipMemsetAsync(edge_count, 0, 16 * sizeof(unsigned int), stream);  // + diagnostics counters, work counter
     if (code != hipSuccess) return code;
     // LDS-resident form when the cell (4 planes + mask) fits beside the hue table
     const size_t lds_bytes = type == CIEDE2000 ? (size_t)(kHueLutSize + 1) * 16 + (size_t)ppad * 16 : (size_t)ppad * 12;
@@ -796,16 +822,16 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         if (in.lds_pad_bytes > 0 &&
             (code = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel<CIEDE2000>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)in.lds_pad_bytes)) != hipSuccess) return code;
-        filter_kernel<CIEDE2000><<<dim3((unsigned)blocks), kBlock, in.lds_pad_bytes, stream>>>(
+        filter_kernel<CIEDE2000><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<CIEDE2000>), blocks)), kBlock, in.lds_pad_bytes, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale);
+            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale, blocks);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
     } else {
-        filter_kernel<RGB_EUCLIDEAN><<<dim3((unsigned)blocks), kBlock, 0, stream>>>(
+        filter_kernel<RGB_EUCLIDEAN><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN>), blocks)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale);
+            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale, blocks);
     }
     return hipGetLastError();
 }
