@@ -174,3 +174,16 @@ def test_euclid_early_exit_bound_keeps_every_contender(oracle, engine, t, size):
     img, lib = cases.inputs(rows, cols, size, 150, t, lattice=size)
     run_both(oracle, engine, cases.square_shape(size), img, lib, t)
     run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(2, 3000))
+
+
+@pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIEDE2000])
+@pytest.mark.parametrize("size", [128, 96, 80, 32, 8])
+def test_early_exit_bound_at_every_cell_size_class(oracle, engine, t, size):
+    """The bound's prelude takes 1, 2 or 4 blocks per lane (cells up to 64, 90 and 128 px wide) and
+    groups start on lane boundaries only then; 80 px (25 groups) and 96 px (36 groups) sit in the
+    2- and 4-block classes with ragged last groups, 8 px cells have a single, mostly empty group.
+    Pruned == unpruned == fp64-only == oracle in each class."""
+    n_lib = 40 if size >= 80 else 90
+    rows, cols = 2 * size + size // 2, 3 * size + size // 4
+    img, lib = cases.inputs(rows, cols, size, n_lib, t, lattice=size)
+    run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(1, 500))
