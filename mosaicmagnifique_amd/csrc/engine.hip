@@ -265,7 +265,7 @@ mm_status prepare_planes(mm_engine* e)
         (st = ensure(e, e->lib_chroma, (size_t)n_var * L * ppad * sizeof(float), "Failed to allocate library chroma planes")) ||
         (st = ensure(e, e->lib_means, (size_t)L * 3 * sizeof(float), "Failed to allocate library means")) ||
         (st = ensure(e, e->pos_mask, pos_mask.size(), "Failed to allocate position masks")) ||
-        (st = ensure(e, e->lib_lsum, (size_t)5 * n_var * L * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")))
+        (st = ensure(e, e->lib_lsum, (size_t)7 * n_var * L * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")))
         return st;
     HIP_TRY(e, hipMemcpyAsync(e->pos_mask.p, pos_mask.data(), pos_mask.size(), hipMemcpyHostToDevice, e->stream),
             "Failed to copy position masks to device");
@@ -313,7 +313,7 @@ mm::Variants variants_of(const mm_engine* e)
     v.lib_stats = (const float*)e->lib_lsum.p;
     v.cell_stats = (const float*)e->cell_lsum.p;
     v.lib_stats_stride = (size_t)e->n_var * e->n_lib * (ppad / 64);
-    v.cell_stats_stride = e->cell_lsum.bytes / sizeof(float) / 5;
+    v.cell_stats_stride = e->cell_lsum.bytes / sizeof(float) / 7;
     v.n_blocks = ppad / 64;
     v.cell_full = (const uint8_t*)e->cell_full.p;
     return v;
@@ -454,7 +454,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     mm_status st;
     if ((st = ensure(e, e->cell_var, (size_t)batch, "Failed to allocate cell variants")) ||
         (st = ensure(e, e->cell_full, (size_t)batch, "Failed to allocate cell flags")) ||
-        (st = ensure(e, e->cell_lsum, (size_t)5 * batch * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
+        (st = ensure(e, e->cell_lsum, (size_t)7 * batch * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
         (st = ensure(e, e->cells, (size_t)batch * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
         (st = ensure(e, e->cmask, (size_t)batch * ppad, "Failed to allocate cell masks")) ||
         (st = ensure(e, e->scores, (size_t)batch * L * sizeof(double), "Failed to allocate variants")))
@@ -536,7 +536,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                     "Error during cell chroma kernel");
         {
             HIP_TRY(e, mm::launch_group_sums((const float*)e->cells.p, (const uint8_t*)e->cmask.p, (size_t)ppad,
-                                             (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 5,
+                                             (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 7,
                                              (size_t)b, ppad, e->stream),
                     "Error during cell group-sum kernel");
         }

@@ -113,7 +113,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
     __shared__ unsigned int next_item;      // ... and workgroups pull (cell, tile) items: the hue table is loaded once
     // block statistics of the cell (early-exit bound), up to 4 blocks per lane
-    __shared__ float cell_st[TYPE == CIEDE2000 ? 5 : 1][TYPE == CIEDE2000 ? 4 * kWave : 1];
+    __shared__ float cell_st[TYPE == CIEDE2000 ? 7 : 1][TYPE == CIEDE2000 ? 4 * kWave : 1];
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long per_group = (long long)cell_group * n_tiles;
@@ -167,10 +167,11 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // worst constants of a 256-pixel group g of the plane order in place of the per-pair ones:
     //   S_L <= S_L((max_g |L_cell - 50| + max_g |L_lib - 50|) / 2)         (the pair's mean lightness lies within; :138-139)
     //   C_bar' <= g(C_bar) = (1.5 - 0.5 sqrt(C_bar^7 / (C_bar^7 + 25^7))) C_bar, increasing, C_bar <= (max_g C_cell + max_g C_lib) / 2
-    //   S_C <= 1 + 0.045 g(.),   |R_T| <= sin(60 deg) * 2 sqrt(g^7 / (g^7 + 25^7))            (d_theta <= 30 deg; :132-136,:145)
+    //   S_C <= 1 + 0.045 g(.),   |R_T| <= sin(60 deg * E) * 2 sqrt(g^7 / (g^7 + 25^7)),  E = the largest exp(-((h_bar' - 275)/25)^2)
+    //   the two blocks' hue ranges allow (below; :132-136,:145)
     // and, by the triangle inequality of the Euclidean norm over the group's pixels,
     //   sum_{p in g} dE00 >= sqrt( (sum|dL|)^2 / S_L^2 + rho ((sum|da|)^2 + (sum|db|)^2) / S_C^2 ),  sum_p |dX| >= |sum_p X_cell - sum_p X_lib|,
-    // which needs FIVE precomputed numbers per image and group (group_sums_kernel) -- no pass
+    // which needs SEVEN precomputed numbers per image and block (group_sums_kernel) -- no pass
     // over the pixels.  Lane g holds group g's bound; a suffix scan turns it into "bound
     // of groups >= j".  The candidate is dropped once
     //   (trusted partial sum of groups < j) + (bound of groups >= j) > limit.
@@ -184,9 +185,9 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     if constexpr (TYPE == CIEDE2000) {
         use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;     // workgroup-uniform
         if (use_lb) {
-            // the cell's five numbers per block (group_sums_kernel) wait in LDS: read per candidate, no registers held
+            // the cell's seven numbers per block (group_sums_kernel) wait in LDS: read per candidate, no registers held
             for (int t = threadIdx.x; t < 4 * groups; t += kBlock)
-                for (int k = 0; k < 5; ++k)
+                for (int k = 0; k < 7; ++k)
                     cell_st[k][t] = var.cell_stats[(size_t)k * var.cell_stats_stride + (size_t)cell * var.n_blocks + t];
             __syncthreads();
         }
@@ -229,7 +230,19 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     const float cbar = 0.5f * (cell_st[4][blk] + st[4 * bs]);
                     const float gc = (1.5f - 0.5f * sqrt_ratio7(cbar)) * cbar;         // >= C_bar' of every pair
                     const float s_c = fmaf(0.045f, gc, 1.0f);
-                    const float rho = 1.0f - 0.86603f * sqrt_ratio7(gc);               // <= 1 - |R_T| / 2
+                    // |R_T| = sin(2 d_theta) R_C, d_theta = 30 deg * exp(-((h_bar' - 275) / 25)^2)  (:132-136,:145): the
+                    // pair's mean hue is the midpoint of its two hues or that +- 180 deg (:107-122), so its offset from
+                    // 275 deg lies in M, M + 180 or M - 180 with M = [(lo_cell + lo_lib) / 2, (hi_cell + hi_lib) / 2]
+                    // (the reference does not wrap h_bar' - 275, which only makes the true exponent more negative)
+                    const float m_lo = 0.5f * (cell_st[5][blk] + st[5 * bs]), m_hi = 0.5f * (cell_st[6][blk] + st[6 * bs]);
+                    const float off0 = fmaxf(0.0f, fmaxf(m_lo, -m_hi));
+                    const float off1 = fmaxf(0.0f, fmaxf(m_lo + 180.0f, -(m_hi + 180.0f)));
+                    const float off2 = fmaxf(0.0f, fmaxf(m_lo - 180.0f, -(m_hi - 180.0f)));
+                    const float off = fminf(off0, fminf(off1, off2));                  // least |h_bar' - 275| any pair can have
+                    const float e_max = fexp2(off * off * (-1.4426950408889634f / 625.0f));
+                    // v_sin_f32 takes revolutions: sin(60 deg * E) = sin(2 pi * E / 6); 1.001 + 1e-5 covers its error
+                    const float sin_2dt = fmaf(__builtin_amdgcn_sinf(e_max * (1.0f / 6.0f)), 1.001f, 1e-5f);
+                    const float rho = fmaxf(1.0f - sqrt_ratio7(gc) * sin_2dt, 0.0f);   // <= 1 - |R_T| / 2,  R_C = 2 sqrt_ratio7
                     // 1e-2: fp32 rounding of two 64-term sums of values <= ~128, with margin
                     const float t_l = fmaxf(fabsf(cell_st[0][blk] - st[0]) - 1e-2f, 0.0f) * frcp(s_l);
                     const float da = fmaxf(fabsf(cell_st[2][blk] - st[2 * bs]) - 1e-2f, 0.0f);
@@ -563,10 +576,15 @@ chroma_planes_kernel(const float* __restrict__ planar, float* __restrict__ chrom
 // Per-image statistics over each 64-position BLOCK of the plane order (four blocks make one of
 // the filter's 256-position groups; the plane order is tile-major, engine.hip prepare_planes, so
 // a block is a compact patch of the image), counting only the positions flagged in `mask`
-// (per image if mask_stride != 0, else shared).  Five arrays of [n_images][n_blocks] floats,
+// (per image if mask_stride != 0, else shared).  Seven arrays of [n_images][n_blocks] floats,
 // `block_stride` floats apart:
 //   0: sum of channel 0              1: max |channel 0 - 50|
 //   2: sum of channel 1              3: sum of channel 2        4: max sqrt(ch1^2 + ch2^2)
+//   5, 6: lowest / highest hue offset from 275 deg of the block's pixels, in degrees, signed in
+//         (-180, 180] with the seam at 95 deg, covering a' = (1 + G) a for every G in [0, 0.5]
+//         (ColourDifference.cpp:50-53,61-83) and widened by 0.01 deg; -180 / +180 ("anywhere") when a
+//         pixel's chroma is below 1e-3 (its hue is arbitrary and the reference's mean-hue rule changes,
+//         :108-109) or its own range crosses the seam.
 // One wave per (image, group): 16 lanes per block.  Feeds the lower bound of filter_kernel's early exit.
 __global__ void __launch_bounds__(kBlock)
 group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ mask, size_t mask_stride,
@@ -584,21 +602,36 @@ group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ 
     const uint32_t m = reinterpret_cast<const uint32_t*>(mask + img * mask_stride)[q];
     const bool on[4] = {(m & 0x000000ffu) != 0, (m & 0x0000ff00u) != 0, (m & 0x00ff0000u) != 0, (m & 0xff000000u) != 0};
     const float xs[4] = {x.x, x.y, x.z, x.w}, as[4] = {a.x, a.y, a.z, a.w}, bs[4] = {b.x, b.y, b.z, b.w};
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, dev = 0.f, cmax = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, dev = 0.f, cmax = 0.f, hlo = 180.0f, hhi = -180.0f;
+    bool anywhere = false;
+    auto offset_from_275 = [](float bb, float aa) {       // hue of (aa, bb) minus 275 deg, wrapped into (-180, 180]
+        float d = atan2f(bb, aa) * 57.29577951308232f - 95.0f;     // - 275 + 180
+        d -= 360.0f * floorf(d * (1.0f / 360.0f));
+        return d - 180.0f;
+    };
     for (int k = 0; k < 4; ++k)
         if (on[k]) {
             s0 += xs[k]; s1 += as[k]; s2 += bs[k];
             dev = fmaxf(dev, fabsf(xs[k] - 50.0f));
-            cmax = fmaxf(cmax, chroma_of(as[k], bs[k]));
+            const float ch = chroma_of(as[k], bs[k]);
+            cmax = fmaxf(cmax, ch);
+            const float p1 = offset_from_275(bs[k], as[k]), p2 = offset_from_275(bs[k], 1.5f * as[k]);
+            anywhere = anywhere || !(ch >= 1e-3f) || !(fabsf(p1 - p2) < 180.0f);
+            hlo = fminf(hlo, fminf(p1, p2)); hhi = fmaxf(hhi, fmaxf(p1, p2));
         }
     for (int off = 8; off > 0; off >>= 1) {              // within the block's 16 lanes
         s0 += __shfl_xor(s0, off, kWave); s1 += __shfl_xor(s1, off, kWave); s2 += __shfl_xor(s2, off, kWave);
         dev = fmaxf(dev, __shfl_xor(dev, off, kWave));
         cmax = fmaxf(cmax, __shfl_xor(cmax, off, kWave));
+        hlo = fminf(hlo, __shfl_xor(hlo, off, kWave)); hhi = fmaxf(hhi, __shfl_xor(hhi, off, kWave));
+        anywhere = anywhere || (__shfl_xor((int)anywhere, off, kWave) != 0);
     }
     if ((lane & 15) == 0) {
         float* o = stats + img * n_blocks + 4 * g + (lane >> 4);
         o[0] = s0; o[block_stride] = dev; o[2 * block_stride] = s1; o[3 * block_stride] = s2; o[4 * block_stride] = cmax;
+        const bool open = anywhere || hlo > hhi;          // hlo > hhi: no active pixel in the block
+        o[5 * block_stride] = open ? -180.0f : hlo - 0.01f;
+        o[6 * block_stride] = open ? 180.0f : hhi + 0.01f;
     }
 }
 

@@ -21,10 +21,10 @@ struct Variants {
     size_t lib_stride;          // floats between the planar libraries of two variants (L*3*ppad)
     size_t chroma_stride;       // floats between their chroma planes (L*ppad)
     int groups[4];
-    // lower bound of the filter's early exit (filter.hip): five statistics per image and
-    // 64-position block over the mask's active positions (group_sums_kernel), as five arrays
-    const float* lib_stats;     // 5 x [V][L][n_blocks], lib_stats_stride floats apart
-    const float* cell_stats;    // 5 x [B][n_blocks], cell_stats_stride floats apart
+    // lower bound of the filter's early exit (filter.hip): seven statistics per image and
+    // 64-position block over the mask's active positions (group_sums_kernel), as seven arrays
+    const float* lib_stats;     // 7 x [V][L][n_blocks], lib_stats_stride floats apart
+    const float* cell_stats;    // 7 x [B][n_blocks], cell_stats_stride floats apart
     size_t lib_stats_stride, cell_stats_stride;
     int n_blocks;               // ppad / 64
     const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask (not clipped)
@@ -56,7 +56,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                          const float* prune_above, hipStream_t stream);
 
 // stats array k (block_stride floats apart), [img][ppad / 64] over plane positions [64 b, 64 b + 64):
-// masked sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma.
+// masked sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma, hue range.
 hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
                              size_t block_stride, size_t n_images, int ppad, hipStream_t stream);
 

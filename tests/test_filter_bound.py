@@ -17,14 +17,43 @@ def sqrt_ratio7(x):
     return np.sqrt(u / (u + 1.0))
 
 
-def group_bound(cell, lib):
+def hue_offsets(px):
+    """Per block: range [lo, hi] of the pixels' hue offsets from 275 deg (signed, in (-180, 180], seam at
+    95 deg), covering a' = (1 + G) a for every G in [0, 0.5]; the full circle when a pixel's chroma is
+    (nearly) zero -- its hue is arbitrary and the reference's mean-hue rule changes -- or when a pixel's
+    own range crosses the seam."""
+    a, b = px[..., 1], px[..., 2]
+
+    def phi(aa):
+        return (np.degrees(np.arctan2(b, aa)) - 275.0 + 180.0) % 360.0 - 180.0
+    p1, p2 = phi(a), phi(1.5 * a)
+    lo, hi = np.minimum(p1, p2).min(-1) - 0.01, np.maximum(p1, p2).max(-1) + 0.01
+    bad = (np.hypot(a, b).min(-1) < 1e-3) | (np.abs(p1 - p2) >= 180.0).any(-1)
+    return np.where(bad, -180.0, lo), np.where(bad, 180.0, hi)
+
+
+def rotation_bound(cell, lib):
+    """Upper bound of exp(-((h_bar' - 275) / 25)^2) over all pixel pairs of the two blocks: the pair's
+    mean hue is the midpoint of the two hues or that +- 180 deg (ColourDifference.cpp:107-122)."""
+    clo, chi = hue_offsets(cell)
+    llo, lhi = hue_offsets(lib)
+    mlo, mhi = 0.5 * (clo + llo), 0.5 * (chi + lhi)
+
+    def dist(lo, hi):
+        return np.maximum(0.0, np.maximum(lo, -hi))
+    d = np.minimum(dist(mlo, mhi), np.minimum(dist(mlo + 180.0, mhi + 180.0), dist(mlo - 180.0, mhi - 180.0)))
+    return np.exp(-(d / 25.0) ** 2)
+
+
+def group_bound(cell, lib, hue_aware=True):
     """cell, lib: [..., n, 3] Lab pixels of one group -> lower bound of sum_p dE00."""
     dev = 0.5 * (np.abs(cell[..., 0] - 50).max(-1) + np.abs(lib[..., 0] - 50).max(-1))
     s_l = 1.0 + 0.015 * dev ** 2 / np.sqrt(20.0 + dev ** 2)
     cbar = 0.5 * (np.hypot(cell[..., 1], cell[..., 2]).max(-1) + np.hypot(lib[..., 1], lib[..., 2]).max(-1))
     gc = (1.5 - 0.5 * sqrt_ratio7(cbar)) * cbar
     s_c = 1.0 + 0.045 * gc
-    rho = 1.0 - 0.86603 * sqrt_ratio7(gc)
+    e_max = rotation_bound(cell, lib) if hue_aware else 1.0
+    rho = 1.0 - sqrt_ratio7(gc) * np.sin(np.radians(60.0) * e_max) * 1.0001          # 1 - |R_T| / 2, R_C = 2 sqrt_ratio7
     d = np.abs(cell.sum(-2) - lib.sum(-2))
     return np.sqrt((d[..., 0] / s_l) ** 2 + rho * (d[..., 1] ** 2 + d[..., 2] ** 2) / s_c ** 2)
 
@@ -51,6 +80,24 @@ def groups(rng, kind, n_groups, n=256):
             return np.stack([np.full_like(r, 50.0), r * np.cos(th), r * np.sin(th)], -1)
         r1 = rng.uniform(20, 100, (n_groups, 1)) + rng.normal(0, 1, (n_groups, n))
         return ray(r1), ray(r1 + rng.uniform(-15, 15, (n_groups, 1)))
+    if kind in ("hue-pairs", "hue-pairs-wide"):       # two narrow hue clusters at every relative position, incl. means at 275 and opposite hues
+        spread = 3.0 if kind == "hue-pairs" else 25.0
+        def cluster():
+            th = np.deg2rad(rng.uniform(0, 360, (n_groups, 1)) + rng.uniform(-spread, spread, (n_groups, n)))
+            r = rng.uniform(15, 110, (n_groups, 1)) + rng.normal(0, 3, (n_groups, n))
+            return np.stack([rng.uniform(20, 80, (n_groups, 1)) + rng.normal(0, 2, (n_groups, n)), r * np.cos(th), r * np.sin(th)], -1)
+        return cluster(), cluster()
+    if kind == "mean-at-275":             # hue clusters placed symmetrically about 275 deg (mean hue exactly where R_T peaks)
+        off = rng.uniform(0, 175, (n_groups, 1))
+        def side(sign):
+            th = np.deg2rad(275.0 + sign * off + rng.uniform(-2, 2, (n_groups, n)))
+            r = rng.uniform(30, 110, (n_groups, 1)) + rng.normal(0, 2, (n_groups, n))
+            return np.stack([rng.uniform(30, 70, (n_groups, 1)) + rng.normal(0, 2, (n_groups, n)), r * np.cos(th), r * np.sin(th)], -1)
+        return side(+1), side(-1)
+    if kind == "grey-pixel-inside":       # colourful blocks with one exactly grey pixel each (hue undefined there)
+        a, b = groups(rng, "hue-pairs", n_groups, n)
+        a[:, 0, 1:] = 0.0; b[:, 1, 1:] = 0.0
+        return a, b
     if kind == "near-grey":
         a, b = rng.uniform(lo, hi, (n_groups, n, 3)), rng.uniform(lo, hi, (n_groups, n, 3))
         a[..., 1:] *= 0.02; b[..., 1:] *= 0.02
@@ -62,16 +109,20 @@ def groups(rng, kind, n_groups, n=256):
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("kind", ["uniform", "patches", "close-patches", "blue", "blue-chroma-shift", "near-grey", "dark-vs-bright"])
-def test_group_bound_never_exceeds_the_true_sum(oracle, kind):
-    rng = np.random.default_rng(sum(map(ord, kind)))
-    cell, lib = groups(rng, kind, 1500)
+@pytest.mark.parametrize("n", [256, 64])
+@pytest.mark.parametrize("kind", ["uniform", "patches", "close-patches", "blue", "blue-chroma-shift", "near-grey", "dark-vs-bright",
+                                  "hue-pairs", "hue-pairs-wide", "mean-at-275", "grey-pixel-inside"])
+def test_group_bound_never_exceeds_the_true_sum(oracle, kind, n):
+    rng = np.random.default_rng(sum(map(ord, kind)) + n)
+    cell, lib = groups(rng, kind, 1500, n)
     cell, lib = cell.astype(np.float32), lib.astype(np.float32)        # what the engine holds
     true = oracle.colour_diff_batch(2, cell.reshape(-1, 3), lib.reshape(-1, 3)).reshape(cell.shape[:2]).sum(1)
     bound = group_bound(cell.astype(np.float64), lib.astype(np.float64))
     assert (bound <= true * (1 + 1e-9) + 1e-9).all(), (kind, (bound / np.maximum(true, 1e-30)).max())
     if kind in ("patches", "dark-vs-bright"):
         assert np.median(bound / true) > 0.25           # and it is worth having
+    if kind == "hue-pairs":                             # the hue-aware rotation bound is what makes it tight here
+        assert np.median(bound / true) > 1.3 * np.median(group_bound(cell.astype(np.float64), lib.astype(np.float64), hue_aware=False) / true)
 
 
 def test_the_constants_are_worst_cases(oracle):
