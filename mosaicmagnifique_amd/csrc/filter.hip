@@ -238,7 +238,9 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     const float off0 = fmaxf(0.0f, fmaxf(m_lo, -m_hi));
                     const float off1 = fmaxf(0.0f, fmaxf(m_lo + 180.0f, -(m_hi + 180.0f)));
                     const float off2 = fmaxf(0.0f, fmaxf(m_lo - 180.0f, -(m_hi - 180.0f)));
-                    const float off = fminf(off0, fminf(off1, off2));                  // least |h_bar' - 275| any pair can have
+                    // all hues of both blocks within less than 180 deg of each other: no pair wraps, the mean is the midpoint
+                    const float span = fmaxf(cell_st[6][blk], st[6 * bs]) - fminf(cell_st[5][blk], st[5 * bs]);
+                    const float off = span < 180.0f ? off0 : fminf(off0, fminf(off1, off2));   // least |h_bar' - 275| any pair can have
                     const float e_max = fexp2(off * off * (-1.4426950408889634f / 625.0f));
                     // v_sin_f32 takes revolutions: sin(60 deg * E) = sin(2 pi * E / 6); 1.001 + 1e-5 covers its error
                     const float sin_2dt = fmaf(__builtin_amdgcn_sinf(e_max * (1.0f / 6.0f)), 1.001f, 1e-5f);

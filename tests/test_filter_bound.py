@@ -42,6 +42,8 @@ def rotation_bound(cell, lib):
     def dist(lo, hi):
         return np.maximum(0.0, np.maximum(lo, -hi))
     d = np.minimum(dist(mlo, mhi), np.minimum(dist(mlo + 180.0, mhi + 180.0), dist(mlo - 180.0, mhi - 180.0)))
+    # every hue of both blocks within less than 180 deg of every other: no pair wraps, the mean is the midpoint
+    d = np.where(np.maximum(chi, lhi) - np.minimum(clo, llo) < 180.0, dist(mlo, mhi), d)
     return np.exp(-(d / 25.0) ** 2)
 
 
