@@ -280,7 +280,7 @@ mm_status mm_shrink_library_bgr(mm_engine *e, int factor);
  * penalty as parallel sweeps to the raster-order fix point ("max_sweeps", default 48, before the
  * chain takes over); "wave_resolve" / "row_pipeline" (default 1): the single-wave and the
  * row-pipelined forms of the chain.  "max_batch" (default 0 = sized
- * from free device memory): cap on the cells scored per device batch.  "spec_k" (default 6):
+ * from free device memory): cap on the cells scored per device batch.  "spec_k" (default 4):
  * length of mm_generate's speculative short lists, 0 = always the full length.  Results are
  * identical whatever the options. */
 mm_status mm_set_option(mm_engine *e, const char *name, int value);

@@ -61,7 +61,7 @@ struct mm_engine {
     int cell_normal = 0;         // normal cell size the area table was built for
     DevBuf area_tab;             // [detail + 1] first | [entries] src | [entries] alpha (kernels.hpp CellResize)
     int area_entries = 0;
-    int spec_k = 6;              // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
+    int spec_k = 4;              // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
     // per distinct mask in that mask's active-pixels-first order whenever either changes

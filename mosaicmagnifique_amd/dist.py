@@ -95,7 +95,7 @@ class ShardedBestFit:
             self._bufs = (key, idx, score, packed)
         return self._bufs[1], self._bufs[2], self._bufs[3]
 
-    def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0, spec_k=6):
+    def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0, spec_k=4):
         """cells: ALL valid cells in raster order (every rank passes the same array).
         Returns (best_fit, best_score) as Engine.generate does, identical on all ranks.
 

@@ -168,7 +168,7 @@ class Engine:
     def candidates_per_cell(self, repeat_range, repeat_addition):
         return self._lib.mm_candidates_per_cell(self.n_library, int(repeat_range), int(repeat_addition))
 
-    def speculative_candidates(self, repeat_range, repeat_addition, spec_k=6):
+    def speculative_candidates(self, repeat_range, repeat_addition, spec_k=4):
         """Length of the short lists worth scoring first (= candidates_per_cell when speculation does not pay)."""
         return self._lib.mm_speculative_candidates(self.n_library, int(repeat_range), int(repeat_addition), int(spec_k))
 

@@ -373,7 +373,7 @@ def test_negative_repeat_addition_promotes_any_candidate(oracle, wave_resolve):
     assert (inner[:, 1:] == inner[:, :-1]).mean() > 0.5        # the bonus makes neighbours agree
 
 
-@pytest.mark.parametrize("spec_k", [0, 2, 3, 6, 10])
+@pytest.mark.parametrize("spec_k", [0, 2, 3, 4, 6, 10])
 def test_speculative_short_lists_are_verified_and_deepened(oracle, engine, spec_k):
     """mm_generate scores short candidate lists first and lets the resolve verify each pick;
     unverified cells are deepened to the full list.  spec_k = 2 / 3 make that happen all the
@@ -391,7 +391,7 @@ def test_speculative_short_lists_are_verified_and_deepened(oracle, engine, spec_
         best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
         tm = engine.timing()
     finally:
-        engine.set_option("spec_k", 6)
+        engine.set_option("spec_k", 4)
     assert np.array_equal(np.where(best == len(lib), -1, best), want)
     valid = state >= 0
     assert (np.abs(score[valid] - want_score[valid]) <= 1e-12 * want_score[valid]).all()
