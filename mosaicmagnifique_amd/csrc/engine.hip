@@ -68,7 +68,6 @@ struct mm_engine {
     DevBuf lib_hwc, perm, inv_perm, cell_var, cell_full, pos_mask, lib_lsum, cell_lsum;
     std::vector<uint8_t> masks_host;
     bool planes_dirty = true;
-    float lib_dmax = 50.0f, target_dmax = 50.0f;    // max |c0 - 50| over the library / the target
     int n_var = 0, var_of_mask[4] = {0, 0, 0, 0}, var_groups[4] = {0, 0, 0, 0};
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
     int use_sweep_resolve = 1;   // mm_set_option("sweep_resolve", 0): raster-order chain instead of parallel sweeps
@@ -137,7 +136,6 @@ constexpr double kTieBand = 1e-9;
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-mm_status target_range(mm_engine* e);
 
 inline bool known_type(int t) { return t == MM_RGB_EUCLIDEAN || t == MM_CIE76 || t == MM_CIEDE2000; }
 
@@ -289,15 +287,7 @@ mm_status prepare_planes(mm_engine* e)
             "Error during library chroma kernel");
     HIP_TRY(e, mm::launch_image_means((const float*)e->lib.p, (float*)e->lib_means.p, L, P, ppad, e->stream),
             "Error during library mean kernel");
-    // range of the first channel (L for Lab inputs): bounds S_L for the filter's lightness bound
-    if ((st = ensure(e, e->counter, 2 * sizeof(unsigned long long), "Failed to allocate counter"))) return st;
-    HIP_TRY(e, hipMemsetAsync(e->counter.p, 0, sizeof(unsigned int), e->stream), "Failed to clear counter");
-    HIP_TRY(e, mm::launch_absmax_offset((const float*)e->lib.p, (size_t)L, (size_t)3 * ppad, ppad, 50.0f,
-                                        (unsigned int*)e->counter.p, e->stream), "Error during range kernel");
-    unsigned int bits = 0;
-    HIP_TRY(e, hipMemcpyAsync(&bits, e->counter.p, sizeof bits, hipMemcpyDeviceToHost, e->stream), "range");
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");   // host vectors go out of scope
-    memcpy(&e->lib_dmax, &bits, sizeof bits);
     e->planes_dirty = false;
     return MM_OK;
 }
@@ -488,11 +478,6 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.tile_candidates = e->tile_candidates;
     fin.lds_pad_bytes = (size_t)e->lds_pad_kb * 1024;
     fin.use_lds_form = e->use_lds_filter < 0 ? (diff_type != MM_CIEDE2000) : e->use_lds_filter;
-    {   // dE00 >= |dL| / S_L(max |L - 50|): S_L = 1 + 0.015 d^2 / sqrt(20 + d^2) grows with d (:138-139)
-        const double d = std::max(50.0, (double)std::max(e->lib_dmax, e->target_dmax));
-        const double s_l_max = 1.0 + 0.015 * d * d / std::sqrt(20.0 + d * d);
-        fin.lb_scale = std::isfinite(d) ? (float)((1.0 - 1e-5) / s_l_max) : 0.0f;
-    }
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     // Early exit needs seeds: K <= M <= 256 of them, and the L proxy distances in LDS.
     const int M = std::min(L, std::min(256, round_up(K + e->extra_seeds, 4)));
@@ -947,7 +932,7 @@ mm_status mm_set_target(mm_engine* e, const float* image, int rows, int cols)
     HIP_TRY(e, hipMemcpy(e->target.p, image, bytes, hipMemcpyHostToDevice), "Failed to copy main image to device");
     e->rows = rows;
     e->cols = cols;
-    return target_range(e);
+    return MM_OK;
 }
 
 namespace {
@@ -1006,20 +991,6 @@ mm_status preprocess_u8(mm_engine* e, const uint8_t* bgr, size_t n_images, int r
         diff_type != MM_RGB_EUCLIDEAN, (const double*)e->srgb_lut.p);
     HIP_TRY(e, hipGetLastError(), "Error during preprocessing kernel");
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
-    return MM_OK;
-}
-
-mm_status target_range(mm_engine* e)
-{
-    mm_status st;
-    if ((st = ensure(e, e->counter, 2 * sizeof(unsigned long long), "Failed to allocate counter"))) return st;
-    HIP_TRY(e, hipMemsetAsync(e->counter.p, 0, sizeof(unsigned int), e->stream), "Failed to clear counter");
-    HIP_TRY(e, mm::launch_absmax_offset((const float*)e->target.p, (size_t)e->rows * e->cols, 3, 1, 50.0f,
-                                        (unsigned int*)e->counter.p, e->stream), "Error during range kernel");
-    unsigned int bits = 0;
-    HIP_TRY(e, hipMemcpyAsync(&bits, e->counter.p, sizeof bits, hipMemcpyDeviceToHost, e->stream), "range");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
-    memcpy(&e->target_dmax, &bits, sizeof bits);
     return MM_OK;
 }
 
@@ -1107,7 +1078,7 @@ mm_status mm_set_target_u8(mm_engine* e, const uint8_t* bgr, int rows, int cols,
     if (st) return st;
     e->rows = rows;
     e->cols = cols;
-    return target_range(e);
+    return MM_OK;
 }
 
 mm_status mm_hue_rotate_u8(mm_engine* e, const uint8_t* bgr, int rows, int cols, float degrees, uint8_t* out)

@@ -107,7 +107,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
               int n_cells, int L, int ppad, int cand_per_block, int cell_group,
               EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
               unsigned int edge_cap, const float* __restrict__ prune_above, int check_every,
-              const float4* __restrict__ hue_lut, Variants var, float lb_scale, long long total_items)
+              const float4* __restrict__ hue_lut, Variants var, long long total_items)
 {
     __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
@@ -181,7 +181,6 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // never enter the exit test: only terms with a proven error bound may prune.
     const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
     bool use_lb = false;
-    (void)lb_scale;
     if constexpr (TYPE == CIEDE2000) {
         use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;     // workgroup-uniform
         if (use_lb) {
@@ -350,7 +349,7 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
                   int n_cells, int L, int ppad, int cand_per_block, int cell_group,
                   EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
                   unsigned int edge_cap, const float* __restrict__ prune_above,
-                  const float4* __restrict__ hue_lut, Variants var, float lb_scale)
+                  const float4* __restrict__ hue_lut, Variants var)
 {
     extern __shared__ float4 smem[];
     float4* lut = smem;                                             // [kHueLutSize + 1] (CIEDE2000)
@@ -477,23 +476,6 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
         acc = wave_sum_f(acc + acc_edge);
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }
-}
-
-// max over i < n_outer, k < n_inner of |x[i*outer_stride + k] - offset|, as float bits (>= 0, so
-// unsigned compare = float compare).  Used for max |L - 50| of the library / target.
-__global__ void __launch_bounds__(kBlock)
-absmax_offset_kernel(const float* __restrict__ x, size_t n_outer, size_t outer_stride, int n_inner,
-                     float offset, unsigned int* __restrict__ out_bits)
-{
-    float m = 0.0f;
-    const size_t total = n_outer * (size_t)n_inner;
-    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
-        const size_t i = t / n_inner;
-        const float d = fabsf(x[i * outer_stride + (t - i * n_inner)] - offset);
-        m = d > m ? d : m;               // NaN never raises the maximum
-    }
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
 }
 
 // One pair for the seed scores: fp32 form, with the fp64 form taken inline on the
@@ -839,7 +821,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                                             (int)lds_bytes)) != hipSuccess) return code;
             kern<<<dim3((unsigned)nblk), kLdsBlock, lds_bytes, stream>>>(
                 in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
-                edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, in.lb_scale);
+                edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var);
             if ((code = hipGetLastError()) != hipSuccess) return code;
             edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                          edges, edge_count, edge_cap, in.hue_lut, in.var);
@@ -849,7 +831,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                                             (int)lds_bytes)) != hipSuccess) return code;
             kern<<<dim3((unsigned)nblk), kLdsBlock, lds_bytes, stream>>>(
                 in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
-                edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, in.lb_scale);
+                edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var);
         }
         return hipGetLastError();
     }
@@ -859,14 +841,14 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)in.lds_pad_bytes)) != hipSuccess) return code;
         filter_kernel<CIEDE2000><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<CIEDE2000>), blocks)), kBlock, in.lds_pad_bytes, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale, blocks);
+            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, blocks);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
     } else {
         filter_kernel<RGB_EUCLIDEAN><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN>), blocks)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, in.lb_scale, blocks);
+            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, blocks);
     }
     return hipGetLastError();
 }
@@ -879,16 +861,6 @@ hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t ma
     if (waves == 0) return hipSuccess;
     group_sums_kernel<<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, stats, block_stride,
                                                                         n_images, n_groups, n_blocks, ppad);
-    return hipGetLastError();
-}
-
-hipError_t launch_absmax_offset(const float* x, size_t n_outer, size_t outer_stride, int n_inner, float offset,
-                                unsigned int* out_bits, hipStream_t stream)
-{
-    const size_t total = n_outer * (size_t)n_inner;
-    const unsigned blocks = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 4096);
-    if (blocks == 0) return hipSuccess;
-    absmax_offset_kernel<<<blocks, kBlock, 0, stream>>>(x, n_outer, outer_stride, n_inner, offset, out_bits);
     return hipGetLastError();
 }
 

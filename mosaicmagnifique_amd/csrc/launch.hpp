@@ -40,7 +40,6 @@ struct FilterInputs {
     const float* lib;           // f32 planar [L][3][ppad]
     const float* lib_chroma;    // f32 [L][ppad]
     const float4* hue_lut;      // [kHueLutSize + 1] {T, dT, sin(2 d_theta), d}  (colour_diff_fast.hpp)
-    float lb_scale;             // slightly under 1 / S_L,max: dE00 >= |dL| * lb_scale (filter.hip)
     int use_lds_form;           // 1: cell tile staged in LDS by 1024-thread workgroups when it fits
     int tile_candidates;        // candidates per workgroup of filter_kernel (0 = default)
     size_t lds_pad_bytes;       // diagnostics: unused dynamic LDS per filter workgroup (lowers the occupancy)
@@ -59,11 +58,6 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
 // masked sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma, hue range.
 hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
                              size_t block_stride, size_t n_images, int ppad, hipStream_t stream);
-
-// max |x - offset| over a strided set, written with atomicMax as float bits into *out_bits
-// (zero it first).
-hipError_t launch_absmax_offset(const float* x, size_t n_outer, size_t outer_stride, int n_inner, float offset,
-                                unsigned int* out_bits, hipStream_t stream);
 
 // Chroma planes of n planar images: [n][3][ppad] -> [n][ppad].
 hipError_t launch_chroma_planes(const float* planar, float* chroma, size_t n_images, int ppad, hipStream_t stream);
