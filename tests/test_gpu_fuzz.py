@@ -1,0 +1,73 @@
+"""Seeded random scenarios through the whole path (u8 inputs -> device pre-processing -> detail
+resize -> filter / re-score / resolve) against the oracle fed the same pre-processed arrays:
+random cell sizes (odd ones too), random masks, spacings, offsets and flips, any detail level,
+every colour difference, repeats on and off.  Each case is small; together they walk the
+corners the hand-written cases do not (ragged last groups of the tile-major plane order,
+2- and 4-block lanes of the early-exit bound, clipped cells at fractional detail ...)."""
+import numpy as np
+import pytest
+
+import cases
+from mosaicmagnifique_amd import GridUtility as G
+from mosaicmagnifique_amd import HIPPhotomosaicGenerator, synth
+from mosaicmagnifique_amd.cellshape import CellGroup, CellShape
+from mosaicmagnifique_amd.colourdifference import Type
+from oracle_ffi import shape_of
+
+pytestmark = pytest.mark.gpu
+
+
+def random_shape(rng, size):
+    kind = rng.integers(3)
+    if kind == 0:
+        return CellShape(size)
+    yy, xx = np.mgrid[0:size, 0:size]
+    if kind == 1:                                   # ellipse
+        c = (size - 1) / 2.0
+        mask = (((yy - c) / (c + 0.6)) ** 2 + ((xx - c) / (c * rng.uniform(0.6, 1.0) + 0.6)) ** 2 <= 1.0)
+    else:                                           # random blobs (some rows / columns may be empty)
+        mask = rng.uniform(size=(size, size)) < rng.uniform(0.3, 0.9)
+        mask[size // 2, size // 2] = True
+    s = CellShape(np.where(mask, 255, 0).astype(np.uint8))
+    s.rowSpacing = int(rng.integers(max(1, size // 2), size + 1))
+    s.colSpacing = int(rng.integers(max(1, size // 2), size + 1))
+    s.alternateRowSpacing = s.rowSpacing if rng.uniform() < 0.5 else int(rng.integers(max(1, size // 2), size + 1))
+    s.alternateColSpacing = s.colSpacing if rng.uniform() < 0.5 else int(rng.integers(max(1, size // 2), size + 1))
+    s.alternateRowOffset = int(rng.integers(0, size // 2 + 1))
+    s.alternateColOffset = int(rng.integers(0, size // 2 + 1))
+    s.alternateColFlipHorizontal, s.alternateColFlipVertical, s.alternateRowFlipHorizontal, s.alternateRowFlipVertical = \
+        (bool(v) for v in rng.integers(0, 2, 4))
+    return s
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_scenario(oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    size = int(rng.choice([8, 13, 16, 17, 24, 31, 32, 33, 40, 50, 64, 72]))
+    shape = random_shape(rng, size)
+    detail = int(rng.choice([100, 100, 50, 75, 60, 33, 25, 90]))
+    t = Type(int(rng.integers(0, 3)))
+    rep = (0, 0) if rng.uniform() < 0.35 else (int(rng.integers(1, 5)), int(rng.choice([1, 40, 700, 50000])))
+    rows = int(rng.integers(size + 1, 4 * size + 7))
+    cols = int(rng.integers(size + 1, 5 * size + 3))
+    n_lib = int(rng.integers(3, 60))
+    img = synth.target_u8(rows, cols, lattice=int(rng.choice([8, 32, 200])), seed=0x7A6 + seed)
+    lib = synth.library_u8(n_lib, size, seed=0x11B + seed)
+    if rng.uniform() < 0.3:                                        # exact duplicates: the lowest index must win
+        lib[int(rng.integers(n_lib))] = lib[int(rng.integers(n_lib))]
+    group = CellGroup(shape)
+    group.setDetail(detail)
+    state = G.getGridState(group, rows, cols)
+    gen = HIPPhotomosaicGenerator(0)
+    gen.setMainImage(img); gen.setLibrary(lib); gen.setColourDifference(t)
+    gen.setCellGroup(group); gen.setGridState(state); gen.setRepeat(*rep)
+    main, libf = gen.preprocessMainImage(), gen.preprocessLibraryImages()
+    assert gen.generateBestFits(), gen.lastError
+    d = group.getCell(0, True)
+    want, want_score, _ = oracle.generate_step(shape_of(group.getCell(0)), d.getSize(), group.getDetail(), main, libf,
+                                               d.masks4(), int(t), rep[0], rep[1], state=state[0])
+    got, score = gen.getBestFits()[0], gen.getBestScores()[0]
+    assert np.array_equal(got, want), (size, detail, int(t), rep, np.argwhere(got != want)[:4].tolist())
+    valid = want >= 0
+    tol = 1e-4 if t == Type.CIEDE2000 else 1e-12
+    assert (np.abs(score[valid] - want_score[valid]) <= tol * np.abs(want_score[valid]) + 1e-300).all()
