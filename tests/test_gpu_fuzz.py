@@ -71,3 +71,28 @@ def test_random_scenario(oracle, seed):
     valid = want >= 0
     tol = 1e-4 if t == Type.CIEDE2000 else 1e-12
     assert (np.abs(score[valid] - want_score[valid]) <= tol * np.abs(want_score[valid]) + 1e-300).all()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenario_with_size_steps(oracle, seed):
+    """The same, over size steps (entropy subdivision on a half-busy image, library halved per step,
+    cells resized per step) wherever the sizes stay consistent; checked step by step."""
+    from test_gpu_detail_steps import run_steps
+    rng = np.random.default_rng(5000 + seed)
+    size = int(rng.choice([16, 24, 32, 40, 48, 64]))
+    steps = int(rng.choice([1, 1, 2])) if size % 8 == 0 else 1
+    detail = int(rng.choice([100, 50, 25])) if size % (4 << steps) == 0 else 100
+    if size == 32 and rng.uniform() < 0.4:
+        detail, steps = 75, 1                                     # 32 -> 24, 16 -> 12: general resize in both steps
+    shape = random_shape(rng, size)
+    # halving keeps spacings >= 1 and the step sizes whole only for even spacings: keep the random ones even
+    for name in ("rowSpacing", "colSpacing", "alternateRowSpacing", "alternateColSpacing"):
+        setattr(shape, name, max(2, getattr(shape, name) // 2 * 2))
+    t = Type(int(rng.integers(0, 3)))
+    rep = (0, 0) if rng.uniform() < 0.4 else (int(rng.integers(1, 4)), int(rng.choice([30, 900])))
+    rows, cols = int(rng.integers(2 * size, 4 * size)), int(rng.integers(2 * size, 5 * size))
+    img = synth.target_u8(rows, cols, lattice=int(rng.choice([16, 64])), seed=0x7A6 + seed)
+    noise = rng.integers(-110, 111, (rows, cols // 2, 1))
+    img[:, cols - cols // 2:] = np.clip(img[:, cols - cols // 2:].astype(np.int16) + noise, 0, 255).astype(np.uint8)   # busy half: splits
+    lib = synth.library_u8(int(rng.integers(5, 50)), size, seed=0x11B + seed)
+    run_steps(oracle, shape, img, lib, t, detail, steps, rep)
