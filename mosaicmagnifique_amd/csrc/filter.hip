@@ -163,7 +163,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     //   dE00^2 = tL^2 + tC^2 + tH^2 + R_T tC tH >= tL^2 + (1 - |R_T|/2) (tC^2 + tH^2)        (:153-157)
     //   tC^2 + tH^2 >= (dC'^2 + dH'^2) / S_C^2            (S_H = 1 + 0.015 C' T <= S_C = 1 + 0.045 C', T < 1.93)
     //   dC'^2 + dH'^2 = |(a1', b1) - (a2', b2)|^2 >= da^2 + db^2                         (a' = (1 + G) a, G >= 0)
-    // so per pair  dE00 >= sqrt( (dL / S_L)^2 + rho (da^2 + db^2) / S_C^2 ),  rho = 1 - |R_T| / 2, and with the
+    // so per pair  dE00 >= sqrt( (dL / S_L)^2 + rho (da^2 + db^2) / S_C^2 ),  rho = 1 - |R_T| / 2 (sharpened below to the
+    // smallest eigenvalue of the chroma / hue form, which also knows that S_H < S_C), and with the
     // worst constants of a 256-pixel group g of the plane order in place of the per-pair ones:
     //   S_L <= S_L((max_g |L_cell - 50| + max_g |L_lib - 50|) / 2)         (the pair's mean lightness lies within; :138-139)
     //   C_bar' <= g(C_bar) = (1.5 - 0.5 sqrt(C_bar^7 / (C_bar^7 + 25^7))) C_bar, increasing, C_bar <= (max_g C_cell + max_g C_lib) / 2
@@ -243,14 +244,21 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     const float e_max = fexp2(off * off * (-1.4426950408889634f / 625.0f));
                     // v_sin_f32 takes revolutions: sin(60 deg * E) = sin(2 pi * E / 6); 1.001 + 1e-5 covers its error
                     const float sin_2dt = fmaf(__builtin_amdgcn_sinf(e_max * (1.0f / 6.0f)), 1.001f, 1e-5f);
-                    const float rho = fmaxf(1.0f - sqrt_ratio7(gc) * sin_2dt, 0.0f);   // <= 1 - |R_T| / 2,  R_C = 2 sqrt_ratio7
+                    const float half_rt = sqrt_ratio7(gc) * sin_2dt;                   // >= |R_T| / 2,  R_C = 2 sqrt_ratio7
                     // 1e-2: fp32 rounding of two 64-term sums of values <= ~128, with margin
                     const float t_l = fmaxf(fabsf(cell_st[0][blk] - st[0]) - 1e-2f, 0.0f) * frcp(s_l);
                     const float da = fmaxf(fabsf(cell_st[2][blk] - st[2 * bs]) - 1e-2f, 0.0f);
                     const float db = fmaxf(fabsf(cell_st[3][blk] - st[3 * bs]) - 1e-2f, 0.0f);
-                    const float inv_c = frcp(s_c);
-                    // 0.9999: v_rsq / v_rcp / v_sqrt are good to ~1 ulp
-                    d += 0.9999f * fsqrt(fmaf(t_l, t_l, rho * fmaf(da, da, db * db) * (inv_c * inv_c)));
+                    // tC^2 + tH^2 + R_T tC tH = (dC', dH') N (dC', dH')^T,  N = [[1/S_C^2, R_T/(2 S_C S_H)], [., 1/S_H^2]].
+                    // Its smallest eigenvalue falls as S_C, S_H or |R_T| grow (it is the minimum of y^T M y / (S_C^2 y1^2 +
+                    // S_H^2 y2^2) with M = [[1, R_T/2], [R_T/2, 1]] positive definite), so the block's worst constants give a
+                    // floor:  >= lambda (dC'^2 + dH'^2) >= lambda (da^2 + db^2);  S_H = 1 + 0.015 C' T <= 1 + 0.015 * 1.5726 g.
+                    const float inv_c = frcp(s_c), inv_h = frcp(fmaf(0.015f * 1.5726f, gc, 1.0f));
+                    const float na = inv_c * inv_c, nc = inv_h * inv_h, nb = half_rt * inv_c * inv_h;
+                    const float half_diff = 0.5f * (na - nc);
+                    // 0.999 and 0.9999: v_rsq / v_rcp / v_sqrt are good to ~1 ulp, and the difference of two close terms
+                    const float lambda = fmaxf(0.999f * (0.5f * (na + nc)) - fsqrt(fmaf(half_diff, half_diff, nb * nb)), 0.0f);
+                    d += 0.9999f * fsqrt(fmaf(t_l, t_l, lambda * fmaf(da, da, db * db)));
                 }
                 // inclusive suffix scan over lanes (lane j <- sum of lanes >= j)
                 for (int off = 1; off < kWave; off <<= 1) {

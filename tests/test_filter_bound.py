@@ -55,9 +55,14 @@ def group_bound(cell, lib, hue_aware=True):
     gc = (1.5 - 0.5 * sqrt_ratio7(cbar)) * cbar
     s_c = 1.0 + 0.045 * gc
     e_max = rotation_bound(cell, lib) if hue_aware else 1.0
-    rho = 1.0 - sqrt_ratio7(gc) * np.sin(np.radians(60.0) * e_max) * 1.0001          # 1 - |R_T| / 2, R_C = 2 sqrt_ratio7
+    r_t = 2.0 * sqrt_ratio7(gc) * np.sin(np.radians(60.0) * e_max) * 1.0001          # >= |R_T|, R_C = 2 sqrt_ratio7
+    # tC^2 + tH^2 + R_T tC tH = (dC', dH') N (dC', dH')^T with N = [[1/S_C^2, R_T/(2 S_C S_H)], [., 1/S_H^2]]: its smallest
+    # eigenvalue falls as S_C, S_H or |R_T| grow, so the worst constants of the block give a floor; S_H <= 1 + 0.015 * 1.5726 g
+    s_h = 1.0 + 0.015 * 1.5726 * gc
+    a, c, b = 1.0 / s_c ** 2, 1.0 / s_h ** 2, r_t / (2.0 * s_c * s_h)
+    lam = np.maximum(0.5 * (a + c) - np.sqrt(0.25 * (a - c) ** 2 + b ** 2), 0.0)
     d = np.abs(cell.sum(-2) - lib.sum(-2))
-    return np.sqrt((d[..., 0] / s_l) ** 2 + rho * (d[..., 1] ** 2 + d[..., 2] ** 2) / s_c ** 2)
+    return np.sqrt((d[..., 0] / s_l) ** 2 + lam * (d[..., 1] ** 2 + d[..., 2] ** 2))
 
 
 def groups(rng, kind, n_groups, n=256):
@@ -135,7 +140,7 @@ def test_the_constants_are_worst_cases(oracle):
     assert (np.diff(g) > 0).all()
     h = np.deg2rad(np.linspace(0, 360, 360001))
     t = 1 - 0.17 * np.cos(h - np.deg2rad(30)) + 0.24 * np.cos(2 * h) + 0.32 * np.cos(3 * h + np.deg2rad(6)) - 0.20 * np.cos(4 * h - np.deg2rad(63))
-    assert 0 < t.min() and t.max() < 1.93 and 0.015 * t.max() < 0.045
+    assert 0 < t.min() and t.max() < 1.5726 and 0.015 * t.max() < 0.045
 
 
 @pytest.mark.parametrize("type_id,kind", [(0, "uniform"), (0, "patches"), (1, "close-patches"), (1, "blue")])
