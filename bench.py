@@ -301,7 +301,7 @@ def main():
             "pair_evals_per_s": total_pa * w["L"] / launches_per_step / per_launch_s if per_launch_s > 0 else 0.0,
             "note": "achieved = bytes a naive stream would move / launch time (SURVEY 8d); the kernel skips pruned "
                     "pixel groups and shares tiles through L2, so measured traffic is lower and frac can pass 1: "
-                    "it is VALU-bound (profiles/r01_v10_configD_pmc_SQ.csv), not HBM-bound",
+                    "it is VALU-bound (profiles/r01_v11_configD_pmc_SQ.csv), not HBM-bound",
         },
         "stage_once_s": stage_s,
         "exact_rescored_per_step": exact / max(args.steps, 1),
