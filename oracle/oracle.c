@@ -779,6 +779,45 @@ int orc_generate_best_fits(const orc_shape *s, const float *img, int rows, int c
                              max_cells, early_exit);
 }
 
+/* The reference's pick for LISTED cells, each taken as the raster loop of
+ * generateBestFits (CPUPhotomosaicGenerator.cpp:63-91) reaches it when every earlier cell
+ * holds the pick recorded in `grid`: getCellAt, the flip state's mask, calculateRepeats over
+ * `grid` (it reads earlier cells only, :185-225), findCellBestFit.  `grid` is not written.
+ * If the answer equals grid[pos] for EVERY valid cell of a raster-order prefix, that prefix
+ * of `grid` is what the sequential loop produces (induction over the raster order), which
+ * lets a checker verify a finished grid with one independent call per cell, in parallel. */
+void orc_picks_given_grid(const orc_shape *s, int detail_size, double detail,
+                          const float *img, int rows, int cols,
+                          const float *lib, int64_t n_lib, const uint8_t *masks,
+                          int type, int repeat_range, int repeat_addition,
+                          int grid_w, int grid_h, const int64_t *grid,
+                          const int32_t *pos_x, const int32_t *pos_y, int n, int early_exit,
+                          int64_t *pick_out, double *score_out)
+{
+    const int size = detail_size;
+    const size_t px = (size_t)size * size;
+    float *cell = (float *)malloc(sizeof(float) * 3u * px);
+    const int rep_cap = repeat_range * (2 * repeat_range + 1) + repeat_range + 1;
+    int64_t *rep_keys = (int64_t *)malloc(sizeof(int64_t) * (size_t)(rep_cap > 0 ? rep_cap : 1));
+    int *rep_vals = (int *)malloc(sizeof(int) * (size_t)(rep_cap > 0 ? rep_cap : 1));
+    for (int k = 0; k < n; ++k) {
+        const int x = pos_x[k] - ORC_PAD_GRID, y = pos_y[k] - ORC_PAD_GRID;   /* padded -> grid coordinates */
+        const orc_rect bounds = orc_cell_at_detail(s, detail_size, detail, x, y, img, rows, cols, cell);
+        int fh, fv;
+        orc_flip_state_at(s, x, y, &fh, &fv);
+        const uint8_t *mask = masks + (size_t)(fh + 2 * fv) * px;
+        const int n_rep = orc_repeats(grid, grid_w, grid_h, pos_x[k], pos_y[k], repeat_range,
+                                      repeat_addition, rep_keys, rep_vals, rep_cap);
+        double best;
+        pick_out[k] = orc_find_cell_best_fit(type, cell, bounds, mask, size, lib, n_lib,
+                                             rep_keys, rep_vals, n_rep, early_exit, &best);
+        if (score_out) score_out[k] = best;
+    }
+    free(cell);
+    free(rep_keys);
+    free(rep_vals);
+}
+
 /* PhotomosaicGeneratorBase::buildPhotomosaic, PhotomosaicGeneratorBase.cpp:110-207,
  * single size step (so `mosaic = mosaicStep`, :197-201).  Library images get an
  * alpha channel of 255 (ImageUtility::addAlphaChannel, Other/ImageUtility.cpp:173-186). */

@@ -106,6 +106,18 @@ int orc_generate_best_fits(const orc_shape *s, const float *img, int rows, int c
                            int grid_w, int grid_h, int64_t *grid, double *scores,
                            int max_cells, int early_exit);
 
+/* The reference's pick for each listed cell (padded grid coordinates pos_x/pos_y) as the
+ * raster loop reaches it when every earlier cell holds the pick in `grid` (read only):
+ * a finished grid whose raster-order prefix passes this for every cell is the grid the
+ * sequential loop produces.  One independent evaluation per cell: a checker may thread it. */
+void orc_picks_given_grid(const orc_shape *s, int detail_size, double detail,
+                          const float *img, int rows, int cols,
+                          const float *lib, int64_t n_lib, const uint8_t *masks,
+                          int type, int repeat_range, int repeat_addition,
+                          int grid_w, int grid_h, const int64_t *grid,
+                          const int32_t *pos_x, const int32_t *pos_y, int n, int early_exit,
+                          int64_t *pick_out, double *score_out);
+
 /* ---- detail levels and size steps ------------------------
  * OpenCV (cv::resize, cv::cvtColor) is a third-party dependency absent from the
  * reference checkout (the project links a system OpenCV 4.x; no version is pinned in

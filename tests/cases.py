@@ -39,7 +39,25 @@ def flippy_shape(size=24):
     return s
 
 
+_last_inputs = {}
+
+
 def inputs(rows, cols, size, n_lib, diff_type, lattice=None, duplicates=()):
+    """_inputs, with the latest LARGE workload kept (read-only): the full-size tests ask for
+    the same one several times in a row and building config D takes ~15 s of numpy."""
+    if (rows * cols + n_lib * size * size) * 12 < (64 << 20):
+        return _inputs(rows, cols, size, n_lib, diff_type, lattice, duplicates)
+    key = (rows, cols, size, n_lib, int(diff_type), lattice, tuple(duplicates))
+    if key not in _last_inputs:
+        _last_inputs.clear()
+        _last_inputs[key] = _inputs(rows, cols, size, n_lib, diff_type, lattice, duplicates)
+    img, lib = _last_inputs[key]
+    img.setflags(write=False)
+    lib.setflags(write=False)
+    return img, lib
+
+
+def _inputs(rows, cols, size, n_lib, diff_type, lattice=None, duplicates=()):
     """(target f32 HWC, library f32 [n][size][size][3]) after the colour conversion of
     the given difference type.  duplicates: (dst, src) pairs -- library image dst
     becomes a copy of src (exact ties)."""

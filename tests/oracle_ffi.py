@@ -92,6 +92,9 @@ class Oracle:
         lib.orc_grid_state_steps.argtypes = [vp, vp, vp, i, d, vp, i, i, vp, vp, vp]
         lib.orc_build_photomosaic_steps.restype = None
         lib.orc_build_photomosaic_steps.argtypes = [vp, i, i, i, vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp]
+        lib.orc_picks_given_grid.restype = None
+        lib.orc_picks_given_grid.argtypes = [ctypes.POINTER(Shape), i, d, vp, i, i, vp, ctypes.c_int64, vp,
+                                             i, i, i, i, i, vp, vp, vp, i, i, vp, vp]
         lib.orc_generate_best_fits.restype = i
         lib.orc_generate_best_fits.argtypes = [ctypes.POINTER(Shape), vp, i, i, vp, ctypes.c_int64, vp,
                                                i, i, i, i, i, vp, vp, i, i]
@@ -164,6 +167,48 @@ class Oracle:
             1 if early_exit else 0)
         return grid, scores, done
 
+    def picks_given_grid(self, shape, img, lib_images, masks, type_id, repeat_range, repeat_addition,
+                         grid, positions, threads=1, early_exit=True):
+        """The reference's pick (and bestVariant) for each padded position (gy, gx) in
+        ``positions`` as its raster loop reaches that cell when every earlier cell holds
+        the pick in ``grid`` (int64 [gh][gw], -1 = nullopt; an engine's sentinel L must be
+        mapped to -1 first).  If the picks equal grid[gy, gx] on every valid cell of a
+        raster-order prefix, that prefix IS the sequential loop's result (induction), so a
+        finished grid is verified with independent per-cell calls -- spread over ``threads``
+        host threads here (ctypes releases the GIL).  Returns (picks int64 [n], scores f64 [n])."""
+        import threading
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        lib_images = np.ascontiguousarray(lib_images, dtype=np.float32)
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        grid = np.ascontiguousarray(grid, dtype=np.int64)
+        pos = np.asarray(positions, dtype=np.int32).reshape(-1, 2)
+        n = len(pos)
+        py = np.ascontiguousarray(pos[:, 0])
+        px = np.ascontiguousarray(pos[:, 1])
+        picks = np.full(n, -2, dtype=np.int64)
+        scores = np.full(n, np.nan, dtype=np.float64)
+        threads = max(1, min(int(threads), n))
+
+        def work(k):
+            # interleaved shares: early cells of the raster tend to cost the same as late ones
+            idx = np.arange(k, n, threads)
+            sx, sy = np.ascontiguousarray(px[idx]), np.ascontiguousarray(py[idx])
+            p = np.empty(len(idx), dtype=np.int64)
+            sc = np.empty(len(idx), dtype=np.float64)
+            self.lib.orc_picks_given_grid(
+                ctypes.byref(shape), shape.size, 1.0, img.ctypes.data, img.shape[0], img.shape[1],
+                lib_images.ctypes.data, lib_images.shape[0], masks.ctypes.data, int(type_id),
+                int(repeat_range), int(repeat_addition), grid.shape[1], grid.shape[0], grid.ctypes.data,
+                sx.ctypes.data, sy.ctypes.data, len(idx), 1 if early_exit else 0, p.ctypes.data, sc.ctypes.data)
+            picks[idx] = p
+            scores[idx] = sc
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return picks, scores
 
     # -- detail levels and size steps ------------------------------------------
     def shrink_f32(self, img, f):

@@ -1,6 +1,20 @@
-"""BASELINE.json's full-size configurations on the GPU, checked through properties
-that do not need a full CPU pass: oracle parity on a raster-order prefix of cells,
-library-reversal equivariance, shard/whole agreement."""
+"""BASELINE.json's full-size configurations on the GPU (the shape of the reference's
+whole-grid CPU == device pins, test/tst_CUDAGenerator.h:163-212,530-815):
+
+* config A: the whole grid against the oracle;
+* config B at 1024 x 1024 (same cells, same library): the whole grid against the oracle;
+* config D: the first TWO FULL ROWS (128 cells, so the repeat window's rows-above half is
+  exercised) against the oracle, verified cell by cell in parallel on the host
+  cores (oracle_ffi.picks_given_grid: the induction over the raster order); 32 random
+  interior cells' two lowest base scores against the oracle without early exit;
+* configs C, D and E's one-rank shard: the default path (early-exit bound + fp32 filter +
+  fp64 arbiter) gives the same whole grid and bit-equal scores as the unpruned path and as
+  the fp64-only path -- the bound and the filter band are content dependent, so they are
+  checked at the sizes that are benchmarked, over every cell;
+* the older properties: oracle parity on a raster-order prefix, library-reversal
+  equivariance, shard/whole agreement."""
+import os
+
 import numpy as np
 import pytest
 
@@ -28,6 +42,101 @@ def prefix_parity(oracle, shape, img, lib, t, rep, best, score, n_prefix, rel_to
         gy, gx = r["grid_y"], r["grid_x"]
         assert best[gy, gx] == want[gy, gx], (gy, gx)
         assert abs(score[gy, gx] - want_score[gy, gx]) <= rel_tol * want_score[gy, gx]
+
+
+_e_shard = {}
+
+
+def e_shard_inputs():
+    """Config E as ONE rank of 8 sees it: the first ceil(29 241 / 8) cells, the target band
+    holding them (full width 8192), the 10 000-image library."""
+    if not _e_shard:
+        t, L, size = Type.CIEDE2000, 10000, 48
+        shape = cases.square_shape(size)
+        group = cases.group_of(shape)
+        full_state = G.getGridState(group, 8192, 8192)[0]
+        assert int((full_state >= 0).sum()) == 171 * 171
+        n_shard = -(-171 * 171 // 8)
+        band_rows = (n_shard // 171 + 2) * size
+        img = synth.preprocess(synth.target_u8(band_rows, 8192, lattice=64), t)
+        lib = synth.preprocess(synth.library_u8(L, size), t)
+        cells = G.cell_records(group, full_state, 8192, 8192)[:n_shard]
+        _e_shard["v"] = (t, L, shape, img, lib, cells, n_shard)
+    return _e_shard["v"]
+
+
+def host_threads(cap=16):
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, cap))
+
+
+def with_options(engine, options, fn):
+    """fn() with the engine options set, then the defaults restored (session-wide engine)."""
+    try:
+        for k, v in options.items():
+            engine.set_option(k, v)
+        return fn()
+    finally:
+        for k in options:
+            engine.set_option(k, 1)
+
+
+def assert_same_on_every_path(engine, cells, gw, gh, t, rep, valid, L):
+    """Default path == early exit off == fp64 only: whole grid, bit-equal scores."""
+    run = lambda: engine.generate(cells, gw, gh, int(t), *rep)
+    best, score = run()
+    tm = engine.timing()
+    assert (best[valid] < L).all() and (best[~valid] == L).all()
+    assert tm["seed_ms"] > 0 and tm["rescore_ms"] > 0          # the pruned two-tier path did run
+    nb, ns = with_options(engine, {"prune": 0}, run)
+    assert np.array_equal(nb, best), int((nb != best).sum())
+    assert np.array_equal(ns[valid], score[valid])
+    fb, fs = with_options(engine, {"filter": 0}, run)
+    assert engine.timing()["rescore_ms"] == 0
+    assert np.array_equal(fb, best), int((fb != best).sum())
+    assert np.array_equal(fs[valid], score[valid])
+    return best, score, tm
+
+
+def test_config_a_rgb_512_square32_l100_whole_grid(oracle, engine):
+    """Config A (BASELINE configs[0], the reference's own CPU-runnable case): 512 x 512 target,
+    32 x 32 square cells, 100 images, RGB-Euclidean -- all 256 cells against the oracle's
+    sequential run; with and without the repeat penalty."""
+    t, L, size = Type.RGB_EUCLIDEAN, 100, 32
+    shape = cases.square_shape(size)
+    img, lib = cases.inputs(512, 512, size, L, t, lattice=64)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, 512, 512)[0]
+    cells = G.cell_records(group, state, 512, 512)
+    assert len(cells) == 256
+    stage(engine, shape, img, lib)
+    valid = state >= 0
+    for rep in ((0, 0), (4, 500)):
+        best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+        want, want_score, done = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), *rep)
+        assert done == 256
+        assert np.array_equal(best[valid], want[valid]) and (best[~valid] == L).all()
+        assert np.array_equal(score[valid], want_score[valid])         # Euclid terms are bit-identical (DESIGN 2)
+
+
+def test_config_b_reduced_rgb_1024_square64_l1000_whole_grid(oracle, engine):
+    """Config B on a 1024 x 1024 target (256 of its 64 x 64 cells, the full 1000-image
+    library): the whole grid against the oracle."""
+    t, L, size = Type.RGB_EUCLIDEAN, 1000, 64
+    shape = cases.square_shape(size)
+    img, lib = cases.inputs(1024, 1024, size, L, t, lattice=64)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, 1024, 1024)[0]
+    cells = G.cell_records(group, state, 1024, 1024)
+    assert len(cells) == 256
+    stage(engine, shape, img, lib)
+    best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t))
+    grid = np.where(best < L, best, -1)
+    pos = np.stack([cells["grid_y"], cells["grid_x"]], axis=1)
+    picks, scores = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), 0, 0, grid, pos,
+                                            threads=host_threads())
+    assert np.array_equal(picks, best[pos[:, 0], pos[:, 1]])
+    assert np.array_equal(scores, score[pos[:, 0], pos[:, 1]])
 
 
 def test_config_b_rgb_2048_square64_l1000(oracle, engine):
@@ -74,6 +183,18 @@ def test_config_c_ciede2000_2048_hexagon_l1000(oracle, engine):
     assert len(clipped) > 100
 
 
+def test_config_c_whole_grid_same_on_every_path(engine):
+    """Config C (Hexagon mask, clipped border cells), all cells: default == unpruned == fp64-only."""
+    t, L = Type.CIEDE2000, 1000
+    shape = cases.hexagon_shape()
+    img, lib = cases.inputs(2048, 2048, 64, L, t, lattice=64)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, 2048, 2048)[0]
+    cells = G.cell_records(group, state, 2048, 2048)
+    stage(engine, shape, img, lib)
+    assert_same_on_every_path(engine, cells, state.shape[1], state.shape[0], t, (0, 0), state >= 0, L)
+
+
 def test_config_d_ciede2000_4096_l5000_repeat4(oracle, engine):
     """Config D (the headline): 4096 cells x 5000 images, repeat range 4 (+500).
     Oracle parity on the first 6 cells of the raster (they already see each other
@@ -100,20 +221,91 @@ def test_config_d_ciede2000_4096_l5000_repeat4(oracle, engine):
     assert same_rep <= same_plain
 
 
+def test_config_d_first_two_rows_and_interior_cells_vs_oracle(oracle, engine):
+    """Config D against the oracle where SURVEY 8(d) asks for it: the first 2 full rows
+    (128 cells; from the second row on a cell's repeat window holds rows above it), each
+    cell evaluated by the oracle exactly as the reference's raster loop reaches it with
+    the earlier cells at the engine's picks -- equality on the whole prefix is equality
+    with the sequential run (induction).  Then 32 random interior cells: their two lowest
+    BASE scores (no penalty) from mm_score_cells against the oracle without early exit;
+    the runner-up is the oracle's pick once the winner carries a large repeat value."""
+    t, L, size, rep = Type.CIEDE2000, 5000, 64, (4, 500)
+    shape = cases.square_shape(size)
+    img, lib = cases.inputs(4096, 4096, size, L, t, lattice=64)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, 4096, 4096)[0]
+    cells = G.cell_records(group, state, 4096, 4096)
+    stage(engine, shape, img, lib)
+    best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    grid = np.where(best < L, best, -1)
+    sh, masks, nthr = shape_of(shape), shape.masks4(), host_threads()
+
+    prefix = cells[:128]
+    assert prefix["grid_y"].max() - prefix["grid_y"].min() == 1          # two full rows of 64
+    pos = np.stack([prefix["grid_y"], prefix["grid_x"]], axis=1)
+    picks, scores = oracle.picks_given_grid(sh, img, lib, masks, int(t), rep[0], rep[1], grid, pos, threads=nthr)
+    got = best[pos[:, 0], pos[:, 1]]
+    assert np.array_equal(picks, got), np.flatnonzero(picks != got)
+    rel = np.abs(scores - score[pos[:, 0], pos[:, 1]]) / scores
+    assert rel.max() <= 1e-4, rel.max()
+    # the window was exercised: second-row picks that differ from the unpenalised choice
+    plain, _ = engine.generate(cells, state.shape[1], state.shape[0], int(t))
+    assert (plain[pos[64:, 0], pos[64:, 1]] != got[64:]).any()
+
+    rng = np.random.default_rng(20261003)
+    inner = cells[(cells["grid_y"] >= 8) & (cells["grid_x"] >= 8)]
+    sample = inner[rng.choice(len(inner), 32, replace=False)]
+    idx, sc = engine.score_cells(sample, int(t), 2)
+    spos = np.stack([sample["grid_y"], sample["grid_x"]], axis=1)
+    empty = np.full_like(grid, -1)
+    first, first_score = oracle.picks_given_grid(sh, img, lib, masks, int(t), 0, 0, empty, spos, threads=nthr,
+                                                 early_exit=False)
+    assert np.array_equal(first, idx[:, 0])
+    assert (np.abs(first_score - sc[:, 0]) <= 1e-4 * first_score).all()
+    # runner-up: put the winner in the cell's left neighbour with a repeat value no score reaches
+    second = np.empty(32, np.int64)
+    second_score = np.empty(32)
+    for k, (gy, gx) in enumerate(spos):
+        g = empty.copy()
+        g[gy, gx - 1] = first[k]
+        p, s = oracle.picks_given_grid(sh, img, lib, masks, int(t), 1, 1 << 30, g, spos[k:k + 1], early_exit=False)
+        second[k], second_score[k] = p[0], s[0]
+    assert np.array_equal(second, idx[:, 1])
+    assert (np.abs(second_score - sc[:, 1]) <= 1e-4 * second_score).all()
+
+
+def test_config_d_whole_grid_same_on_every_path(engine):
+    """Config D, all 4096 cells: default == unpruned == fp64-only, indices and scores."""
+    t, L, size, rep = Type.CIEDE2000, 5000, 64, (4, 500)
+    shape = cases.square_shape(size)
+    img, lib = cases.inputs(4096, 4096, size, L, t, lattice=64)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, 4096, 4096)[0]
+    cells = G.cell_records(group, state, 4096, 4096)
+    stage(engine, shape, img, lib)
+    assert_same_on_every_path(engine, cells, state.shape[1], state.shape[0], t, rep, state >= 0, L)
+
+
+def test_config_e_shard_same_on_every_path(engine):
+    """Config E's first 1/8 shard (3656 cells of 48 x 48, 10 000 images): the candidate lists of
+    the default path == unpruned == fp64-only, indices and scores."""
+    t, L, shape, img, lib, cells, n_shard = e_shard_inputs()
+    stage(engine, shape, img, lib)
+    k = engine.candidates_per_cell(0, 0)
+    run = lambda: engine.score_cells(cells, int(t), k)
+    idx, sc = run()
+    assert engine.timing()["seed_ms"] > 0
+    for options in ({"prune": 0}, {"filter": 0}):
+        i2, s2 = with_options(engine, options, run)
+        assert np.array_equal(i2, idx), (options, int((i2 != idx).sum()))
+        assert np.array_equal(s2, sc), options
+
+
 def test_config_e_one_rank_shard_48px_cells_l10000(oracle, engine):
     """Config E as ONE rank of 8 sees it: the first 1/8 of the 29 241 cells (48x48
     cells, 10 000 images, CIEDE2000), scored with the split API.  The target band
     holding those cells is generated at full width (8192)."""
-    t, L, size = Type.CIEDE2000, 10000, 48
-    shape = cases.square_shape(size)
-    group = cases.group_of(shape)
-    full_state = G.getGridState(group, 8192, 8192)[0]
-    assert int((full_state >= 0).sum()) == 171 * 171
-    n_shard = -(-171 * 171 // 8)
-    band_rows = (n_shard // 171 + 2) * size
-    img = synth.preprocess(synth.target_u8(band_rows, 8192, lattice=64), t)
-    lib = synth.preprocess(synth.library_u8(L, size), t)
-    cells = G.cell_records(group, full_state, 8192, 8192)[:n_shard]
+    t, L, shape, img, lib, cells, n_shard = e_shard_inputs()
     stage(engine, shape, img, lib)
     k = engine.candidates_per_cell(0, 0)
     idx, sc = engine.score_cells(cells, int(t), k)
