@@ -1,26 +1,42 @@
 #!/usr/bin/env python3
 """Headline benchmark: cells matched / second on the photomosaic best-fit path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config D|B|C|A|E8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config D|A|B|C|E|E8]
+                    [--scaling weak|strong] [--mcs FILE.mcs] [--mil FILE.mil]
 
 A "step" is one full pass of the hot path (generateBestFits for one size step)
 over the whole cell batch, with library, masks and target already resident in
 HBM.  Default workload = BASELINE.json config D, the one the north-star target is
 quoted on: 4096x4096 target, 64x64 square cells (4096 cells), 5000-image library,
-CIEDE2000, repeat range 4 (+500).  N > 1 (launched by torch.distributed.run, one
-rank per GPU over RCCL) is weak scaling: every rank scores one config-D band of
-cells (the target is the config-D image repeated per band, so the job is a
-4096 x 4096*N mosaic), one all-gather of the candidate lists, identical resolve
-on every rank.
+CIEDE2000, repeat range 4 (+500).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
-(score_kernel): algorithmic bytes per launch (sum over cells of
-L*Pa*12 + Pa*12 + Pa) over its average launch time from HIP events on the
-engine's stream.  `cpu_baseline` is the CPU oracle (a port of the reference's
-single-threaded generator, early exit on) timed on a bounded prefix of the same
-workload, rank 0 at N=1 only.
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL):
+  * config D (default): WEAK scaling -- every rank scores one config-D band of cells
+    (the target is the config-D image repeated per band, so the job is a
+    4096 x 4096*N mosaic), one all-gather of the candidate lists, identical
+    resolve on every rank;
+  * config E (BASELINE config 5: 8192x8192 target, 48x48 cells -> 171 x 171 = 29 241
+    cells with the last row / column clipped to 32 px, 10 000 images, CIEDE2000):
+    STRONG scaling -- the fixed cell list is cut into ceil(29 241 / N) contiguous
+    shards, one all-gather, identical resolve.  --scaling overrides either default.
+Communicator set-up and staging happen before the timed region and are reported
+(`stage_once_s`, `comm_init_s`).
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel
+(filter_kernel): for CIEDE2000 it is bound by VALU issue, so `achieved` is its VALU
+wave-instruction rate in fma-equivalent TFLOP/s (128 flop per wave-instruction)
+against the fp32 vector peak; the instruction count comes from the rocprofv3 SQ pass
+recorded in profiles/pmc_traffic.json for exactly these kernel sources and this
+configuration (checked by a hash of the sources and by the launch's own always-on
+visited-groups counter).  `roofline.hbm` is the measured fabric-side traffic of the
+same launch against HBM peak; the bytes a naive stream would move are
+kept as `effective_algorithmic_gbs` and are NOT a fraction of anything.
+`cpu_baseline` is the CPU oracle (a port of the reference's single-threaded
+generator, early exit on) timed on a bounded prefix of the same workload, rank 0
+at N=1 only.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,37 +48,75 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction x 128 flop
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2.0
 
 CONFIGS = {
-    # name: (rows, cols, cell, shape, L, diff type, repeat range, addition, cpu sample cells)
+    # name: (rows, cols, cell, shape, L, diff type, repeat range, addition, cells of the 1-thread CPU sample)
     "A": (512, 512, 32, "square", 100, 0, 0, 0, 256),
     "B": (2048, 2048, 64, "square", 1000, 0, 0, 0, 256),
     "C": (2048, 2048, 64, "hexagon", 1000, 2, 0, 0, 48),
     "D": (4096, 4096, 64, "square", 5000, 2, 4, 500, 8),
-    "E8": (1056, 8192, 48, "square", 10000, 2, 0, 0, 4),     # one rank's band of config E
+    "E": (8192, 8192, 48, "square", 10000, 2, 0, 0, 4),      # BASELINE config 5, the whole grid
+    "E8": (8192, 8192, 48, "square", 10000, 2, 0, 0, 4),     # ... one rank's shard of it (first ceil(29 241 / 8) cells)
 }
 TYPE_NAMES = {0: "RGB-Euclidean", 1: "CIE76", 2: "CIEDE2000"}
 
 
-def build_workload(name, world):
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the engine's kernel sources: ties a PMC record to the code it measured."""
+    from mosaicmagnifique_amd import _build
+    h = hashlib.sha256()
+    for path in sorted(_build.SOURCES + [p for p in _build.HEADERS if os.sep + "csrc" + os.sep in p]):
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_workload(name, world, scaling="weak", mcs=None, mil=None):
     import cases
     from mosaicmagnifique_amd import GridUtility as G
     from mosaicmagnifique_amd import synth
     rows, cols, size, shape_name, L, t, rng, add, cpu_cells = CONFIGS[name]
-    shape = cases.hexagon_shape() if shape_name == "hexagon" else cases.square_shape(size)
+    if mcs:                                   # the project's own cell shape file, resized to the config's cell size
+        from mosaicmagnifique_amd.cellshape import CellShape
+        shape = CellShape.loadFromFile(mcs).resized(size)
+        shape_name = "%s (%s)" % (shape.name or "mcs", os.path.basename(mcs))
+    else:
+        shape = cases.hexagon_shape() if shape_name == "hexagon" else cases.square_shape(size)
     group = cases.group_of(shape)
-    img = synth.preprocess(synth.target_u8(rows, cols, lattice=64), t)
-    lib = synth.preprocess(synth.library_u8(L, size), t)
+    if mil:                                   # the project's own image library file
+        from mosaicmagnifique_amd import imageutil
+        from mosaicmagnifique_amd.imagelibrary import ImageLibrary
+        library = ImageLibrary.loadFromFile(mil)
+        lib_u8 = library.getImages()
+        if library.getImageSize() != size:
+            lib_u8 = np.stack([imageutil.resize_area_u8(im, size, size) for im in lib_u8])
+        L = len(lib_u8)
+    else:
+        lib_u8 = synth.library_u8(L, size)
     state1 = G.getGridState(group, rows, cols)[0]
     cells1 = G.cell_records(group, state1, rows, cols)
-    if world == 1:
+    band_rows_px = rows
+    if name == "E8":                          # one rank's shard: the band of the target holding its cells
+        n_shard = -(-len(cells1) // 8)
+        cells1 = cells1[:n_shard]
+        band_rows_px = min(rows, (int(cells1["y"].max()) // size + 2) * size)
+    img_u8 = synth.target_u8(band_rows_px, cols, lattice=64)
+    big = band_rows_px * cols > 4096 * 4096   # convert on the device (mm_set_*_u8) instead of ~1 min of numpy per rank
+    w = dict(name=name, shape=shape, shape_name=shape_name, t=t, rep=(rng, add), L=L, size=size,
+             rows=band_rows_px, cols=cols, cpu_cells=cpu_cells, state_single=state1,
+             device_preprocess=big, img_u8=img_u8, lib_u8=lib_u8, scaling=scaling)
+    if not big:
+        w["img"] = synth.preprocess(img_u8, t)
+        w["lib"] = synth.preprocess(lib_u8, t)
+    if world == 1 or scaling == "strong":
         cells, grid_w, grid_h = cells1, state1.shape[1], state1.shape[0]
     else:
         # weak scaling: `world` bands, each the single-GPU image; band b's cells read the
         # same target pixels (y unchanged) but sit `b * band_rows` grid rows lower.
         if shape_name != "square":
-            raise SystemExit("multi-GPU bands are defined for square cells")
+            raise SystemExit("weak-scaled bands are defined for square cells")
         band_rows = state1.shape[0] - G.PAD_GRID
         parts = []
         for b in range(world):
@@ -71,9 +125,27 @@ def build_workload(name, world):
             parts.append(c)
         cells = np.concatenate(parts)
         grid_w, grid_h = state1.shape[1], band_rows * world + G.PAD_GRID
-    return dict(name=name, shape=shape, img=img, lib=lib, cells=cells, cells_single=cells1,
-                grid_w=grid_w, grid_h=grid_h, t=t, rep=(rng, add), L=L, size=size,
-                rows=rows, cols=cols, cpu_cells=cpu_cells, state_single=state1)
+    w.update(cells=cells, cells_single=cells1, grid_w=grid_w, grid_h=grid_h)
+    return w
+
+
+def stage(engine, w):
+    """Library, masks and target to HBM (once, before the timed region)."""
+    if w["device_preprocess"]:
+        engine.set_library_u8(w["lib_u8"], w["t"])
+        engine.set_target_u8(w["img_u8"], w["t"])
+    else:
+        engine.set_library(w["lib"])
+        engine.set_target(w["img"])
+    engine.set_masks(w["shape"].masks4())
+
+
+def host_arrays(engine, w):
+    """The f32 arrays the engine holds, for the CPU oracle (identical inputs on both sides)."""
+    if "img" not in w:
+        w["img"] = engine.get_target(w["rows"], w["cols"])
+        w["lib"] = engine.get_library()
+    return w["img"], w["lib"]
 
 
 def algorithmic_bytes(w, cells):
@@ -96,20 +168,6 @@ def algorithmic_bytes(w, cells):
     return total_pa * (w["L"] * 12 + 13), total_pa
 
 
-def cpu_baseline(w):
-    """The oracle (port of CPUPhotomosaicGenerator, 1 thread, early exit) on the
-    first `cpu_cells` valid cells in raster order of the same inputs."""
-    import oracle_ffi
-    o = oracle_ffi.load()
-    n = w["cpu_cells"]
-    t0 = time.perf_counter()
-    grid, scores, done = o.generate_best_fits(
-        oracle_ffi.shape_of(w["shape"]), w["img"], w["lib"], w["shape"].masks4(), w["t"],
-        w["rep"][0], w["rep"][1], max_cells=n, state=w["state_single"])
-    dt = time.perf_counter() - t0
-    return grid, scores, done, dt
-
-
 def host_cores(cap=16):
     """Threads for the all-cores leg: the affinity mask, cut by the cgroup CPU quota when there
     is one, and by `cap` (a one-GPU box's CPU share is 16 cores whatever the mask says)."""
@@ -123,37 +181,54 @@ def host_cores(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_baseline_all_cores(w, per_thread=2):
-    """the same port on every host core of this process's CPU share -- one
-    thread per core, each scoring its own `per_thread` valid cells (no repeat penalty: base
-    scores are what parallelises; the penalty resolve is negligible on the CPU too).
-    ctypes releases the GIL inside the oracle call."""
-    import threading
-
+def cpu_baseline(w, img, lib):
+    """The oracle (port of CPUPhotomosaicGenerator, 1 thread, early exit) on the
+    first `cpu_cells` valid cells in raster order of the same inputs."""
     import oracle_ffi
     o = oracle_ffi.load()
-    cores = host_cores()
-    state = w["state_single"]
-    valid = np.argwhere(state >= 0)
-    cores = max(1, min(cores, len(valid) // per_thread))
-    shape = oracle_ffi.shape_of(w["shape"])
-    masks = w["shape"].masks4()
-    done = [0] * cores
-
-    def work(k):
-        mine = np.full(state.shape, -1, dtype=np.int64)
-        for gy, gx in valid[k * per_thread:(k + 1) * per_thread]:
-            mine[gy, gx] = state[gy, gx]
-        done[k] = o.generate_best_fits(shape, w["img"], w["lib"], masks, w["t"], 0, 0, state=mine)[2]
-
-    threads = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    n = w["cpu_cells"]
     t0 = time.perf_counter()
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
+    grid, scores, done = o.generate_best_fits(
+        oracle_ffi.shape_of(w["shape"]), img, lib, w["shape"].masks4(), w["t"],
+        w["rep"][0], w["rep"][1], max_cells=n, state=w["state_single"])
     dt = time.perf_counter() - t0
-    return sum(done), cores, dt
+    return grid, scores, done, dt
+
+
+def cpu_parity_rows(w, img, lib, best, n_cells):
+    """index parity where the repeat window is exercised -- the first `n_cells` valid
+    cells in raster order (config D: 2 full rows), each evaluated by the oracle exactly as the
+    reference's raster loop reaches it with the earlier cells at the engine's picks; equality on
+    the whole prefix is equality with the sequential run (induction over the raster order,
+    oracle_ffi.picks_given_grid).  One thread per host core: also the all-cores CPU rate."""
+    import oracle_ffi
+    o = oracle_ffi.load()
+    recs = w["cells_single"][:n_cells]
+    pos = np.stack([recs["grid_y"], recs["grid_x"]], axis=1)
+    grid = np.where(best < w["L"], best, -1)[:w["state_single"].shape[0]]
+    cores = host_cores()
+    t0 = time.perf_counter()
+    picks, scores = o.picks_given_grid(oracle_ffi.shape_of(w["shape"]), img, lib, w["shape"].masks4(), w["t"],
+                                       w["rep"][0], w["rep"][1], grid, pos, threads=cores)
+    dt = time.perf_counter() - t0
+    return pos, picks, scores, cores, dt
+
+
+def pmc_record(w, opts):
+    """rocprofv3 PMC passes of this same command, summarised per launch of the dominant kernel by
+    profiles/summarise_pmc.py.  Only a record measured on exactly these kernel sources, this
+    configuration and these engine options is used; anything else is reported as absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "profiles/pmc_traffic.json missing"
+    entry = json.load(open(path)).get(w["name"])
+    if not entry:
+        return None, "no PMC record for config %s" % w["name"]
+    if entry.get("kernel_src_sha16") != kernel_source_hash():
+        return None, "PMC record is for kernel sources %s, this build is %s" % (entry.get("kernel_src_sha16"), kernel_source_hash())
+    if sorted(entry.get("options", [])) != sorted(opts):
+        return None, "PMC record was taken with options %s" % entry.get("options")
+    return entry, "profiles/pmc_traffic.json (rocprofv3 --pmc, separate passes: FETCH_SIZE x2 + WRITE_SIZE; SQ_INSTS_VALU)"
 
 
 def main():
@@ -162,7 +237,12 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="D", choices=sorted(CONFIGS))
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="N > 1: weak = one config band per rank (default for D), strong = the fixed cell list "
+                         "cut into N contiguous shards (default for E)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
+    ap.add_argument("--mcs", default=None, help="cell shape from a MosaicMagnifique .mcs file (resized to the config's cell size)")
+    ap.add_argument("--mil", default=None, help="library from a MosaicMagnifique .mil file (resized to the config's cell size)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine tuning option (mm_set_option), for experiments")
     args = ap.parse_args()
@@ -185,6 +265,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
+    scaling = args.scaling or ("strong" if args.config == "E" else "weak")
 
     import torch
     from mosaicmagnifique_amd.dist import ShardedBestFit
@@ -194,23 +275,25 @@ def main():
     # MOSAIC_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL init, device-side
     # candidate lists, all-gather, resolve from device memory) even with one rank.
     use_dist = world > 1 or os.environ.get("MOSAIC_BENCH_FORCE_DIST") == "1"
+    comm_init_s = 0.0
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        t_comm = time.perf_counter()
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()                          # builds the communicator before anything is timed
+        comm_init_s = time.perf_counter() - t_comm
 
-    w = build_workload(args.config, world)
+    w = build_workload(args.config, world, scaling, args.mcs, args.mil)
     engine = Engine(local_rank)
     for item in args.opt:
         name, value = item.split("=")
         engine.set_option(name, int(value))
     t_stage = time.perf_counter()
-    engine.set_library(w["lib"])
-    engine.set_masks(w["shape"].masks4())
-    engine.set_target(w["img"])
+    stage(engine, w)
     stage_s = time.perf_counter() - t_stage
 
     cells, gw, gh, t, rep = w["cells"], w["grid_w"], w["grid_h"], w["t"], w["rep"]
@@ -230,13 +313,16 @@ def main():
         best, score = step()
     fence()
     t0 = time.perf_counter()
-    score_ms, launches, exact = 0.0, 0, 0
+    score_ms, launches, exact, visited, groups_all, dropped = 0.0, 0, 0, 0, 0, 0
     for _ in range(args.steps):
         best, score = step()
         tm = engine.timing()
         score_ms += tm["score_ms"]
         launches += tm["score_launches"]
         exact += tm["exact_rescored"]
+        visited += tm["visited_groups"]
+        groups_all += tm["total_groups"]
+        dropped += tm["bound_dropped"]
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -251,20 +337,81 @@ def main():
     n_cells = len(cells)
     engine_uses_filter = tm.get("rescore_ms", 0) > 0 or tm.get("seed_ms", 0) > 0
     value = n_cells * args.steps / elapsed
-    my_cells = w["cells_single"]                      # what ONE rank's score launches cover
+    # what ONE rank's score launches cover
+    if world > 1 and scaling == "strong":
+        from mosaicmagnifique_amd.dist import shard_range
+        lo, hi = shard_range(n_cells, world, 0)
+        my_cells = cells[lo:hi]
+    else:
+        my_cells = w["cells_single"]
     alg_bytes, total_pa = algorithmic_bytes(w, my_cells)
-    per_launch_s = (score_ms / 1e3) / max(launches, 1)
-    launches_per_step = max(launches, 1) / max(args.steps, 1)
-    achieved = alg_bytes / launches_per_step / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-    # HBM-side traffic of the dominant kernel from rocprofv3 PMC passes of this same
-    # command (profiles/summarise_pmc.py; FETCH_SIZE doubled as the gfx950 guide says)
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        entry = json.load(open(pmc_path)).get(w["name"])
-        if entry:
-            traffic = entry["traffic_bytes_per_launch"]
-            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+    launches = max(launches, 1)
+    per_launch_s = (score_ms / 1e3) / launches
+    launches_per_step = launches / max(args.steps, 1)
+    alg_per_launch = alg_bytes / launches_per_step
+    visited_per_launch = visited / launches
+    pairs_alg = total_pa * w["L"] / launches_per_step
+    ciede = t == 2 and engine_uses_filter
+
+    pmc, pmc_src = pmc_record(w, args.opt) if world == 1 else (None, "PMC records are single-GPU")
+    roof = {
+        "kernel": "filter_kernel" if engine_uses_filter else "score_kernel",
+        "avg_launch_ms": per_launch_s * 1e3,
+        "launches_per_step": launches_per_step,
+        "effective_algorithmic_gbs": alg_per_launch / per_launch_s / 1e9 if per_launch_s > 0 else 0.0,
+        "algorithmic_bytes_per_launch": alg_per_launch,
+        "pair_evals_algorithmic_per_s": pairs_alg / per_launch_s if per_launch_s > 0 else 0.0,
+        "visited_groups_per_launch": visited_per_launch,
+        "visited_fraction_of_groups": visited / groups_all if groups_all else None,
+        "candidates_dropped_by_block_bound": dropped / max(launches, 1),
+        # a visited group = 256 pixel positions of one (cell, candidate): what was actually evaluated
+        "pair_evals_visited_per_s": visited_per_launch * 256 / per_launch_s if per_launch_s > 0 and visited else None,
+        "pmc_source": pmc_src,
+        "kernel_src_sha16": kernel_source_hash(),
+    }
+    traffic = pmc["traffic_bytes_per_launch"] if pmc else None
+    hbm = None
+    if traffic is not None and per_launch_s > 0:
+        hbm = {"achieved": traffic / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+               "note": "fabric-side bytes (L2 misses; Infinity-Cache hits are counted) of one launch / its duration"}
+    roof["traffic"] = traffic
+    roof["hbm"] = hbm
+    if ciede:
+        # VALU-issue-bound: price the launch's VALU wave-instructions against the fp32 vector peak
+        roof["bound"] = "valu"
+        roof["unit"] = "TFLOP/s"
+        roof["peak"] = VALU_PEAK_TFLOPS
+        insts = None
+        if pmc and pmc.get("SQ_INSTS_VALU_per_launch"):
+            # the instruction count scales with the work actually done: tie it to this run by the
+            # always-on visited-groups counter (identical when the PMC run did the same work)
+            ref_visited = pmc.get("visited_groups_per_launch") or visited_per_launch
+            scale = visited_per_launch / ref_visited if ref_visited else 1.0
+            insts = pmc["SQ_INSTS_VALU_per_launch"] * scale
+            roof["valu_wave_insts_per_launch"] = insts
+            roof["visited_groups_vs_pmc_run"] = scale
+        if insts and per_launch_s > 0:
+            rate = insts / per_launch_s
+            roof["achieved"] = rate * 128 / 1e12
+            roof["frac"] = rate / VALU_PEAK_WAVE_INSTS
+            roof["note"] = ("VALU wave-instructions per second x 128 (fma-equivalent flop per wave64 instruction) against "
+                            "the fp32 vector peak = 1024 SIMDs x 2.4 GHz / 2 cycles; transcendentals (10 of ~104 per "
+                            "pixel pair) issue at quarter rate, so the mix's own ceiling is below 1")
+        else:
+            roof["achieved"] = None
+            roof["frac"] = None
+            roof["note"] = "no PMC record for this build/config: VALU rate not priced (run tests/tools_profile.sh)"
+    else:
+        # RGB-Euclid / fp64-only: memory-side view, from measured traffic only
+        roof["bound"] = "hbm"
+        roof["unit"] = "GB/s"
+        roof["peak"] = HBM_PEAK_GBS
+        roof["achieved"] = hbm["achieved"] if hbm else None
+        roof["frac"] = hbm["frac"] if hbm else None
+        roof["note"] = ("achieved = measured fabric-side traffic / launch time; without a PMC record of this build the "
+                        "fraction is not reported (the algorithmic figure is an effective rate, not a fraction)")
+
     out = {
         "metric": "cells matched/sec (whole node)",
         "value": value,
@@ -274,47 +421,33 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling if world > 1 else "weak",
         "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
+        "dtype": "f32 filter + f64 arbiter" if engine_uses_filter else "f64",
+        "data": "synthetic" if not (args.mcs or args.mil) else "synthetic target; %s" % ", ".join(
+            os.path.basename(p) for p in (args.mcs, args.mil) if p),
         "config": {
             "workload": "config %s: %dx%d target%s, %dx%d %s cells, %d-image library, %s, repeat range %d (+%d)" % (
-                w["name"], w["cols"], w["rows"] * world, " (%d bands of %d rows)" % (world, w["rows"]) if world > 1 else "",
-                w["size"], w["size"], CONFIGS[w["name"]][3], w["L"], TYPE_NAMES[t], rep[0], rep[1]),
+                w["name"], w["cols"], w["rows"] * (world if scaling == "weak" else 1),
+                " (%d bands of %d rows)" % (world, w["rows"]) if world > 1 and scaling == "weak" else "",
+                w["size"], w["size"], w["shape_name"], w["L"], TYPE_NAMES[t], rep[0], rep[1]),
             "cells": n_cells,
             "library_images": w["L"],
-            "parallelism": "cell-shard x%d + 1 all-gather" % world if world > 1 else "single GPU",
+            "parallelism": ("cell-shard x%d (%s) + 1 all-gather" % (world, scaling)) if world > 1 else "single GPU",
         },
-        "roofline": {
-            "kernel": "filter_kernel" if engine_uses_filter else "score_kernel",
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": alg_bytes / launches_per_step,
-            "avg_launch_ms": per_launch_s * 1e3,
-            "launches_per_step": launches_per_step,
-            "pair_evals_per_s": total_pa * w["L"] / launches_per_step / per_launch_s if per_launch_s > 0 else 0.0,
-            "note": "achieved = bytes a naive stream would move / launch time (SURVEY 8d); the kernel skips pruned "
-                    "pixel groups and shares tiles through L2, so measured traffic is lower and frac can pass 1: "
-                    "it is VALU-bound (profiles/r01_v11_configD_pmc_SQ.csv), not HBM-bound",
-        },
+        "roofline": roof,
         "stage_once_s": stage_s,
+        "comm_init_s": comm_init_s,
         "exact_rescored_per_step": exact / max(args.steps, 1),
         "last_step_device_ms": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
     }
 
     if world == 1:
         # what a plain coalesced read stream reaches on this device (4 GiB, past the Infinity Cache)
-        measured = engine.stream_read_gbs(4 << 30, 5)
-        out["roofline"]["peak_measured"] = measured
-        out["roofline"]["frac_of_measured"] = achieved / measured if measured > 0 else None
+        out["roofline"]["hbm_stream_read_measured_gbs"] = engine.stream_read_gbs(4 << 30, 5)
     if world == 1 and not args.no_cpu:
-        grid, cscore, done, dt = cpu_baseline(w)
+        img, lib = host_arrays(engine, w)
+        grid, cscore, done, dt = cpu_baseline(w, img, lib)
         recs = my_cells[:done]
         same = all(best[r["grid_y"], r["grid_x"]] == grid[r["grid_y"], r["grid_x"]] for r in recs)
         rel = max(abs(score[r["grid_y"], r["grid_x"]] - cscore[r["grid_y"], r["grid_x"]])
@@ -322,17 +455,31 @@ def main():
         out["cpu_baseline"] = {
             "value": done / dt, "unit": "cells/s", "cores": 1, "kind": "port",
             "sample": "first %d valid cells in raster order of the same workload (oracle/oracle.c, "
-                      "early exit on, %.1f s)" % (done, dt),
+                      "sequential, early exit on, %.1f s)" % (done, dt),
         }
-        out["parity_on_cpu_sample"] = {"indices_equal": bool(same), "max_rel_score_err": rel}
         out["speedup_vs_cpu"] = value / (done / dt)
-        n_all, cores, dt_all = cpu_baseline_all_cores(w)
-        out["cpu_baseline_all_cores"] = {
-            "value": n_all / dt_all, "unit": "cells/s", "cores": cores, "kind": "port",
-            "sample": "%d valid cells, %d per thread, one thread per host core of this process, base scores "
-                      "only (oracle/oracle.c, early exit on, %.1f s)" % (n_all, n_all // max(cores, 1), dt_all),
+        # parity where the repeat window is exercised + the all-cores rate: the first 2 grid rows
+        row_cells = int((my_cells["grid_y"] <= my_cells["grid_y"][0] + 1).sum())
+        n_par = min(len(my_cells), max(row_cells, 16) if rep[0] > 0 else 64, 256)
+        pos, picks, pscores, cores, dt_all = cpu_parity_rows(w, img, lib, best, n_par)
+        got = best[pos[:, 0], pos[:, 1]]
+        prel = np.abs(pscores - score[pos[:, 0], pos[:, 1]]) / np.maximum(pscores, 1e-300)
+        out["parity_on_cpu_sample"] = {
+            "indices_equal": bool(same and np.array_equal(picks, got)),
+            "max_rel_score_err": float(max(rel, prel.max())),
+            "cells": int(n_par),
+            "sample": "first %d valid cells in raster order (%s), each evaluated by the oracle as the reference's raster "
+                      "loop reaches it given the earlier picks -- equality on the prefix = equality with the sequential "
+                      "run; plus the %d cells of the sequential 1-thread leg" % (
+                          n_par, "2 full grid rows: the repeat window's rows-above half is exercised" if rep[0] > 0 else "no repeat penalty",
+                          done),
         }
-        out["speedup_vs_cpu_all_cores"] = value / (n_all / dt_all)
+        out["cpu_baseline_all_cores"] = {
+            "value": n_par / dt_all, "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": "the same %d cells, one thread per host core of this process, repeat penalty from the finished grid "
+                      "(oracle/oracle.c, early exit on, %.1f s)" % (n_par, dt_all),
+        }
+        out["speedup_vs_cpu_all_cores"] = value / (n_par / dt_all)
     emit(json.dumps(out))
     if use_dist:
         os.dup2(2, 1)

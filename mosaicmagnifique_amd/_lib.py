@@ -28,7 +28,8 @@ class MMTiming(ctypes.Structure):
                 ("dense_cells", ctypes.c_int64), ("edge_pairs", ctypes.c_int64),
                 ("seed_ms", ctypes.c_double), ("build_ms", ctypes.c_double),
                 ("spec_rounds", ctypes.c_int64), ("deepened_cells", ctypes.c_int64),
-                ("resolve_sweeps", ctypes.c_int64)]
+                ("resolve_sweeps", ctypes.c_int64), ("visited_groups", ctypes.c_int64),
+                ("total_groups", ctypes.c_int64), ("bound_dropped", ctypes.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -92,7 +93,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB
+    # MOSAIC_HIP_LIB: an alternative build of the same engine (kernel tuning experiments)
+    return os.environ.get("MOSAIC_HIP_LIB") or _build.LIB
 
 
 def load():

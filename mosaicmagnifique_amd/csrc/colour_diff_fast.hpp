@@ -59,12 +59,16 @@ __device__ __forceinline__ float sqrt_ratio7_scaled(float s)
 // on the mean hue angle ALONE, so both are tabulated over the circle and interpolated
 // linearly.  The index is the "diamond angle" of the mean-hue unit vector (hc, hs):
 //   t = 2 - copysign(1 + hc / (|hc| + |hs|), hs)   in [0, 4),  monotone in the angle,
-// which needs one v_rcp_f32 and no inverse trig.  Entry i holds {T, dT, G, dG}, G = -2 sin(2 d_theta)
-// (so that R_T = G R_C / 2 is one multiply, :136,:145), at
-// t_i = 4 i / kHueLutSize with d* the difference to entry i+1 (kHueLutSize + 1 entries;
-// the last repeats the first).  Built in fp64 on the host (engine.hip build_hue_lut).
+// which needs one v_rcp_f32 and no inverse trig.  Entry i holds {T, G}, G = -2 sin(2 d_theta)
+// (so that R_T = G R_C / 2 is one multiply, :136,:145), at t_i = 4 i / kHueLutSize; a lookup reads
+// entries i and i + 1 (one ds_read2_b64) and interpolates between them, so the table has
+// kHueLutSize + 2 entries: entry N repeats entry 0 and entry N + 1 entry 1.  8 bytes per entry --
+// 16 KB of LDS, not the 32 KB of a {value, slope} table: what lets six filter workgroups share a
+// CU's LDS.  Built in fp64 on the host (engine.hip build_hue_lut).
 // Interpolation error at 2048 entries: < 2e-5 on T, < 2e-5 on G.
 constexpr int kHueLutSize = 2048;
+constexpr int kHueLutEntries = kHueLutSize + 2;
+using HueEntry = float2;
 
 // Returns the fp32 estimate; *needs_exact is set when the pair sits on the
 // opposite-hue discontinuity and the caller must use the fp64 form instead.
@@ -86,7 +90,7 @@ constexpr int kHueLutSize = 2048;
 // colour (C' is never below 1e-18); two greys give direction (0, 0),
 // where T and R_T are multiplied by a zero mean chroma.
 __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, float c1, float c2,
-                                                const float4* __restrict__ lut, bool* needs_exact)
+                                                const HueEntry* __restrict__ lut, bool* needs_exact)
 {
     // G, a', C' (:50-59)
     const float one_g = 1.5f - 0.5f * sqrt_ratio7_of_sum(c1 + c2);       // 1 + G
@@ -114,9 +118,9 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     const float x = fmaf(-(float)(kHueLutSize / 4), copysignf(1.0f + qd, hy), (float)(kHueLutSize / 2));   // (2 - c) N/4
     const int idx = min(max((int)x, 0), kHueLutSize);          // x in [0, N]: truncation = floor; entry N repeats entry 0
     const float fr = __builtin_amdgcn_fractf(x);                // x - floor(x), one instruction
-    const float4 en = lut[idx];
-    const float t = fmaf(fr, en.y, en.x);
-    const float s2 = fmaf(fr, en.w, en.z);
+    const HueEntry e0 = lut[idx], e1 = lut[idx + 1];
+    const float t = fmaf(fr, e1.x - e0.x, e0.x);
+    const float s2 = fmaf(fr, e1.y - e0.y, e0.y);
 
     const float csum = c1p + c2p;                           // 2 * mean C'
     const float r_t = s2 * sqrt_ratio7_of_sum(csum);            // :136,:145; the table holds -2 sin(2 d_theta)

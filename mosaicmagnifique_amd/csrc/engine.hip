@@ -59,6 +59,7 @@ struct mm_engine {
     int cell_scale = 1;          // mm_set_cell_scale / mm_set_cell_resize: normal-cell pixels per detail pixel and
                                  // axis when that is a whole number, 0 = any ratio (area table in `area_tab`)
     int cell_normal = 0;         // normal cell size the area table was built for
+    int area_detail = 0;         // detail cell size the area table was built (and laid out) for
     DevBuf area_tab;             // [detail + 1] first | [entries] src | [entries] alpha (kernels.hpp CellResize)
     int area_entries = 0;
     int spec_k = 4;              // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
@@ -80,6 +81,8 @@ struct mm_engine {
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
     int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
     int use_prune = 1;           // mm_set_option("prune", 0): filter pass without early exit
+    int xcd_aware = 1;           // mm_set_option("xcd_aware", 0): one item order for the whole device
+    int xcd_cells = 0;           // mm_set_option("xcd_cells", n): cells per sub-group of an XCD's share (0 = default)
 
     mm_timing timing{};
 };
@@ -149,6 +152,13 @@ mm_status check_ready(mm_engine* e)
         set_err(e, "library image size %d != mask size %d (detail cell size must match, "
                    "PhotomosaicGeneratorBase.cpp:262-271)", e->lib_size, e->mask_size);
         return MM_INVALID_ARGUMENT;
+    }
+    if (e->cell_scale == 0 && e->area_detail != e->lib_size) {
+        // the resize table is indexed by detail pixels: a library that changed size since
+        // mm_set_cell_resize would read it out of bounds (cell_resize_of)
+        set_err(e, "the cell resize table was built for a detail size of %d but the library is %d px now: "
+                   "call mm_set_cell_resize again", e->area_detail, e->lib_size);
+        return MM_NOT_READY;
     }
     return MM_OK;
 }
@@ -310,7 +320,7 @@ mm::Variants variants_of(const mm_engine* e)
 }
 
 // The hue table of colour_diff_fast.hpp, in fp64 from the reference formulas: entry i is the
-// mean hue whose diamond angle is t_i = 4 i / N; {T, dT, G, dG} with G = -2 sin(2 d_theta),
+// mean hue whose diamond angle is t_i = 4 i / N; {T, G} with G = -2 sin(2 d_theta),
 // d_theta = rad(30) exp(-((h - rad(275)) / rad(25))^2) and h in [0, 2 pi) NOT wrapped around
 // 275 degrees (ColourDifference.cpp:124-133,145).
 std::vector<float> build_hue_lut()
@@ -332,13 +342,10 @@ std::vector<float> build_hue_lut()
         const double z = (h - rad(275.0)) / rad(25.0);
         G[i] = -2.0 * std::sin(2.0 * rad(30.0) * std::exp(-z * z));      // R_T = G * sqrt(C^7 / (C^7 + 25^7)), :136,:145
     }
-    std::vector<float> lut((size_t)(N + 1) * 4);
-    for (int i = 0; i <= N; ++i) {
-        const int j = std::min(i + 1, N);
-        lut[(size_t)4 * i + 0] = (float)T[i];
-        lut[(size_t)4 * i + 1] = (float)(T[j] - T[i]);
-        lut[(size_t)4 * i + 2] = (float)G[i];
-        lut[(size_t)4 * i + 3] = (float)(G[j] - G[i]);
+    std::vector<float> lut((size_t)mm::kHueLutEntries * 2);       // entries 0 .. N + 1: N repeats 0, N + 1 repeats 1
+    for (int i = 0; i < mm::kHueLutEntries; ++i) {
+        lut[(size_t)2 * i + 0] = (float)T[i % N];
+        lut[(size_t)2 * i + 1] = (float)G[i % N];
     }
     return lut;
 }
@@ -457,7 +464,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             (st = ensure(e, e->cont_f, (size_t)batch * Kc * sizeof(float), "Failed to allocate contenders")) ||
             (st = ensure(e, e->cont_s, (size_t)batch * Kc * sizeof(double), "Failed to allocate contenders")) ||
             (st = ensure(e, e->flags, (size_t)batch, "Failed to allocate cell flags")) ||
-            (st = ensure(e, e->edge_count, 16 * sizeof(unsigned int), "Failed to allocate edge counter")) ||
+            (st = ensure(e, e->edge_count, mm::kFilterCounterWords * sizeof(unsigned int), "Failed to allocate edge counter")) ||
             (st = ensure(e, e->edges, (size_t)edge_cap * sizeof(mm::EdgeEntry), "Failed to allocate edge list")))
             return st;
     }
@@ -473,11 +480,13 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.cells = (const float*)e->cells.p; fin.cmask = (const uint8_t*)e->cmask.p;
     fin.cells_f0 = (const float*)e->cells_f0.p;
     fin.cell_chroma = (const float*)e->cell_chroma.p; fin.lib = (const float*)e->lib.p;
-    fin.lib_chroma = (const float*)e->lib_chroma.p; fin.hue_lut = (const float4*)e->hue_lut.p;
+    fin.lib_chroma = (const float*)e->lib_chroma.p; fin.hue_lut = (const float2*)e->hue_lut.p;
     fin.var = variants_of(e);
     fin.tile_candidates = e->tile_candidates;
     fin.lds_pad_bytes = (size_t)e->lds_pad_kb * 1024;
     fin.use_lds_form = e->use_lds_filter < 0 ? (diff_type != MM_CIEDE2000) : e->use_lds_filter;
+    fin.xcd_aware = e->xcd_aware;
+    fin.xcd_cells = e->xcd_cells;
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     // Early exit needs seeds: K <= M <= 256 of them, and the L proxy distances in LDS.
     const int M = std::min(L, std::min(256, round_up(K + e->extra_seeds, 4)));
@@ -565,10 +574,18 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         HIP_TRY(e, hipEventRecord(e->ev[9], e->stream), "event");
 
         flags_host.resize((size_t)b);
-        unsigned int edge_n = 0;
+        unsigned int counters[8] = {0};          // [0] logged discontinuity pairs, [2..7] three u64 work counters
         HIP_TRY(e, hipMemcpyAsync(flags_host.data(), e->flags.p, (size_t)b, hipMemcpyDeviceToHost, e->stream), "flags");
-        HIP_TRY(e, hipMemcpyAsync(&edge_n, e->edge_count.p, sizeof edge_n, hipMemcpyDeviceToHost, e->stream), "edge count");
+        HIP_TRY(e, hipMemcpyAsync(counters, e->edge_count.p, sizeof counters, hipMemcpyDeviceToHost, e->stream), "edge count");
         HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+        const unsigned int edge_n = counters[0];
+        {
+            unsigned long long work[3];
+            memcpy(work, counters + 2, sizeof work);
+            e->timing.visited_groups += (int64_t)work[0];
+            e->timing.total_groups += (int64_t)work[1];
+            e->timing.bound_dropped += (int64_t)work[2];
+        }
         e->timing.stage_ms += elapsed(e->ev[0], e->ev[1]);
         e->timing.seed_ms += elapsed(e->ev[1], e->ev[4]);
         e->timing.score_ms += elapsed(e->ev[4], e->ev[2]);
@@ -1154,6 +1171,7 @@ mm_status mm_set_cell_resize(mm_engine* e, int normal_size, int detail_size)
     HIP_TRY(e, hipMemcpy(base + detail_size + 1 + n, alpha.data(), n * sizeof(float), hipMemcpyHostToDevice), "Failed to copy resize table");
     e->area_entries = (int)n;
     e->cell_normal = normal_size;
+    e->area_detail = detail_size;
     e->cell_scale = 0;
     return MM_OK;
 }
@@ -1600,6 +1618,8 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "lds_pad_kb") == 0) { e->lds_pad_kb = std::min(120, std::max(0, value)); return MM_OK; }
     if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }
     if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "xcd_aware") == 0) { e->xcd_aware = value != 0; return MM_OK; }
+    if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);
     return MM_INVALID_ARGUMENT;
 }
@@ -1667,7 +1687,7 @@ mm_status mm_filter_diff_batch(mm_engine* e, int diff_type, const float* first, 
     if (code == hipSuccess)
         code = mm::launch_pair_fast(diff_type == MM_CIEDE2000 ? mm::CIEDE2000 : mm::RGB_EUCLIDEAN,
                                     (const float*)a.p, (const float*)b.p, n, (float*)o.p, 1,
-                                    (const float4*)e->hue_lut.p, e->stream);
+                                    (const float2*)e->hue_lut.p, e->stream);
     if (code == hipSuccess) code = hipMemcpyAsync(out, o.p, n * sizeof(float), hipMemcpyDeviceToHost, e->stream);
     if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
     release(a); release(b); release(o);

@@ -19,6 +19,12 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
+// Waves per SIMD the dominant kernel is compiled for: 5 -> at most 96 VGPRs (the 16 KB hue table and
+// the block statistics leave room for six workgroups per CU).  Overridable for experiments.
+#ifndef MM_FILTER_WAVES
+#define MM_FILTER_WAVES 5
+#endif
+
 __device__ __forceinline__ float wave_sum_f(float v)
 {
 #pragma unroll
@@ -59,7 +65,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
 // p and q (read from the precomputed planes), lut = the hue table in LDS.
 template <int TYPE>
 __device__ __forceinline__ float pair_fast(const PxF& p, const PxF& q, float cp, float cq,
-                                           const float4* lut, bool* edge)
+                                           const HueEntry* lut, bool* edge)
 {
     if constexpr (TYPE == CIEDE2000) {
         return ciede2000_fast(p, q, cp, cq, lut, edge);
@@ -70,13 +76,16 @@ __device__ __forceinline__ float pair_fast(const PxF& p, const PxF& q, float cp,
 }
 
 // The hue table, global -> LDS, by the whole workgroup.
-__device__ __forceinline__ void load_hue_lut(float4* lds, const float4* __restrict__ global)
+__device__ __forceinline__ void load_hue_lut(HueEntry* lds, const HueEntry* __restrict__ global)
 {
-    for (int i = threadIdx.x; i <= kHueLutSize; i += blockDim.x) lds[i] = global[i];
+    for (int i = threadIdx.x; i < kHueLutEntries; i += blockDim.x) lds[i] = global[i];
     __syncthreads();
 }
 
 struct LibGroup { float4 q0, q1, q2, qc; };
+
+// Angle in degrees wrapped into [-180, 180].
+__device__ __forceinline__ float wrap180(float v) { return fmaf(-360.0f, rintf(v * (1.0f / 360.0f)), v); }
 
 // Loads at (uniform base) + (32-bit byte offset): the form global_load takes with the
 // base in SGPRs and one VGPR offset shared by all planes -- no 64-bit address arithmetic.
@@ -96,49 +105,84 @@ __device__ __forceinline__ LibGroup load_lib_group(const float4* b0, const float
     return g;
 }
 
+// Work counters of a launch, at edge_count + kCounterBase (u32 indices; the u64 ones are 8-byte aligned):
+//   +0,1  u64  256-pixel groups visited          +2,3  u64  groups a full visit of every candidate would take
+//   +4,5  u64  candidates dropped by the block bound alone (no pixel touched)
+//   +6    u32  unused                            +8 .. +15  u32  next item of XCD 0 .. 7 (persistent workgroups)
+constexpr int kCounterBase = 2;
+constexpr int kItemCounters = 16;
+constexpr int kCounterWords = 32;        // words cleared per launch (edge count, work counters, item counters)
+
+// XCD this wave runs on (0..7): hwreg(HW_REG_XCC_ID, 0, 4).  Used for L2 affinity only.
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
+
 // Same work decomposition as score_kernel (kernels.hpp): one wave per
 // (cell, candidate), lanes over float4 pixel groups, 4 waves = 4 candidates of
 // one cell; cells fastest within a group so resident workgroups share library tiles.
+//
+// XCD-aware item order.  The cells of a launch are split into 8 contiguous shares, one per XCD; a
+// persistent workgroup takes items of ITS XCD's share first (hwreg XCC_ID; a counter per XCD), in the
+// order cells-fastest inside a sub-group of `cell_group` cells, so the workgroups sharing one 4 MB L2
+// work on `cell_group` cells x a couple of candidate tiles at a time instead of all 8 L2s each seeing
+// every cell and every tile of the launch.  A workgroup whose XCD has run dry steals from the next
+// ones (the result does not depend on who scores what).
 template <int TYPE>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MM_FILTER_WAVES, MM_FILTER_WAVES)))
 filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
               const float* __restrict__ cell_chroma, const float* __restrict__ lib,
               const float* __restrict__ lib_chroma, float* __restrict__ scores,
               int n_cells, int L, int ppad, int cand_per_block, int cell_group,
               EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
               unsigned int edge_cap, const float* __restrict__ prune_above, int check_every,
-              const float4* __restrict__ hue_lut, Variants var, long long total_items)
+              const HueEntry* __restrict__ hue_lut, Variants var, int xcd_shares)
 {
-    __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
+    __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
     __shared__ unsigned int next_item;      // ... and workgroups pull (cell, tile) items: the hue table is loaded once
+    __shared__ int item_share;              // the XCD share next_item belongs to (-1: none left)
     // block statistics of the cell (early-exit bound), up to 4 blocks per lane
     __shared__ float cell_st[TYPE == CIEDE2000 ? 7 : 1][TYPE == CIEDE2000 ? 4 * kWave : 1];
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
-    const long long per_group = (long long)cell_group * n_tiles;
     const float* const lib_base = lib;
     const float* const lib_chroma_base = lib_chroma;
+    unsigned int* const item_counter = edge_count + kItemCounters;
+    const int my_share = xcd_shares > 1 ? xcc_id() % xcd_shares : 0;
+    int first_live = 0;                     // thread 0: shares before my_share + first_live (cyclically) are exhausted
+    unsigned long long n_visited = 0, n_groups_all = 0, n_bound_dropped = 0;     // this wave's work counters
     // Persistent workgroups: as many as the device holds at once, each taking the next item of the
-    // launch order (cells fastest inside a group of cells, so the workgroups resident together share
-    // a few candidate tiles in L2) from a global counter.  A 33 KB table per 32-candidate tile was
+    // launch order from a global counter.  A 33 KB table per 32-candidate tile was
     // three times the HBM traffic of the launch in L2 -> LDS copies, and its latency idled the waves
     // at every workgroup start.
     for (;;) {
     __syncthreads();                        // the previous item is done with next_candidate / cell_st
     if (threadIdx.x == 0) {
-        next_item = atomicAdd(edge_count + 8, 1u);
+        int share = -1;
+        unsigned int item = 0;
+        for (int k = first_live; k < xcd_shares; ++k) {
+            const int sh = (my_share + k) % xcd_shares;
+            const long long lo = (long long)n_cells * sh / xcd_shares, hi = (long long)n_cells * (sh + 1) / xcd_shares;
+            const unsigned int it = atomicAdd(item_counter + sh, 1u);
+            if ((long long)it < (hi - lo) * n_tiles) { share = sh; item = it; break; }
+            first_live = k + 1;             // that share is exhausted for good
+        }
+        next_item = item;
+        item_share = share;
         next_candidate = kBlock / kWave;
     }
     __syncthreads();
-    // read back as a scalar: everything derived from it (cell, tile, plane addresses) stays in SGPRs
+    // read back as scalars: everything derived from them (cell, tile, plane addresses) stays in SGPRs
+    const int share = __builtin_amdgcn_readfirstlane(item_share);
+    if (share < 0) break;
     const long long bid = (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)next_item);
-    if (bid >= total_items) break;
+    const int share_lo = (int)((long long)n_cells * share / xcd_shares);
+    const int share_cells = (int)((long long)n_cells * (share + 1) / xcd_shares) - share_lo;
+    const long long per_group = (long long)cell_group * n_tiles;
     const int group = (int)(bid / per_group);
     const long long rem = bid - (long long)group * per_group;
-    const int cells_here = min(cell_group, n_cells - group * cell_group);
+    const int cells_here = min(cell_group, share_cells - group * cell_group);
     const int tile = (int)(rem / cells_here);
-    const int cell = group * cell_group + (int)(rem - (long long)tile * cells_here);
+    const int cell = share_lo + group * cell_group + (int)(rem - (long long)tile * cells_here);
     if (tile >= n_tiles || cell >= n_cells) continue;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -230,17 +274,18 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     const float cbar = 0.5f * (cell_st[4][blk] + st[4 * bs]);
                     const float gc = (1.5f - 0.5f * sqrt_ratio7(cbar)) * cbar;         // >= C_bar' of every pair
                     const float s_c = fmaf(0.045f, gc, 1.0f);
-                    // |R_T| = sin(2 d_theta) R_C, d_theta = 30 deg * exp(-((h_bar' - 275) / 25)^2)  (:132-136,:145): the
-                    // pair's mean hue is the midpoint of its two hues or that +- 180 deg (:107-122), so its offset from
-                    // 275 deg lies in M, M + 180 or M - 180 with M = [(lo_cell + lo_lib) / 2, (hi_cell + hi_lib) / 2]
-                    // (the reference does not wrap h_bar' - 275, which only makes the true exponent more negative)
-                    const float m_lo = 0.5f * (cell_st[5][blk] + st[5 * bs]), m_hi = 0.5f * (cell_st[6][blk] + st[6 * bs]);
-                    const float off0 = fmaxf(0.0f, fmaxf(m_lo, -m_hi));
-                    const float off1 = fmaxf(0.0f, fmaxf(m_lo + 180.0f, -(m_hi + 180.0f)));
-                    const float off2 = fmaxf(0.0f, fmaxf(m_lo - 180.0f, -(m_hi - 180.0f)));
-                    // all hues of both blocks within less than 180 deg of each other: no pair wraps, the mean is the midpoint
-                    const float span = fmaxf(cell_st[6][blk], st[6 * bs]) - fminf(cell_st[5][blk], st[5 * bs]);
-                    const float off = span < 180.0f ? off0 : fminf(off0, fminf(off1, off2));   // least |h_bar' - 275| any pair can have
+                    // |R_T| = sin(2 d_theta) R_C, d_theta = 30 deg * exp(-((h_bar' - 275) / 25)^2)  (:132-136,:145).  Each block's
+                    // hues lie on an arc (centre c as an offset from 275 deg, half-width w: statistics 5, 6); a pair's mean hue
+                    // is the midpoint of the shorter arc between its two hues (:107-122), i.e. within (w1 + w2) / 2 of
+                    // c1 + D / 2 with D = wrap(c2 - c1) -- or of the opposite point when some pair can be more than 180 deg
+                    // apart (|D| + w1 + w2 >= 180).  The reference does not wrap h_bar' - 275; the circular distance is
+                    // never larger, so this exponent is never more negative than the true one.
+                    const float c1 = cell_st[5][blk], w1 = cell_st[6][blk], c2 = st[5 * bs], w2 = st[6 * bs];
+                    const float delta = wrap180(c2 - c1);
+                    const float mid = fabsf(wrap180(fmaf(0.5f, delta, c1)));
+                    const float hw = 0.5f * (w1 + w2);
+                    const float d0 = fmaxf(0.0f, mid - hw), d1 = fmaxf(0.0f, (180.0f - mid) - hw);
+                    const float off = (fabsf(delta) + w1 + w2 >= 180.0f) ? fminf(d0, d1) : d0;   // least |h_bar' - 275| any pair can have
                     const float e_max = fexp2(off * off * (-1.4426950408889634f / 625.0f));
                     // v_sin_f32 takes revolutions: sin(60 deg * E) = sin(2 pi * E / 6); 1.001 + 1e-5 covers its error
                     const float sin_2dt = fmaf(__builtin_amdgcn_sinf(e_max * (1.0f / 6.0f)), 1.001f, 1e-5f);
@@ -271,9 +316,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         float acc = 0.0f;          // terms with a proven error bound
         float acc_edge = 0.0f;     // terms awaiting the fp64 patch
-#ifdef MM_COUNT_VISITS
         int visited = 0;
-#endif
         if (!pruned && groups > 0) {
             // One 256-pixel group of the candidate against the cell; true = candidate dropped.
             auto visit = [&](const LibGroup& cur, int j) -> bool {
@@ -284,9 +327,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 }
                 const int q = lane + kWave * j;
                 const unsigned int off = (unsigned int)q * 16u;
-#ifdef MM_COUNT_VISITS
                 visited += 1;
-#endif
                 const float4 p0 = ld4(c0, off), p1 = ld4(c1, off), p2 = ld4(c2, off);
                 float4 pc{0.f, 0.f, 0.f, 0.f};
                 if constexpr (TYPE == CIEDE2000) pc = ld4(cc, off);
@@ -318,26 +359,27 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 }
                 return false;
             };
-            // The library group of the next iteration is fetched while this one computes.  Two
-            // register sets take turns (unrolled by two) so the hand-over costs no moves.
-            LibGroup ga = load_lib_group<TYPE>(b0, b1, b2, bc, lane), gb = ga;
-            for (int j = 0; j < groups; j += 2) {
-                if (j + 1 < groups) gb = load_lib_group<TYPE>(b0, b1, b2, bc, lane + kWave * (j + 1));
-                if (visit(ga, j)) { pruned = true; break; }
-                if (j + 1 >= groups) break;
-                if (j + 2 < groups) ga = load_lib_group<TYPE>(b0, b1, b2, bc, lane + kWave * (j + 2));
-                if (visit(gb, j + 1)) { pruned = true; break; }
+            // No register prefetch of the next group: at 5 waves per SIMD the other waves cover a group's load
+            // latency (a group is ~430 VALU instructions), and the second register set was what kept the
+            // kernel at 4 waves (155 VGPRs wanted, 128 allowed, spills).
+            for (int j = 0; j < groups; ++j) {
+                const LibGroup g = load_lib_group<TYPE>(b0, b1, b2, bc, lane + kWave * j);
+                if (visit(g, j)) { pruned = true; break; }
             }
         }
-#ifdef MM_COUNT_VISITS
-        if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(edge_count + 2), (unsigned long long)visited);
-                         atomicAdd(reinterpret_cast<unsigned long long*>(edge_count + 4), (unsigned long long)groups);
-                         if (pruned && visited == 0) atomicAdd(reinterpret_cast<unsigned long long*>(edge_count + 6), 1ull); }
-#endif
+        n_visited += (unsigned int)visited;
+        n_groups_all += (unsigned int)groups;
+        n_bound_dropped += (pruned && visited == 0) ? 1u : 0u;
         acc = wave_sum_f(acc + acc_edge);
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }
     }   // next item
+    if ((threadIdx.x & 63) == 0) {           // one set of atomics per wave and launch
+        unsigned long long* c = reinterpret_cast<unsigned long long*>(edge_count + kCounterBase);
+        atomicAdd(c, n_visited);
+        atomicAdd(c + 1, n_groups_all);
+        atomicAdd(c + 2, n_bound_dropped);
+    }
 }
 
 // LDS-resident form of filter_kernel: a 1024-thread workgroup (16 waves) stages ONE cell
@@ -357,11 +399,11 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
                   int n_cells, int L, int ppad, int cand_per_block, int cell_group,
                   EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
                   unsigned int edge_cap, const float* __restrict__ prune_above,
-                  const float4* __restrict__ hue_lut, Variants var)
+                  const HueEntry* __restrict__ hue_lut, Variants var)
 {
     extern __shared__ float4 smem[];
-    float4* lut = smem;                                             // [kHueLutSize + 1] (CIEDE2000)
-    float4* s0 = smem + (TYPE == CIEDE2000 ? kHueLutSize + 1 : 0);  // cell planes, ppad/4 float4 each
+    HueEntry* lut = reinterpret_cast<HueEntry*>(smem);              // [kHueLutEntries] (CIEDE2000), 16-byte multiple
+    float4* s0 = smem + (TYPE == CIEDE2000 ? kHueLutEntries / 2 : 0);  // cell planes, ppad/4 float4 each
     const int pq = ppad / 4;
     float4* s1 = s0 + pq;
     float4* s2 = s1 + pq;
@@ -384,7 +426,7 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
 
     // stage the hue table and the cell (active groups only)
     if constexpr (TYPE == CIEDE2000)
-        for (int i = threadIdx.x; i <= kHueLutSize; i += kLdsBlock) lut[i] = hue_lut[i];
+        for (int i = threadIdx.x; i < kHueLutEntries; i += kLdsBlock) lut[i] = hue_lut[i];
     {
         const float4* g0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
         const float4* gf = reinterpret_cast<const float4*>(cells_f0 + (size_t)cell * ppad);     // NaN = inactive
@@ -489,7 +531,7 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
 // One pair for the seed scores: fp32 form, with the fp64 form taken inline on the
 // hue discontinuity (the seeds are few, the divergence is irrelevant there).
 template <int TYPE>
-__device__ __forceinline__ float pair_seed(const PxF& p, const PxF& q, float cp, float cq, const float4* lut)
+__device__ __forceinline__ float pair_seed(const PxF& p, const PxF& q, float cp, float cq, const HueEntry* lut)
 {
     bool edge;
     float v = pair_fast<TYPE>(p, q, cp, cq, lut, &edge);
@@ -507,9 +549,9 @@ seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
                   const float* __restrict__ cell_chroma, const float* __restrict__ lib,
                   const float* __restrict__ lib_chroma, const int32_t* __restrict__ seeds,
                   float* __restrict__ seed_score, int n_cells, int M, int ppad,
-                  const float4* __restrict__ hue_lut, Variants var)
+                  const HueEntry* __restrict__ hue_lut, Variants var)
 {
-    __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
+    __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long w = (long long)blockIdx.x * (kBlock / kWave) + wave;
@@ -572,11 +614,13 @@ chroma_planes_kernel(const float* __restrict__ planar, float* __restrict__ chrom
 // `block_stride` floats apart:
 //   0: sum of channel 0              1: max |channel 0 - 50|
 //   2: sum of channel 1              3: sum of channel 2        4: max sqrt(ch1^2 + ch2^2)
-//   5, 6: lowest / highest hue offset from 275 deg of the block's pixels, in degrees, signed in
-//         (-180, 180] with the seam at 95 deg, covering a' = (1 + G) a for every G in [0, 0.5]
-//         (ColourDifference.cpp:50-53,61-83) and widened by 0.01 deg; -180 / +180 ("anywhere") when a
-//         pixel's chroma is below 1e-3 (its hue is arbitrary and the reference's mean-hue rule changes,
-//         :108-109) or its own range crosses the seam.
+//   5, 6: the arc of the hue circle holding every active pixel's hue: centre as an offset from 275 deg in
+//         [-180, 180], and half-width, in degrees.  A pixel's hue is that of (g a, b) for every g = 1 + G in
+//         [1, 1.5] (ColourDifference.cpp:50-53,61-83): both ends count.  Deviations are measured from the
+//         direction of the block's summed (a, b), so no fixed seam cuts a block in two; widened by 0.02 deg;
+//         the whole circle (centre 0, half-width 180) when the sum vanishes, a pixel's chroma is below 1e-3
+//         (its hue is arbitrary and the reference's mean-hue rule changes, :108-109), a pixel lies more than
+//         170 deg off the sum, or the block has no active pixel.
 // One wave per (image, group): 16 lanes per block.  Feeds the lower bound of filter_kernel's early exit.
 __global__ void __launch_bounds__(kBlock)
 group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ mask, size_t mask_stride,
@@ -594,36 +638,44 @@ group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ 
     const uint32_t m = reinterpret_cast<const uint32_t*>(mask + img * mask_stride)[q];
     const bool on[4] = {(m & 0x000000ffu) != 0, (m & 0x0000ff00u) != 0, (m & 0x00ff0000u) != 0, (m & 0xff000000u) != 0};
     const float xs[4] = {x.x, x.y, x.z, x.w}, as[4] = {a.x, a.y, a.z, a.w}, bs[4] = {b.x, b.y, b.z, b.w};
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, dev = 0.f, cmax = 0.f, hlo = 180.0f, hhi = -180.0f;
-    bool anywhere = false;
-    auto offset_from_275 = [](float bb, float aa) {       // hue of (aa, bb) minus 275 deg, wrapped into (-180, 180]
-        float d = atan2f(bb, aa) * 57.29577951308232f - 95.0f;     // - 275 + 180
-        d -= 360.0f * floorf(d * (1.0f / 360.0f));
-        return d - 180.0f;
-    };
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, dev = 0.f, cmax = 0.f;
+    bool anywhere = false, any = false;
     for (int k = 0; k < 4; ++k)
         if (on[k]) {
             s0 += xs[k]; s1 += as[k]; s2 += bs[k];
             dev = fmaxf(dev, fabsf(xs[k] - 50.0f));
             const float ch = chroma_of(as[k], bs[k]);
             cmax = fmaxf(cmax, ch);
-            const float p1 = offset_from_275(bs[k], as[k]), p2 = offset_from_275(bs[k], 1.5f * as[k]);
-            anywhere = anywhere || !(ch >= 1e-3f) || !(fabsf(p1 - p2) < 180.0f);
-            hlo = fminf(hlo, fminf(p1, p2)); hhi = fmaxf(hhi, fmaxf(p1, p2));
+            anywhere = anywhere || !(ch >= 1e-3f);
+            any = true;
         }
     for (int off = 8; off > 0; off >>= 1) {              // within the block's 16 lanes
         s0 += __shfl_xor(s0, off, kWave); s1 += __shfl_xor(s1, off, kWave); s2 += __shfl_xor(s2, off, kWave);
         dev = fmaxf(dev, __shfl_xor(dev, off, kWave));
         cmax = fmaxf(cmax, __shfl_xor(cmax, off, kWave));
-        hlo = fminf(hlo, __shfl_xor(hlo, off, kWave)); hhi = fmaxf(hhi, __shfl_xor(hhi, off, kWave));
         anywhere = anywhere || (__shfl_xor((int)anywhere, off, kWave) != 0);
+        any = any || (__shfl_xor((int)any, off, kWave) != 0);
+    }
+    // second pass: every pixel's hue (both ends of its g-range) against the direction of the block's sum
+    const float ref = atan2f(s2, s1) * 57.29577951308232f;
+    float dlo = 180.0f, dhi = -180.0f, far = 0.0f;
+    for (int k = 0; k < 4; ++k)
+        if (on[k]) {
+            const float e1 = wrap180(atan2f(bs[k], as[k]) * 57.29577951308232f - ref);
+            const float e2 = wrap180(atan2f(bs[k], 1.5f * as[k]) * 57.29577951308232f - ref);
+            dlo = fminf(dlo, fminf(e1, e2)); dhi = fmaxf(dhi, fmaxf(e1, e2));
+            far = fmaxf(far, fmaxf(fabsf(e1), fabsf(e2)));
+        }
+    for (int off = 8; off > 0; off >>= 1) {
+        dlo = fminf(dlo, __shfl_xor(dlo, off, kWave)); dhi = fmaxf(dhi, __shfl_xor(dhi, off, kWave));
+        far = fmaxf(far, __shfl_xor(far, off, kWave));
     }
     if ((lane & 15) == 0) {
         float* o = stats + img * n_blocks + 4 * g + (lane >> 4);
         o[0] = s0; o[block_stride] = dev; o[2 * block_stride] = s1; o[3 * block_stride] = s2; o[4 * block_stride] = cmax;
-        const bool open = anywhere || hlo > hhi;          // hlo > hhi: no active pixel in the block
-        o[5 * block_stride] = open ? -180.0f : hlo - 0.01f;
-        o[6 * block_stride] = open ? 180.0f : hhi + 0.01f;
+        const bool open = anywhere || !any || !(far <= 170.0f) || !(fmaf(s1, s1, s2 * s2) >= 1e-6f);
+        o[5 * block_stride] = open ? 0.0f : wrap180(ref + 0.5f * (dlo + dhi) - 275.0f);
+        o[6 * block_stride] = open ? 180.0f : 0.5f * (dhi - dlo) + 0.02f;
     }
 }
 
@@ -654,10 +706,10 @@ template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
 seed_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
             const float* __restrict__ lib_means, int L, int ppad, int M,
-            int32_t* __restrict__ seeds, const float4* __restrict__ hue_lut)
+            int32_t* __restrict__ seeds, const HueEntry* __restrict__ hue_lut)
 {
     extern __shared__ float proxy[];                 // [L]
-    __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
+    __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     __shared__ float red[4][kBlock / kWave];
     __shared__ float best_v[kBlock / kWave];
@@ -754,9 +806,9 @@ edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ cell_
                 const float* __restrict__ lib, const float* __restrict__ lib_chroma,
                 float* __restrict__ scores, int L, int ppad,
                 const EdgeEntry* __restrict__ edges, const unsigned int* __restrict__ edge_count,
-                unsigned int edge_cap, const float4* __restrict__ hue_lut, Variants var)
+                unsigned int edge_cap, const HueEntry* __restrict__ hue_lut, Variants var)
 {
-    __shared__ float4 lut[kHueLutSize + 1];
+    __shared__ HueEntry lut[kHueLutEntries];
     load_hue_lut(lut, hue_lut);
     const unsigned int n = min(*edge_count, edge_cap);
     for (unsigned int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -777,9 +829,9 @@ edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ cell_
 template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
 pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ second,
-                 size_t n, float* __restrict__ out, int flag_edges, const float4* __restrict__ hue_lut)
+                 size_t n, float* __restrict__ out, int flag_edges, const HueEntry* __restrict__ hue_lut)
 {
-    __shared__ float4 lut[TYPE == CIEDE2000 ? kHueLutSize + 1 : 1];
+    __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
          i += (size_t)gridDim.x * kBlock) {
@@ -812,12 +864,15 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long blocks = (long long)n_cells * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    // one share of the cells per XCD (8 on MI355X); small launches keep one share so no XCD idles on an empty one
+    const int xcd_shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
+    const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : 64) : cell_group;
     const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
     const int check_every = groups > 16 ? groups / 16 : 1;
-    hipError_t code = hipMemsetAsync(edge_count, 0, 16 * sizeof(unsigned int), stream);  // + diagnostics counters, work counter
+    hipError_t code = hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);  // + work counters, item counters
     if (code != hipSuccess) return code;
     // LDS-resident form when the cell (4 planes + mask) fits beside the hue table
-    const size_t lds_bytes = type == CIEDE2000 ? (size_t)(kHueLutSize + 1) * 16 + (size_t)ppad * 16 : (size_t)ppad * 12;
+    const size_t lds_bytes = type == CIEDE2000 ? (size_t)kHueLutEntries * sizeof(HueEntry) + (size_t)ppad * 16 : (size_t)ppad * 12;
     if (in.use_lds_form && lds_bytes <= 156 * 1024) {
         const int cpb = 64;
         const long long tiles = (L + cpb - 1) / cpb;
@@ -849,14 +904,14 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)in.lds_pad_bytes)) != hipSuccess) return code;
         filter_kernel<CIEDE2000><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<CIEDE2000>), blocks)), kBlock, in.lds_pad_bytes, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, blocks);
+            item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
     } else {
         filter_kernel<RGB_EUCLIDEAN><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN>), blocks)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            cell_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, blocks);
+            item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares);
     }
     return hipGetLastError();
 }
@@ -910,7 +965,7 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
 }
 
 hipError_t launch_pair_fast(int type, const float* first, const float* second, size_t n,
-                            float* out, int flag_edges, const float4* hue_lut, hipStream_t stream)
+                            float* out, int flag_edges, const HueEntry* hue_lut, hipStream_t stream)
 {
     const int blocks = (int)((n + kBlock - 1) / kBlock < 8192 ? (n + kBlock - 1) / kBlock : 8192);
     if (type == CIEDE2000)

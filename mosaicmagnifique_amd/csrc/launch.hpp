@@ -39,11 +39,18 @@ struct FilterInputs {
     const float* cell_chroma;   // f32 [B][ppad]  sqrt(a^2+b^2) per cell pixel (CIEDE2000 only)
     const float* lib;           // f32 planar [L][3][ppad]
     const float* lib_chroma;    // f32 [L][ppad]
-    const float4* hue_lut;      // [kHueLutSize + 1] {T, dT, sin(2 d_theta), d}  (colour_diff_fast.hpp)
+    const float2* hue_lut;      // [kHueLutSize + 2] {T, -2 sin(2 d_theta)}  (colour_diff_fast.hpp)
     int use_lds_form;           // 1: cell tile staged in LDS by 1024-thread workgroups when it fits
     int tile_candidates;        // candidates per workgroup of filter_kernel (0 = default)
     size_t lds_pad_bytes;       // diagnostics: unused dynamic LDS per filter workgroup (lowers the occupancy)
+    int xcd_aware;              // 1: persistent workgroups take the cells of their own XCD's share first (L2 affinity)
+    int xcd_cells;              // cells per sub-group of an XCD's share (0 = default 64)
 };
+
+// Words of the counter block launch_filter clears and filter_kernel fills (u32 indices into edge_count):
+// [0] discontinuity pairs logged; [2,3] [4,5] [6,7] u64: pixel groups visited, groups of a full visit,
+// candidates dropped by the block bound alone; [16..23] item counters of the persistent workgroups.
+constexpr int kFilterCounterWords = 32;
 
 // Tier-1 filter scores f32 [n_cells][L] (see filter.hip).  Pairs on the discontinuity
 // are logged to `edges` (capacity edge_cap, count in *edge_count, which may exceed
@@ -78,6 +85,6 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
 // fp32 filter form of the per-pair difference (accuracy harness).  flag_edges != 0
 // writes -1 for pairs the filter hands to the fp64 form.
 hipError_t launch_pair_fast(int type, const float* first, const float* second, size_t n,
-                            float* out, int flag_edges, const float4* hue_lut, hipStream_t stream);
+                            float* out, int flag_edges, const float2* hue_lut, hipStream_t stream);
 
 }  // namespace mm

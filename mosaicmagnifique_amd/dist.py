@@ -95,7 +95,24 @@ class ShardedBestFit:
             self._bufs = (key, idx, score, packed)
         return self._bufs[1], self._bufs[2], self._bufs[3]
 
-    def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0, spec_k=4):
+    def _same_on_all_ranks(self, todo, device):
+        """Every rank must derive the SAME set of unverified cells (identical inputs, identical
+        deterministic resolve) or the next all-gather would pair up different rounds and hang:
+        one tiny all-reduce (count and a checksum, MIN and MAX) turns a divergence into an error."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
+            return
+        digest = [float(len(todo)), float(int(todo.sum()) % 1000003), float(int((todo * todo % 7919).sum()) % 1000003)]
+        lo = torch.tensor(digest, dtype=torch.float64, device=device)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("ranks disagree on the cells to deepen (rank %d: %d cells): inputs or engines differ"
+                               % (self.rank, len(todo)))
+
+    def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0, spec_k=None):
         """cells: ALL valid cells in raster order (every rank passes the same array).
         Returns (best_fit, best_score) as Engine.generate does, identical on all ranks.
 
@@ -105,6 +122,8 @@ class ShardedBestFit:
         and resolved again, until no cell is left unverified."""
         import torch
         n = len(cells)
+        if spec_k is None:                      # the engine's own option, as mm_generate honours it
+            spec_k = getattr(self.engine, "options", {}).get("spec_k", 4)
         k = self.engine.candidates_per_cell(repeat_range, repeat_addition)
         ks = self.engine.speculative_candidates(repeat_range, repeat_addition, spec_k)
         speculate = ks < k and n > 0
@@ -131,6 +150,7 @@ class ShardedBestFit:
                 return out
             best, best_score, insufficient = out
             todo = np.nonzero((insufficient != 0) & (deep == 0))[0]
+            self._same_on_all_ranks(todo.astype(np.int64), idx.device)
             if len(todo) == 0:
                 return best, best_score
             deep[todo] = 1

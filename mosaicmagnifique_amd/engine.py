@@ -41,6 +41,7 @@ class Engine:
         self.device = int(device)
         self.n_library = 0
         self.size = 0
+        self.options = {}           # what set_option was given (the C ABI has no getter)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -246,6 +247,7 @@ class Engine:
     def set_option(self, name, value):
         """mm_set_option: "filter" 1 (default, two-tier fp32 filter + fp64 re-score) or 0 (fp64 only)."""
         self._check(self._lib.mm_set_option(self._h, name.encode(), int(value)))
+        self.options[name] = int(value)
 
     def stream_read_gbs(self, nbytes=4 << 30, repeats=5):
         """Calibration: GB/s of a coalesced float4 read stream over ``nbytes`` of device memory."""

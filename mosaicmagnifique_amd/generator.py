@@ -42,9 +42,13 @@ class HIPPhotomosaicGenerator:
         self.m_wasCanceled = ctypes.c_int(0)
         self.m_bestScores = []
         self._progress_listeners = []
-        self._staged = None          # what is resident on the device: (lib id, img id, type, mask id)
+        # What is resident on the device is tracked by a counter every setter bumps (the C++
+        # mirror's m_staleInputs), never by object identity: an array edited in place or a freed
+        # id() reused by a new array must not leave stale data on the GPU.
+        self._inputs_version = 0
+        self._staged = None          # _inputs_version the resident library / target were staged at
         self._staged_bgr = None
-        self._masks_key = None
+        self._masks_key = None       # (_inputs_version, size step) the resident masks belong to
         self._lib_step = 0          # size step the resident library is at (it is halved per step)
         self._rows = self._cols = 0
         self.lastError = ""
@@ -54,16 +58,19 @@ class HIPPhotomosaicGenerator:
         """u8 BGR ``[rows][cols][3]`` (converted like preprocessMainImage) or an
         already preprocessed f32 array."""
         self.m_img = np.asarray(img)
+        self._inputs_version += 1
 
     def setLibrary(self, lib):
         """Sequence / array of square u8 BGR images at the cell size, or f32 preprocessed."""
         self.m_lib = np.asarray(lib)
+        self._inputs_version += 1
 
     def setColourDifference(self, t):
         t = ColourDifference.Type(t)
         if t == ColourDifference.Type.MAX:
             raise ValueError("No function for given type")     # ColourDifference.cpp:23
         self.m_colourDiffType = t
+        self._inputs_version += 1
 
     def setColourScheme(self, t=ColourScheme.Type.NONE):
         """PhotomosaicGeneratorBase::setColourScheme (PhotomosaicGeneratorBase.cpp:64-69).
@@ -82,9 +89,15 @@ class HIPPhotomosaicGenerator:
         if t == ColourScheme.Type.MAX:
             raise ValueError("No function for given type")      # ColourScheme.cpp:31
         self.m_colourSchemeType = t
+        self._inputs_version += 1
 
     def setCellGroup(self, cellGroup):
         self.m_cells = cellGroup
+        self._inputs_version += 1
+
+    def invalidate(self):
+        """Call after editing an input array or the cell group IN PLACE: the next generate re-stages."""
+        self._inputs_version += 1
 
     def getCellGroup(self):
         return self.m_cells
@@ -153,8 +166,7 @@ class HIPPhotomosaicGenerator:
         return self.m_engine.get_library()
 
     def _ensure_staged(self, force=False):
-        key = (id(self.m_lib), id(self.m_img), self.m_colourDiffType, self.m_colourSchemeType,
-               id(self.m_cells.getCell(0, True)))
+        key = (self._inputs_version, self.m_cells.getDetail(), self.m_cells.getSizeSteps())
         if force or key != self._staged:
             self._stage()
             self._staged = key
@@ -197,9 +209,10 @@ class HIPPhotomosaicGenerator:
             if detailShape.getSize() != self.m_engine.size:
                 raise NotImplementedError("detail cell of %d px against a %d px library at step %d"
                                           % (detailShape.getSize(), self.m_engine.size, step))
-            if self._masks_key != id(detailShape):
+            masks_key = (self._staged, step)
+            if self._masks_key != masks_key:
                 self.m_engine.set_masks(detailShape.masks4())
-                self._masks_key = id(detailShape)
+                self._masks_key = masks_key
             self.m_engine.set_cell_resize(self.m_cells.getCellSize(step), detailShape.getSize())
             state = self.m_bestFits[step]
             cells = GridUtility.cell_records(self.m_cells, state, self._rows, self._cols, step)

@@ -17,33 +17,46 @@ def sqrt_ratio7(x):
     return np.sqrt(u / (u + 1.0))
 
 
-def hue_offsets(px):
-    """Per block: range [lo, hi] of the pixels' hue offsets from 275 deg (signed, in (-180, 180], seam at
-    95 deg), covering a' = (1 + G) a for every G in [0, 0.5]; the full circle when a pixel's chroma is
-    (nearly) zero -- its hue is arbitrary and the reference's mean-hue rule changes -- or when a pixel's
-    own range crosses the seam."""
-    a, b = px[..., 1], px[..., 2]
+def wrap180(v):
+    """Angle in degrees wrapped into [-180, 180] (round-half-even, like v_rndne_f32)."""
+    return v - 360.0 * np.rint(v / 360.0)
 
-    def phi(aa):
-        return (np.degrees(np.arctan2(b, aa)) - 275.0 + 180.0) % 360.0 - 180.0
-    p1, p2 = phi(a), phi(1.5 * a)
-    lo, hi = np.minimum(p1, p2).min(-1) - 0.01, np.maximum(p1, p2).max(-1) + 0.01
-    bad = (np.hypot(a, b).min(-1) < 1e-3) | (np.abs(p1 - p2) >= 180.0).any(-1)
-    return np.where(bad, -180.0, lo), np.where(bad, 180.0, hi)
+
+def hue_arcs(px):
+    """Per block: the arc of the hue circle that holds every pixel's hue, as (centre, half-width) in
+    degrees, the centre given as its offset from 275 deg in [-180, 180] -- the kernel's statistics 5 and 6
+    (filter.hip group_sums_kernel).  A pixel's hue is that of (g a, b) for every g = 1 + G in [1, 1.5]
+    (ColourDifference.cpp:50-53,61-83): both ends are taken.  Deviations are measured from the direction
+    of the block's summed (a, b), so no fixed seam cuts through a block; the whole circle (half-width 180)
+    when that sum vanishes, when a pixel's chroma is (nearly) zero -- its hue is arbitrary and the
+    reference's mean-hue rule changes (:108-109) -- or when a pixel lies more than 170 deg off the sum."""
+    a, b = px[..., 1], px[..., 2]
+    sa, sb = a.sum(-1, keepdims=True), b.sum(-1, keepdims=True)
+    ref = np.degrees(np.arctan2(sb, sa))
+    d1 = wrap180(np.degrees(np.arctan2(b, a)) - ref)
+    d2 = wrap180(np.degrees(np.arctan2(b, 1.5 * a)) - ref)
+    lo, hi = np.minimum(d1, d2).min(-1), np.maximum(d1, d2).max(-1)
+    bad = (np.hypot(a, b).min(-1) < 1e-3) | (np.hypot(sa, sb)[..., 0] < 1e-3) | (np.maximum(np.abs(d1), np.abs(d2)).max(-1) > 170.0)
+    centre = wrap180(ref[..., 0] + 0.5 * (lo + hi) - 275.0)
+    half = 0.5 * (hi - lo) + 0.02
+    return np.where(bad, 0.0, centre), np.where(bad, 180.0, half)
 
 
 def rotation_bound(cell, lib):
-    """Upper bound of exp(-((h_bar' - 275) / 25)^2) over all pixel pairs of the two blocks: the pair's
-    mean hue is the midpoint of the two hues or that +- 180 deg (ColourDifference.cpp:107-122)."""
-    clo, chi = hue_offsets(cell)
-    llo, lhi = hue_offsets(lib)
-    mlo, mhi = 0.5 * (clo + llo), 0.5 * (chi + lhi)
-
-    def dist(lo, hi):
-        return np.maximum(0.0, np.maximum(lo, -hi))
-    d = np.minimum(dist(mlo, mhi), np.minimum(dist(mlo + 180.0, mhi + 180.0), dist(mlo - 180.0, mhi - 180.0)))
-    # every hue of both blocks within less than 180 deg of every other: no pair wraps, the mean is the midpoint
-    d = np.where(np.maximum(chi, lhi) - np.minimum(clo, llo) < 180.0, dist(mlo, mhi), d)
+    """Upper bound of exp(-((h_bar' - 275) / 25)^2) over all pixel pairs of the two blocks.  A pair's mean
+    hue is the midpoint of the shorter arc between its two hues (ColourDifference.cpp:107-122); with the
+    blocks' arcs (c1, w1), (c2, w2) and D = wrap(c2 - c1) that midpoint lies within (w1 + w2) / 2 of
+    c1 + D / 2 -- or of the opposite point when some pair can be further than 180 deg apart
+    (|D| + w1 + w2 >= 180).  The reference does not wrap h_bar' - 275; the circular distance used here
+    is never larger, so the exponent is never more negative than the true one."""
+    c1, w1 = hue_arcs(cell)
+    c2, w2 = hue_arcs(lib)
+    delta = wrap180(c2 - c1)
+    mid = np.abs(wrap180(c1 + 0.5 * delta))
+    hw = 0.5 * (w1 + w2)
+    d0 = np.maximum(0.0, mid - hw)
+    d1 = np.maximum(0.0, (180.0 - mid) - hw)
+    d = np.where(np.abs(delta) + w1 + w2 >= 180.0, np.minimum(d0, d1), d0)
     return np.exp(-(d / 25.0) ** 2)
 
 
@@ -101,6 +114,15 @@ def groups(rng, kind, n_groups, n=256):
             r = rng.uniform(30, 110, (n_groups, 1)) + rng.normal(0, 2, (n_groups, n))
             return np.stack([rng.uniform(30, 70, (n_groups, 1)) + rng.normal(0, 2, (n_groups, n)), r * np.cos(th), r * np.sin(th)], -1)
         return side(+1), side(-1)
+    if kind in ("seam-95", "opposite"):   # hues around 95 deg (opposite 275: where a fixed seam would cut the block);
+        def cluster(centre, spread):      # clusters (nearly) opposite each other: the mean hue flips by 180 deg inside the block pair
+            th = np.deg2rad(centre + rng.uniform(-spread, spread, (n_groups, n)))
+            r = rng.uniform(15, 110, (n_groups, 1)) + rng.normal(0, 3, (n_groups, n))
+            return np.stack([rng.uniform(20, 80, (n_groups, 1)) + rng.normal(0, 2, (n_groups, n)), r * np.cos(th), r * np.sin(th)], -1)
+        if kind == "seam-95":
+            return cluster(95.0 + rng.uniform(-30, 30, (n_groups, 1)), 20.0), cluster(95.0 + rng.uniform(-30, 30, (n_groups, 1)), 20.0)
+        base = rng.uniform(0, 360, (n_groups, 1))
+        return cluster(base, 4.0), cluster(base + 180.0 + rng.uniform(-6, 6, (n_groups, 1)), 4.0)
     if kind == "grey-pixel-inside":       # colourful blocks with one exactly grey pixel each (hue undefined there)
         a, b = groups(rng, "hue-pairs", n_groups, n)
         a[:, 0, 1:] = 0.0; b[:, 1, 1:] = 0.0
@@ -118,7 +140,7 @@ def groups(rng, kind, n_groups, n=256):
 
 @pytest.mark.parametrize("n", [256, 64])
 @pytest.mark.parametrize("kind", ["uniform", "patches", "close-patches", "blue", "blue-chroma-shift", "near-grey", "dark-vs-bright",
-                                  "hue-pairs", "hue-pairs-wide", "mean-at-275", "grey-pixel-inside"])
+                                  "hue-pairs", "hue-pairs-wide", "mean-at-275", "grey-pixel-inside", "seam-95", "opposite"])
 def test_group_bound_never_exceeds_the_true_sum(oracle, kind, n):
     rng = np.random.default_rng(sum(map(ord, kind)) + n)
     cell, lib = groups(rng, kind, 1500, n)

@@ -116,7 +116,8 @@ def test_config_a_rgb_512_square32_l100_whole_grid(oracle, engine):
         want, want_score, done = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), *rep)
         assert done == 256
         assert np.array_equal(best[valid], want[valid]) and (best[~valid] == L).all()
-        assert np.array_equal(score[valid], want_score[valid])         # Euclid terms are bit-identical
+        # Euclid terms are bit-identical; only the summation order differs (parallel vs sequential fp64)
+        assert (np.abs(score[valid] - want_score[valid]) <= 1e-12 * want_score[valid]).all()
 
 
 def test_config_b_reduced_rgb_1024_square64_l1000_whole_grid(oracle, engine):
@@ -136,7 +137,7 @@ def test_config_b_reduced_rgb_1024_square64_l1000_whole_grid(oracle, engine):
     picks, scores = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), 0, 0, grid, pos,
                                             threads=host_threads())
     assert np.array_equal(picks, best[pos[:, 0], pos[:, 1]])
-    assert np.array_equal(scores, score[pos[:, 0], pos[:, 1]])
+    assert (np.abs(scores - score[pos[:, 0], pos[:, 1]]) <= 1e-12 * scores).all()
 
 
 def test_config_b_rgb_2048_square64_l1000(oracle, engine):
