@@ -97,6 +97,8 @@ typedef struct mm_timing {
     int64_t visited_groups;   /* 256-pixel groups the filter kernel evaluated (always-on counter) */
     int64_t total_groups;     /* groups a full evaluation of every (cell, candidate) would take */
     int64_t bound_dropped;    /* candidates the block bound dropped before any pixel was read */
+    int64_t band_alarms;      /* sampled cells where a candidate the fp32 band excluded beat a contender in fp64
+                               * (must stay 0; such a cell is re-done fp64-only) */
 } mm_timing;
 
 /* Progress: called on the calling thread between device batches with
@@ -307,6 +309,15 @@ mm_status mm_colour_diff_batch(mm_engine *e, int diff_type,
 mm_status mm_filter_diff_batch(mm_engine *e, int diff_type,
                                const float *first, const float *second,
                                size_t n, float *out);
+
+/* Diagnostics: what backs the error band the engine trusts the fp32 filter with.  A structured
+ * sweep generated and reduced on the device -- mode 0: hue x hue x chroma x chroma x lightness
+ * (3.8e9 distinct grid points per seed, jittered by `seed`); mode 1: the same chroma / lightness
+ * grid on both sides of the opposite-hue discontinuity (hue difference 180 deg +- 1e-7 .. 3e-2 rad).
+ * out: max |fp32 - fp64|, max (|err| - 6e-5 v), max |err| / (band px_abs + 6e-5 v) -- the share of
+ * the trusted band the worst pair uses, must stay below 1 --, the largest fp64 value met, pairs
+ * handed to the fp64 form, pairs measured. */
+mm_status mm_debug_filter_band_sweep(mm_engine *e, int mode, uint64_t seed, uint64_t n_pairs, double out[6]);
 
 /* Diagnostics: {pixel groups visited by the filter kernel, groups a full visit takes,
  * candidates dropped outright by the lightness bound} of the last batch.  Only builds

@@ -29,7 +29,8 @@ class MMTiming(ctypes.Structure):
                 ("seed_ms", ctypes.c_double), ("build_ms", ctypes.c_double),
                 ("spec_rounds", ctypes.c_int64), ("deepened_cells", ctypes.c_int64),
                 ("resolve_sweeps", ctypes.c_int64), ("visited_groups", ctypes.c_int64),
-                ("total_groups", ctypes.c_int64), ("bound_dropped", ctypes.c_int64)]
+                ("total_groups", ctypes.c_int64), ("bound_dropped", ctypes.c_int64),
+                ("band_alarms", ctypes.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -86,6 +87,8 @@ SIGNATURES = {
     "mm_colour_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),
     "mm_filter_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),
     "mm_debug_visit_counters": (ctypes.c_int, [_VP, _VP]),
+    "mm_debug_filter_band_sweep": (ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
+                                                  ctypes.POINTER(ctypes.c_double)]),
     "mm_debug_stream_read": (ctypes.c_int, [_VP, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
 }
 

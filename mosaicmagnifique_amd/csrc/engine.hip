@@ -50,7 +50,7 @@ struct mm_engine {
     // per-call workspaces (grown on demand, kept)
     DevBuf recs, cells, cmask, scores, cand_i, cand_s, grid, best, counter, scratch;
     // two-tier scoring workspaces
-    DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s;
+    DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s, sentinel;
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut;
     DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
@@ -83,6 +83,9 @@ struct mm_engine {
     int use_prune = 1;           // mm_set_option("prune", 0): filter pass without early exit
     int xcd_aware = 1;           // mm_set_option("xcd_aware", 0): one item order for the whole device
     int xcd_cells = 0;           // mm_set_option("xcd_cells", n): cells per sub-group of an XCD's share (0 = default)
+    int band_pct = 100;          // mm_set_option("band_pct", n): diagnostics -- trust only n % of the filter band (tests of the guards)
+    int band_guard_every = 64;   // mm_set_option("band_guard", n): every n-th cell of a batch re-scores the best candidate the
+                                 // filter band excluded in fp64 (0 = off); an excluded candidate that wins is a band failure
 
     mm_timing timing{};
 };
@@ -368,11 +371,15 @@ mm_status ensure_hue_lut(mm_engine* e)
 // tests/test_gpu_filter.py): CIEDE2000 max |err| = 2.5e-4 + 1.8e-5 * value (the relative part
 // is the linear interpolation of the hue table); the bound trusted here is 4x the absolute
 // and 3x the relative part.  Euclid: three roundings of a value <= 442.
-mm::FilterBand filter_band(int diff_type, int ppad)
+mm::FilterBand filter_band(int diff_type, int ppad, int percent = 100)
 {
     mm::FilterBand b;
     b.px_abs = diff_type == MM_CIEDE2000 ? 1e-3f : 5e-4f;
     b.rel = (diff_type == MM_CIEDE2000 ? 6e-5f : 0.0f) + 2e-5f + 1.2e-7f * (float)(ppad / 64);
+    if (percent != 100) {            // diagnostics only (mm_set_option "band_pct"): a deliberately wrong band, to see the guards fire
+        b.px_abs *= 0.01f * (float)percent;
+        b.rel *= 0.01f * (float)percent;
+    }
     return b;
 }
 
@@ -464,11 +471,12 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             (st = ensure(e, e->cont_f, (size_t)batch * Kc * sizeof(float), "Failed to allocate contenders")) ||
             (st = ensure(e, e->cont_s, (size_t)batch * Kc * sizeof(double), "Failed to allocate contenders")) ||
             (st = ensure(e, e->flags, (size_t)batch, "Failed to allocate cell flags")) ||
+            (st = ensure(e, e->sentinel, (size_t)batch * sizeof(int32_t), "Failed to allocate band guard slots")) ||
             (st = ensure(e, e->edge_count, mm::kFilterCounterWords * sizeof(unsigned int), "Failed to allocate edge counter")) ||
             (st = ensure(e, e->edges, (size_t)edge_cap * sizeof(mm::EdgeEntry), "Failed to allocate edge list")))
             return st;
     }
-    const mm::FilterBand band = filter_band(diff_type, ppad);
+    const mm::FilterBand band = filter_band(diff_type, ppad, e->band_pct);
     const int ftype = diff_type == MM_CIEDE2000 ? mm::CIEDE2000 : mm::RGB_EUCLIDEAN;
     if (two_tier) {
         if ((st = ensure_hue_lut(e)) ||
@@ -552,7 +560,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
 
         mm::contenders_kernel<<<b, mm::kBlock, 0, e->stream>>>(
             (const float*)e->scores.p, (const uint8_t*)e->cmask.p, L, ppad, K, Kc, band,
-            (int32_t*)e->cont_i.p, (float*)e->cont_f.p, (uint8_t*)e->flags.p);
+            (int32_t*)e->cont_i.p, (float*)e->cont_f.p, (uint8_t*)e->flags.p, (int32_t*)e->sentinel.p, e->band_guard_every);
         HIP_TRY(e, hipGetLastError(), "Error during contender selection kernel");
         HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
 
@@ -569,7 +577,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
 
         mm::rerank_kernel<<<b, mm::kBlock, 0, e->stream>>>(
             (const int32_t*)e->cont_i.p, (const float*)e->cont_f.p, (const double*)e->cont_s.p,
-            (const uint8_t*)e->cmask.p, Kc, K, ppad, band, kTieBand, ci, cs, (uint8_t*)e->flags.p, KW, rmap);
+            (const uint8_t*)e->cmask.p, Kc, K, ppad, band, kTieBand, ci, cs, (uint8_t*)e->flags.p, KW, rmap,
+            (const int32_t*)e->sentinel.p);
         HIP_TRY(e, hipGetLastError(), "Error during re-rank kernel");
         HIP_TRY(e, hipEventRecord(e->ev[9], e->stream), "event");
 
@@ -598,8 +607,10 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         dense_cells.clear();
         dense_slots.clear();
         const bool all_dense = edge_n > edge_cap;        // discontinuity log overflowed
-        for (int i = 0; i < b; ++i)
+        for (int i = 0; i < b; ++i) {
+            if (flags_host[(size_t)i] & 4) e->timing.band_alarms += 1;
             if (all_dense || flags_host[(size_t)i]) { dense_cells.push_back(cells_host[done + i]); dense_slots.push_back(done + i); }
+        }
         if (!dense_cells.empty()) {
             const int nd = (int)dense_cells.size();
             if ((st = ensure(e, e->dense_recs, (size_t)nd * sizeof(mm_cell), "Failed to allocate cell records")) ||
@@ -887,7 +898,7 @@ void mm_destroy(mm_engine* e)
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
                        &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0, &e->area_tab,
-                       &e->sweep_counts })
+                       &e->sweep_counts, &e->sentinel })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1603,6 +1614,34 @@ mm_status mm_debug_stream_read(mm_engine* e, size_t bytes, int repeats, double* 
     return MM_OK;
 }
 
+// Backs filter_band(): a structured sweep (hue x hue x chroma x chroma x lightness, and both sides of
+// the opposite-hue discontinuity) of the fp32 CIEDE2000 filter form against the fp64 form, generated
+// and reduced on the device.  out[0..3] = max |err|, max (|err| - rel v), max |err| / (px_abs + rel v)
+// -- the share of the trusted band the worst pair uses -- and the largest fp64 value met;
+// out[4], out[5] = pairs handed to the fp64 form / pairs measured.
+mm_status mm_debug_filter_band_sweep(mm_engine* e, int mode, uint64_t seed, uint64_t n_pairs, double out[6])
+{
+    if (!e || !out || (mode != 0 && mode != 1) || n_pairs == 0) return MM_INVALID_ARGUMENT;
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    mm_status st = ensure_hue_lut(e);
+    if (st) return st;
+    DevBuf buf;
+    if ((st = ensure(e, buf, 6 * sizeof(unsigned long long), "Failed to allocate sweep result"))) return st;
+    const mm::FilterBand band = filter_band(MM_CIEDE2000, 0);
+    // the per-pair part of the band: px_abs absolute, 6e-5 relative (the rest of band.rel is the accumulation's)
+    hipError_t code = mm::launch_band_sweep(mode, seed, n_pairs, band.px_abs, 6e-5f, (const float2*)e->hue_lut.p,
+                                            (unsigned long long*)buf.p, e->stream);
+    unsigned long long raw[6] = {0};
+    if (code == hipSuccess) code = hipMemcpyAsync(raw, buf.p, sizeof raw, hipMemcpyDeviceToHost, e->stream);
+    if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
+    release(buf);
+    if (code != hipSuccess) return hip_fail(e, code, "Error during filter band sweep", __FILE__, __LINE__);
+    for (int k = 0; k < 4; ++k) memcpy(&out[k], &raw[k], sizeof(double));
+    out[4] = (double)raw[4];
+    out[5] = (double)raw[5];
+    return MM_OK;
+}
+
 mm_status mm_set_option(mm_engine* e, const char* name, int value)
 {
     if (!e || !name) return MM_INVALID_ARGUMENT;
@@ -1620,6 +1659,8 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "xcd_aware") == 0) { e->xcd_aware = value != 0; return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "band_pct") == 0) { e->band_pct = std::min(1000, std::max(0, value)); return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);
     return MM_INVALID_ARGUMENT;
 }

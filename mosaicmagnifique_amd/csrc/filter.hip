@@ -206,7 +206,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // CIEDE2000 exits earlier still, through a lower bound on the pixels NOT yet visited:
     //   dE00^2 = tL^2 + tC^2 + tH^2 + R_T tC tH >= tL^2 + (1 - |R_T|/2) (tC^2 + tH^2)        (:153-157)
     //   tC^2 + tH^2 >= (dC'^2 + dH'^2) / S_C^2            (S_H = 1 + 0.015 C' T <= S_C = 1 + 0.045 C', T < 1.93)
-    //   dC'^2 + dH'^2 = |(a1', b1) - (a2', b2)|^2 >= da^2 + db^2                         (a' = (1 + G) a, G >= 0)
+    //   dC'^2 + dH'^2 = |(a1', b1) - (a2', b2)|^2 = ((1 + G) da)^2 + db^2 >= (g_min da)^2 + db^2   (a' = (1 + G) a, G >= G(largest mean chroma))
     // so per pair  dE00 >= sqrt( (dL / S_L)^2 + rho (da^2 + db^2) / S_C^2 ),  rho = 1 - |R_T| / 2 (sharpened below to the
     // smallest eigenvalue of the chroma / hue form, which also knows that S_H < S_C), and with the
     // worst constants of a 256-pixel group g of the plane order in place of the per-pair ones:
@@ -272,7 +272,9 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     const float s_l = fmaf(0.015f * x2, frsq(20.0f + x2), 1.0f);
                     // S_C and R_T likewise from the largest chroma of the two blocks (see above)
                     const float cbar = 0.5f * (cell_st[4][blk] + st[4 * bs]);
-                    const float gc = (1.5f - 0.5f * sqrt_ratio7(cbar)) * cbar;         // >= C_bar' of every pair
+                    // 1 + G of every pair is at least g_min: G falls as the pair's mean chroma grows (:50-53), and that is <= cbar
+                    const float g_min = 1.5f - 0.5f * sqrt_ratio7(cbar);
+                    const float gc = g_min * cbar;                                     // >= C_bar' of every pair
                     const float s_c = fmaf(0.045f, gc, 1.0f);
                     // |R_T| = sin(2 d_theta) R_C, d_theta = 30 deg * exp(-((h_bar' - 275) / 25)^2)  (:132-136,:145).  Each block's
                     // hues lie on an arc (centre c as an offset from 275 deg, half-width w: statistics 5, 6); a pair's mean hue
@@ -292,7 +294,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     const float half_rt = sqrt_ratio7(gc) * sin_2dt;                   // >= |R_T| / 2,  R_C = 2 sqrt_ratio7
                     // 1e-2: fp32 rounding of two 64-term sums of values <= ~128, with margin
                     const float t_l = fmaxf(fabsf(cell_st[0][blk] - st[0]) - 1e-2f, 0.0f) * frcp(s_l);
-                    const float da = fmaxf(fabsf(cell_st[2][blk] - st[2 * bs]) - 1e-2f, 0.0f);
+                    // dC'^2 + dH'^2 = ((1 + G) da)^2 + db^2 >= (g_min da)^2 + db^2
+                    const float da = fmaxf(fabsf(cell_st[2][blk] - st[2 * bs]) - 1e-2f, 0.0f) * g_min;
                     const float db = fmaxf(fabsf(cell_st[3][blk] - st[3 * bs]) - 1e-2f, 0.0f);
                     // tC^2 + tH^2 + R_T tC tH = (dC', dH') N (dC', dH')^T,  N = [[1/S_C^2, R_T/(2 S_C S_H)], [., 1/S_H^2]].
                     // Its smallest eigenvalue falls as S_C, S_H or |R_T| grow (it is the minimum of y^T M y / (S_C^2 y1^2 +
@@ -845,7 +848,97 @@ pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ seco
     }
 }
 
+// Structured sweep of the fp32 CIEDE2000 filter form against the fp64 form, pairs generated on the
+// device (no host arrays: 10^10 pairs take about a second).  What backs the error band the engine
+// trusts the filter with (engine.hip filter_band): per pair |fp32 - fp64| <= px_abs + rel * fp64.
+//   mode 0: hue1 x hue2 (512 x 512 steps of the circle, jittered) x chroma1 x chroma2 (24 x 24 levels from
+//           exactly grey over 1e-4 to 150, jittered) x 25 lightness pairs (L1 in {0,25,50,75,100}, dL in
+//           {-40,-5,0,5,40}, jittered) = 3.8e9 pairs per seed;
+//   mode 1: the same chroma / lightness grid with hue2 = hue1 + 180 deg + d, d = +-(1e-7 .. 3e-2 rad, 64 log
+//           steps): both sides of the opposite-hue discontinuity, where the fp32 branch choice matters.
+// Pairs the filter hands to the fp64 form (needs_exact) are counted, not measured.
+// out: [0] max |err|  [1] max (|err| - rel * v)  [2] max |err| / (px_abs + rel * v)  [3] max fp64 value
+//      as bit patterns of non-negative doubles (atomicMax on u64), [4] handed-over pairs, [5] pairs measured.
+__device__ __forceinline__ unsigned int sweep_hash(unsigned long long x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return (unsigned int)x;
+}
+
+__global__ void __launch_bounds__(kBlock)
+band_sweep_kernel(int mode, unsigned long long seed, unsigned long long n_pairs, float px_abs, float rel,
+                  const HueEntry* __restrict__ hue_lut, unsigned long long* __restrict__ out)
+{
+    __shared__ HueEntry lut[kHueLutEntries];
+    load_hue_lut(lut, hue_lut);
+    const float chroma_levels[24] = {0.0f, 1e-4f, 1e-2f, 0.3f, 1.0f, 2.0f, 4.0f, 7.0f, 10.0f, 14.0f, 18.0f, 22.0f,
+                                     25.0f, 28.0f, 32.0f, 38.0f, 45.0f, 55.0f, 65.0f, 80.0f, 95.0f, 110.0f, 128.0f, 150.0f};
+    const float l_levels[5] = {0.0f, 25.0f, 50.0f, 75.0f, 100.0f}, dl_levels[5] = {-40.0f, -5.0f, 0.0f, 5.0f, 40.0f};
+    double m_err = 0.0, m_abs = 0.0, m_ratio = 0.0, m_val = 0.0;
+    unsigned long long handed = 0, measured = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n_pairs;
+         i += (unsigned long long)gridDim.x * kBlock) {
+        unsigned long long r = i;
+        const int li = (int)(r % 25); r /= 25;
+        const int c2i = (int)(r % 24); r /= 24;
+        const int c1i = (int)(r % 24); r /= 24;
+        const unsigned int u = sweep_hash(i * 0x9e3779b97f4a7c15ull + seed);
+        const float j0 = (float)(u & 1023u) * (1.0f / 1024.0f), j1 = (float)((u >> 10) & 1023u) * (1.0f / 1024.0f),
+                    j2 = (float)((u >> 20) & 1023u) * (1.0f / 1024.0f);
+        double h1, h2;
+        if (mode == 0) {
+            const int h2i = (int)(r % 512); r /= 512;
+            const int h1i = (int)(r % 512);
+            h1 = 6.283185307179586 * ((double)h1i + j0) / 512.0;
+            h2 = 6.283185307179586 * ((double)h2i + j1) / 512.0;
+        } else {
+            const int di = (int)(r % 128); r /= 128;
+            const int h1i = (int)(r % 512);
+            h1 = 6.283185307179586 * ((double)h1i + j0) / 512.0;
+            const double mag = 1e-7 * exp(((double)(di >> 1) + j1) * (log(3e5) / 64.0));     // 1e-7 .. 3e-2 rad
+            h2 = h1 + 3.141592653589793 + ((di & 1) ? mag : -mag);
+        }
+        const float ch1 = chroma_levels[c1i] * (1.0f + 0.05f * (j2 - 0.5f)), ch2 = chroma_levels[c2i] * (1.0f + 0.05f * (j0 - 0.5f));
+        const float l1 = fminf(fmaxf(l_levels[li / 5] + 6.0f * (j1 - 0.5f), 0.0f), 100.0f);
+        const float l2 = fminf(fmaxf(l1 + dl_levels[li % 5] + 2.0f * (j2 - 0.5f), 0.0f), 100.0f);
+        const PxF p{l1, (float)(ch1 * cos(h1)), (float)(ch1 * sin(h1))}, q{l2, (float)(ch2 * cos(h2)), (float)(ch2 * sin(h2))};
+        bool edge;
+        const float fast = ciede2000_fast(p, q, chroma_of(p.c1, p.c2), chroma_of(q.c1, q.c2), lut, &edge);
+        if (edge) { handed += 1; continue; }
+        const double exact = ciede2000(Px{p.c0, p.c1, p.c2}, Px{q.c0, q.c1, q.c2});
+        const double err = fabs((double)fast - exact);
+        m_err = fmax(m_err, err);
+        m_abs = fmax(m_abs, err - (double)rel * exact);
+        m_ratio = fmax(m_ratio, err / ((double)px_abs + (double)rel * exact));
+        m_val = fmax(m_val, exact);
+        measured += 1;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        m_err = fmax(m_err, __shfl_xor(m_err, off, kWave)); m_abs = fmax(m_abs, __shfl_xor(m_abs, off, kWave));
+        m_ratio = fmax(m_ratio, __shfl_xor(m_ratio, off, kWave)); m_val = fmax(m_val, __shfl_xor(m_val, off, kWave));
+        handed += __shfl_xor(handed, off, kWave); measured += __shfl_xor(measured, off, kWave);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // non-negative doubles order like their bit patterns
+        atomicMax(out + 0, (unsigned long long)__double_as_longlong(m_err));
+        atomicMax(out + 1, (unsigned long long)__double_as_longlong(fmax(m_abs, 0.0)));
+        atomicMax(out + 2, (unsigned long long)__double_as_longlong(m_ratio));
+        atomicMax(out + 3, (unsigned long long)__double_as_longlong(m_val));
+        atomicAdd(out + 4, handed);
+        atomicAdd(out + 5, measured);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_band_sweep(int mode, unsigned long long seed, unsigned long long n_pairs, float px_abs, float rel,
+                             const HueEntry* hue_lut, unsigned long long* out6, hipStream_t stream)
+{
+    hipError_t code = hipMemsetAsync(out6, 0, 6 * sizeof(unsigned long long), stream);
+    if (code != hipSuccess) return code;
+    band_sweep_kernel<<<256 * 16, kBlock, 0, stream>>>(mode, seed, n_pairs, px_abs, rel, hue_lut, out6);
+    return hipGetLastError();
+}
 
 hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,

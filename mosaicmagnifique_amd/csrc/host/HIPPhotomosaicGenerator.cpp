@@ -3,7 +3,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <stdexcept>
+#include <thread>
+
+#include <zlib.h>
 
 // ---------------------------------------------------------------------------- CellShape
 CellShape::CellShape(int size, std::vector<uint8_t> mask) : m_size(size)
@@ -31,6 +35,7 @@ CellShape CellShape::resized(int size) const
     if (m_size == 0 || size == m_size) return *this;
     CellShape out(size, ImageUtility::resizeArea(m_masks[0], m_size, m_size, 1, size, size));
     const double ratio = (double)size / m_size;
+    out.name = name;
     out.rowSpacing = std::max((int)std::floor(rowSpacing * ratio), 1);
     out.colSpacing = std::max((int)std::floor(colSpacing * ratio), 1);
     out.alternateRowSpacing = std::max((int)std::floor(alternateRowSpacing * ratio), 1);
@@ -45,6 +50,142 @@ CellShape CellShape::resized(int size) const
 }
 
 // ---------------------------------------------------------------------------- CellGroup
+// ---------------------------------------------------------------------------- .mcs reader
+namespace {
+
+struct BigEndianReader {
+    const std::vector<uint8_t>& d;
+    size_t pos = 0;
+    uint32_t u32()
+    {
+        if (pos + 4 > d.size()) throw std::runtime_error("unexpected end of .mcs file");
+        const uint32_t v = ((uint32_t)d[pos] << 24) | ((uint32_t)d[pos + 1] << 16) | ((uint32_t)d[pos + 2] << 8) | d[pos + 3];
+        pos += 4;
+        return v;
+    }
+    uint8_t u8()
+    {
+        if (pos + 1 > d.size()) throw std::runtime_error("unexpected end of .mcs file");
+        return d[pos++];
+    }
+    std::vector<uint8_t> bytes(size_t n)
+    {
+        if (pos + n > d.size()) throw std::runtime_error("unexpected end of .mcs file");
+        std::vector<uint8_t> out(d.begin() + (long)pos, d.begin() + (long)(pos + n));
+        pos += n;
+        return out;
+    }
+};
+
+// 8-bit non-interlaced PNG (grey, grey+alpha, RGB or RGBA) -> its first channel; what cv::imdecode(...,
+// IMREAD_GRAYSCALE) of the masks QImage / OpenCV write gives for a grey image.  zlib does the inflating.
+std::vector<uint8_t> decodePngFirstChannel(const std::vector<uint8_t>& png, int& rows, int& cols)
+{
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (png.size() < 8 || !std::equal(sig, sig + 8, png.begin())) throw std::runtime_error("mask is not a PNG");
+    BigEndianReader r{png, 8};
+    std::vector<uint8_t> idat;
+    int channels = 0;
+    for (;;) {
+        const uint32_t len = r.u32();
+        const std::vector<uint8_t> type = r.bytes(4);
+        const std::vector<uint8_t> body = r.bytes(len);
+        r.u32();                                         // CRC (zlib's own checksum guards the pixel data)
+        const std::string t(type.begin(), type.end());
+        if (t == "IHDR") {
+            BigEndianReader h{body};
+            cols = (int)h.u32(); rows = (int)h.u32();
+            const int depth = h.u8(), colour = h.u8();
+            h.u8(); h.u8();
+            const int interlace = h.u8();
+            channels = colour == 0 ? 1 : colour == 4 ? 2 : colour == 2 ? 3 : colour == 6 ? 4 : 0;
+            if (depth != 8 || channels == 0 || interlace != 0) throw std::runtime_error("unsupported PNG mask (need 8-bit, non-interlaced, no palette)");
+        } else if (t == "IDAT") idat.insert(idat.end(), body.begin(), body.end());
+        else if (t == "IEND") break;
+    }
+    if (channels == 0 || rows <= 0 || cols <= 0) throw std::runtime_error("PNG mask without a header");
+    const size_t stride = (size_t)cols * channels;
+    std::vector<uint8_t> raw((stride + 1) * (size_t)rows);
+    uLongf got = (uLongf)raw.size();
+    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size())
+        throw std::runtime_error("PNG mask does not inflate");
+    std::vector<uint8_t> prev(stride, 0), cur(stride), out((size_t)rows * cols);
+    for (int y = 0; y < rows; ++y) {
+        const uint8_t* line = raw.data() + (size_t)y * (stride + 1);
+        for (size_t x = 0; x < stride; ++x) {
+            const int a = x >= (size_t)channels ? cur[x - channels] : 0, b = prev[x], c = x >= (size_t)channels ? prev[x - channels] : 0;
+            int pred = 0;
+            switch (line[0]) {                           // PNG filter types 0..4
+            case 0: break;
+            case 1: pred = a; break;
+            case 2: pred = b; break;
+            case 3: pred = (a + b) / 2; break;
+            case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                      pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+            default: throw std::runtime_error("bad PNG filter");
+            }
+            cur[x] = (uint8_t)(line[1 + x] + pred);
+        }
+        for (int x = 0; x < cols; ++x) out[(size_t)y * cols + x] = cur[(size_t)x * channels];
+        prev.swap(cur);
+    }
+    return out;
+}
+
+}  // namespace
+
+CellShape CellShape::loadFromFile(const std::string& path)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::vector<uint8_t> data;
+    uint8_t buf[65536];
+    for (size_t n; (n = fread(buf, 1, sizeof buf, f)) > 0;) data.insert(data.end(), buf, buf + n);
+    fclose(f);
+    BigEndianReader r{data};
+    if (r.u32() != 0x87AECFB1u) throw std::runtime_error("File is not a valid .mcs: " + path);     // CellShape.cpp:392-395
+    const uint32_t version = r.u32();
+    if (version > 8) throw std::runtime_error(".mcs uses a newer file version: " + path);
+    if (version < 7) throw std::runtime_error(".mcs uses an outdated file version: " + path);
+    std::string name;
+    const uint32_t nameBytes = r.u32();                  // QString: byte length (0xFFFFFFFF = null), UTF-16BE
+    if (nameBytes != 0xFFFFFFFFu) {
+        const std::vector<uint8_t> utf16 = r.bytes(nameBytes);
+        for (size_t i = 0; i + 1 < utf16.size(); i += 2) {
+            const unsigned cp = ((unsigned)utf16[i] << 8) | utf16[i + 1];
+            if (cp < 0x80) name += (char)cp;             // UTF-8 of the BMP code point (shape names are short labels)
+            else if (cp < 0x800) { name += (char)(0xC0 | (cp >> 6)); name += (char)(0x80 | (cp & 0x3F)); }
+            else { name += (char)(0xE0 | (cp >> 12)); name += (char)(0x80 | ((cp >> 6) & 0x3F)); name += (char)(0x80 | (cp & 0x3F)); }
+        }
+    }
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> mask;
+    if (version >= 8) mask = decodePngFirstChannel(r.bytes(r.u32()), rows, cols);
+    else {
+        r.u32();                                         // cv::Mat type
+        rows = (int)r.u32(); cols = (int)r.u32();
+        mask = r.bytes(r.u32());
+        if (mask.size() != (size_t)rows * cols) throw std::runtime_error("raw .mcs mask is not 8-bit single channel");
+    }
+    if (rows != cols) throw std::runtime_error(".mcs mask is not square");
+    CellShape shape;
+    shape.m_size = rows;
+    shape.name = name;
+    for (int m = 0; m < 4; ++m) {                        // the four pre-flipped variants, as stored (no re-threshold)
+        shape.m_masks[m].resize(mask.size());
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < cols; ++x)
+                shape.m_masks[m][(size_t)y * cols + x] = mask[(size_t)((m & 2) ? rows - 1 - y : y) * cols + ((m & 1) ? cols - 1 - x : x)];
+    }
+    auto i32 = [&] { return (int)r.u32(); };
+    shape.rowSpacing = i32(); shape.colSpacing = i32();
+    shape.alternateRowSpacing = i32(); shape.alternateColSpacing = i32();
+    shape.alternateRowOffset = i32(); shape.alternateColOffset = i32();
+    shape.alternateColFlipHorizontal = r.u8() != 0; shape.alternateColFlipVertical = r.u8() != 0;
+    shape.alternateRowFlipHorizontal = r.u8() != 0; shape.alternateRowFlipVertical = r.u8() != 0;
+    return shape;
+}
+
 void CellGroup::setCellShape(const CellShape& shape)
 {
     m_cells.at(0) = shape;
@@ -308,13 +449,31 @@ MosaicBestFit getGridState(const CellGroup& cells, const Image8* mainImage, int 
 }  // namespace GridUtility
 
 // ---------------------------------------------------------------------------- generator
-HIPPhotomosaicGenerator::HIPPhotomosaicGenerator(int device)
+HIPPhotomosaicGenerator::HIPPhotomosaicGenerator(int device) : HIPPhotomosaicGenerator(std::vector<int>{device}) {}
+
+HIPPhotomosaicGenerator::HIPPhotomosaicGenerator(const std::vector<int>& devices)
 {
-    if (mm_create(device, &m_engine) != MM_OK)
-        throw std::runtime_error(std::string("HIP engine: ") + mm_last_error(nullptr));
+    if (devices.empty()) throw std::invalid_argument("HIP engine: no device given");
+    for (int device : devices) {
+        mm_engine* e = nullptr;
+        if (mm_create(device, &e) != MM_OK) {
+            for (mm_engine* made : m_engines) mm_destroy(made);
+            throw std::runtime_error(std::string("HIP engine: ") + mm_last_error(nullptr));
+        }
+        m_engines.push_back(e);
+    }
+    m_engine = m_engines.front();
 }
 
-HIPPhotomosaicGenerator::~HIPPhotomosaicGenerator() { mm_destroy(m_engine); }
+HIPPhotomosaicGenerator::~HIPPhotomosaicGenerator() { for (mm_engine* e : m_engines) mm_destroy(e); }
+
+bool HIPPhotomosaicGenerator::setEngineOption(const char* name, int value)
+{
+    if (std::string(name) == "spec_k") m_specK = value;
+    for (mm_engine* e : m_engines)
+        if (mm_set_option(e, name, value) != MM_OK) { m_lastError = mm_last_error(e); return false; }
+    return true;
+}
 
 void HIPPhotomosaicGenerator::setMainImage(const Image& img) { m_img = img; m_img8 = Image8{}; m_rows = img.rows; m_cols = img.cols; m_staleInputs = true; }
 void HIPPhotomosaicGenerator::setLibrary(const std::vector<Image>& lib) { m_lib = lib; m_lib8.clear(); m_libCount = lib.size(); m_staleInputs = true; }
@@ -477,6 +636,20 @@ void onProgress(int done, void* user)
 // preprocessMainImage / preprocessLibraryImages (PhotomosaicGeneratorBase.cpp:223-290) -> device.
 bool HIPPhotomosaicGenerator::stageInputs()
 {
+    // library and target are replicated on every engine (<= ~1.1 GB even for an 8192^2 target with
+    // 10 000 images: nothing against 288 GB of HBM per GPU)
+    mm_engine* const first = m_engine;
+    bool ok = true;
+    for (size_t i = 0; i < m_engines.size() && ok; ++i) {
+        m_engine = m_engines[i];
+        ok = stageInputsOn();
+    }
+    m_engine = first;
+    return ok;
+}
+
+bool HIPPhotomosaicGenerator::stageInputsOn()
+{
     const int detailSize = m_cells.getCellSize(0, true);
     const int type = (int)m_colourDiffType;
     mm_status st = MM_OK;
@@ -534,20 +707,28 @@ bool HIPPhotomosaicGenerator::generateBestFits()
         const CellShape& detail = m_cells.getCell(step, true);
         if (detail.getSize() <= 0 || detail.getSize() > normal.getSize()) { m_lastError = "detail cell larger than the cell"; return false; }
         mm_status st;
-        if (step > 0 && (st = mm_shrink_library(m_engine, 2)) != MM_OK) return fail(st);       // batchResizeMat, :95-99
         const std::vector<uint8_t> masks = masks4(detail);
-        if ((st = mm_set_masks(m_engine, masks.data(), detail.getSize())) != MM_OK) return fail(st);
-        if ((st = mm_set_cell_resize(m_engine, normal.getSize(), detail.getSize())) != MM_OK) return fail(st);   // getCellAt's resize, :313-315
+        for (mm_engine* e : m_engines) {
+            auto failOn = [&](mm_status code) { m_lastError = mm_last_error(e); (void)code; return false; };
+            if (step > 0 && (st = mm_shrink_library(e, 2)) != MM_OK) return failOn(st);       // batchResizeMat, :95-99
+            if ((st = mm_set_masks(e, masks.data(), detail.getSize())) != MM_OK) return failOn(st);
+            if ((st = mm_set_cell_resize(e, normal.getSize(), detail.getSize())) != MM_OK) return failOn(st);   // getCellAt's resize, :313-315
+        }
 
         GridUtility::StepBestFit& grid = m_bestFits[step];
         const int gridH = (int)grid.size(), gridW = (int)grid.at(0).size();
         const std::vector<mm_cell> cells = cellRecords(step, false);
         std::vector<int64_t> bestFit((size_t)gridW * gridH);
         ProgressScope scope{this, progressBase, (int)std::pow(4, (steps - 1) - step)};        // progressStep, :54
-        st = mm_generate(m_engine, cells.data(), (int)cells.size(), gridW, gridH, (int)m_colourDiffType,
-                         m_repeatRange, m_repeatAddition, bestFit.data(), nullptr,
-                         progress ? onProgress : nullptr, &scope, &m_wasCanceled);
-        if (st != MM_OK) return fail(st);
+        if (m_engines.size() > 1) {
+            if (!generateStepSharded(cells, gridW, gridH, bestFit)) return false;
+            if (progress) progress(progressBase + (int)cells.size() * scope.weight);
+        } else {
+            st = mm_generate(m_engine, cells.data(), (int)cells.size(), gridW, gridH, (int)m_colourDiffType,
+                             m_repeatRange, m_repeatAddition, bestFit.data(), nullptr,
+                             progress ? onProgress : nullptr, &scope, &m_wasCanceled);
+            if (st != MM_OK) return fail(st);
+        }
         progressBase += gridW * gridH * scope.weight;
 
         // Write back where the grid state has a value (CUDAPhotomosaicGenerator.cpp:310-324);
@@ -560,7 +741,79 @@ bool HIPPhotomosaicGenerator::generateBestFits()
                 if (v >= 0 && v < (int64_t)m_libCount) cell = (size_t)v; else cell = std::nullopt;
             }
     }
-    mm_set_cell_scale(m_engine, 1);
+    for (mm_engine* e : m_engines) mm_set_cell_scale(e, 1);
     if (progress) progress(getMaxProgress());
     return true;
+}
+
+// One size step over several engines: contiguous shards of ceil(n / engines) cells in raster order,
+// one host thread per engine (base scores of different cells are independent), the lists land in
+// ONE host array (the "gather"), then the verifying resolve on the first engine; cells whose short
+// list could not be vouched for are deepened by their owner and the resolve runs again -- the loop
+// of mm_generate (engine.hip), with the engines in place of the batches.
+bool HIPPhotomosaicGenerator::generateStepSharded(const std::vector<mm_cell>& cells, int gridW, int gridH,
+                                                  std::vector<int64_t>& bestFit)
+{
+    const int n = (int)cells.size(), type = (int)m_colourDiffType, engines = (int)m_engines.size();
+    const int K = std::max(1, mm_candidates_per_cell((int)m_libCount, m_repeatRange, m_repeatAddition));
+    const int Ks = std::max(1, mm_speculative_candidates((int)m_libCount, m_repeatRange, m_repeatAddition, m_specK));
+    const bool speculate = Ks < K && n > 0;
+    const int per = n > 0 ? (n + engines - 1) / engines : 0;
+    std::vector<int32_t> index((size_t)std::max(n, 1) * K, -1);
+    std::vector<double> score((size_t)std::max(n, 1) * K, 0.0);
+    std::vector<mm_status> status((size_t)engines, MM_OK);
+
+    // rows: cell numbers to score (empty = the engine's whole shard), fill = entries per list
+    auto scoreOn = [&](const std::vector<std::vector<int>>& rows, int fill) {
+        std::vector<std::thread> threads;
+        for (int g = 0; g < engines; ++g)
+            threads.emplace_back([&, g] {
+                const int lo = std::min(g * per, n), hi = std::min(lo + per, n);
+                if (rows.empty()) {
+                    if (hi > lo)
+                        status[(size_t)g] = mm_score_cells_partial(m_engines[(size_t)g], cells.data() + lo, hi - lo, type, K, fill,
+                                                                   index.data() + (size_t)lo * K, score.data() + (size_t)lo * K, 0,
+                                                                   nullptr, nullptr, &m_wasCanceled);
+                    return;
+                }
+                const std::vector<int>& mine = rows[(size_t)g];
+                if (mine.empty()) return;
+                std::vector<mm_cell> sub;
+                for (int c : mine) sub.push_back(cells[(size_t)c]);
+                std::vector<int32_t> si(mine.size() * (size_t)K);
+                std::vector<double> ss(mine.size() * (size_t)K);
+                status[(size_t)g] = mm_score_cells_partial(m_engines[(size_t)g], sub.data(), (int)sub.size(), type, K, fill,
+                                                           si.data(), ss.data(), 0, nullptr, nullptr, &m_wasCanceled);
+                if (status[(size_t)g] != MM_OK) return;
+                for (size_t r = 0; r < mine.size(); ++r) {
+                    std::copy(si.begin() + r * K, si.begin() + (r + 1) * K, index.begin() + (size_t)mine[r] * K);
+                    std::copy(ss.begin() + r * K, ss.begin() + (r + 1) * K, score.begin() + (size_t)mine[r] * K);
+                }
+            });
+        for (std::thread& t : threads) t.join();
+        for (int g = 0; g < engines; ++g)
+            if (status[(size_t)g] != MM_OK) {
+                if (status[(size_t)g] != MM_CANCELLED) m_lastError = mm_last_error(m_engines[(size_t)g]);
+                return false;
+            }
+        return true;
+    };
+
+    if (!scoreOn({}, Ks)) return false;
+    std::vector<uint8_t> deep((size_t)std::max(n, 1), 0), insufficient((size_t)std::max(n, 1), 0);
+    for (;;) {
+        if (m_wasCanceled) return false;
+        const mm_status st = mm_resolve_verify(m_engine, cells.data(), n, gridW, gridH, type, m_repeatRange, m_repeatAddition,
+                                               K, Ks, index.data(), score.data(), 0,
+                                               speculate ? deep.data() : nullptr, speculate ? insufficient.data() : nullptr,
+                                               bestFit.data(), nullptr);
+        if (st != MM_OK) { m_lastError = mm_last_error(m_engine); return false; }
+        if (!speculate) return true;
+        std::vector<std::vector<int>> todo((size_t)engines);
+        bool any = false;
+        for (int c = 0; c < n; ++c)
+            if (insufficient[(size_t)c] && !deep[(size_t)c]) { todo[(size_t)std::min(c / per, engines - 1)].push_back(c); deep[(size_t)c] = 1; any = true; }
+        if (!any) return true;
+        if (!scoreOn(todo, K)) return false;            // the owners deepen their unverified cells to the full length
+    }
 }

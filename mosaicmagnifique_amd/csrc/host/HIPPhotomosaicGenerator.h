@@ -78,6 +78,12 @@ public:
     // CellShape::resized (CellShape.cpp:281-312): mask resized + re-thresholded, spacings
     // floored (never < 1), offsets floored, flip flags copied.
     CellShape resized(int size) const;
+    // CellShape::loadFromFile (CellShape.cpp:373-434) without Qt / OpenCV: big-endian QDataStream -- u32 magic
+    // 0x87AECFB1, u32 version (7 or 8), QString name (UTF-16BE), the mask (v8: PNG in a QByteArray; v7: raw
+    // type / rows / cols + bytes, CustomQDataStream.h:22-87), 6 x i32 spacings / offsets, 4 x bool flips.
+    // The mask is kept as stored (not re-thresholded), as the reference does.  Throws std::runtime_error.
+    static CellShape loadFromFile(const std::string& path);
+    std::string name;
     int rowSpacing = 0, colSpacing = 0, alternateRowSpacing = 0, alternateColSpacing = 0;
     int alternateRowOffset = 0, alternateColOffset = 0;
     bool alternateColFlipHorizontal = false, alternateColFlipVertical = false;
@@ -123,7 +129,17 @@ inline MosaicBestFit getGridState(const CellGroup& cells, int imageRows, int ima
 class HIPPhotomosaicGenerator {
 public:
     explicit HIPPhotomosaicGenerator(int device = 0);
+    // Several GPUs from ONE process (the reference's generator is single-device,
+    // CUDA/CUDAPhotomosaicGenerator.h:31): one engine per entry of `devices` (an id may be listed more
+    // than once), library / masks / target replicated, the valid cells of a step cut into contiguous
+    // shards scored concurrently by one host thread per engine (mm_score_cells_partial), the candidate
+    // lists merged on the host, and ONE verifying resolve (mm_resolve_verify) on the first engine --
+    // the same speculate-and-verify loop as mm_generate, so the grid equals the single-device one.
+    explicit HIPPhotomosaicGenerator(const std::vector<int>& devices);
     ~HIPPhotomosaicGenerator();
+    size_t deviceCount() const { return m_engines.size(); }
+    // mm_set_option on every engine (tuning / tests).
+    bool setEngineOption(const char* name, int value);
     HIPPhotomosaicGenerator(const HIPPhotomosaicGenerator&) = delete;
     HIPPhotomosaicGenerator& operator=(const HIPPhotomosaicGenerator&) = delete;
 
@@ -161,7 +177,10 @@ public:
     mm_timing timing() const;
 
 private:
-    mm_engine* m_engine = nullptr;
+    mm_engine* m_engine = nullptr;          // m_engines[0]: the one that resolves and paints
+    std::vector<mm_engine*> m_engines;
+    int m_specK = 4;                        // speculative short lists of the multi-engine path (option "spec_k")
+    bool generateStepSharded(const std::vector<mm_cell>& cells, int gridW, int gridH, std::vector<int64_t>& bestFit);
     Image m_img;
     std::vector<Image> m_lib;
     Image8 m_img8;
@@ -169,6 +188,7 @@ private:
     int m_rows = 0, m_cols = 0;
     size_t m_libCount = 0;
     bool stageInputs();
+    bool stageInputsOn();           // ... onto m_engine
     std::vector<std::vector<uint8_t>> m_libBgr;
     bool m_staleInputs = true, m_staleBgr = true;
     std::vector<mm_cell> cellRecords(size_t step, bool painting) const;

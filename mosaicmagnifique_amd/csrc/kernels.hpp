@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(kBlock)
 contenders_kernel(const float* __restrict__ fscores, const uint8_t* __restrict__ cmask,
                   int L, int ppad, int K, int Kc, FilterBand band,
                   int32_t* __restrict__ cont_index, float* __restrict__ cont_filter,
-                  uint8_t* __restrict__ flags)
+                  uint8_t* __restrict__ flags, int32_t* __restrict__ sentinel, int sample_every)
 {
     __shared__ ScoreIdx sh[kBlock / kWave];
     __shared__ int n_cont;
@@ -580,8 +580,28 @@ contenders_kernel(const float* __restrict__ fscores, const uint8_t* __restrict__
     }
     __syncthreads();
     const int n = n_cont;
-    for (int t = n + threadIdx.x; t < Kc; t += kBlock) { ci[t] = -1; cf[t] = 0.0f; }
-    if (threadIdx.x == 0) flags[blockIdx.x] = n > Kc ? 1 : 0;
+    // Run-time guard of the band (sampled cells): the best candidate the band EXCLUDED (finite filter
+    // score above the threshold) rides along as a sentinel; rerank_kernel compares its fp64 score with
+    // the K-th contender's -- if the excluded one is truly better, the band was too narrow for this
+    // content and the cell is re-done fp64-only (flag bit 2) and counted (mm_timing.band_alarms).
+    int sent = -1;
+    if (sentinel && sample_every > 0 && blockIdx.x % (unsigned)sample_every == 0 && n < Kc) {
+        ScoreIdx best{kInf, 0x7fffffff};
+        for (int l = threadIdx.x; l < L; l += kBlock) {
+            const double sc = (double)row[l];
+            if (sc > thr && sc < kInf && lex_less(sc, l, best.s, best.i)) { best.s = sc; best.i = l; }
+        }
+        best = block_min(best, sh);
+        if (best.i != 0x7fffffff) {
+            sent = n;
+            if (threadIdx.x == 0) { ci[n] = best.i; cf[n] = (float)best.s; }
+        }
+    }
+    for (int t = n + (sent >= 0 ? 1 : 0) + threadIdx.x; t < Kc; t += kBlock) { ci[t] = -1; cf[t] = 0.0f; }
+    if (threadIdx.x == 0) {
+        flags[blockIdx.x] = n > Kc ? 1 : 0;
+        if (sentinel) sentinel[blockIdx.x] = sent;
+    }
 }
 
 // fp64 reference-form score of every contender: one wave per (cell, slot), same
@@ -636,10 +656,12 @@ rerank_kernel(const int32_t* __restrict__ cont_index, const float* __restrict__ 
               const double* __restrict__ cont_score, const uint8_t* __restrict__ cmask,
               int Kc, int K, int ppad, FilterBand band, double tie_band,
               int32_t* __restrict__ cand_index, double* __restrict__ cand_score,
-              uint8_t* __restrict__ flags, int KW, const int* __restrict__ row_map)
+              uint8_t* __restrict__ flags, int KW, const int* __restrict__ row_map,
+              const int32_t* __restrict__ sentinel)
 {
     __shared__ ScoreIdx sh[kBlock / kWave];
     __shared__ int n_active;
+    const int sent = sentinel ? sentinel[blockIdx.x] : -1;      // slot of the band guard's excluded candidate, not ranked
     const size_t out = (size_t)(row_map ? row_map[blockIdx.x] : (int)blockIdx.x) * KW;
     for (int t = K + threadIdx.x; t < KW; t += kBlock) { cand_index[out + t] = -1; cand_score[out + t] = kInf; }
     const int32_t* ci = cont_index + (size_t)blockIdx.x * Kc;
@@ -667,12 +689,14 @@ rerank_kernel(const int32_t* __restrict__ cont_index, const float* __restrict__ 
         ScoreIdx best{kInf, 0x7fffffff};
         for (int t = threadIdx.x; t < Kc; t += kBlock) {
             const int l = ci[t];
-            if (l < 0) continue;
+            if (l < 0 || t == sent) continue;
             const double s = cs[t];
             if (lex_less(prev_s, prev_i, s, l) && lex_less(s, l, best.s, best.i)) { best.s = s; best.i = l; }
         }
         best = block_min(best, sh);
         const bool none = best.i == 0x7fffffff;
+        if (r == K - 1 && !none && sent >= 0 && threadIdx.x == 0 && lex_less(cs[sent], ci[sent], best.s, best.i))
+            flags[blockIdx.x] |= 4;             // an excluded candidate beats the K-th contender: the band failed here
         if (r == K) {
             if (!none && threadIdx.x == 0 && best.s <= prev_s + fabs(prev_s) * (4.0 * tie_band))
                 cand_index[out + K - 1] = -(prev_i + 2);

@@ -87,4 +87,10 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
 hipError_t launch_pair_fast(int type, const float* first, const float* second, size_t n,
                             float* out, int flag_edges, const float2* hue_lut, hipStream_t stream);
 
+// Structured device-side sweep of the fp32 CIEDE2000 filter form against the fp64 form (filter.hip
+// band_sweep_kernel): out6 = {max |err|, max (|err| - rel v), max |err| / (px_abs + rel v), max v} as
+// double bit patterns, pairs handed to the fp64 form, pairs measured.
+hipError_t launch_band_sweep(int mode, unsigned long long seed, unsigned long long n_pairs, float px_abs, float rel,
+                             const float2* hue_lut, unsigned long long* out6, hipStream_t stream);
+
 }  // namespace mm

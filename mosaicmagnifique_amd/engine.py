@@ -255,6 +255,12 @@ class Engine:
         self._check(self._lib.mm_debug_stream_read(self._h, int(nbytes), int(repeats), ctypes.byref(out)))
         return out.value
 
+    def filter_band_sweep(self, mode, n_pairs, seed=0):
+        """mm_debug_filter_band_sweep -> dict(max_err, max_abs_part, band_share, max_value, handed_over, measured)."""
+        out = (ctypes.c_double * 6)()
+        self._check(self._lib.mm_debug_filter_band_sweep(self._h, int(mode), int(seed), int(n_pairs), out))
+        return dict(zip(("max_err", "max_abs_part", "band_share", "max_value", "handed_over", "measured"), list(out)))
+
     def timing(self):
         t = _lib.MMTiming()
         self._check(self._lib.mm_get_timing(self._h, ctypes.byref(t)))

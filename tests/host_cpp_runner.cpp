@@ -27,7 +27,13 @@ int main(int argc, char** argv)
     const bool u8 = (h[19] & 1) != 0;
     const int scheme = h[19] >> 1;
 
-    HIPPhotomosaicGenerator generator(0);
+    // MOSAIC_HOST_DEVICES="0,0": the single-process multi-engine path (one engine per listed device id)
+    std::vector<int> devices;
+    if (const char* list = getenv("MOSAIC_HOST_DEVICES"))
+        for (const char* p = list; *p;) { devices.push_back((int)strtol(p, const_cast<char**>(&p), 10)); if (*p == ',') ++p; }
+    if (devices.empty()) devices.push_back(0);
+    HIPPhotomosaicGenerator generator(devices);
+    if (const char* k = getenv("MOSAIC_HOST_SPEC_K")) generator.setEngineOption("spec_k", atoi(k));
     Image8 img8{rows, cols, {}};
     std::vector<uint8_t> mask((size_t)size * size);
     if (u8) {

@@ -1,0 +1,46 @@
+// Test driver for CellShape::loadFromFile of the C++ host mirror: prints, per .mcs file given, one JSON
+// line with what tests/golden/cells_mcs.json records (name, size, active pixels, FNV-1a of the
+// thresholded mask, tiling parameters, and the same after resized(64)).
+#include <cstdio>
+#include <string>
+
+#include "../mosaicmagnifique_amd/csrc/host/HIPPhotomosaicGenerator.h"
+
+static void params(const CellShape& s)
+{
+    printf("{\"rowSpacing\": %d, \"colSpacing\": %d, \"alternateRowSpacing\": %d, \"alternateColSpacing\": %d, "
+           "\"alternateRowOffset\": %d, \"alternateColOffset\": %d, \"alternateColFlipHorizontal\": %s, "
+           "\"alternateColFlipVertical\": %s, \"alternateRowFlipHorizontal\": %s, \"alternateRowFlipVertical\": %s}",
+           s.rowSpacing, s.colSpacing, s.alternateRowSpacing, s.alternateColSpacing, s.alternateRowOffset, s.alternateColOffset,
+           s.alternateColFlipHorizontal ? "true" : "false", s.alternateColFlipVertical ? "true" : "false",
+           s.alternateRowFlipHorizontal ? "true" : "false", s.alternateRowFlipVertical ? "true" : "false");
+}
+
+int main(int argc, char** argv)
+{
+    for (int i = 1; i < argc; ++i) {
+        try {
+            const CellShape shape = CellShape::loadFromFile(argv[i]);
+            const auto& mask = shape.getCellMask(false, false);
+            unsigned long long fnv = 1469598103934665603ull;
+            long active = 0;
+            for (uint8_t v : mask) { const int on = v > 127; active += on; fnv = (fnv ^ (unsigned)on) * 1099511628211ull; }
+            const CellShape small = shape.getSize() >= 64 ? shape.resized(64) : shape;     // no enlargement (INTER_CUBIC) in the hot path
+            long small_active = 0;
+            for (uint8_t v : small.getCellMask(false, false)) small_active += v != 0;
+            // flipped variants: the (1,1) mask read backwards must be the (0,0) mask
+            const auto& both = shape.getCellMask(true, true);
+            bool flips_ok = both.size() == mask.size();
+            for (size_t k = 0; flips_ok && k < mask.size(); ++k) flips_ok = both[mask.size() - 1 - k] == mask[k];
+            printf("{\"name\": \"%s\", \"size\": %d, \"active\": %ld, \"mask_fnv\": \"%016llx\", \"flips_ok\": %s, \"params\": ",
+                   shape.name.c_str(), shape.getSize(), active, fnv, flips_ok ? "true" : "false");
+            params(shape);
+            printf(", \"resized64\": {\"active\": %ld, \"params\": ", small_active);
+            params(small);
+            printf("}}\n");
+        } catch (const std::exception& e) {
+            printf("{\"error\": \"%s\"}\n", e.what());
+        }
+    }
+    return 0;
+}

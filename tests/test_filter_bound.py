@@ -65,7 +65,8 @@ def group_bound(cell, lib, hue_aware=True):
     dev = 0.5 * (np.abs(cell[..., 0] - 50).max(-1) + np.abs(lib[..., 0] - 50).max(-1))
     s_l = 1.0 + 0.015 * dev ** 2 / np.sqrt(20.0 + dev ** 2)
     cbar = 0.5 * (np.hypot(cell[..., 1], cell[..., 2]).max(-1) + np.hypot(lib[..., 1], lib[..., 2]).max(-1))
-    gc = (1.5 - 0.5 * sqrt_ratio7(cbar)) * cbar
+    g_min = 1.5 - 0.5 * sqrt_ratio7(cbar)        # 1 + G of every pair is at least this: G falls as the pair's mean chroma grows (:50-53)
+    gc = g_min * cbar
     s_c = 1.0 + 0.045 * gc
     e_max = rotation_bound(cell, lib) if hue_aware else 1.0
     r_t = 2.0 * sqrt_ratio7(gc) * np.sin(np.radians(60.0) * e_max) * 1.0001          # >= |R_T|, R_C = 2 sqrt_ratio7
@@ -75,7 +76,8 @@ def group_bound(cell, lib, hue_aware=True):
     a, c, b = 1.0 / s_c ** 2, 1.0 / s_h ** 2, r_t / (2.0 * s_c * s_h)
     lam = np.maximum(0.5 * (a + c) - np.sqrt(0.25 * (a - c) ** 2 + b ** 2), 0.0)
     d = np.abs(cell.sum(-2) - lib.sum(-2))
-    return np.sqrt((d[..., 0] / s_l) ** 2 + lam * (d[..., 1] ** 2 + d[..., 2] ** 2))
+    # dC'^2 + dH'^2 = |(a1', b1) - (a2', b2)|^2 = ((1 + G) da)^2 + db^2 >= (g_min da)^2 + db^2
+    return np.sqrt((d[..., 0] / s_l) ** 2 + lam * ((g_min * d[..., 1]) ** 2 + d[..., 2] ** 2))
 
 
 def groups(rng, kind, n_groups, n=256):

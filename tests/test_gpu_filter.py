@@ -53,6 +53,63 @@ def test_ciede2000_filter_error_is_inside_the_band(engine):
             assert handed_over.mean() < 1e-4, name
 
 
+def test_ciede2000_filter_band_structured_sweep(engine):
+    """What backs the band the engine trusts the filter with (engine.hip filter_band: 1e-3 + 6e-5 * value
+    per pixel pair): a structured sweep generated and reduced on the device -- hue x hue (512 x 512 jittered
+    steps of the circle) x chroma x chroma (24 x 24 levels from exactly grey over 1e-4 to 150) x 25 lightness
+    pairs, three jitter seeds = 1.1e10 pairs -- and both sides of the opposite-hue discontinuity (hue
+    difference 180 deg +- 1e-7 .. 3e-2 rad: where the fp32 branch choice could differ from the fp64 one).
+    The worst pair must use less than half of the trusted band."""
+    grid = 512 * 512 * 24 * 24 * 25
+    measured = 0
+    for seed in range(3):
+        r = engine.filter_band_sweep(0, grid, seed=seed)
+        print("band sweep mode 0 seed %d: %s" % (seed, r))
+        measured += r["measured"]
+        assert r["band_share"] <= 0.5, r
+        assert r["max_value"] > 100                      # the sweep reaches the far corners of Lab
+        assert r["handed_over"] < 1e-4 * grid
+    assert measured >= 1.1e10
+    r = engine.filter_band_sweep(1, 512 * 128 * 24 * 24 * 25, seed=7)
+    print("band sweep mode 1: %s" % r)
+    assert r["band_share"] <= 0.5, r
+    assert r["handed_over"] > 0 and r["measured"] > 5e8    # both: pairs inside the hand-over zone and just outside it
+
+
+def test_band_guard_is_silent_on_honest_content_and_loud_on_a_broken_band(oracle, engine):
+    """The run-time guard of the band: on sampled cells the best candidate the band EXCLUDED rides along
+    as a sentinel and is re-scored in fp64; it must never beat a contender (mm_timing.band_alarms stays 0,
+    also with every cell sampled and with hundreds of near-duplicates crowding the band's edge).  That
+    the guard can fire at all is shown with a deliberately wrong band (option band_pct = 0: the filter's
+    fp32 order is trusted to the last bit) on a library of near-duplicates, whose fp32 and fp64 orders differ."""
+    t = Type.CIEDE2000
+    shape = cases.square_shape(32)
+    img, lib = cases.inputs(160, 192, 32, 300, t)
+    lib2 = lib.copy()
+    rng = np.random.default_rng(5)
+    for i in range(1, 250):
+        lib2[i] = lib2[0] + rng.normal(0, 2e-4, lib2[0].shape).astype(np.float32)
+    lib3 = lib.copy()                       # differences far below the fp32 resolution of a score: the filter's order is noise
+    for i in range(1, 250):
+        lib3[i] = lib3[0] + rng.normal(0, 4e-6, lib3[0].shape).astype(np.float32)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, img.shape[0], img.shape[1])[0]
+    cells = G.cell_records(group, state, img.shape[0], img.shape[1])
+    try:
+        engine.set_option("band_guard", 1)               # every cell carries a sentinel
+        tm = run_both(oracle, engine, shape, img, lib, t, rep=(2, 300))
+        assert tm["band_alarms"] == 0 and tm["dense_cells"] == 0
+        tm = run_both(oracle, engine, shape, img, lib2, t)
+        assert tm["band_alarms"] == 0
+        engine.set_option("band_pct", 0)
+        engine.set_library(lib3); engine.set_masks(shape.masks4()); engine.set_target(img)
+        engine.generate(cells, state.shape[1], state.shape[0], int(t))
+        assert engine.timing()["band_alarms"] > 0
+    finally:
+        engine.set_option("band_pct", 100)
+        engine.set_option("band_guard", 64)
+
+
 def test_euclid_filter_error_is_inside_the_band(engine):
     rng = np.random.default_rng(4)
     a = rng.uniform(LO, HI, (1 << 21, 3)).astype(np.float32)

@@ -21,7 +21,7 @@ def build_runner(out):
     cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-Wall", "-Wextra", "-o", out,
            os.path.join(ROOT, "tests", "host_cpp_runner.cpp"),
            os.path.join(HOST, "HIPPhotomosaicGenerator.cpp"),
-           "-L" + lib_dir, "-lmosaic_hip", "-Wl,-rpath," + lib_dir]
+           "-L" + lib_dir, "-lmosaic_hip", "-Wl,-rpath," + lib_dir, "-lz", "-pthread"]
     subprocess.run(cmd, check=True)
     return out
 
@@ -152,3 +152,35 @@ def test_host_cpp_colour_scheme(oracle, tmp_path):
     plain, _, _ = oracle.generate_best_fits(shape_of(shape), synth.preprocess(img, t), synth.preprocess(lib, t),
                                             shape.masks4(), int(t), *rep)
     assert not np.array_equal(got, plain)          # the scheme really changed the picture
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,spec_k", [("0,0", None), ("0,0,0", "2")])
+def test_host_cpp_several_engines_in_one_process(oracle, tmp_path, devices, spec_k):
+    """The single-process multi-GPU path of the C++ host (HIPPhotomosaicGenerator(devices)): one engine
+    per listed device -- two / three engines on device 0 here, as one GPU is what the box has --, the
+    cells of a step cut into contiguous shards scored by one host thread per engine, lists merged on the
+    host, ONE verifying resolve.  The grid must equal the oracle's sequential run; spec_k = 2 forces
+    the deepening rounds (short lists that the repeat penalty outruns) through the sharded path too."""
+    from mosaicmagnifique_amd import synth
+    shape, t, rep = cases.hexagon_shape(), Type.CIEDE2000, (2, 300)
+    size = shape.getSize()
+    rows, cols, n_lib = 5 * size + 5, 6 * size + 9, 60
+    lib_u8 = synth.library_u8(n_lib, size)
+    img = synth.preprocess(synth.target_u8(rows, cols, lattice=4 * size), t)        # smooth: neighbours collide
+    lib = synth.preprocess(lib_u8, t)
+    scenario, result = tmp_path / "scenario.bin", tmp_path / "result.bin"
+    with open(scenario, "wb") as f:
+        f.write(header_of(shape, rows, cols, n_lib, t, rep).tobytes()); f.write(img.tobytes()); f.write(lib.tobytes())
+        f.write(shape.getCellMask(False, False).tobytes())
+        f.write(lib_u8.tobytes())
+    runner = build_runner(str(tmp_path / "runner"))
+    env = dict(os.environ, MOSAIC_HOST_DEVICES=devices)
+    if spec_k:
+        env["MOSAIC_HOST_SPEC_K"] = spec_k
+    subprocess.run([runner, str(scenario), str(result)], check=True, timeout=300, env=env)
+    (got,), mosaic = read_result(result, rows, cols)
+    want, _, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), *rep)
+    assert np.array_equal(got, want)
+    want_mosaic = oracle.build_photomosaic(shape_of(shape), rows, cols, lib_u8, shape.masks4(), want, (7, 8, 9, 10))
+    assert np.array_equal(mosaic, want_mosaic)

@@ -60,3 +60,110 @@ def test_mcs_round_trip(tmp_path):
         back = CellShape.loadFromFile(path)
         assert back.to_dict() == shape.to_dict()
         assert np.array_equal(back.masks4(), shape.masks4())
+
+
+# ---- the reference's shipped cell shapes (Cells/*.mcs) and the C++ reader ----------------------------
+import json  # noqa: E402
+import os  # noqa: E402
+import subprocess  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, ".."))
+CELLS_DIR = "/root/reference/Cells"
+SHIPPED = json.load(open(os.path.join(HERE, "golden", "cells_mcs.json")))["shapes"]
+
+
+def fnv_of(mask):
+    h = 1469598103934665603
+    for on in (np.asarray(mask).reshape(-1) > 127).astype(np.uint8).tolist():
+        h = ((h ^ on) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def build_mcs_runner(out):
+    from mosaicmagnifique_amd import _build
+    lib_dir = os.path.dirname(_build.build())
+    host = os.path.join(ROOT, "mosaicmagnifique_amd", "csrc", "host")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", out,
+                    os.path.join(HERE, "mcs_reader_runner.cpp"), os.path.join(host, "HIPPhotomosaicGenerator.cpp"),
+                    "-L" + lib_dir, "-lmosaic_hip", "-Wl,-rpath," + lib_dir, "-lz", "-pthread"], check=True)
+    return out
+
+
+def run_mcs_runner(runner, paths):
+    res = subprocess.run([runner] + [str(p) for p in paths], check=True, capture_output=True, text=True, timeout=120)
+    return [json.loads(line) for line in res.stdout.splitlines()]
+
+
+def test_fixture_lists_all_ten_shipped_shapes():
+    assert len(SHIPPED) == 10 and {s["file"] for s in SHIPPED} >= {"Hexagon.mcs", "YinAndYang.mcs", "Puzzle.mcs"}
+    for s in SHIPPED:
+        assert s["version"] == 8 and s["size"] == 512 and 0 < s["active"] < 512 * 512
+    hexagon = next(s for s in SHIPPED if s["file"] == "Hexagon.mcs")
+    # the facts SURVEY 8c lists for the shape the reference's own generator tests load (tst_CUDAGenerator.h:36)
+    assert (hexagon["name"], hexagon["active"], hexagon["params"]["rowSpacing"], hexagon["params"]["colSpacing"],
+            hexagon["params"]["alternateRowOffset"]) == ("Hexagon", 169400, 385, 440, 220)
+    assert hexagon["resized64"]["active"] == 2648 and hexagon["resized64"]["params"]["rowSpacing"] == 48
+
+
+@pytest.mark.skipif(not os.path.isdir(CELLS_DIR), reason="the reference checkout (Cells/*.mcs) is not on this machine")
+def test_python_reader_on_the_shipped_shapes():
+    """Every shape the reference ships, parsed by the package's reader, against the committed facts."""
+    import hashlib
+    from mosaicmagnifique_amd.cellshape import CellShape
+    for want in SHIPPED:
+        path = os.path.join(CELLS_DIR, want["file"])
+        assert hashlib.sha256(open(path, "rb").read()).hexdigest() == want["file_sha256"]
+        shape = CellShape.loadFromFile(path)
+        mask = shape.getCellMask()
+        assert (shape.name, shape.getSize(), int((mask > 127).sum())) == (want["name"], want["size"], want["active"])
+        assert hashlib.sha256((mask > 127).astype("u1").tobytes()).hexdigest() == want["mask_sha256"]
+        assert {k: v for k, v in shape.to_dict().items() if k != "name"} == want["params"]
+        small = shape.resized(64)
+        assert int((small.getCellMask() != 0).sum()) == want["resized64"]["active"]
+        assert {k: v for k, v in small.to_dict().items() if k != "name"} == want["resized64"]["params"]
+        for fh in (False, True):
+            for fv in (False, True):
+                assert np.array_equal(shape.getCellMask(fh, fv), mask[::-1 if fv else 1, ::-1 if fh else 1])
+
+
+def test_cpp_reader_agrees_with_the_python_reader(tmp_path):
+    """CellShape::loadFromFile of the C++ host (big-endian stream + its own PNG decoder over zlib): the
+    shipped shapes when the checkout is here, and always files written by the package's writer (v8,
+    PNG-encoded) and a hand-packed v7 file (raw mask, CustomQDataStream.h:27-37)."""
+    import cases
+    from mosaicmagnifique_amd.cellshape import MCS_MAGIC, CellShape
+    runner = build_mcs_runner(str(tmp_path / "mcs_runner"))
+    paths = []
+    for k, shape in enumerate((cases.hexagon_shape(), cases.flippy_shape(), cases.square_shape(48))):
+        shape.name = "shape-%d é" % k
+        p = tmp_path / ("written-%d.mcs" % k)
+        shape.saveToFile(p)
+        paths.append(p)
+    rng = np.random.default_rng(8)
+    raw_mask = (rng.integers(0, 2, (40, 40)) * 255).astype(np.uint8)
+    p = tmp_path / "v7.mcs"
+    with open(p, "wb") as f:
+        name = "raw seven".encode("utf-16-be")
+        f.write(struct.pack(">II", MCS_MAGIC, 7)); f.write(struct.pack(">I", len(name))); f.write(name)
+        f.write(struct.pack(">IIII", 0, 40, 40, raw_mask.size)); f.write(raw_mask.tobytes())
+        f.write(struct.pack(">iiiiii", 31, 37, 29, 35, 4, 6)); f.write(struct.pack(">BBBB", 1, 0, 0, 1))
+    paths.append(p)
+    if os.path.isdir(CELLS_DIR):
+        paths += [os.path.join(CELLS_DIR, s["file"]) for s in SHIPPED]
+    got = run_mcs_runner(runner, paths)
+    assert len(got) == len(paths)
+    for path, g in zip(paths, got):
+        assert "error" not in g, (path, g)
+        shape = CellShape.loadFromFile(path)
+        mask = shape.getCellMask()
+        assert (g["name"], g["size"], g["active"]) == (shape.name, shape.getSize(), int((mask > 127).sum())), path
+        assert g["mask_fnv"] == fnv_of(mask) and g["flips_ok"]
+        assert g["params"] == {k: v for k, v in shape.to_dict().items() if k != "name"}
+        if shape.getSize() >= 64:
+            small = shape.resized(64)
+            assert g["resized64"]["active"] == int((small.getCellMask() != 0).sum())
+            assert g["resized64"]["params"] == {k: v for k, v in small.to_dict().items() if k != "name"}
+    bad = tmp_path / "bad.mcs"
+    bad.write_bytes(struct.pack(">II", 0x12345678, 8))
+    assert "not a valid .mcs" in run_mcs_runner(runner, [bad])[0]["error"]

@@ -45,7 +45,7 @@ def block_constants(cb, lb):
     a, c, b = 1.0 / s_c ** 2, 1.0 / s_h ** 2, half_rt / (s_c * s_h)
     lam = np.maximum(0.5 * (a + c) - np.sqrt(0.25 * (a - c) ** 2 + b ** 2), 0.0)
     rho = 1.0 - half_rt
-    return s_l, lam, rho
+    return s_l, lam, rho, 1.5 - 0.5 * sqrt_ratio7(cbar)
 
 
 def main():
@@ -69,9 +69,9 @@ def main():
         r = cells[ci]
         cell = w["img"][r["y"]:r["y"] + size, r["x"]:r["x"] + size].reshape(-1, 3)[order].astype(np.float64)
         cb = cell.reshape(nb, 64, 3)
-        s_l, lam, rho = block_constants(cb, lb)
+        s_l, lam, rho, gmin = block_constants(cb, lb)
         d = np.abs(cb.sum(1)[None] - lb.sum(2))                                   # [L][nb][3]
-        blk = np.sqrt((d[..., 0] / s_l) ** 2 + lam * (d[..., 1] ** 2 + d[..., 2] ** 2))       # block bound [L][nb]
+        blk = np.sqrt((d[..., 0] / s_l) ** 2 + lam * ((gmin * d[..., 1]) ** 2 + d[..., 2] ** 2))       # block bound [L][nb]
         grp_rest = blk.reshape(L, nb // 4, 4).sum(2)
         rest = np.cumsum(grp_rest[:, ::-1], 1)[:, ::-1]                            # rest[:, j] = bound of groups >= j
         rest = np.concatenate([rest, np.zeros((L, 1))], 1)
