@@ -83,7 +83,10 @@ struct mm_engine {
     int use_prune = 1;           // mm_set_option("prune", 0): filter pass without early exit
     int xcd_aware = 1;           // mm_set_option("xcd_aware", 0): one item order for the whole device
     int xcd_cells = 0;           // mm_set_option("xcd_cells", n): cells per sub-group of an XCD's share (0 = default)
-    int band_pct = 100;          // mm_set_option("band_pct", n): diagnostics -- trust only n % of the filter band (tests of the guards)
+    size_t batch_per_cell = 0;   // workspace bytes per cell the batch capacity below was computed for
+    int batch_capacity = 0;      // cells per device batch the last hipMemGetInfo allowed (0 = not asked yet)
+    int band_pct = 100;          // mm_set_option("band_pct", n): diagnostics -- trust only n % of the filter band (tests of the
+                                 // guards; a negative value turns the band inside out: true contenders get excluded)
     int band_guard_every = 64;   // mm_set_option("band_guard", n): every n-th cell of a batch re-scores the best candidate the
                                  // filter band excluded in fp64 (0 = off); an excluded candidate that wins is a band failure
 
@@ -443,17 +446,24 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     const int Kc = two_tier ? std::min(L, round_up(K + 32, 4)) : 0;
 
     // Batch so that scores + gathered cells stay within a fixed budget.
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(e, hipMemGetInfo(&free_b, &total_b), "Failed to query device memory");
     const size_t per_cell = (size_t)L * sizeof(double) + (size_t)ppad * 17 + (size_t)Kc * 16 + 1;
-    size_t budget = std::min<size_t>(free_b / 2 + e->scores.bytes + e->cells.bytes + e->cmask.bytes,
-                                     (size_t)6 << 30);
-    if (budget < per_cell) {
-        set_err(e, "Not enough device memory: one cell needs %zu bytes of workspace, %zu free",
-                per_cell, free_b);
-        return MM_OUT_OF_MEMORY;
+    // hipMemGetInfo is a driver round trip: asked again only when this call needs more cells per batch than the
+    // last budget allowed (the workspaces below are kept between calls)
+    const int want_cells = std::min(n, 32768);
+    if (e->batch_per_cell != per_cell || e->batch_capacity < want_cells) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(e, hipMemGetInfo(&free_b, &total_b), "Failed to query device memory");
+        const size_t budget = std::min<size_t>(free_b / 2 + e->scores.bytes + e->cells.bytes + e->cmask.bytes,
+                                               (size_t)6 << 30);
+        if (budget < per_cell) {
+            set_err(e, "Not enough device memory: one cell needs %zu bytes of workspace, %zu free",
+                    per_cell, free_b);
+            return MM_OUT_OF_MEMORY;
+        }
+        e->batch_per_cell = per_cell;
+        e->batch_capacity = (int)std::min<size_t>(budget / per_cell, 32768);
     }
-    int batch = (int)std::min<size_t>((size_t)n, std::min<size_t>(budget / per_cell, 32768));
+    int batch = std::min(n, e->batch_capacity);
     if (e->max_batch_cells > 0) batch = std::min(batch, e->max_batch_cells);
     mm_status st;
     if ((st = ensure(e, e->cell_var, (size_t)batch, "Failed to allocate cell variants")) ||
@@ -1660,7 +1670,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "xcd_aware") == 0) { e->xcd_aware = value != 0; return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }
-    if (strcmp(name, "band_pct") == 0) { e->band_pct = std::min(1000, std::max(0, value)); return MM_OK; }
+    if (strcmp(name, "band_pct") == 0) { e->band_pct = std::min(1000, std::max(-1000, value)); return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);
     return MM_INVALID_ARGUMENT;
 }

@@ -126,8 +126,16 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // work on `cell_group` cells x a couple of candidate tiles at a time instead of all 8 L2s each seeing
 // every cell and every tile of the launch.  A workgroup whose XCD has run dry steals from the next
 // ones (the result does not depend on who scores what).
-template <int TYPE>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MM_FILTER_WAVES, MM_FILTER_WAVES)))
+//
+// CELL_LDS = true: the LDS-resident cell tile.  A larger workgroup (THREADS = 640: ten waves) stages the
+// cell's three colour planes -- only the groups holding active pixels; channel 0 with NaN at inactive
+// pixels -- in LDS once per item and every wave of it walks its candidates against that copy, so the
+// global loads of the pixel loop are the library planes only.  The cell's chroma plane is not staged
+// (it would be the 16 KB that keep a second workgroup off the CU): chroma is recomputed from a and b
+// with the very instructions that filled the plane (chroma_of), bit for bit.  48 KB of cell + 16 KB
+// hue table + statistics = 66 KB per workgroup: two workgroups = 20 waves per CU, 5 per SIMD.
+template <int TYPE, int THREADS, bool CELL_LDS>
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(MM_FILTER_WAVES, MM_FILTER_WAVES)))
 filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
               const float* __restrict__ cell_chroma, const float* __restrict__ lib,
               const float* __restrict__ lib_chroma, float* __restrict__ scores,
@@ -141,7 +149,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     __shared__ unsigned int next_item;      // ... and workgroups pull (cell, tile) items: the hue table is loaded once
     __shared__ int item_share;              // the XCD share next_item belongs to (-1: none left)
     // block statistics of the cell (early-exit bound), up to 4 blocks per lane
-    __shared__ float cell_st[TYPE == CIEDE2000 ? 7 : 1][TYPE == CIEDE2000 ? 4 * kWave : 1];
+    __shared__ float cell_st[TYPE == CIEDE2000 ? 7 : 1][TYPE == CIEDE2000 ? (CELL_LDS ? kWave : 4 * kWave) : 1];
+    extern __shared__ float4 cell_tile[];   // CELL_LDS: [3][ppad / 4] -- channel 0 (NaN = inactive), a, b
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const float* const lib_base = lib;
@@ -168,7 +177,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         next_item = item;
         item_share = share;
-        next_candidate = kBlock / kWave;
+        next_candidate = THREADS / kWave;
     }
     __syncthreads();
     // read back as scalars: everything derived from them (cell, tile, plane addresses) stays in SGPRs
@@ -196,6 +205,15 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     const float4* c1 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad) + ppad / 4;
     const float4* c2 = c1 + ppad / 4;
     const float4* cc = reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
+    const int pq = ppad / 4;
+    if constexpr (CELL_LDS) {                             // stage the cell (active groups only); the barrier below covers it
+        const int nq = groups * kWave;
+        for (int q = threadIdx.x; q < nq; q += THREADS) {
+            cell_tile[q] = c0[q];
+            cell_tile[pq + q] = c1[q];
+            cell_tile[2 * pq + q] = c2[q];
+        }
+    }
 
     // Early exit, the device form of the reference's `variant < bestVariant` loop guards
     // (CPUPhotomosaicGenerator.cpp:149,153): every term is >= 0, so once the running
@@ -227,15 +245,15 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
     bool use_lb = false;
     if constexpr (TYPE == CIEDE2000) {
-        use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;     // workgroup-uniform
+        use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= (CELL_LDS ? kWave / 4 : kWave);     // workgroup-uniform
         if (use_lb) {
             // the cell's seven numbers per block (group_sums_kernel) wait in LDS: read per candidate, no registers held
-            for (int t = threadIdx.x; t < 4 * groups; t += kBlock)
+            for (int t = threadIdx.x; t < 4 * groups; t += THREADS)
                 for (int k = 0; k < 7; ++k)
                     cell_st[k][t] = var.cell_stats[(size_t)k * var.cell_stats_stride + (size_t)cell * var.n_blocks + t];
-            __syncthreads();
         }
     }
+    if (use_lb || CELL_LDS) __syncthreads();              // workgroup-uniform
 
     // blocks per lane in the bound's prelude: 1, 2 or 4 (a power of two, so groups start on lane boundaries)
     const int lane_shift = groups <= 16 ? 0 : (groups <= 32 ? 1 : 2), per_lane = 1 << lane_shift;
@@ -331,9 +349,15 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const int q = lane + kWave * j;
                 const unsigned int off = (unsigned int)q * 16u;
                 visited += 1;
-                const float4 p0 = ld4(c0, off), p1 = ld4(c1, off), p2 = ld4(c2, off);
-                float4 pc{0.f, 0.f, 0.f, 0.f};
-                if constexpr (TYPE == CIEDE2000) pc = ld4(cc, off);
+                float4 p0, p1, p2, pc{0.f, 0.f, 0.f, 0.f};
+                if constexpr (CELL_LDS) {
+                    p0 = cell_tile[q]; p1 = cell_tile[pq + q]; p2 = cell_tile[2 * pq + q];
+                    if constexpr (TYPE == CIEDE2000)
+                        pc = float4{chroma_of(p1.x, p2.x), chroma_of(p1.y, p2.y), chroma_of(p1.z, p2.z), chroma_of(p1.w, p2.w)};
+                } else {
+                    p0 = ld4(c0, off); p1 = ld4(c1, off); p2 = ld4(c2, off);
+                    if constexpr (TYPE == CIEDE2000) pc = ld4(cc, off);
+                }
                 const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, qc = cur.qc;
                 bool e0, e1, e2, e3;
                 const float v0 = pair_fast<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
@@ -947,20 +971,54 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : 32, cell_group = 512;
     // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited), times two
     // so a finishing workgroup's slot refills at once
-    auto persistent_grid = [&](const void* kern, long long items) -> unsigned {
-        int dev = 0, cus = 256, per_cu = 4;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, in.lds_pad_bytes) != hipSuccess || per_cu < 1) per_cu = 4;
+    auto persistent_grid = [&](const void* kern, long long items, int threads, size_t dyn_lds) -> unsigned {
+        // the occupancy query costs a fraction of a millisecond: asked once per (kernel, LDS size), not per launch
+        struct Known { const void* kern; size_t lds; int dev, slots; };
+        static thread_local Known known[8];
+        static thread_local int n_known = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        for (int i = 0; i < n_known; ++i)
+            if (known[i].kern == kern && known[i].lds == dyn_lds && known[i].dev == dev)
+                return (unsigned)std::min<long long>(items, (long long)known[i].slots);
+        int cus = 256, per_cu = 4;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 4;
         (void)hipGetLastError();
+        if (n_known < 8) known[n_known++] = Known{kern, dyn_lds, dev, cus * per_cu * 2};
         return (unsigned)std::min<long long>(items, (long long)cus * per_cu * 2);
     };
+    const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
+    // The LDS-resident cell tile (CIEDE2000, early exit on): ten-wave workgroups, the cell's colour planes staged once
+    // per item.  Needs one block per lane in the bound's prelude (<= 16 groups = cells up to 64 x 64) and the three
+    // planes beside the hue table, twice per CU.
+    if (type == CIEDE2000 && in.use_lds_form && prune_above != nullptr && groups <= kWave / 4 && (size_t)ppad * 12 <= 56 * 1024) {
+        constexpr int kTileThreads = 640;
+        const int cpb = in.tile_candidates > 0 ? in.tile_candidates : 64;
+        const long long tiles = (L + cpb - 1) / cpb, items = (long long)n_cells * tiles;
+        if (items <= 0 || items > 0x7fffffffLL) return hipErrorInvalidValue;
+        const int shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
+        const int sub = shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : 64) : 512;
+        hipError_t code = hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);
+        if (code != hipSuccess) return code;
+        auto kern = filter_kernel<CIEDE2000, kTileThreads, true>;
+        const size_t dyn = (size_t)ppad * 12 + in.lds_pad_bytes;
+        if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess)
+            return code;
+        kern<<<dim3(persistent_grid(reinterpret_cast<const void*>(kern), items, kTileThreads, dyn)), kTileThreads, dyn, stream>>>(
+            in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, sub,
+            edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares);
+        if ((code = hipGetLastError()) != hipSuccess) return code;
+        edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
+                                                     edges, edge_count, edge_cap, in.hue_lut, in.var);
+        return hipGetLastError();
+    }
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long blocks = (long long)n_cells * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // one share of the cells per XCD (8 on MI355X); small launches keep one share so no XCD idles on an empty one
     const int xcd_shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
     const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : 64) : cell_group;
-    const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
     const int check_every = groups > 16 ? groups / 16 : 1;
     hipError_t code = hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);  // + work counters, item counters
     if (code != hipSuccess) return code;
@@ -993,16 +1051,16 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     }
     if (type == CIEDE2000) {
         if (in.lds_pad_bytes > 0 &&
-            (code = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel<CIEDE2000>),
+            (code = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel<CIEDE2000, kBlock, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)in.lds_pad_bytes)) != hipSuccess) return code;
-        filter_kernel<CIEDE2000><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<CIEDE2000>), blocks)), kBlock, in.lds_pad_bytes, stream>>>(
+        filter_kernel<CIEDE2000, kBlock, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<CIEDE2000, kBlock, false>), blocks, kBlock, in.lds_pad_bytes)), kBlock, in.lds_pad_bytes, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
     } else {
-        filter_kernel<RGB_EUCLIDEAN><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN>), blocks)), kBlock, 0, stream>>>(
+        filter_kernel<RGB_EUCLIDEAN, kBlock, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN, kBlock, false>), blocks, kBlock, 0)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares);
     }

@@ -695,8 +695,10 @@ rerank_kernel(const int32_t* __restrict__ cont_index, const float* __restrict__ 
         }
         best = block_min(best, sh);
         const bool none = best.i == 0x7fffffff;
-        if (r == K - 1 && !none && sent >= 0 && threadIdx.x == 0 && lex_less(cs[sent], ci[sent], best.s, best.i))
-            flags[blockIdx.x] |= 4;             // an excluded candidate beats the K-th contender: the band failed here
+        // the band failed here if the candidate it EXCLUDED (the sentinel) beats the K-th contender in fp64, or if it
+        // excluded a scored candidate although fewer than K contenders were kept
+        if (r < K && sent >= 0 && threadIdx.x == 0 && (none || (r == K - 1 && lex_less(cs[sent], ci[sent], best.s, best.i))))
+            flags[blockIdx.x] |= 4;
         if (r == K) {
             if (!none && threadIdx.x == 0 && best.s <= prev_s + fabs(prev_s) * (4.0 * tie_band))
                 cand_index[out + K - 1] = -(prev_i + 2);

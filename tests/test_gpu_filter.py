@@ -80,8 +80,8 @@ def test_band_guard_is_silent_on_honest_content_and_loud_on_a_broken_band(oracle
     """The run-time guard of the band: on sampled cells the best candidate the band EXCLUDED rides along
     as a sentinel and is re-scored in fp64; it must never beat a contender (mm_timing.band_alarms stays 0,
     also with every cell sampled and with hundreds of near-duplicates crowding the band's edge).  That
-    the guard can fire at all is shown with a deliberately wrong band (option band_pct = 0: the filter's
-    fp32 order is trusted to the last bit) on a library of near-duplicates, whose fp32 and fp64 orders differ."""
+    the guard fires when the band is wrong is shown with a deliberately inverted one (option band_pct = -100:
+    the threshold drops below the K-th lowest filter score, so true contenders are excluded)."""
     t = Type.CIEDE2000
     shape = cases.square_shape(32)
     img, lib = cases.inputs(160, 192, 32, 300, t)
@@ -89,9 +89,6 @@ def test_band_guard_is_silent_on_honest_content_and_loud_on_a_broken_band(oracle
     rng = np.random.default_rng(5)
     for i in range(1, 250):
         lib2[i] = lib2[0] + rng.normal(0, 2e-4, lib2[0].shape).astype(np.float32)
-    lib3 = lib.copy()                       # differences far below the fp32 resolution of a score: the filter's order is noise
-    for i in range(1, 250):
-        lib3[i] = lib3[0] + rng.normal(0, 4e-6, lib3[0].shape).astype(np.float32)
     group = cases.group_of(shape)
     state = G.getGridState(group, img.shape[0], img.shape[1])[0]
     cells = G.cell_records(group, state, img.shape[0], img.shape[1])
@@ -101,12 +98,14 @@ def test_band_guard_is_silent_on_honest_content_and_loud_on_a_broken_band(oracle
         assert tm["band_alarms"] == 0 and tm["dense_cells"] == 0
         tm = run_both(oracle, engine, shape, img, lib2, t)
         assert tm["band_alarms"] == 0
-        engine.set_option("band_pct", 0)
-        engine.set_library(lib3); engine.set_masks(shape.masks4()); engine.set_target(img)
+        engine.set_option("band_pct", -100)              # the band inside out: the threshold falls BELOW the K-th score
+        engine.set_option("prune", 0)                    # (every score finite: the excluded contender is there to be seen)
+        engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
         engine.generate(cells, state.shape[1], state.shape[0], int(t))
-        assert engine.timing()["band_alarms"] > 0
+        assert engine.timing()["band_alarms"] == len(cells)     # every cell: a true contender was excluded, the guard saw it
     finally:
         engine.set_option("band_pct", 100)
+        engine.set_option("prune", 1)
         engine.set_option("band_guard", 64)
 
 
