@@ -559,9 +559,11 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         if (prune)
             HIP_TRY(e, mm::launch_prune_limits(ftype, fin, (const float*)e->lib_means.p, b, L, ppad,
                                                M, K, band.px_abs, band.rel, (int32_t*)e->seeds.p,
-                                               (float*)e->seed_score.p, (float*)e->limits.p, e->stream),
+                                               (float*)e->seed_score.p, (float*)e->limits.p, (float*)e->scores.p, e->stream),
                     "Error during seed / pruning limit kernels");
         HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
+        fin.seeds = prune ? (const int32_t*)e->seeds.p : nullptr;
+        fin.n_seeds = prune ? M : 0;
         HIP_TRY(e, mm::launch_filter(ftype, fin, (float*)e->scores.p, b, L, ppad,
                                      (mm::EdgeEntry*)e->edges.p, (unsigned int*)e->edge_count.p, edge_cap,
                                      prune ? (const float*)e->limits.p : nullptr, e->stream),

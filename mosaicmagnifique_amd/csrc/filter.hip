@@ -142,9 +142,11 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
               int n_cells, int L, int ppad, int cand_per_block, int cell_group,
               EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
               unsigned int edge_cap, const float* __restrict__ prune_above, int check_every,
-              const HueEntry* __restrict__ hue_lut, Variants var, int xcd_shares)
+              const HueEntry* __restrict__ hue_lut, Variants var, int xcd_shares,
+              const int32_t* __restrict__ seeds, int n_seeds)
 {
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
+    __shared__ int seed_ids[256];           // the cell's seeds: their scores are in the row already (launch_prune_limits)
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
     __shared__ unsigned int next_item;      // ... and workgroups pull (cell, tile) items: the hue table is loaded once
     __shared__ int item_share;              // the XCD share next_item belongs to (-1: none left)
@@ -206,6 +208,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     const float4* c2 = c1 + ppad / 4;
     const float4* cc = reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
     const int pq = ppad / 4;
+    for (int t = threadIdx.x; t < n_seeds; t += THREADS) seed_ids[t] = seeds[(size_t)cell * n_seeds + t];
     if constexpr (CELL_LDS) {                             // stage the cell (active groups only); the barrier below covers it
         const int nq = groups * kWave;
         for (int q = threadIdx.x; q < nq; q += THREADS) {
@@ -253,7 +256,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     cell_st[k][t] = var.cell_stats[(size_t)k * var.cell_stats_stride + (size_t)cell * var.n_blocks + t];
         }
     }
-    if (use_lb || CELL_LDS) __syncthreads();              // workgroup-uniform
+    if (use_lb || CELL_LDS || n_seeds > 0) __syncthreads();   // workgroup-uniform
 
     // blocks per lane in the bound's prelude: 1, 2 or 4 (a power of two, so groups start on lane boundaries)
     const int lane_shift = groups <= 16 ? 0 : (groups <= 32 ? 1 : 2), per_lane = 1 << lane_shift;
@@ -265,6 +268,12 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             int nxt = 0;
             if (lane == 0) nxt = atomicAdd(&next_candidate, 1);
             idx = __builtin_amdgcn_readfirstlane(nxt);      // scalar: library addresses stay in SGPRs
+        }
+        if (n_seeds > 0) {
+            // scored already as a seed (seed_score_kernel left its score in the row): nothing to do
+            bool hit = false;
+            for (int t = lane; t < n_seeds; t += kWave) hit = hit || seed_ids[t] == l;
+            if (__builtin_amdgcn_ballot_w64(hit) != 0) continue;
         }
         const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
         const float4* b1 = b0 + ppad / 4;
@@ -576,7 +585,7 @@ seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
                   const float* __restrict__ cell_chroma, const float* __restrict__ lib,
                   const float* __restrict__ lib_chroma, const int32_t* __restrict__ seeds,
                   float* __restrict__ seed_score, int n_cells, int M, int ppad,
-                  const HueEntry* __restrict__ hue_lut, Variants var)
+                  const HueEntry* __restrict__ hue_lut, Variants var, float* __restrict__ scores, int L)
 {
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
@@ -616,7 +625,12 @@ seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
              + ((m & 0x00ff0000u) ? v2 : 0.0f) + ((m & 0xff000000u) ? v3 : 0.0f);
     }
     acc = wave_sum_f(acc);
-    if (lane == 0) seed_score[w] = acc;
+    if (lane == 0) {
+        seed_score[w] = acc;
+        // the seed IS a filter score of this (cell, candidate): deposited in the score row; filter_kernel looks the
+        // candidate up in the cell's seed list and leaves it alone instead of scoring it a second time
+        if (scores) scores[(size_t)cell * L + l] = acc;
+    }
 }
 
 // Chroma sqrt(a^2 + b^2) of every pixel of n planar images: [n][3][ppad] -> [n][ppad].
@@ -1007,7 +1021,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             return code;
         kern<<<dim3(persistent_grid(reinterpret_cast<const void*>(kern), items, kTileThreads, dyn)), kTileThreads, dyn, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, sub,
-            edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares);
+            edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares, in.seeds, in.seeds ? in.n_seeds : 0);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
@@ -1055,14 +1069,16 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)in.lds_pad_bytes)) != hipSuccess) return code;
         filter_kernel<CIEDE2000, kBlock, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<CIEDE2000, kBlock, false>), blocks, kBlock, in.lds_pad_bytes)), kBlock, in.lds_pad_bytes, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares);
+            item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares,
+            in.seeds, in.seeds ? in.n_seeds : 0);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
     } else {
         filter_kernel<RGB_EUCLIDEAN, kBlock, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN, kBlock, false>), blocks, kBlock, 0)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares);
+            item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares,
+            in.seeds, in.seeds ? in.n_seeds : 0);
     }
     return hipGetLastError();
 }
@@ -1095,7 +1111,7 @@ hipError_t launch_image_means(const float* planar, float* means, int n_images, i
 
 hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* lib_means, int n_cells, int L,
                                int ppad, int M, int K, float px_abs, float rel, int32_t* seeds,
-                               float* seed_score, float* limit, hipStream_t stream)
+                               float* seed_score, float* limit, float* scores, hipStream_t stream)
 {
     if (M > 256 || M < K || (size_t)L * sizeof(float) > 100 * 1024) return hipErrorInvalidValue;
     const size_t lds = (size_t)L * sizeof(float);
@@ -1103,11 +1119,11 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
     if (type == CIEDE2000) {
         seed_kernel<CIEDE2000><<<n_cells, kBlock, lds, stream>>>(in.cells, in.cmask, lib_means, L, ppad, M, seeds, in.hue_lut);
         seed_score_kernel<CIEDE2000><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(
-            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut, in.var);
+            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut, in.var, scores, L);
     } else {
         seed_kernel<RGB_EUCLIDEAN><<<n_cells, kBlock, lds, stream>>>(in.cells, in.cmask, lib_means, L, ppad, M, seeds, in.hue_lut);
         seed_score_kernel<RGB_EUCLIDEAN><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(
-            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut, in.var);
+            in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut, in.var, scores, L);
     }
     hipError_t code = hipGetLastError();
     if (code != hipSuccess) return code;

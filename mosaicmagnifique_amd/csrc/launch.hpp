@@ -45,6 +45,8 @@ struct FilterInputs {
     size_t lds_pad_bytes;       // diagnostics: unused dynamic LDS per filter workgroup (lowers the occupancy)
     int xcd_aware;              // 1: persistent workgroups take the cells of their own XCD's share first (L2 affinity)
     int xcd_cells;              // cells per sub-group of an XCD's share (0 = default 64)
+    const int32_t* seeds;       // [B][n_seeds] candidates launch_prune_limits scored already (their scores are in the
+    int n_seeds;                // score rows): filter_kernel skips them.  null / 0: none.  n_seeds <= 256.
 };
 
 // Words of the counter block launch_filter clears and filter_kernel fills (u32 indices into edge_count):
@@ -77,10 +79,12 @@ hipError_t launch_image_means(const float* planar, float* means, int n_images, i
 // proximity are scored in full; the K-th lowest of them bounds the cell's K-th lowest
 // score from above, so a candidate whose running sum passes limit[cell] cannot be a
 // contender.  seeds [n][M] i32, seed_score [n][M] f32, limit [n] f32 are workspaces /
-// outputs.  Requires K <= M <= 256 and L floats to fit LDS beside the hue table (L <= 25600).
+// outputs.  scores (the filter's f32 [n][L] rows): each seed's score is also left at its place there, so that
+// launch_filter, given the seed lists (FilterInputs::seeds), need not score those candidates again.
+// Requires K <= M <= 256 and L floats to fit LDS beside the hue table (L <= 25600).
 hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* lib_means, int n_cells, int L,
                                int ppad, int M, int K, float px_abs, float rel, int32_t* seeds,
-                               float* seed_score, float* limit, hipStream_t stream);
+                               float* seed_score, float* limit, float* scores, hipStream_t stream);
 
 // fp32 filter form of the per-pair difference (accuracy harness).  flag_edges != 0
 // writes -1 for pairs the filter hands to the fp64 form.

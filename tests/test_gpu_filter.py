@@ -166,7 +166,7 @@ def opposite_hue_inputs(rng, size, n_lib, rows, cols, jitter):
 
 def test_discontinuity_pairs_are_patched_in_fp64(oracle, engine):
     rng = np.random.default_rng(8)
-    img, lib = opposite_hue_inputs(rng, 16, 24, 48, 48, jitter=3e-5)
+    img, lib = opposite_hue_inputs(rng, 16, 90, 48, 48, jitter=3e-5)     # more images than seeds: the filter pass has work
     tm = run_both(oracle, engine, cases.square_shape(16), img, lib, Type.CIEDE2000, rep=(1, 20))
     assert tm["edge_pairs"] > 1000 and tm["dense_cells"] == 0
 
