@@ -52,7 +52,7 @@ struct mm_engine {
     // two-tier scoring workspaces
     DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s, sentinel;
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
-    DevBuf lib_chroma, cell_chroma, hue_lut;
+    DevBuf lib_chroma, cell_chroma, hue_lut, lib_il, cells_il;
     DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
     DevBuf stage_u8, srgb_lut, shrink_tmp, covered, cells_f0;
     int mosaic_rows = 0, mosaic_cols = 0;       // the mosaic kept between mm_build_photomosaic_step calls
@@ -81,6 +81,8 @@ struct mm_engine {
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
     int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
     int use_prune = 1;           // mm_set_option("prune", 0): filter pass without early exit
+    int sort_groups = 1;         // mm_set_option("sort_groups", 0): a candidate's pixel groups are visited in plane order
+    int use_interleave = 1;      // mm_set_option("interleave", 0): the filter kernel reads the planar arrays (eight bases per pair)
     int xcd_aware = 1;           // mm_set_option("xcd_aware", 0): one item order for the whole device
     int xcd_cells = 0;           // mm_set_option("xcd_cells", n): cells per sub-group of an XCD's share (0 = default)
     size_t batch_per_cell = 0;   // workspace bytes per cell the batch capacity below was computed for
@@ -303,6 +305,10 @@ mm_status prepare_planes(mm_engine* e)
             "Error during library chroma kernel");
     HIP_TRY(e, mm::launch_image_means((const float*)e->lib.p, (float*)e->lib_means.p, L, P, ppad, e->stream),
             "Error during library mean kernel");
+    // the interleaved copy the dominant kernel reads ([group][plane][256]: one base address per image)
+    if ((st = ensure(e, e->lib_il, (size_t)n_var * L * 4 * ppad * sizeof(float), "Failed to allocate interleaved library"))) return st;
+    HIP_TRY(e, mm::launch_interleave((const float*)e->lib.p, (const float*)e->lib_chroma.p, nullptr, (float*)e->lib_il.p,
+                                     (size_t)n_var * L, ppad, e->stream), "Error during library interleave kernel");
     HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");   // host vectors go out of scope
     e->planes_dirty = false;
     return MM_OK;
@@ -491,7 +497,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     if (two_tier) {
         if ((st = ensure_hue_lut(e)) ||
             (st = ensure(e, e->cell_chroma, (size_t)batch * ppad * sizeof(float), "Failed to allocate cell chroma planes")) ||
-            (st = ensure(e, e->cells_f0, (size_t)batch * ppad * sizeof(float), "Failed to allocate cell planes")))
+            (st = ensure(e, e->cells_f0, (size_t)batch * ppad * sizeof(float), "Failed to allocate cell planes")) ||
+            (st = ensure(e, e->cells_il, (size_t)batch * 4 * ppad * sizeof(float), "Failed to allocate interleaved cells")))
             return st;
     }
     mm::FilterInputs fin{};
@@ -503,6 +510,9 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.tile_candidates = e->tile_candidates;
     fin.lds_pad_bytes = (size_t)e->lds_pad_kb * 1024;
     fin.use_lds_form = e->use_lds_filter < 0 ? (diff_type != MM_CIEDE2000) : e->use_lds_filter;
+    fin.lib_il = e->use_interleave && diff_type == MM_CIEDE2000 ? (const float*)e->lib_il.p : nullptr;
+    fin.cells_il = e->use_interleave && diff_type == MM_CIEDE2000 ? (const float*)e->cells_il.p : nullptr;
+    fin.sort_groups = e->sort_groups;
     fin.xcd_aware = e->xcd_aware;
     fin.xcd_cells = e->xcd_cells;
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
@@ -543,9 +553,13 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
             (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, (float*)e->cells_f0.p);
         HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
-        if (diff_type == MM_CIEDE2000)
+        if (diff_type == MM_CIEDE2000) {
             HIP_TRY(e, mm::launch_chroma_planes((const float*)e->cells.p, (float*)e->cell_chroma.p, (size_t)b, ppad, e->stream),
                     "Error during cell chroma kernel");
+            if (e->use_interleave)
+                HIP_TRY(e, mm::launch_interleave((const float*)e->cells.p, (const float*)e->cell_chroma.p, (const float*)e->cells_f0.p,
+                                                 (float*)e->cells_il.p, (size_t)b, ppad, e->stream), "Error during cell interleave kernel");
+        }
         {
             HIP_TRY(e, mm::launch_group_sums((const float*)e->cells.p, (const uint8_t*)e->cmask.p, (size_t)ppad,
                                              (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 7,
@@ -910,7 +924,7 @@ void mm_destroy(mm_engine* e)
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
                        &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0, &e->area_tab,
-                       &e->sweep_counts, &e->sentinel })
+                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1669,6 +1683,8 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "lds_pad_kb") == 0) { e->lds_pad_kb = std::min(120, std::max(0, value)); return MM_OK; }
     if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }
     if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "sort_groups") == 0) { e->sort_groups = value != 0; return MM_OK; }
+    if (strcmp(name, "interleave") == 0) { e->use_interleave = value != 0; return MM_OK; }
     if (strcmp(name, "xcd_aware") == 0) { e->xcd_aware = value != 0; return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }

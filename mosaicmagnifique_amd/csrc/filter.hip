@@ -134,7 +134,14 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // (it would be the 16 KB that keep a second workgroup off the CU): chroma is recomputed from a and b
 // with the very instructions that filled the plane (chroma_of), bit for bit.  48 KB of cell + 16 KB
 // hue table + statistics = 66 KB per workgroup: two workgroups = 20 waves per CU, 5 per SIMD.
-template <int TYPE, int THREADS, bool CELL_LDS>
+//
+// IL = true: interleaved images.  The pixel loop reads FOUR planes per side (channel 0, a, b, chroma); as four
+// separate arrays they cost eight 64-bit base addresses in SGPRs per (cell, candidate), which is what pushed
+// the kernel over the SGPR file (70 spilled, reloaded with ~55 v_readlane per candidate).  In the interleaved
+// copy (interleave_kernel) an image is [group][plane][256 positions]: the four planes of a group are 1 KB
+// apart, inside the 13-bit immediate offset of global_load, so ONE base per image and one VGPR offset
+// address everything, and the groups a candidate visits before its early exit are one contiguous prefix.
+template <int TYPE, int THREADS, bool CELL_LDS, bool IL>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(MM_FILTER_WAVES, MM_FILTER_WAVES)))
 filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
               const float* __restrict__ cell_chroma, const float* __restrict__ lib,
@@ -143,7 +150,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
               EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
               unsigned int edge_cap, const float* __restrict__ prune_above, int check_every,
               const HueEntry* __restrict__ hue_lut, Variants var, int xcd_shares,
-              const int32_t* __restrict__ seeds, int n_seeds)
+              const int32_t* __restrict__ seeds, int n_seeds, int sort_groups)
 {
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     __shared__ int seed_ids[256];           // the cell's seeds: their scores are in the row already (launch_prune_limits)
@@ -199,22 +206,24 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int v = var.cell_var[cell];
     const int groups = var.groups[v];                    // only the variant's active pixels
-    lib = lib_base + (size_t)v * var.lib_stride;
-    lib_chroma = lib_chroma_base + (size_t)v * var.chroma_stride;
+    lib = lib_base + (size_t)v * (IL ? var.chroma_stride * 4 : var.lib_stride);
+    lib_chroma = IL ? nullptr : lib_chroma_base + (size_t)v * var.chroma_stride;
     // channel 0 from the plane that holds NaN at inactive pixels: their terms come out as
     // max(NaN, 0) = 0 (colour_diff_fast.hpp), so there is no mask to load or test here
-    const float4* c0 = reinterpret_cast<const float4*>(cells_f0 + (size_t)cell * ppad);
-    const float4* c1 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad) + ppad / 4;
-    const float4* c2 = c1 + ppad / 4;
-    const float4* cc = reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
+    // IL: cells_f0 is the interleaved copy [cell][group][4][256]; planes of a group 64 float4 apart
+    const float4* c0 = reinterpret_cast<const float4*>(cells_f0 + (size_t)cell * (IL ? 4 : 1) * ppad);
+    const float4* c1 = IL ? c0 + kWave : reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad) + ppad / 4;
+    const float4* c2 = IL ? c0 + 2 * kWave : c1 + ppad / 4;
+    const float4* cc = IL ? c0 + 3 * kWave : reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
     const int pq = ppad / 4;
     for (int t = threadIdx.x; t < n_seeds; t += THREADS) seed_ids[t] = seeds[(size_t)cell * n_seeds + t];
     if constexpr (CELL_LDS) {                             // stage the cell (active groups only); the barrier below covers it
         const int nq = groups * kWave;
         for (int q = threadIdx.x; q < nq; q += THREADS) {
-            cell_tile[q] = c0[q];
-            cell_tile[pq + q] = c1[q];
-            cell_tile[2 * pq + q] = c2[q];
+            const int src = IL ? (q & (kWave - 1)) + 4 * kWave * (q >> 6) : q;      // interleaved: group q / 64, position q % 64
+            cell_tile[q] = c0[src];
+            cell_tile[pq + q] = c1[src];
+            cell_tile[2 * pq + q] = c2[src];
         }
     }
 
@@ -275,12 +284,14 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             for (int t = lane; t < n_seeds; t += kWave) hit = hit || seed_ids[t] == l;
             if (__builtin_amdgcn_ballot_w64(hit) != 0) continue;
         }
-        const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
-        const float4* b1 = b0 + ppad / 4;
-        const float4* b2 = b1 + ppad / 4;
-        const float4* bc = reinterpret_cast<const float4*>(lib_chroma + (size_t)l * ppad);
+        const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * (IL ? 4 : 3) * ppad);
+        const float4* b1 = IL ? b0 + kWave : b0 + ppad / 4;
+        const float4* b2 = IL ? b0 + 2 * kWave : b1 + ppad / 4;
+        const float4* bc = IL ? b0 + 3 * kWave : reinterpret_cast<const float4*>(lib_chroma + (size_t)l * ppad);
         bool pruned = false;
-        float rest = 0.0f;                 // lane j: lightness bound of groups >= j
+        float rest = 0.0f;                 // lane k: bound of the groups not yet visited at step k (see rest_at)
+        int order = lane;                  // lane k: the group visited k-th
+        const bool sorted = TYPE == CIEDE2000 && use_lb && lane_shift == 0 && sort_groups != 0;
         if constexpr (TYPE == CIEDE2000) {
             if (use_lb) {
                 // Lane k takes blocks k*m .. k*m+m-1 (m = blocks per lane: 1 up to 64 x 64 cells, so a lane
@@ -335,6 +346,38 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     const float lambda = fmaxf(0.999f * (0.5f * (na + nc)) - fsqrt(fmaf(half_diff, half_diff, nb * nb)), 0.0f);
                     d += 0.9999f * fsqrt(fmaf(t_l, t_l, lambda * fmaf(da, da, db * db)));
                 }
+                if (sorted) {
+                    // Visit the groups in DESCENDING order of their bounds.  The order is free -- the test is "sum of the
+                    // visited groups + bound of the unvisited ones > limit" whichever groups were visited -- and a group's
+                    // true sum exceeds its bound roughly in proportion to the bound, so the largest bounds are replaced by
+                    // true sums first and the candidate is dropped ~12 % of the visits earlier (simulated on config D).
+                    // One block per lane here (groups <= 16): quad j of the wave = group j.
+                    auto quad_swap = [](float x, int ctrl_tag) {
+                        const int r = ctrl_tag == 1 ? __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false)    // quad_perm [1,0,3,2]
+                                                    : __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+                        return __builtin_bit_cast(float, r);
+                    };
+                    float g = d + quad_swap(d, 1);
+                    g += quad_swap(g, 2);                                       // every lane of quad j: bound of group j (0 past the last group)
+                    const int j = lane >> 2, t = lane & 3;
+                    // unique integer keys: the bound's bits (non-negative floats order like integers) with the group number
+                    // in the low 4 bits, lower group first among equals
+                    const int key = (__builtin_bit_cast(int, g) & ~15) | (15 - j);
+                    // lane (j, t) counts the groups 4 t .. 4 t + 3 that come before group j; the quad adds its four counts up
+                    const int pull = t * 64;                                    // byte address of lane 16 t = quad 4 t
+                    int before = 0;
+                    before += __builtin_amdgcn_ds_bpermute(pull, key) > key;
+                    before += __builtin_amdgcn_ds_bpermute(pull + 16, key) > key;
+                    before += __builtin_amdgcn_ds_bpermute(pull + 32, key) > key;
+                    before += __builtin_amdgcn_ds_bpermute(pull + 48, key) > key;
+                    before += __builtin_amdgcn_mov_dpp(before, 0xB1, 0xf, 0xf, false);
+                    before += __builtin_amdgcn_mov_dpp(before, 0x4E, 0xf, 0xf, false);     // rank of group j (groups past the last have the smallest keys)
+                    // scatter (group number, bound) to the lane of their rank; every lane pushes somewhere unique
+                    const int dest = t != 0 ? 16 + 3 * j + t - 1 : before;
+                    order = __builtin_amdgcn_ds_permute(dest * 4, j);
+                    d = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dest * 4, __builtin_bit_cast(int, g)));
+                    if (lane >= 16) d = 0.0f;                                   // lanes 0..15: bounds in visiting order
+                }
                 // inclusive suffix scan over lanes (lane j <- sum of lanes >= j)
                 for (int off = 1; off < kWave; off <<= 1) {
                     const float up = __shfl_down(d, off, kWave);
@@ -349,14 +392,16 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         int visited = 0;
         if (!pruned && groups > 0) {
             // One 256-pixel group of the candidate against the cell; true = candidate dropped.
-            auto visit = [&](const LibGroup& cur, int j) -> bool {
-                if (j != 0 && j % check_every == 0) {
-                    // group j starts at block 4 j = the first block of lane (4 j) >> lane_shift
-                    const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), (4 * j) >> lane_shift)) : 0.0f;
+            auto visit = [&](const LibGroup& cur, int j, int step) -> bool {
+                if (step != 0 && step % check_every == 0) {
+                    // bound of what is still unvisited: sorted, lane `step` of the scan over the visiting order; else group
+                    // `step` starts at block 4 step = the first block of lane (4 step) >> lane_shift
+                    const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), sorted ? step : (4 * step) >> lane_shift)) : 0.0f;
                     if (wave_sum_dpp(acc) + rest_j > limit) return true;
                 }
                 const int q = lane + kWave * j;
-                const unsigned int off = (unsigned int)q * 16u;
+                // byte offset of this lane's float4 in plane 0 of group j (interleaved: a group is 4 KB, planes 1 KB apart)
+                const unsigned int off = IL ? (unsigned int)lane * 16u + (unsigned int)j * 4096u : (unsigned int)q * 16u;
                 visited += 1;
                 float4 p0, p1, p2, pc{0.f, 0.f, 0.f, 0.f};
                 if constexpr (CELL_LDS) {
@@ -398,9 +443,10 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             // No register prefetch of the next group: at 5 waves per SIMD the other waves cover a group's load
             // latency (a group is ~430 VALU instructions), and the second register set was what kept the
             // kernel at 4 waves (155 VGPRs wanted, 128 allowed, spills).
-            for (int j = 0; j < groups; ++j) {
-                const LibGroup g = load_lib_group<TYPE>(b0, b1, b2, bc, lane + kWave * j);
-                if (visit(g, j)) { pruned = true; break; }
+            for (int step = 0; step < groups; ++step) {
+                const int j = sorted ? __builtin_amdgcn_readlane(order, step) : step;
+                const LibGroup g = load_lib_group<TYPE>(b0, b1, b2, bc, IL ? lane + 4 * kWave * j : lane + kWave * j);
+                if (visit(g, j, step)) { pruned = true; break; }
             }
         }
         n_visited += (unsigned int)visited;
@@ -645,6 +691,25 @@ chroma_planes_kernel(const float* __restrict__ planar, float* __restrict__ chrom
         const float4 a = base[ppad / 4 + q], b = base[2 * (size_t)(ppad / 4) + q];
         reinterpret_cast<float4*>(chroma + img * (size_t)ppad)[q] =
             float4{chroma_of(a.x, b.x), chroma_of(a.y, b.y), chroma_of(a.z, b.z), chroma_of(a.w, b.w)};
+    }
+}
+
+// Interleaved copy of n planar images for filter_kernel<IL>: [n][3][ppad] (+ chroma [n][ppad], + an optional
+// replacement of channel 0, e.g. the NaN-marked one of the cells) -> [n][ppad / 256][4][256].
+__global__ void __launch_bounds__(kBlock)
+interleave_kernel(const float* __restrict__ planar, const float* __restrict__ chroma, const float* __restrict__ plane0,
+                  float* __restrict__ out, size_t n_images, int ppad)
+{
+    const size_t per = (size_t)(ppad / 4), total = n_images * per;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const size_t img = t / per;
+        const int q = (int)(t - img * per);                       // float4 position in a plane
+        const float4* src = reinterpret_cast<const float4*>(planar + img * 3 * (size_t)ppad);
+        float4* dst = reinterpret_cast<float4*>(out + img * 4 * (size_t)ppad) + (size_t)(q >> 6) * 4 * kWave + (q & (kWave - 1));
+        dst[0] = plane0 ? reinterpret_cast<const float4*>(plane0 + img * (size_t)ppad)[q] : src[q];
+        dst[kWave] = src[per + q];
+        dst[2 * kWave] = src[2 * per + q];
+        dst[3 * kWave] = chroma ? reinterpret_cast<const float4*>(chroma + img * (size_t)ppad)[q] : float4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -1015,13 +1080,14 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         const int sub = shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : 64) : 512;
         hipError_t code = hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);
         if (code != hipSuccess) return code;
-        auto kern = filter_kernel<CIEDE2000, kTileThreads, true>;
+        auto kern = in.lib_il && in.cells_il ? filter_kernel<CIEDE2000, kTileThreads, true, true> : filter_kernel<CIEDE2000, kTileThreads, true, false>;
+        const bool il = in.lib_il && in.cells_il;
         const size_t dyn = (size_t)ppad * 12 + in.lds_pad_bytes;
         if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)) != hipSuccess)
             return code;
         kern<<<dim3(persistent_grid(reinterpret_cast<const void*>(kern), items, kTileThreads, dyn)), kTileThreads, dyn, stream>>>(
-            in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, sub,
-            edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares, in.seeds, in.seeds ? in.n_seeds : 0);
+            in.cells, il ? in.cells_il : in.cells_f0, in.cell_chroma, il ? in.lib_il : in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, sub,
+            edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares, in.seeds, in.seeds ? in.n_seeds : 0, in.sort_groups);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
@@ -1063,23 +1129,36 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         }
         return hipGetLastError();
     }
+    const bool il = in.lib_il && in.cells_il;
     if (type == CIEDE2000) {
+        auto kern = il ? filter_kernel<CIEDE2000, kBlock, false, true> : filter_kernel<CIEDE2000, kBlock, false, false>;
         if (in.lds_pad_bytes > 0 &&
-            (code = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_kernel<CIEDE2000, kBlock, false>),
+            (code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)in.lds_pad_bytes)) != hipSuccess) return code;
-        filter_kernel<CIEDE2000, kBlock, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<CIEDE2000, kBlock, false>), blocks, kBlock, in.lds_pad_bytes)), kBlock, in.lds_pad_bytes, stream>>>(
-            in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
+        kern<<<dim3(persistent_grid(reinterpret_cast<const void*>(kern), blocks, kBlock, in.lds_pad_bytes)), kBlock, in.lds_pad_bytes, stream>>>(
+            il ? nullptr : in.cells, il ? in.cells_il : in.cells_f0, il ? nullptr : in.cell_chroma, il ? in.lib_il : in.lib,
+            il ? nullptr : in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares,
-            in.seeds, in.seeds ? in.n_seeds : 0);
+            in.seeds, in.seeds ? in.n_seeds : 0, in.sort_groups);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
     } else {
-        filter_kernel<RGB_EUCLIDEAN, kBlock, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN, kBlock, false>), blocks, kBlock, 0)), kBlock, 0, stream>>>(
+        filter_kernel<RGB_EUCLIDEAN, kBlock, false, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN, kBlock, false, false>), blocks, kBlock, 0)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares,
-            in.seeds, in.seeds ? in.n_seeds : 0);
+            in.seeds, in.seeds ? in.n_seeds : 0, in.sort_groups);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_interleave(const float* planar, const float* chroma, const float* plane0, float* out,
+                             size_t n_images, int ppad, hipStream_t stream)
+{
+    const size_t total = n_images * (size_t)(ppad / 4);
+    const unsigned blocks = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 65536);
+    if (blocks == 0) return hipSuccess;
+    interleave_kernel<<<blocks, kBlock, 0, stream>>>(planar, chroma, plane0, out, n_images, ppad);
     return hipGetLastError();
 }
 

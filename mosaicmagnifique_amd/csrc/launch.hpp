@@ -45,6 +45,9 @@ struct FilterInputs {
     size_t lds_pad_bytes;       // diagnostics: unused dynamic LDS per filter workgroup (lowers the occupancy)
     int xcd_aware;              // 1: persistent workgroups take the cells of their own XCD's share first (L2 affinity)
     int xcd_cells;              // cells per sub-group of an XCD's share (0 = default 64)
+    int sort_groups;            // 1: a candidate's groups are visited in descending order of their bounds (cells up to 64 x 64)
+    const float* lib_il;        // interleaved copies for filter_kernel<IL> (launch_interleave): [V][L][ppad/256][4][256] and
+    const float* cells_il;      // [B][ppad/256][4][256] (plane 0 = cells_f0); null: the planar arrays are read
     const int32_t* seeds;       // [B][n_seeds] candidates launch_prune_limits scored already (their scores are in the
     int n_seeds;                // score rows): filter_kernel skips them.  null / 0: none.  n_seeds <= 256.
 };
@@ -67,6 +70,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
 // masked sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma, hue range.
 hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
                              size_t block_stride, size_t n_images, int ppad, hipStream_t stream);
+
+// Interleaved copy of n planar images (+ chroma, + optional replacement of channel 0): [n][ppad/256][4][256].
+hipError_t launch_interleave(const float* planar, const float* chroma, const float* plane0, float* out,
+                             size_t n_images, int ppad, hipStream_t stream);
 
 // Chroma planes of n planar images: [n][3][ppad] -> [n][ppad].
 hipError_t launch_chroma_planes(const float* planar, float* chroma, size_t n_images, int ppad, hipStream_t stream);
