@@ -105,6 +105,57 @@ __device__ __forceinline__ LibGroup load_lib_group(const float4* b0, const float
     return g;
 }
 
+// Lower bound of  sum over a block's pixel pairs of dE00  from the seven statistics of the cell's block (c_*) and the
+// library image's block (l_*): sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma, hue arc
+// centre (offset from 275 deg) and half-width (group_sums_kernel).  The derivation is in filter_kernel's comment.
+// slack: what the fp32 rounding of the two sums can hide (1e-2 for 64-term sums of values <= ~128, 5e-2 for 256 terms).
+__device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa, float c_sb, float c_cmax, float c_hc, float c_hw,
+                                             float l_sl, float l_dev, float l_sa, float l_sb, float l_cmax, float l_hc, float l_hw,
+                                             float slack)
+{
+    // S_L of every pair of the block: |L_bar - 50| <= (max|L_cell - 50| + max|L_lib - 50|) / 2
+    // over the block's active pixels, and S_L grows with it (:138-139)
+    const float x = 0.5f * (c_dev + l_dev);
+    const float x2 = x * x;
+    const float s_l = fmaf(0.015f * x2, frsq(20.0f + x2), 1.0f);
+    // S_C and R_T likewise from the largest chroma of the two blocks (see above)
+    const float cbar = 0.5f * (c_cmax + l_cmax);
+    // 1 + G of every pair is at least g_min: G falls as the pair's mean chroma grows (:50-53), and that is <= cbar
+    const float g_min = 1.5f - 0.5f * sqrt_ratio7(cbar);
+    const float gc = g_min * cbar;                                     // >= C_bar' of every pair
+    const float s_c = fmaf(0.045f, gc, 1.0f);
+    // |R_T| = sin(2 d_theta) R_C, d_theta = 30 deg * exp(-((h_bar' - 275) / 25)^2)  (:132-136,:145).  Each block's
+    // hues lie on an arc (centre c as an offset from 275 deg, half-width w: statistics 5, 6); a pair's mean hue
+    // is the midpoint of the shorter arc between its two hues (:107-122), i.e. within (w1 + w2) / 2 of
+    // c1 + D / 2 with D = wrap(c2 - c1) -- or of the opposite point when some pair can be more than 180 deg
+    // apart (|D| + w1 + w2 >= 180).  The reference does not wrap h_bar' - 275; the circular distance is
+    // never larger, so this exponent is never more negative than the true one.
+    const float c1 = c_hc, w1 = c_hw, c2 = l_hc, w2 = l_hw;
+    const float delta = wrap180(c2 - c1);
+    const float mid = fabsf(wrap180(fmaf(0.5f, delta, c1)));
+    const float hw = 0.5f * (w1 + w2);
+    const float d0 = fmaxf(0.0f, mid - hw), d1 = fmaxf(0.0f, (180.0f - mid) - hw);
+    const float off = (fabsf(delta) + w1 + w2 >= 180.0f) ? fminf(d0, d1) : d0;   // least |h_bar' - 275| any pair can have
+    const float e_max = fexp2(off * off * (-1.4426950408889634f / 625.0f));
+    // v_sin_f32 takes revolutions: sin(60 deg * E) = sin(2 pi * E / 6); 1.001 + 1e-5 covers its error
+    const float sin_2dt = fmaf(__builtin_amdgcn_sinf(e_max * (1.0f / 6.0f)), 1.001f, 1e-5f);
+    const float half_rt = sqrt_ratio7(gc) * sin_2dt;                   // >= |R_T| / 2,  R_C = 2 sqrt_ratio7
+    const float t_l = fmaxf(fabsf(c_sl - l_sl) - slack, 0.0f) * frcp(s_l);
+    // dC'^2 + dH'^2 = ((1 + G) da)^2 + db^2 >= (g_min da)^2 + db^2
+    const float da = fmaxf(fabsf(c_sa - l_sa) - slack, 0.0f) * g_min;
+    const float db = fmaxf(fabsf(c_sb - l_sb) - slack, 0.0f);
+    // tC^2 + tH^2 + R_T tC tH = (dC', dH') N (dC', dH')^T,  N = [[1/S_C^2, R_T/(2 S_C S_H)], [., 1/S_H^2]].
+    // Its smallest eigenvalue falls as S_C, S_H or |R_T| grow (it is the minimum of y^T M y / (S_C^2 y1^2 +
+    // S_H^2 y2^2) with M = [[1, R_T/2], [R_T/2, 1]] positive definite), so the block's worst constants give a
+    // floor:  >= lambda (dC'^2 + dH'^2) >= lambda (da^2 + db^2);  S_H = 1 + 0.015 C' T <= 1 + 0.015 * 1.5726 g.
+    const float inv_c = frcp(s_c), inv_h = frcp(fmaf(0.015f * 1.5726f, gc, 1.0f));
+    const float na = inv_c * inv_c, nc = inv_h * inv_h, nb = half_rt * inv_c * inv_h;
+    const float half_diff = 0.5f * (na - nc);
+    // 0.999 and 0.9999: v_rsq / v_rcp / v_sqrt are good to ~1 ulp, and the difference of two close terms
+    const float lambda = fmaxf(0.999f * (0.5f * (na + nc)) - fsqrt(fmaf(half_diff, half_diff, nb * nb)), 0.0f);
+    return 0.9999f * fsqrt(fmaf(t_l, t_l, lambda * fmaf(da, da, db * db)));
+}
+
 // Work counters of a launch, at edge_count + kCounterBase (u32 indices; the u64 ones are 8-byte aligned):
 //   +0,1  u64  256-pixel groups visited          +2,3  u64  groups a full visit of every candidate would take
 //   +4,5  u64  candidates dropped by the block bound alone (no pixel touched)
@@ -154,6 +205,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
 {
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     __shared__ int seed_ids[256];           // the cell's seeds: their scores are in the row already (launch_prune_limits)
+    __shared__ float cell_gs[TYPE == CIEDE2000 ? 7 : 1][TYPE == CIEDE2000 ? 16 : 1];   // the cell's statistics per 256-position group
+    __shared__ unsigned int alive_mask[2];  // candidates of the tile that passed the group-level bound (<= 64 per tile)
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
     __shared__ unsigned int next_item;      // ... and workgroups pull (cell, tile) items: the hue table is loaded once
     __shared__ int item_share;              // the XCD share next_item belongs to (-1: none left)
@@ -167,7 +220,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     unsigned int* const item_counter = edge_count + kItemCounters;
     const int my_share = xcd_shares > 1 ? xcc_id() % xcd_shares : 0;
     int first_live = 0;                     // thread 0: shares before my_share + first_live (cyclically) are exhausted
-    unsigned long long n_visited = 0, n_groups_all = 0, n_bound_dropped = 0;     // this wave's work counters
+    unsigned int n_visited = 0, n_groups_all = 0, n_bound_dropped = 0;     // work counters, per lane (a wave's share of a launch fits 32 bits)
     // Persistent workgroups: as many as the device holds at once, each taking the next item of the
     // launch order from a global counter.  A 33 KB table per 32-candidate tile was
     // three times the HBM traffic of the launch in L2 -> LDS copies, and its latency idled the waves
@@ -265,24 +318,85 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     cell_st[k][t] = var.cell_stats[(size_t)k * var.cell_stats_stride + (size_t)cell * var.n_blocks + t];
         }
     }
-    if (use_lb || CELL_LDS || n_seeds > 0) __syncthreads();   // workgroup-uniform
-
     // blocks per lane in the bound's prelude: 1, 2 or 4 (a power of two, so groups start on lane boundaries)
     const int lane_shift = groups <= 16 ? 0 : (groups <= 32 ? 1 : 2), per_lane = 1 << lane_shift;
     const int l_base = tile * cand_per_block;
     const int n_here = min(cand_per_block, L - l_base);
-    for (int idx = wave; idx < n_here;) {
-        const int l = l_base + idx;
-        {   // the next candidate of this tile not yet taken by any wave
+    // Two levels of the bound.  The per-block prelude below costs ~300 instructions per candidate and half of the
+    // candidates end there.  The same bound from the statistics of whole 256-position GROUPS (sixteen numbers per
+    // image instead of sixty-four) is weaker -- it drops ~85 % of what the block level drops -- but sixteen lanes
+    // hold a candidate, so one pass of the wave judges FOUR candidates: ~40 instructions each.  Stage 1: the waves
+    // share the tile's candidates four at a time and leave a mask of the survivors in LDS; stage 2: the waves pull
+    // survivors from the mask and give each the block-level prelude and the pixel loop.
+    bool two_level = false;
+    if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && cand_per_block <= 64 && var.lib_gstats != nullptr;
+    if (two_level) {
+        if (threadIdx.x < 16 * 7) {
+            const int k = threadIdx.x >> 4, g = threadIdx.x & 15;
+            cell_gs[k][g] = g < groups ? var.cell_gstats[(size_t)k * var.cell_gstats_stride + (size_t)cell * var.n_groups + g] : 0.0f;
+        }
+        if (threadIdx.x < 2) alive_mask[threadIdx.x] = 0u;
+    }
+    if (use_lb || CELL_LDS || n_seeds > 0) __syncthreads();   // workgroup-uniform
+    if (two_level) {
+        const int q = lane >> 4, g = lane & 15;             // candidate of the pass, group
+        for (int first = 4 * wave; first < n_here; first += 4 * (THREADS / kWave)) {
+            const int idx = first + q;
+            const int l = l_base + idx;
+            float b = 0.0f;
+            bool seed = false;
+            if (idx < n_here) {
+                for (int t = 0; t < n_seeds; ++t) seed = seed || seed_ids[t] == l;       // scored already: not a survivor
+                if (g < groups) {
+                    const float* st = var.lib_gstats + ((size_t)v * L + l) * var.n_groups + g;
+                    const size_t bs = var.lib_gstats_stride;
+                    b = stats_bound(cell_gs[0][g], cell_gs[1][g], cell_gs[2][g], cell_gs[3][g], cell_gs[4][g], cell_gs[5][g], cell_gs[6][g],
+                                    st[0], st[bs], st[2 * bs], st[3 * bs], st[4 * bs], st[5 * bs], st[6 * bs], 5e-2f);
+                }
+            }
+            // sum over the candidate's 16 lanes (a DPP row)
+            b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x128, 0xf, 0xf, false));   // row_ror:8
+            b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x124, 0xf, 0xf, false));   // row_ror:4
+            b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x122, 0xf, 0xf, false));   // row_ror:2
+            b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x121, 0xf, 0xf, false));   // row_ror:1
+            if (g == 0 && idx < n_here && !seed) {
+                if (b > limit) {
+                    scores[(size_t)cell * L + l] = __builtin_huge_valf();
+                    n_bound_dropped += 1;       // (per lane; summed over the wave's lanes at the end)
+                } else {
+                    atomicOr(&alive_mask[idx >> 5], 1u << (idx & 31));
+                }
+                n_groups_all += (unsigned int)groups;
+            }
+        }
+        if (threadIdx.x == 0) next_candidate = 0;           // stage 2 counts survivors from 0
+        __syncthreads();
+    }
+    const unsigned long long survivors = two_level ? ((unsigned long long)alive_mask[1] << 32) | alive_mask[0] : 0ull;
+    const int n_todo = two_level ? __builtin_popcountll(survivors) : n_here;
+    for (int turn = two_level ? 0 : wave; ;) {
+        if (two_level) {                                    // the next survivor not yet taken by any wave
             int nxt = 0;
             if (lane == 0) nxt = atomicAdd(&next_candidate, 1);
-            idx = __builtin_amdgcn_readfirstlane(nxt);      // scalar: library addresses stay in SGPRs
+            turn = __builtin_amdgcn_readfirstlane(nxt);
         }
-        if (n_seeds > 0) {
-            // scored already as a seed (seed_score_kernel left its score in the row): nothing to do
-            bool hit = false;
-            for (int t = lane; t < n_seeds; t += kWave) hit = hit || seed_ids[t] == l;
-            if (__builtin_amdgcn_ballot_w64(hit) != 0) continue;
+        if (turn >= n_todo) break;
+        int idx = turn;
+        if (two_level) {                                    // the turn-th set bit of the mask
+            const bool mine = ((survivors >> lane) & 1ull) != 0 && __builtin_popcountll(survivors & ((1ull << lane) - 1ull)) == turn;
+            idx = __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine));
+        }
+        const int l = l_base + idx;
+        if (!two_level) {   // the next candidate of this tile not yet taken by any wave
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(&next_candidate, 1);
+            turn = __builtin_amdgcn_readfirstlane(nxt);      // scalar: library addresses stay in SGPRs
+            if (n_seeds > 0) {
+                // scored already as a seed (seed_score_kernel left its score in the row): nothing to do
+                bool hit = false;
+                for (int t = lane; t < n_seeds; t += kWave) hit = hit || seed_ids[t] == l;
+                if (__builtin_amdgcn_ballot_w64(hit) != 0) continue;
+            }
         }
         const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * (IL ? 4 : 3) * ppad);
         const float4* b1 = IL ? b0 + kWave : b0 + ppad / 4;
@@ -303,48 +417,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     if (blk >= n_blk) break;
                     const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + blk;
                     const size_t bs = var.lib_stats_stride;
-                    // S_L of every pair of the block: |L_bar - 50| <= (max|L_cell - 50| + max|L_lib - 50|) / 2
-                    // over the block's active pixels, and S_L grows with it (:138-139)
-                    const float x = 0.5f * (cell_st[1][blk] + st[bs]);
-                    const float x2 = x * x;
-                    const float s_l = fmaf(0.015f * x2, frsq(20.0f + x2), 1.0f);
-                    // S_C and R_T likewise from the largest chroma of the two blocks (see above)
-                    const float cbar = 0.5f * (cell_st[4][blk] + st[4 * bs]);
-                    // 1 + G of every pair is at least g_min: G falls as the pair's mean chroma grows (:50-53), and that is <= cbar
-                    const float g_min = 1.5f - 0.5f * sqrt_ratio7(cbar);
-                    const float gc = g_min * cbar;                                     // >= C_bar' of every pair
-                    const float s_c = fmaf(0.045f, gc, 1.0f);
-                    // |R_T| = sin(2 d_theta) R_C, d_theta = 30 deg * exp(-((h_bar' - 275) / 25)^2)  (:132-136,:145).  Each block's
-                    // hues lie on an arc (centre c as an offset from 275 deg, half-width w: statistics 5, 6); a pair's mean hue
-                    // is the midpoint of the shorter arc between its two hues (:107-122), i.e. within (w1 + w2) / 2 of
-                    // c1 + D / 2 with D = wrap(c2 - c1) -- or of the opposite point when some pair can be more than 180 deg
-                    // apart (|D| + w1 + w2 >= 180).  The reference does not wrap h_bar' - 275; the circular distance is
-                    // never larger, so this exponent is never more negative than the true one.
-                    const float c1 = cell_st[5][blk], w1 = cell_st[6][blk], c2 = st[5 * bs], w2 = st[6 * bs];
-                    const float delta = wrap180(c2 - c1);
-                    const float mid = fabsf(wrap180(fmaf(0.5f, delta, c1)));
-                    const float hw = 0.5f * (w1 + w2);
-                    const float d0 = fmaxf(0.0f, mid - hw), d1 = fmaxf(0.0f, (180.0f - mid) - hw);
-                    const float off = (fabsf(delta) + w1 + w2 >= 180.0f) ? fminf(d0, d1) : d0;   // least |h_bar' - 275| any pair can have
-                    const float e_max = fexp2(off * off * (-1.4426950408889634f / 625.0f));
-                    // v_sin_f32 takes revolutions: sin(60 deg * E) = sin(2 pi * E / 6); 1.001 + 1e-5 covers its error
-                    const float sin_2dt = fmaf(__builtin_amdgcn_sinf(e_max * (1.0f / 6.0f)), 1.001f, 1e-5f);
-                    const float half_rt = sqrt_ratio7(gc) * sin_2dt;                   // >= |R_T| / 2,  R_C = 2 sqrt_ratio7
-                    // 1e-2: fp32 rounding of two 64-term sums of values <= ~128, with margin
-                    const float t_l = fmaxf(fabsf(cell_st[0][blk] - st[0]) - 1e-2f, 0.0f) * frcp(s_l);
-                    // dC'^2 + dH'^2 = ((1 + G) da)^2 + db^2 >= (g_min da)^2 + db^2
-                    const float da = fmaxf(fabsf(cell_st[2][blk] - st[2 * bs]) - 1e-2f, 0.0f) * g_min;
-                    const float db = fmaxf(fabsf(cell_st[3][blk] - st[3 * bs]) - 1e-2f, 0.0f);
-                    // tC^2 + tH^2 + R_T tC tH = (dC', dH') N (dC', dH')^T,  N = [[1/S_C^2, R_T/(2 S_C S_H)], [., 1/S_H^2]].
-                    // Its smallest eigenvalue falls as S_C, S_H or |R_T| grow (it is the minimum of y^T M y / (S_C^2 y1^2 +
-                    // S_H^2 y2^2) with M = [[1, R_T/2], [R_T/2, 1]] positive definite), so the block's worst constants give a
-                    // floor:  >= lambda (dC'^2 + dH'^2) >= lambda (da^2 + db^2);  S_H = 1 + 0.015 C' T <= 1 + 0.015 * 1.5726 g.
-                    const float inv_c = frcp(s_c), inv_h = frcp(fmaf(0.015f * 1.5726f, gc, 1.0f));
-                    const float na = inv_c * inv_c, nc = inv_h * inv_h, nb = half_rt * inv_c * inv_h;
-                    const float half_diff = 0.5f * (na - nc);
-                    // 0.999 and 0.9999: v_rsq / v_rcp / v_sqrt are good to ~1 ulp, and the difference of two close terms
-                    const float lambda = fmaxf(0.999f * (0.5f * (na + nc)) - fsqrt(fmaf(half_diff, half_diff, nb * nb)), 0.0f);
-                    d += 0.9999f * fsqrt(fmaf(t_l, t_l, lambda * fmaf(da, da, db * db)));
+                    d += stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
+                                     st[0], st[bs], st[2 * bs], st[3 * bs], st[4 * bs], st[5 * bs], st[6 * bs], 1e-2f);
                 }
                 if (sorted) {
                     // Visit the groups in DESCENDING order of their bounds.  The order is free -- the test is "sum of the
@@ -372,8 +446,14 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     before += __builtin_amdgcn_ds_bpermute(pull + 48, key) > key;
                     before += __builtin_amdgcn_mov_dpp(before, 0xB1, 0xf, 0xf, false);
                     before += __builtin_amdgcn_mov_dpp(before, 0x4E, 0xf, 0xf, false);     // rank of group j (groups past the last have the smallest keys)
-                    // scatter (group number, bound) to the lane of their rank; every lane pushes somewhere unique
-                    const int dest = t != 0 ? 16 + 3 * j + t - 1 : before;
+                    // Only the `sort_groups` largest bounds are visited out of order; the other groups follow in plane order
+                    // (position = groups of lower number that are not among the largest), which keeps most of a candidate's
+                    // reads a contiguous run -- the L2 hit rate falls when every candidate walks its own permutation.
+                    const unsigned long long tail_lanes = __builtin_amdgcn_ballot_w64(t == 0 && before >= sort_groups);
+                    const int below = __builtin_popcountll(tail_lanes & ((1ull << lane) - 1ull));
+                    const int pos = before < sort_groups ? before : sort_groups + below;
+                    // scatter (group number, bound) to the lane of their place; every lane pushes somewhere unique
+                    const int dest = t != 0 ? 16 + 3 * j + t - 1 : pos;
                     order = __builtin_amdgcn_ds_permute(dest * 4, j);
                     d = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dest * 4, __builtin_bit_cast(int, g)));
                     if (lane >= 16) d = 0.0f;                                   // lanes 0..15: bounds in visiting order
@@ -449,18 +529,27 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 if (visit(g, j, step)) { pruned = true; break; }
             }
         }
-        n_visited += (unsigned int)visited;
-        n_groups_all += (unsigned int)groups;
-        n_bound_dropped += (pruned && visited == 0) ? 1u : 0u;
+        if (lane == 0) {                        // the counters are per lane (stage 1 counts on the candidates' first lanes)
+            n_visited += (unsigned int)visited;
+            if (!two_level) n_groups_all += (unsigned int)groups;
+            n_bound_dropped += (pruned && visited == 0) ? 1u : 0u;
+        }
         acc = wave_sum_f(acc + acc_edge);
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }
     }   // next item
-    if ((threadIdx.x & 63) == 0) {           // one set of atomics per wave and launch
-        unsigned long long* c = reinterpret_cast<unsigned long long*>(edge_count + kCounterBase);
-        atomicAdd(c, n_visited);
-        atomicAdd(c + 1, n_groups_all);
-        atomicAdd(c + 2, n_bound_dropped);
+    {   // one set of atomics per wave and launch
+        for (int off = 32; off > 0; off >>= 1) {
+            n_visited += __shfl_xor(n_visited, off, kWave);
+            n_groups_all += __shfl_xor(n_groups_all, off, kWave);
+            n_bound_dropped += __shfl_xor(n_bound_dropped, off, kWave);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* c = reinterpret_cast<unsigned long long*>(edge_count + kCounterBase);
+            atomicAdd(c, (unsigned long long)n_visited);
+            atomicAdd(c + 1, (unsigned long long)n_groups_all);
+            atomicAdd(c + 2, (unsigned long long)n_bound_dropped);
+        }
     }
 }
 
@@ -727,7 +816,10 @@ interleave_kernel(const float* __restrict__ planar, const float* __restrict__ ch
 //         the whole circle (centre 0, half-width 180) when the sum vanishes, a pixel's chroma is below 1e-3
 //         (its hue is arbitrary and the reference's mean-hue rule changes, :108-109), a pixel lies more than
 //         170 deg off the sum, or the block has no active pixel.
-// One wave per (image, group): 16 lanes per block.  Feeds the lower bound of filter_kernel's early exit.
+// One wave per (image, group); LPB lanes per block: 16 -> the seven numbers per 64-position block, 64 -> per
+// 256-position group (the coarse first level of the bound, n_blocks = groups then).  Feeds the lower bound of
+// filter_kernel's early exit.
+template <int LPB>
 __global__ void __launch_bounds__(kBlock)
 group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ mask, size_t mask_stride,
                   float* __restrict__ stats, size_t block_stride, size_t n_images, int n_groups,
@@ -755,7 +847,7 @@ group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ 
             anywhere = anywhere || !(ch >= 1e-3f);
             any = true;
         }
-    for (int off = 8; off > 0; off >>= 1) {              // within the block's 16 lanes
+    for (int off = LPB / 2; off > 0; off >>= 1) {        // within the block's lanes
         s0 += __shfl_xor(s0, off, kWave); s1 += __shfl_xor(s1, off, kWave); s2 += __shfl_xor(s2, off, kWave);
         dev = fmaxf(dev, __shfl_xor(dev, off, kWave));
         cmax = fmaxf(cmax, __shfl_xor(cmax, off, kWave));
@@ -772,12 +864,12 @@ group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ 
             dlo = fminf(dlo, fminf(e1, e2)); dhi = fmaxf(dhi, fmaxf(e1, e2));
             far = fmaxf(far, fmaxf(fabsf(e1), fabsf(e2)));
         }
-    for (int off = 8; off > 0; off >>= 1) {
+    for (int off = LPB / 2; off > 0; off >>= 1) {
         dlo = fminf(dlo, __shfl_xor(dlo, off, kWave)); dhi = fmaxf(dhi, __shfl_xor(dhi, off, kWave));
         far = fmaxf(far, __shfl_xor(far, off, kWave));
     }
-    if ((lane & 15) == 0) {
-        float* o = stats + img * n_blocks + 4 * g + (lane >> 4);
+    if ((lane & (LPB - 1)) == 0) {
+        float* o = stats + img * n_blocks + (kWave / LPB) * g + lane / LPB;
         o[0] = s0; o[block_stride] = dev; o[2 * block_stride] = s1; o[3 * block_stride] = s2; o[4 * block_stride] = cmax;
         const bool open = anywhere || !any || !(far <= 170.0f) || !(fmaf(s1, s1, s2 * s2) >= 1e-6f);
         o[5 * block_stride] = open ? 0.0f : wrap180(ref + 0.5f * (dlo + dhi) - 275.0f);
@@ -1068,6 +1160,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         return (unsigned)std::min<long long>(items, (long long)cus * per_cu * 2);
     };
     const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
+    const int sort_groups = in.sort_groups < 0 ? (groups >= 12 ? 16 : 0) : in.sort_groups;
     // The LDS-resident cell tile (CIEDE2000, early exit on): ten-wave workgroups, the cell's colour planes staged once
     // per item.  Needs one block per lane in the bound's prelude (<= 16 groups = cells up to 64 x 64) and the three
     // planes beside the hue table, twice per CU.
@@ -1087,7 +1180,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             return code;
         kern<<<dim3(persistent_grid(reinterpret_cast<const void*>(kern), items, kTileThreads, dyn)), kTileThreads, dyn, stream>>>(
             in.cells, il ? in.cells_il : in.cells_f0, in.cell_chroma, il ? in.lib_il : in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, sub,
-            edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares, in.seeds, in.seeds ? in.n_seeds : 0, in.sort_groups);
+            edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares, in.seeds, in.seeds ? in.n_seeds : 0, sort_groups);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
@@ -1139,7 +1232,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             il ? nullptr : in.cells, il ? in.cells_il : in.cells_f0, il ? nullptr : in.cell_chroma, il ? in.lib_il : in.lib,
             il ? nullptr : in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares,
-            in.seeds, in.seeds ? in.n_seeds : 0, in.sort_groups);
+            in.seeds, in.seeds ? in.n_seeds : 0, sort_groups);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var);
@@ -1147,7 +1240,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         filter_kernel<RGB_EUCLIDEAN, kBlock, false, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN, kBlock, false, false>), blocks, kBlock, 0)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares,
-            in.seeds, in.seeds ? in.n_seeds : 0, in.sort_groups);
+            in.seeds, in.seeds ? in.n_seeds : 0, sort_groups);
     }
     return hipGetLastError();
 }
@@ -1168,8 +1261,19 @@ hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t ma
     const int n_groups = ppad / 256, n_blocks = ppad / 64;
     const size_t waves = n_images * (size_t)n_groups;
     if (waves == 0) return hipSuccess;
-    group_sums_kernel<<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, stats, block_stride,
-                                                                        n_images, n_groups, n_blocks, ppad);
+    group_sums_kernel<16><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, stats, block_stride,
+                                                                            n_images, n_groups, n_blocks, ppad);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_sums256(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
+                                size_t block_stride, size_t n_images, int ppad, hipStream_t stream)
+{
+    const int n_groups = ppad / 256;
+    const size_t waves = n_images * (size_t)n_groups;
+    if (waves == 0) return hipSuccess;
+    group_sums_kernel<64><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, stats, block_stride,
+                                                                            n_images, n_groups, n_groups, ppad);
     return hipGetLastError();
 }
 

@@ -28,6 +28,11 @@ struct Variants {
     size_t lib_stats_stride, cell_stats_stride;
     int n_blocks;               // ppad / 64
     const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask (not clipped)
+    // the same seven statistics per 256-position GROUP (launch_group_sums256): the coarse first level of the bound
+    const float* lib_gstats;    // 7 x [V][L][n_groups], lib_gstats_stride floats apart (null: single-level bound)
+    const float* cell_gstats;   // 7 x [B][n_groups], cell_gstats_stride floats apart
+    size_t lib_gstats_stride, cell_gstats_stride;
+    int n_groups;               // ppad / 256
 };
 
 // Device inputs of the fp32 filter kernels.
@@ -45,7 +50,8 @@ struct FilterInputs {
     size_t lds_pad_bytes;       // diagnostics: unused dynamic LDS per filter workgroup (lowers the occupancy)
     int xcd_aware;              // 1: persistent workgroups take the cells of their own XCD's share first (L2 affinity)
     int xcd_cells;              // cells per sub-group of an XCD's share (0 = default 64)
-    int sort_groups;            // 1: a candidate's groups are visited in descending order of their bounds (cells up to 64 x 64)
+    int sort_groups;            // n > 0: a candidate's n largest-bound groups are visited first, by descending bound, the rest in
+                                // plane order (cells up to 64 x 64); 0: plane order
     const float* lib_il;        // interleaved copies for filter_kernel<IL> (launch_interleave): [V][L][ppad/256][4][256] and
     const float* cells_il;      // [B][ppad/256][4][256] (plane 0 = cells_f0); null: the planar arrays are read
     const int32_t* seeds;       // [B][n_seeds] candidates launch_prune_limits scored already (their scores are in the
@@ -74,6 +80,10 @@ hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t ma
 // Interleaved copy of n planar images (+ chroma, + optional replacement of channel 0): [n][ppad/256][4][256].
 hipError_t launch_interleave(const float* planar, const float* chroma, const float* plane0, float* out,
                              size_t n_images, int ppad, hipStream_t stream);
+
+// The same seven statistics per 256-position GROUP ([img][ppad / 256]): the coarse first level of the bound.
+hipError_t launch_group_sums256(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
+                                size_t block_stride, size_t n_images, int ppad, hipStream_t stream);
 
 // Chroma planes of n planar images: [n][3][ppad] -> [n][ppad].
 hipError_t launch_chroma_planes(const float* planar, float* chroma, size_t n_images, int ppad, hipStream_t stream);

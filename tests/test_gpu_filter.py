@@ -243,3 +243,21 @@ def test_early_exit_bound_at_every_cell_size_class(oracle, engine, t, size):
     rows, cols = 2 * size + size // 2, 3 * size + size // 4
     img, lib = cases.inputs(rows, cols, size, n_lib, t, lattice=size)
     run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(1, 500))
+
+
+@pytest.mark.parametrize("size", [40, 48, 64])
+@pytest.mark.parametrize("sort_groups", [0, 1, 3, 16])
+def test_visiting_order_of_the_groups_does_not_change_the_result(oracle, engine, size, sort_groups):
+    """A candidate's 256-pixel groups may be visited in any order (the exit test is "sum of the visited groups
+    + bound of the unvisited ones > limit"): plane order, the n largest bounds first then plane order, or
+    all by descending bound -- pruned == unpruned == fp64-only == oracle each time; 40 and 48 px cells have
+    a ragged last group, 64 px fills all 16."""
+    t = Type.CIEDE2000
+    rows, cols = 3 * size + size // 3, 4 * size + size // 5
+    img, lib = cases.inputs(rows, cols, size, 120, t, lattice=size)
+    try:
+        engine.set_option("sort_groups", sort_groups)
+        tm = run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(1, 400))
+        assert tm["visited_groups"] > 0 and tm["bound_dropped"] > 0
+    finally:
+        engine.set_option("sort_groups", -1)
