@@ -74,7 +74,7 @@ struct mm_engine {
     int use_sweep_resolve = 1;   // mm_set_option("sweep_resolve", 0): raster-order chain instead of parallel sweeps
     int max_sweeps = 48;         // mm_set_option("max_sweeps", n): sweeps before falling back to the chain
     int use_lds_filter = -1;     // mm_set_option("lds_filter", 0/1); -1 = auto (Euclid only: it is the L2-bound one)
-    int extra_seeds = 22;        // mm_set_option("seeds", n): proxy-chosen seeds beyond the list length
+    int extra_seeds = 14;        // mm_set_option("seeds", n): proxy-chosen seeds beyond the list length (10..30 measured: flat within 1 %)
     int lds_pad_kb = 0;          // mm_set_option("lds_pad_kb", n): diagnostics -- extra LDS per filter workgroup (lowers occupancy)
     int tile_candidates = 0;     // mm_set_option("tile", n): candidates per filter workgroup (0 = default)
     int max_batch_cells = 0;     // mm_set_option("max_batch", n): cap on cells per device batch (0 = from memory)

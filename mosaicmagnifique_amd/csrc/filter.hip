@@ -1139,7 +1139,9 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream)
 {
-    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : 32, cell_group = 512;
+    // 64 candidates per item: what the survivor mask of the two-level bound holds; measured against 32 and 48 with
+    // the XCD sub-group at 32 / 64 / 128 cells: config D within 1 %, config E's 48 x 48 cells -7 % launch time
+    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : 64, cell_group = 512;
     // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited), times two
     // so a finishing workgroup's slot refills at once
     auto persistent_grid = [&](const void* kern, long long items, int threads, size_t dyn_lds) -> unsigned {
@@ -1191,7 +1193,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // one share of the cells per XCD (8 on MI355X); small launches keep one share so no XCD idles on an empty one
     const int xcd_shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
-    const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : 64) : cell_group;
+    const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : 128) : cell_group;
     const int check_every = groups > 16 ? groups / 16 : 1;
     hipError_t code = hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);  // + work counters, item counters
     if (code != hipSuccess) return code;
