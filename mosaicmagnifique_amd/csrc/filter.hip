@@ -1139,9 +1139,13 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream)
 {
-    // 64 candidates per item: what the survivor mask of the two-level bound holds; measured against 32 and 48 with
-    // the XCD sub-group at 32 / 64 / 128 cells: config D within 1 %, config E's 48 x 48 cells -7 % launch time
-    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : 64, cell_group = 512;
+    const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
+    // Candidates per item and cells per XCD sub-group, measured at 32 / 48 / 64 x 32 / 64 / 128: small cells (config E's
+    // 48 x 48: 9 groups) gain 7 % of the launch from 64-candidate items (the two-level bound's survivor mask holds 64)
+    // and 128-cell sub-groups; 64 x 64 cells run the same within 1 % either way, but the larger working set costs
+    // 40 % more fabric traffic (303 GB instead of 217 GB per launch), so they keep 32 / 64.
+    const bool small_cells = groups < 12;
+    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : (small_cells ? 64 : 32), cell_group = 512;
     // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited), times two
     // so a finishing workgroup's slot refills at once
     auto persistent_grid = [&](const void* kern, long long items, int threads, size_t dyn_lds) -> unsigned {
@@ -1161,7 +1165,6 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         if (n_known < 8) known[n_known++] = Known{kern, dyn_lds, dev, cus * per_cu * 2};
         return (unsigned)std::min<long long>(items, (long long)cus * per_cu * 2);
     };
-    const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
     const int sort_groups = in.sort_groups < 0 ? (groups >= 12 ? 16 : 0) : in.sort_groups;
     // The LDS-resident cell tile (CIEDE2000, early exit on): ten-wave workgroups, the cell's colour planes staged once
     // per item.  Needs one block per lane in the bound's prelude (<= 16 groups = cells up to 64 x 64) and the three
@@ -1193,7 +1196,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // one share of the cells per XCD (8 on MI355X); small launches keep one share so no XCD idles on an empty one
     const int xcd_shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
-    const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : 128) : cell_group;
+    const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : (small_cells ? 128 : 64)) : cell_group;
     const int check_every = groups > 16 ? groups / 16 : 1;
     hipError_t code = hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);  // + work counters, item counters
     if (code != hipSuccess) return code;

@@ -49,7 +49,7 @@ struct FilterInputs {
     int tile_candidates;        // candidates per workgroup of filter_kernel (0 = default)
     size_t lds_pad_bytes;       // diagnostics: unused dynamic LDS per filter workgroup (lowers the occupancy)
     int xcd_aware;              // 1: persistent workgroups take the cells of their own XCD's share first (L2 affinity)
-    int xcd_cells;              // cells per sub-group of an XCD's share (0 = default 128)
+    int xcd_cells;              // cells per sub-group of an XCD's share (0 = default: 64, or 128 for cells below 12 groups)
     int sort_groups;            // n > 0: a candidate's n largest-bound groups are visited first, by descending bound, the rest in
                                 // plane order (cells up to 64 x 64); 0: plane order
     const float* lib_il;        // interleaved copies for filter_kernel<IL> (launch_interleave): [V][L][ppad/256][4][256] and
