@@ -167,3 +167,27 @@ def test_cpp_reader_agrees_with_the_python_reader(tmp_path):
     bad = tmp_path / "bad.mcs"
     bad.write_bytes(struct.pack(">II", 0x12345678, 8))
     assert "not a valid .mcs" in run_mcs_runner(runner, [bad])[0]["error"]
+
+
+def test_bench_consumes_mcs_and_mil_files(tmp_path):
+    """bench.py --mcs / --mil (the purpose of N4: running the benchmark on the project's own files): the
+    workload built from a written .mcs and .mil carries the file's shape, resized to the configuration's
+    cell size, and the file's images."""
+    import sys
+    import cases
+    sys.path.insert(0, ROOT)
+    import bench
+    shape = cases.hexagon_shape()
+    shape.name = "Hexagon"
+    mcs, mil = tmp_path / "h.mcs", tmp_path / "l.mil"
+    shape.saveToFile(mcs)
+    lib = ImageLibrary(128)
+    images = synth.library_u8(7, 128)
+    for i, im in enumerate(images):
+        lib.addImage(im, "i%d" % i)
+    lib.saveToFile(mil)
+    w = bench.build_workload("C", 1, mcs=str(mcs), mil=str(mil))
+    assert w["L"] == 7 and w["lib_u8"].shape == (7, 64, 64, 3)          # 128 px images shrunk (INTER_AREA) to the 64 px cell
+    assert np.array_equal(w["lib_u8"][3], images[3].reshape(64, 2, 64, 2, 3).astype(np.uint32).sum((1, 3)).__add__(2).__floordiv__(4).astype(np.uint8))
+    assert np.array_equal(w["shape"].masks4(), shape.masks4()) and "h.mcs" in w["shape_name"]
+    assert len(w["cells"]) == 1694 and bench.algorithmic_bytes(w, w["cells_single"])[1] == 4206946
