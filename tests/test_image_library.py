@@ -191,3 +191,40 @@ def test_bench_consumes_mcs_and_mil_files(tmp_path):
     assert np.array_equal(w["lib_u8"][3], images[3].reshape(64, 2, 64, 2, 3).astype(np.uint32).sum((1, 3)).__add__(2).__floordiv__(4).astype(np.uint8))
     assert np.array_equal(w["shape"].masks4(), shape.masks4()) and "h.mcs" in w["shape_name"]
     assert len(w["cells"]) == 1694 and bench.algorithmic_bytes(w, w["cells_single"])[1] == 4206946
+
+
+def test_cpp_reader_survives_truncated_and_corrupted_files(tmp_path):
+    """The C++ .mcs reader parses files from disk: every truncation and single-byte corruption of a valid file
+    must end in a reported error or a valid shape -- never a crash -- under AddressSanitizer + UBSan (CPU build)."""
+    import random
+    import cases
+    from mosaicmagnifique_amd import _build
+    lib_dir = os.path.dirname(_build.build())
+    host = os.path.join(ROOT, "mosaicmagnifique_amd", "csrc", "host")
+    runner = str(tmp_path / "mcs_asan")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-o", runner,
+                    os.path.join(HERE, "mcs_reader_runner.cpp"), os.path.join(host, "HIPPhotomosaicGenerator.cpp"),
+                    "-L" + lib_dir, "-lmosaic_hip", "-Wl,-rpath," + lib_dir, "-lz", "-pthread"], check=True)
+    shape = cases.hexagon_shape()
+    shape.name = "Hexagon"
+    good = tmp_path / "good.mcs"
+    shape.saveToFile(good)
+    src = good.read_bytes()
+    paths = []
+    for n in list(range(0, len(src), 37)) + [len(src) - 1]:
+        p = tmp_path / ("t%d.mcs" % n)
+        p.write_bytes(src[:n])
+        paths.append(p)
+    rnd = random.Random(1)
+    for k in range(60):
+        b = bytearray(src)
+        b[rnd.randrange(8, len(b))] ^= 0xFF
+        p = tmp_path / ("c%d.mcs" % k)
+        p.write_bytes(bytes(b))
+        paths.append(p)
+    res = subprocess.run([runner] + [str(p) for p in paths], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert res.returncode == 0 and "ERROR" not in res.stderr and "runtime error" not in res.stderr, res.stderr[-2000:]
+    out = [json.loads(line) for line in res.stdout.splitlines()]
+    assert len(out) == len(paths)
+    assert sum("error" in o for o in out[:len(src) // 37 + 2]) == len(src) // 37 + 2        # every truncation is refused
