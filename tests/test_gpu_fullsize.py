@@ -266,11 +266,17 @@ def test_config_d_first_two_rows_and_interior_cells_vs_oracle(oracle, engine):
     # runner-up: put the winner in the cell's left neighbour with a repeat value no score reaches
     second = np.empty(32, np.int64)
     second_score = np.empty(32)
-    for k, (gy, gx) in enumerate(spos):
+
+    def runner_up(k):
+        gy, gx = spos[k]
         g = empty.copy()
         g[gy, gx - 1] = first[k]
         p, s = oracle.picks_given_grid(sh, img, lib, masks, int(t), 1, 1 << 30, g, spos[k:k + 1], early_exit=False)
         second[k], second_score[k] = p[0], s[0]
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(nthr) as pool:                   # ctypes releases the GIL inside the oracle
+        list(pool.map(runner_up, range(32)))
     assert np.array_equal(second, idx[:, 1])
     assert (np.abs(second_score - sc[:, 1]) <= 1e-4 * second_score).all()
 
