@@ -96,3 +96,41 @@ def test_random_scenario_with_size_steps(oracle, seed):
     img[:, cols - cols // 2:] = np.clip(img[:, cols - cols // 2:].astype(np.int16) + noise, 0, 255).astype(np.uint8)   # busy half: splits
     lib = synth.library_u8(int(rng.integers(5, 50)), size, seed=0x11B + seed)
     run_steps(oracle, shape, img, lib, t, detail, steps, rep)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MOSAIC_FUZZ_LARGE", "24"))))     # soak: MOSAIC_FUZZ_LARGE=300
+def test_random_scenario_large_library(oracle, engine, seed):
+    """Scenarios the small ones above cannot reach: hundreds of library images (so most candidates are NOT seeds
+    and go through the two-level bound, the bound-ordered visits and the early exit), 48 / 56 / 64 px cells with
+    random masks, and at least 512 cells (so the persistent workgroups split the cells into per-XCD shares).
+    Every cell is checked by the oracle as the reference's raster loop reaches it, given the engine's earlier
+    picks (oracle_ffi.picks_given_grid: equality on the whole raster = equality with the sequential run)."""
+    import os
+    rng = np.random.default_rng(9000 + seed)
+    size = int(rng.choice([48, 56, 64]))
+    shape = random_shape(rng, size)
+    t = Type.CIEDE2000 if seed % 3 != 2 else Type.CIE76
+    rep = (0, 0) if seed % 2 else (int(rng.integers(1, 5)), int(rng.choice([40, 700])))
+    n_lib = int(rng.integers(150, 400))
+    rows = cols = 23 * max(shape.rowSpacing, shape.colSpacing, shape.alternateRowSpacing, shape.alternateColSpacing) + int(rng.integers(0, size))
+    img = synth.preprocess(synth.target_u8(rows, cols, lattice=int(rng.choice([32, 200])), seed=0x7A6 + seed), t)
+    lib = synth.preprocess(synth.library_u8(n_lib, size, seed=0x11B + seed), t)
+    group = CellGroup(shape)
+    state = G.getGridState(group, rows, cols)[0]
+    cells = G.cell_records(group, state, rows, cols)
+    assert len(cells) >= 512
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    tm = engine.timing()
+    if t == Type.CIEDE2000:
+        assert tm["visited_groups"] > 0 and tm["band_alarms"] == 0
+    grid = np.where(best < n_lib, best, -1)
+    pos = np.stack([cells["grid_y"], cells["grid_x"]], axis=1)
+    threads = min(16, len(os.sched_getaffinity(0)))
+    picks, scores = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), rep[0], rep[1], grid, pos,
+                                            threads=threads)
+    got = best[pos[:, 0], pos[:, 1]]
+    assert np.array_equal(np.where(got == n_lib, -1, got), picks), np.flatnonzero(np.where(got == n_lib, -1, got) != picks)[:5]
+    ok = picks >= 0
+    tol = 1e-4 if t == Type.CIEDE2000 else 1e-12
+    assert (np.abs(score[pos[ok, 0], pos[ok, 1]] - scores[ok]) <= tol * np.abs(scores[ok]) + 1e-300).all()
