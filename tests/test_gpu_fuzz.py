@@ -40,7 +40,7 @@ def random_shape(rng, size):
     return s
 
 
-@pytest.mark.parametrize("seed", range(150))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MOSAIC_FUZZ_SMALL", "150"))))       # soak: MOSAIC_FUZZ_SMALL=1500
 def test_random_scenario(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     size = int(rng.choice([8, 13, 16, 17, 24, 31, 32, 33, 40, 50, 64, 72]))
