@@ -320,8 +320,8 @@ mm_status mm_filter_diff_batch(mm_engine *e, int diff_type,
 mm_status mm_debug_filter_band_sweep(mm_engine *e, int mode, uint64_t seed, uint64_t n_pairs, double out[6]);
 
 /* Diagnostics: {pixel groups visited by the filter kernel, groups a full visit takes,
- * candidates dropped outright by the lightness bound} of the last batch.  Only builds
- * with -DMM_COUNT_VISITS count; otherwise zeros. */
+ * candidates dropped outright by the bound} of the last filter launch (always counted; the
+ * sums over a generate are in mm_timing). */
 mm_status mm_debug_visit_counters(mm_engine *e, unsigned long long out[3]);
 
 /* Calibration: GB/s a plain coalesced float4 read stream over `bytes` of device memory reaches

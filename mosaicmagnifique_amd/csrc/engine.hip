@@ -1620,8 +1620,8 @@ mm_status mm_build_photomosaic_step(mm_engine* e, const mm_cell* cells, int n_ce
     return MM_OK;
 }
 
-// Diagnostics (builds with -DMM_COUNT_VISITS only fill them): pixel groups visited by the
-// filter kernel, groups a full visit would take, candidates dropped by the lightness bound.
+// Diagnostics: pixel groups visited by the filter kernel, groups a full visit would take, candidates
+// dropped by the bound -- of the last filter launch (always counted; mm_timing sums them over a generate).
 mm_status mm_debug_visit_counters(mm_engine* e, unsigned long long out[3])
 {
     if (!e || !out || !e->edge_count.p) return MM_INVALID_ARGUMENT;
