@@ -271,6 +271,12 @@ def main():
     from mosaicmagnifique_amd.dist import ShardedBestFit
     from mosaicmagnifique_amd.engine import Engine
 
+    # MOSAIC_BENCH_REHEARSAL=1: every rank drives GPU 0 and the collective runs over gloo -- the N > 1
+    # code path of this script on a one-GPU box (RCCL refuses two ranks on one device).  Timings of such
+    # a run mean nothing (the ranks share the device); the JSON line says so.
+    rehearsal = os.environ.get("MOSAIC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # MOSAIC_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL init, device-side
     # candidate lists, all-gather, resolve from device memory) even with one rank.
@@ -283,7 +289,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         t_comm = time.perf_counter()
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist.barrier()                          # builds the communicator before anything is timed
         comm_init_s = time.perf_counter() - t_comm
 
@@ -424,7 +433,7 @@ def main():
         "scaling": scaling if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f32 filter + f64 arbiter" if engine_uses_filter else "f64",
-        "data": "synthetic" if not (args.mcs or args.mil) else "synthetic target; %s" % ", ".join(
+        "data": "synthetic (REHEARSAL: all ranks on one GPU over gloo, timings void)" if rehearsal else "synthetic" if not (args.mcs or args.mil) else "synthetic target; %s" % ", ".join(
             os.path.basename(p) for p in (args.mcs, args.mil) if p),
         "config": {
             "workload": "config %s: %dx%d target%s, %dx%d %s cells, %d-image library, %s, repeat range %d (+%d)" % (
