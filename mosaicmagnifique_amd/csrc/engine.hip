@@ -66,7 +66,7 @@ struct mm_engine {
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
     // per distinct mask in that mask's active-pixels-first order whenever either changes
-    DevBuf lib_hwc, perm, inv_perm, cell_var, cell_full, pos_mask, lib_lsum, cell_lsum, lib_gsum, cell_gsum;
+    DevBuf lib_hwc, perm, inv_perm, cell_var, cell_full, pos_mask, lib_lsum, cell_lsum;
     std::vector<uint8_t> masks_host;
     bool planes_dirty = true;
     int n_var = 0, var_of_mask[4] = {0, 0, 0, 0}, var_groups[4] = {0, 0, 0, 0};
@@ -81,8 +81,8 @@ struct mm_engine {
     int use_wave_resolve = 1;    // mm_set_option("wave_resolve", 0): workgroup-per-cell resolve
     int use_filter = 1;          // mm_set_option("filter", 0) forces the fp64-only path
     int use_prune = 1;           // mm_set_option("prune", 0): filter pass without early exit
-    int two_level = 1;           // mm_set_option("two_level", 0): the bound's coarse first level (statistics per 256-position group,
-                                 // four candidates per wave pass) is skipped
+    int two_level = 1;           // mm_set_option("two_level", 0): the bound is evaluated per candidate by the wave that walks its pixels,
+                                 // not four candidates per wave pass ahead of the pixel loops (filter_kernel's two stages)
     int sort_groups = -1;        // mm_set_option("sort_groups", n): the n largest-bound pixel groups of a candidate are visited first,
                                  // in descending order of their bounds, the others in plane order (0: plane order, 16: all sorted);
                                  // -1 = auto: all sorted from 12 groups per cell on (measured: 64 x 64 cells -6 % launch time,
@@ -286,8 +286,7 @@ mm_status prepare_planes(mm_engine* e)
         (st = ensure(e, e->lib_chroma, (size_t)n_var * L * ppad * sizeof(float), "Failed to allocate library chroma planes")) ||
         (st = ensure(e, e->lib_means, (size_t)L * 3 * sizeof(float), "Failed to allocate library means")) ||
         (st = ensure(e, e->pos_mask, pos_mask.size(), "Failed to allocate position masks")) ||
-        (st = ensure(e, e->lib_lsum, (size_t)7 * n_var * L * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
-        (st = ensure(e, e->lib_gsum, (size_t)7 * n_var * L * (ppad / 256) * sizeof(float), "Failed to allocate group statistics")))
+        (st = ensure(e, e->lib_lsum, (size_t)7 * n_var * L * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")))
         return st;
     HIP_TRY(e, hipMemcpyAsync(e->pos_mask.p, pos_mask.data(), pos_mask.size(), hipMemcpyHostToDevice, e->stream),
             "Failed to copy position masks to device");
@@ -306,11 +305,6 @@ mm_status prepare_planes(mm_engine* e)
                                          (float*)e->lib_lsum.p + (size_t)v * L * (ppad / 64),
                                          (size_t)n_var * L * (ppad / 64), (size_t)L, ppad, e->stream),
                 "Error during library group-sum kernel");
-        HIP_TRY(e, mm::launch_group_sums256((const float*)e->lib.p + (size_t)v * L * 3 * ppad,
-                                            (const uint8_t*)e->pos_mask.p + (size_t)v * ppad, 0,
-                                            (float*)e->lib_gsum.p + (size_t)v * L * (ppad / 256),
-                                            (size_t)n_var * L * (ppad / 256), (size_t)L, ppad, e->stream),
-                "Error during library group-statistics kernel");
     }
     HIP_TRY(e, mm::launch_chroma_planes((const float*)e->lib.p, (float*)e->lib_chroma.p, (size_t)n_var * L, ppad, e->stream),
             "Error during library chroma kernel");
@@ -339,11 +333,7 @@ mm::Variants variants_of(const mm_engine* e)
     v.cell_stats_stride = e->cell_lsum.bytes / sizeof(float) / 7;
     v.n_blocks = ppad / 64;
     v.cell_full = (const uint8_t*)e->cell_full.p;
-    v.lib_gstats = e->two_level ? (const float*)e->lib_gsum.p : nullptr;
-    v.cell_gstats = (const float*)e->cell_gsum.p;
-    v.lib_gstats_stride = (size_t)e->n_var * e->n_lib * (ppad / 256);
-    v.cell_gstats_stride = e->cell_gsum.bytes / sizeof(float) / 7;
-    v.n_groups = ppad / 256;
+    v.two_stage = e->two_level;
     return v;
 }
 
@@ -491,7 +481,6 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     if ((st = ensure(e, e->cell_var, (size_t)batch, "Failed to allocate cell variants")) ||
         (st = ensure(e, e->cell_full, (size_t)batch, "Failed to allocate cell flags")) ||
         (st = ensure(e, e->cell_lsum, (size_t)7 * batch * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
-        (st = ensure(e, e->cell_gsum, (size_t)7 * batch * (ppad / 256) * sizeof(float), "Failed to allocate group statistics")) ||
         (st = ensure(e, e->cells, (size_t)batch * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
         (st = ensure(e, e->cmask, (size_t)batch * ppad, "Failed to allocate cell masks")) ||
         (st = ensure(e, e->scores, (size_t)batch * L * sizeof(double), "Failed to allocate variants")))
@@ -582,11 +571,6 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                                              (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 7,
                                              (size_t)b, ppad, e->stream),
                     "Error during cell group-sum kernel");
-            if (diff_type == MM_CIEDE2000)
-                HIP_TRY(e, mm::launch_group_sums256((const float*)e->cells.p, (const uint8_t*)e->cmask.p, (size_t)ppad,
-                                                    (float*)e->cell_gsum.p, e->cell_gsum.bytes / sizeof(float) / 7,
-                                                    (size_t)b, ppad, e->stream),
-                        "Error during cell group-statistics kernel");
         }
         HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
 
@@ -946,7 +930,7 @@ void mm_destroy(mm_engine* e)
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
                        &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0, &e->area_tab,
-                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il, &e->lib_gsum, &e->cell_gsum })
+                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il })
         release(*b);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);

@@ -205,13 +205,14 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
 {
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     __shared__ int seed_ids[256];           // the cell's seeds: their scores are in the row already (launch_prune_limits)
-    __shared__ float cell_gs[TYPE == CIEDE2000 ? 7 : 1][TYPE == CIEDE2000 ? 16 : 1];   // the cell's statistics per 256-position group
+    // stage 1 -> stage 2: the bound of every 256-position group of the tile's candidates (<= 64 per tile, <= 16 groups)
+    __shared__ float cand_gb[TYPE == CIEDE2000 ? 64 : 1][TYPE == CIEDE2000 ? 16 : 1];
     __shared__ unsigned int alive_mask[2];  // candidates of the tile that passed the group-level bound (<= 64 per tile)
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
     __shared__ unsigned int next_item;      // ... and workgroups pull (cell, tile) items: the hue table is loaded once
     __shared__ int item_share;              // the XCD share next_item belongs to (-1: none left)
     // block statistics of the cell (early-exit bound), up to 4 blocks per lane
-    __shared__ float cell_st[TYPE == CIEDE2000 ? 7 : 1][TYPE == CIEDE2000 ? (CELL_LDS ? kWave : 4 * kWave) : 1];
+    __shared__ __attribute__((aligned(16))) float cell_st[TYPE == CIEDE2000 ? 7 : 1][TYPE == CIEDE2000 ? (CELL_LDS ? kWave : 4 * kWave) : 1];
     extern __shared__ float4 cell_tile[];   // CELL_LDS: [3][ppad / 4] -- channel 0 (NaN = inactive), a, b
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
@@ -322,21 +323,15 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     const int lane_shift = groups <= 16 ? 0 : (groups <= 32 ? 1 : 2), per_lane = 1 << lane_shift;
     const int l_base = tile * cand_per_block;
     const int n_here = min(cand_per_block, L - l_base);
-    // Two levels of the bound.  The per-block prelude below costs ~300 instructions per candidate and half of the
-    // candidates end there.  The same bound from the statistics of whole 256-position GROUPS (sixteen numbers per
-    // image instead of sixty-four) is weaker -- it drops ~85 % of what the block level drops -- but sixteen lanes
-    // hold a candidate, so one pass of the wave judges FOUR candidates: ~40 instructions each.  Stage 1: the waves
-    // share the tile's candidates four at a time and leave a mask of the survivors in LDS; stage 2: the waves pull
-    // survivors from the mask and give each the block-level prelude and the pixel loop.
+    // Two stages.  The bound of a candidate takes one stats_bound per 64-position block (~75 instructions, ten of them
+    // transcendental) and half of the candidates end there, so it is computed where all 64 lanes work on it.  Stage 1:
+    // sixteen lanes hold a candidate, lane g its group g = four blocks, so one pass of the wave judges FOUR candidates;
+    // the waves share the tile's candidates four at a time, leave every candidate's sixteen group bounds in LDS and a
+    // mask of the survivors.  Stage 2: the waves pull survivors from the mask; a survivor's prelude is then a read of its
+    // group bounds, the visiting order and a scan -- ~60 instructions instead of ~300 -- before the pixel loop.
     bool two_level = false;
-    if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && cand_per_block <= 64 && var.lib_gstats != nullptr;
-    if (two_level) {
-        if (threadIdx.x < 16 * 7) {
-            const int k = threadIdx.x >> 4, g = threadIdx.x & 15;
-            cell_gs[k][g] = g < groups ? var.cell_gstats[(size_t)k * var.cell_gstats_stride + (size_t)cell * var.n_groups + g] : 0.0f;
-        }
-        if (threadIdx.x < 2) alive_mask[threadIdx.x] = 0u;
-    }
+    if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && cand_per_block <= 64 && var.two_stage != 0;
+    if (two_level && threadIdx.x < 2) alive_mask[threadIdx.x] = 0u;
     if (use_lb || CELL_LDS || n_seeds > 0) __syncthreads();   // workgroup-uniform
     if (two_level) {
         const int q = lane >> 4, g = lane & 15;             // candidate of the pass, group
@@ -348,11 +343,23 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             if (idx < n_here) {
                 for (int t = 0; t < n_seeds; ++t) seed = seed || seed_ids[t] == l;       // scored already: not a survivor
                 if (g < groups) {
-                    const float* st = var.lib_gstats + ((size_t)v * L + l) * var.n_groups + g;
-                    const size_t bs = var.lib_gstats_stride;
-                    b = stats_bound(cell_gs[0][g], cell_gs[1][g], cell_gs[2][g], cell_gs[3][g], cell_gs[4][g], cell_gs[5][g], cell_gs[6][g],
-                                    st[0], st[bs], st[2 * bs], st[3 * bs], st[4 * bs], st[5 * bs], st[6 * bs], 5e-2f);
+                    // the group's four blocks are four consecutive floats of each statistic
+                    const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + 4 * g;
+                    const size_t bs = var.lib_stats_stride;
+                    float4 ls[7];
+                    for (int k = 0; k < 7; ++k) ls[k] = *reinterpret_cast<const float4*>(st + k * bs);
+                    auto block = [&](int i, float l0, float l1, float l2, float l3, float l4, float l5, float l6) {
+                        const int blk = 4 * g + i;
+                        b += stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
+                                         l0, l1, l2, l3, l4, l5, l6, 1e-2f);
+                        __builtin_amdgcn_sched_barrier(0);  // one block at a time: four interleaved evaluations do not fit the registers
+                    };
+                    block(0, ls[0].x, ls[1].x, ls[2].x, ls[3].x, ls[4].x, ls[5].x, ls[6].x);
+                    block(1, ls[0].y, ls[1].y, ls[2].y, ls[3].y, ls[4].y, ls[5].y, ls[6].y);
+                    block(2, ls[0].z, ls[1].z, ls[2].z, ls[3].z, ls[4].z, ls[5].z, ls[6].z);
+                    block(3, ls[0].w, ls[1].w, ls[2].w, ls[3].w, ls[4].w, ls[5].w, ls[6].w);
                 }
+                cand_gb[idx][g] = b;                        // 0 for the groups past the last
             }
             // sum over the candidate's 16 lanes (a DPP row)
             b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x128, 0xf, 0xf, false));   // row_ror:8
@@ -406,19 +413,24 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         float rest = 0.0f;                 // lane k: bound of the groups not yet visited at step k (see rest_at)
         int order = lane;                  // lane k: the group visited k-th
         const bool sorted = TYPE == CIEDE2000 && use_lb && lane_shift == 0 && sort_groups != 0;
+        const bool by_group = sorted || two_level;          // lane k of `rest`: visiting step k (else: block k)
         if constexpr (TYPE == CIEDE2000) {
             if (use_lb) {
                 // Lane k takes blocks k*m .. k*m+m-1 (m = blocks per lane: 1 up to 64 x 64 cells, so a lane
-                // is a quarter of a group; 4 at 128 x 128: a lane is a group).
+                // is a quarter of a group; 4 at 128 x 128: a lane is a group).  After stage 1 the group bounds wait in LDS.
                 const int n_blk = 4 * groups;
                 float d = 0.0f;
-                for (int i = 0; i < per_lane; ++i) {
-                    const int blk = lane * per_lane + i;
-                    if (blk >= n_blk) break;
-                    const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + blk;
-                    const size_t bs = var.lib_stats_stride;
-                    d += stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
-                                     st[0], st[bs], st[2 * bs], st[3 * bs], st[4 * bs], st[5 * bs], st[6 * bs], 1e-2f);
+                if (two_level) {
+                    if (!sorted) d = lane < 16 ? cand_gb[idx][lane] : 0.0f;       // lane k: bound of group k
+                } else {
+                    for (int i = 0; i < per_lane; ++i) {
+                        const int blk = lane * per_lane + i;
+                        if (blk >= n_blk) break;
+                        const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + blk;
+                        const size_t bs = var.lib_stats_stride;
+                        d += stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
+                                         st[0], st[bs], st[2 * bs], st[3 * bs], st[4 * bs], st[5 * bs], st[6 * bs], 1e-2f);
+                    }
                 }
                 if (sorted) {
                     // Visit the groups in DESCENDING order of their bounds.  The order is free -- the test is "sum of the
@@ -431,8 +443,13 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                                                     : __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
                         return __builtin_bit_cast(float, r);
                     };
-                    float g = d + quad_swap(d, 1);
-                    g += quad_swap(g, 2);                                       // every lane of quad j: bound of group j (0 past the last group)
+                    float g;                                                    // every lane of quad j: bound of group j (0 past the last group)
+                    if (two_level) {
+                        g = cand_gb[idx][lane >> 2];
+                    } else {
+                        g = d + quad_swap(d, 1);
+                        g += quad_swap(g, 2);
+                    }
                     const int j = lane >> 2, t = lane & 3;
                     // unique integer keys: the bound's bits (non-negative floats order like integers) with the group number
                     // in the low 4 bits, lower group first among equals
@@ -458,8 +475,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     d = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dest * 4, __builtin_bit_cast(int, g)));
                     if (lane >= 16) d = 0.0f;                                   // lanes 0..15: bounds in visiting order
                 }
-                // inclusive suffix scan over lanes (lane j <- sum of lanes >= j)
-                for (int off = 1; off < kWave; off <<= 1) {
+                // inclusive suffix scan over lanes (lane j <- sum of lanes >= j); group bounds fill lanes 0..15 only
+                for (int off = 1; off < (by_group ? 16 : kWave); off <<= 1) {
                     const float up = __shfl_down(d, off, kWave);
                     if (lane + off < kWave) d += up;
                 }
@@ -476,7 +493,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 if (step != 0 && step % check_every == 0) {
                     // bound of what is still unvisited: sorted, lane `step` of the scan over the visiting order; else group
                     // `step` starts at block 4 step = the first block of lane (4 step) >> lane_shift
-                    const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), sorted ? step : (4 * step) >> lane_shift)) : 0.0f;
+                    const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), by_group ? step : (4 * step) >> lane_shift)) : 0.0f;
                     if (wave_sum_dpp(acc) + rest_j > limit) return true;
                 }
                 const int q = lane + kWave * j;
@@ -816,10 +833,8 @@ interleave_kernel(const float* __restrict__ planar, const float* __restrict__ ch
 //         the whole circle (centre 0, half-width 180) when the sum vanishes, a pixel's chroma is below 1e-3
 //         (its hue is arbitrary and the reference's mean-hue rule changes, :108-109), a pixel lies more than
 //         170 deg off the sum, or the block has no active pixel.
-// One wave per (image, group); LPB lanes per block: 16 -> the seven numbers per 64-position block, 64 -> per
-// 256-position group (the coarse first level of the bound, n_blocks = groups then).  Feeds the lower bound of
-// filter_kernel's early exit.
-template <int LPB>
+// One wave per (image, group), sixteen lanes per block.  Feeds the lower bound of filter_kernel's early exit.
+constexpr int LPB = 16;
 __global__ void __launch_bounds__(kBlock)
 group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ mask, size_t mask_stride,
                   float* __restrict__ stats, size_t block_stride, size_t n_images, int n_groups,
@@ -1266,19 +1281,8 @@ hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t ma
     const int n_groups = ppad / 256, n_blocks = ppad / 64;
     const size_t waves = n_images * (size_t)n_groups;
     if (waves == 0) return hipSuccess;
-    group_sums_kernel<16><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, stats, block_stride,
+    group_sums_kernel<<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, stats, block_stride,
                                                                             n_images, n_groups, n_blocks, ppad);
-    return hipGetLastError();
-}
-
-hipError_t launch_group_sums256(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
-                                size_t block_stride, size_t n_images, int ppad, hipStream_t stream)
-{
-    const int n_groups = ppad / 256;
-    const size_t waves = n_images * (size_t)n_groups;
-    if (waves == 0) return hipSuccess;
-    group_sums_kernel<64><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, stats, block_stride,
-                                                                            n_images, n_groups, n_groups, ppad);
     return hipGetLastError();
 }
 

@@ -28,11 +28,7 @@ struct Variants {
     size_t lib_stats_stride, cell_stats_stride;
     int n_blocks;               // ppad / 64
     const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask (not clipped)
-    // the same seven statistics per 256-position GROUP (launch_group_sums256): the coarse first level of the bound
-    const float* lib_gstats;    // 7 x [V][L][n_groups], lib_gstats_stride floats apart (null: single-level bound)
-    const float* cell_gstats;   // 7 x [B][n_groups], cell_gstats_stride floats apart
-    size_t lib_gstats_stride, cell_gstats_stride;
-    int n_groups;               // ppad / 256
+    int two_stage;              // 1: the bound is evaluated four candidates per wave pass ahead of the pixel loops (filter_kernel)
 };
 
 // Device inputs of the fp32 filter kernels.
@@ -80,10 +76,6 @@ hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t ma
 // Interleaved copy of n planar images (+ chroma, + optional replacement of channel 0): [n][ppad/256][4][256].
 hipError_t launch_interleave(const float* planar, const float* chroma, const float* plane0, float* out,
                              size_t n_images, int ppad, hipStream_t stream);
-
-// The same seven statistics per 256-position GROUP ([img][ppad / 256]): the coarse first level of the bound.
-hipError_t launch_group_sums256(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
-                                size_t block_stride, size_t n_images, int ppad, hipStream_t stream);
 
 // Chroma planes of n planar images: [n][3][ppad] -> [n][ppad].
 hipError_t launch_chroma_planes(const float* planar, float* chroma, size_t n_images, int ppad, hipStream_t stream);
