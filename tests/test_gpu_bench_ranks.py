@@ -25,11 +25,11 @@ def run_ranks(n, port, *extra):
 
 
 @pytest.mark.gpu
-def test_two_ranks_weak_bands_of_config_c():
-    single = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C", "--steps", "1",
+def test_two_ranks_weak_bands_of_config_b():
+    single = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "B", "--steps", "1",
                                         "--warmup", "0", "--no-cpu"], cwd=ROOT, capture_output=True, text=True,
                                        timeout=300, check=True).stdout.strip().splitlines()[-1])
-    out = run_ranks(2, 29541, "--config", "C")
+    out = run_ranks(2, 29541, "--config", "B")       # weak bands need square cells: B (config D is the same path, 25 s)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 2
     assert out["config"]["cells"] == 2 * single["config"]["cells"]          # one band per rank
     assert "REHEARSAL" in out["data"] and out["value"] > 0
