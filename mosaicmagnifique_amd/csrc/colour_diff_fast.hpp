@@ -108,15 +108,24 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
 
     const float e = pp + fabsf(dot);
     const float r = frsq(0.5f * e);                                         // = 2 rsq(2 e);  e >= P >= 1e-36
-    const float d_h = acute ? cross * r : copysignf(e * r, cross);          // dH'  (:102): 2 cross rsq(2e) | sign 2e rsq(2e)
+    // sign transplants as plain bit operations on one shared mask (full-rate, where v_bfi_b32 is not)
+    const unsigned int sgn = __float_as_uint(cross) & 0x80000000u;
+    // (both arms are computed before the selects: three v_cndmask, no divergent branch)
+    const float dh_acute = cross * r, dh_obtuse = __uint_as_float(__float_as_uint(e * r) | sgn);   // e r > 0
+    const float d_h = acute ? dh_acute : dh_obtuse;                         // dH'  (:102): 2 cross rsq(2e) | sign 2e rsq(2e)
 
     // mean hue direction -> table index -> T and sin(2 d_theta)
     const float sx = a1 * c2p, sy = b1 * c2p, tx = a2 * c1p, ty = b2 * c1p;
-    const float hx = acute ? sx + tx : copysignf(1.0f, cross) * (ty - sy);
-    const float hy = acute ? sy + ty : copysignf(1.0f, cross) * (sx - tx);
-    const float qd = hx * frcp(fmaxf(fabsf(hx) + fabsf(hy), 1e-36f));
-    const float x = fmaf(-(float)(kHueLutSize / 4), copysignf(1.0f + qd, hy), (float)(kHueLutSize / 2));   // (2 - c) N/4
-    const int idx = min(max((int)x, 0), kHueLutSize);          // x in [0, N]: truncation = floor; entry N repeats entry 0
+    const float hx_acute = sx + tx, hx_obtuse = __uint_as_float(__float_as_uint(ty - sy) ^ sgn);
+    const float hy_acute = sy + ty, hy_obtuse = __uint_as_float(__float_as_uint(sx - tx) ^ sgn);
+    const float hx = acute ? hx_acute : hx_obtuse;
+    const float hy = acute ? hy_acute : hy_obtuse;
+    const float qd = hx * frcp((fabsf(hx) + 1e-36f) + fabsf(hy));           // |qd| <= 1 + 1 ulp (v_rcp_f32: 1 ulp)
+    // (2 - c) N/4 with the factor N/4 shortened by 2^-13: even c = +-(2 + 2 ulp) keeps x inside [0, N], where
+    // truncation = floor and fract = x - floor(x) agree (2.4e-4 of a table step at most; the table's own error is
+    // 2e-5 of a value).  Entry N repeats entry 0 and N + 1 entry 1: no clamp.  NaN (an inactive pixel) converts to 0.
+    const float x = fmaf(-((float)(kHueLutSize / 4) - 0x1p-13f), copysignf(1.0f + qd, hy), (float)(kHueLutSize / 2));
+    const int idx = (int)x;
     const float fr = __builtin_amdgcn_fractf(x);                // x - floor(x), one instruction
     const HueEntry e0 = lut[idx], e1 = lut[idx + 1];
     const float t = fmaf(fr, e1.x - e0.x, e0.x);

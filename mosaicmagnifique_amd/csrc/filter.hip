@@ -517,7 +517,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const float v3 = pair_fast<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
                 if constexpr (TYPE == CIEDE2000) {
                     // discontinuity pairs are rare (~1e-5): one wave-wide test, then the slow branch
-                    const bool a0 = p0.x == p0.x, a1 = p0.y == p0.y, a2 = p0.z == p0.z, a3 = p0.w == p0.w;   // not NaN = active
+                    // not NaN = active; the interleaved cell carries the NaN in channel 1 too, which keeps e0..e3 false by itself
+                    const bool a0 = IL || p0.x == p0.x, a1 = IL || p0.y == p0.y, a2 = IL || p0.z == p0.z, a3 = IL || p0.w == p0.w;
                     if (__builtin_amdgcn_ballot_w64((e0 && a0) || (e1 && a1) || (e2 && a2) || (e3 && a3)) != 0) {
                         acc += ((e0 && a0) ? 0.0f : v0) + ((e1 && a1) ? 0.0f : v1)
                              + ((e2 && a2) ? 0.0f : v2) + ((e3 && a3) ? 0.0f : v3);
@@ -812,8 +813,16 @@ interleave_kernel(const float* __restrict__ planar, const float* __restrict__ ch
         const int q = (int)(t - img * per);                       // float4 position in a plane
         const float4* src = reinterpret_cast<const float4*>(planar + img * 3 * (size_t)ppad);
         float4* dst = reinterpret_cast<float4*>(out + img * 4 * (size_t)ppad) + (size_t)(q >> 6) * 4 * kWave + (q & (kWave - 1));
-        dst[0] = plane0 ? reinterpret_cast<const float4*>(plane0 + img * (size_t)ppad)[q] : src[q];
-        dst[kWave] = src[per + q];
+        const float4 first = plane0 ? reinterpret_cast<const float4*>(plane0 + img * (size_t)ppad)[q] : src[q];
+        float4 second = src[per + q];
+        // a NaN in the replacement of channel 0 marks an inactive pixel: channel 1 carries the mark too, so that every
+        // quantity of the pair is NaN there (no "on the discontinuity" verdict for a pixel that does not count)
+        if (first.x != first.x) second.x = first.x;
+        if (first.y != first.y) second.y = first.y;
+        if (first.z != first.z) second.z = first.z;
+        if (first.w != first.w) second.w = first.w;
+        dst[0] = first;
+        dst[kWave] = second;
         dst[2 * kWave] = src[2 * per + q];
         dst[3 * kWave] = chroma ? reinterpret_cast<const float4*>(chroma + img * (size_t)ppad)[q] : float4{0.f, 0.f, 0.f, 0.f};
     }
