@@ -89,11 +89,16 @@ using HueEntry = float2;
 // needs no case of its own: dot = cross = P = 0 gives dH' = 0 and the direction of the other
 // colour (C' is never below 1e-18); two greys give direction (0, 0),
 // where T and R_T are multiplied by a zero mean chroma.
+//
+// PREP = true: the operands come from the filter kernel's interleaved copies (filter.hip interleave_kernel), which
+// hold channel 0 as L / 2 - 25 and the chroma as C / 50 -- the mean lightness offset (:138) is then one addition and
+// the mean chroma over 25 (:50-53) needs no multiply; S_L is carried as S_L / 2 against the halved lightness difference.
+template <bool PREP = false>
 __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, float c1, float c2,
                                                 const HueEntry* __restrict__ lut, bool* needs_exact)
 {
     // G, a', C' (:50-59)
-    const float one_g = 1.5f - 0.5f * sqrt_ratio7_of_sum(c1 + c2);       // 1 + G
+    const float one_g = 1.5f - 0.5f * (PREP ? sqrt_ratio7_scaled(c1 + c2) : sqrt_ratio7_of_sum(c1 + c2));       // 1 + G
     const float a1 = one_g * p.c1, a2 = one_g * q.c1;
     const float b1 = p.c2, b2 = q.c2;
     // + 1e-36: C' >= 1e-18 > 0 (rsq stays finite, a grey colour keeps a direction below)
@@ -133,9 +138,10 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
 
     const float csum = c1p + c2p;                           // 2 * mean C'
     const float r_t = s2 * sqrt_ratio7_of_sum(csum);            // :136,:145; the table holds -2 sin(2 d_theta)
-    const float lb = 0.5f * (p.c0 + q.c0) - 50.0f;
+    const float lb = PREP ? p.c0 + q.c0 : 0.5f * (p.c0 + q.c0) - 50.0f;
     const float l2 = lb * lb;
-    const float s_l = fmaf(0.015f * l2, frsq(20.0f + l2), 1.0f);
+    const float s_l = PREP ? fmaf(0.0075f * l2, frsq(20.0f + l2), 0.5f)     // S_L / 2: d_l below is half the difference
+                           : fmaf(0.015f * l2, frsq(20.0f + l2), 1.0f);
     const float s_c = fmaf(0.0225f, csum, 1.0f);
     const float s_h = fmaf(0.0075f * csum, t, 1.0f);
 

@@ -63,12 +63,12 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
 // opposite-hue discontinuity (colour_diff_fast.hpp): the filter kernel logs it and
 // edge_fix_kernel later replaces its fp32 term by the fp64 one.  cp, cq = chroma of
 // p and q (read from the precomputed planes), lut = the hue table in LDS.
-template <int TYPE>
+template <int TYPE, bool PREP = false>
 __device__ __forceinline__ float pair_fast(const PxF& p, const PxF& q, float cp, float cq,
                                            const HueEntry* lut, bool* edge)
 {
     if constexpr (TYPE == CIEDE2000) {
-        return ciede2000_fast(p, q, cp, cq, lut, edge);
+        return ciede2000_fast<PREP>(p, q, cp, cq, lut, edge);
     } else {
         *edge = false;
         return euclidean_fast(p, q);
@@ -83,6 +83,8 @@ __device__ __forceinline__ void load_hue_lut(HueEntry* lds, const HueEntry* __re
 }
 
 struct LibGroup { float4 q0, q1, q2, qc; };
+
+constexpr float kChromaPrep = 0.02f;    // interleaved copies hold chroma / 50 (ciede2000_fast<PREP>)
 
 // Angle in degrees wrapped into [-180, 180].
 __device__ __forceinline__ float wrap180(float v) { return fmaf(-360.0f, rintf(v * (1.0f / 360.0f)), v); }
@@ -330,43 +332,49 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // mask of the survivors.  Stage 2: the waves pull survivors from the mask; a survivor's prelude is then a read of its
     // group bounds, the visiting order and a scan -- ~60 instructions instead of ~300 -- before the pixel loop.
     bool two_level = false;
-    if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && cand_per_block <= 64 && var.two_stage != 0;
+    if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && groups > 0 && cand_per_block <= 64 && var.two_stage != 0;
     if (two_level && threadIdx.x < 2) alive_mask[threadIdx.x] = 0u;
     if (use_lb || CELL_LDS || n_seeds > 0) __syncthreads();   // workgroup-uniform
     if (two_level) {
-        const int q = lane >> 4, g = lane & 15;             // candidate of the pass, group
-        for (int first = 4 * wave; first < n_here; first += 4 * (THREADS / kWave)) {
+        // lanes (q, g): candidate q of the pass, group g < groups -- 64 / groups candidates per pass (four at 16 groups,
+        // seven at the 9 groups of a 48 x 48 cell), packed so that no lane idles on a group the cell does not have
+        const int per_pass = kWave / groups;
+        const int q = lane / groups, g = lane - q * groups;
+        for (int first = per_pass * wave; first < n_here; first += per_pass * (THREADS / kWave)) {
             const int idx = first + q;
             const int l = l_base + idx;
+            const bool valid = q < per_pass && idx < n_here;
             float b = 0.0f;
-            bool seed = false;
-            if (idx < n_here) {
-                for (int t = 0; t < n_seeds; ++t) seed = seed || seed_ids[t] == l;       // scored already: not a survivor
-                if (g < groups) {
-                    // the group's four blocks are four consecutive floats of each statistic
-                    const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + 4 * g;
-                    const size_t bs = var.lib_stats_stride;
-                    float4 ls[7];
-                    for (int k = 0; k < 7; ++k) ls[k] = *reinterpret_cast<const float4*>(st + k * bs);
-                    auto block = [&](int i, float l0, float l1, float l2, float l3, float l4, float l5, float l6) {
-                        const int blk = 4 * g + i;
-                        b += stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
-                                         l0, l1, l2, l3, l4, l5, l6, 1e-2f);
-                        __builtin_amdgcn_sched_barrier(0);  // one block at a time: four interleaved evaluations do not fit the registers
-                    };
-                    block(0, ls[0].x, ls[1].x, ls[2].x, ls[3].x, ls[4].x, ls[5].x, ls[6].x);
-                    block(1, ls[0].y, ls[1].y, ls[2].y, ls[3].y, ls[4].y, ls[5].y, ls[6].y);
-                    block(2, ls[0].z, ls[1].z, ls[2].z, ls[3].z, ls[4].z, ls[5].z, ls[6].z);
-                    block(3, ls[0].w, ls[1].w, ls[2].w, ls[3].w, ls[4].w, ls[5].w, ls[6].w);
-                }
-                cand_gb[idx][g] = b;                        // 0 for the groups past the last
+            // scored already as a seed: not a survivor.  The candidate's lanes share the seed list out; one ballot gathers the hits
+            bool hit = false;
+            if (valid)
+                for (int t = g; t < n_seeds; t += groups) hit = hit || seed_ids[t] == l;
+            const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
+            const bool seed = ((hits >> (q * groups)) & ((1ull << groups) - 1ull)) != 0ull;     // (q * groups < 64 where it matters: valid lanes)
+            if (valid) {
+                // the group's four blocks are four consecutive floats of each statistic
+                const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + 4 * g;
+                const size_t bs = var.lib_stats_stride;
+                float4 ls[7];
+                for (int k = 0; k < 7; ++k) ls[k] = *reinterpret_cast<const float4*>(st + k * bs);
+                auto block = [&](int i, float l0, float l1, float l2, float l3, float l4, float l5, float l6) {
+                    const int blk = 4 * g + i;
+                    b += stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
+                                     l0, l1, l2, l3, l4, l5, l6, 1e-2f);
+                    __builtin_amdgcn_sched_barrier(0);  // one block at a time: four interleaved evaluations do not fit the registers
+                };
+                block(0, ls[0].x, ls[1].x, ls[2].x, ls[3].x, ls[4].x, ls[5].x, ls[6].x);
+                block(1, ls[0].y, ls[1].y, ls[2].y, ls[3].y, ls[4].y, ls[5].y, ls[6].y);
+                block(2, ls[0].z, ls[1].z, ls[2].z, ls[3].z, ls[4].z, ls[5].z, ls[6].z);
+                block(3, ls[0].w, ls[1].w, ls[2].w, ls[3].w, ls[4].w, ls[5].w, ls[6].w);
+                cand_gb[idx][g] = b;                        // (stage 2 reads the first `groups` entries only)
             }
-            // sum over the candidate's 16 lanes (a DPP row)
-            b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x128, 0xf, 0xf, false));   // row_ror:8
-            b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x124, 0xf, 0xf, false));   // row_ror:4
-            b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x122, 0xf, 0xf, false));   // row_ror:2
-            b += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x121, 0xf, 0xf, false));   // row_ror:1
-            if (g == 0 && idx < n_here && !seed) {
+            // sum over the candidate's lanes: a suffix scan that stops at the segment's end; its first lane gets the total
+            for (int off = 1; off < 16; off <<= 1) {
+                const float up = __shfl_down(b, off, kWave);
+                if (g + off < groups) b += up;
+            }
+            if (g == 0 && valid && !seed) {
                 if (b > limit) {
                     scores[(size_t)cell * L + l] = __builtin_huge_valf();
                     n_bound_dropped += 1;       // (per lane; summed over the wave's lanes at the end)
@@ -421,7 +429,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const int n_blk = 4 * groups;
                 float d = 0.0f;
                 if (two_level) {
-                    if (!sorted) d = lane < 16 ? cand_gb[idx][lane] : 0.0f;       // lane k: bound of group k
+                    if (!sorted) d = lane < groups ? cand_gb[idx][lane] : 0.0f;   // lane k: bound of group k
                 } else {
                     for (int i = 0; i < per_lane; ++i) {
                         const int blk = lane * per_lane + i;
@@ -445,7 +453,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     };
                     float g;                                                    // every lane of quad j: bound of group j (0 past the last group)
                     if (two_level) {
-                        g = cand_gb[idx][lane >> 2];
+                        g = (lane >> 2) < groups ? cand_gb[idx][lane >> 2] : 0.0f;
                     } else {
                         g = d + quad_swap(d, 1);
                         g += quad_swap(g, 2);
@@ -503,18 +511,21 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 float4 p0, p1, p2, pc{0.f, 0.f, 0.f, 0.f};
                 if constexpr (CELL_LDS) {
                     p0 = cell_tile[q]; p1 = cell_tile[pq + q]; p2 = cell_tile[2 * pq + q];
-                    if constexpr (TYPE == CIEDE2000)
+                    if constexpr (TYPE == CIEDE2000) {
                         pc = float4{chroma_of(p1.x, p2.x), chroma_of(p1.y, p2.y), chroma_of(p1.z, p2.z), chroma_of(p1.w, p2.w)};
+                        if constexpr (IL)    // as interleave_kernel stores it (__fmul_rn: a product the compiler may not contract into a later sum)
+                            pc = float4{__fmul_rn(kChromaPrep, pc.x), __fmul_rn(kChromaPrep, pc.y), __fmul_rn(kChromaPrep, pc.z), __fmul_rn(kChromaPrep, pc.w)};
+                    }
                 } else {
                     p0 = ld4(c0, off); p1 = ld4(c1, off); p2 = ld4(c2, off);
                     if constexpr (TYPE == CIEDE2000) pc = ld4(cc, off);
                 }
                 const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, qc = cur.qc;
                 bool e0, e1, e2, e3;
-                const float v0 = pair_fast<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
-                const float v1 = pair_fast<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
-                const float v2 = pair_fast<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
-                const float v3 = pair_fast<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
+                const float v0 = pair_fast<TYPE, IL>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
+                const float v1 = pair_fast<TYPE, IL>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
+                const float v2 = pair_fast<TYPE, IL>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
+                const float v3 = pair_fast<TYPE, IL>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
                 if constexpr (TYPE == CIEDE2000) {
                     // discontinuity pairs are rare (~1e-5): one wave-wide test, then the slow branch
                     // not NaN = active; the interleaved cell carries the NaN in channel 1 too, which keeps e0..e3 false by itself
@@ -813,7 +824,7 @@ interleave_kernel(const float* __restrict__ planar, const float* __restrict__ ch
         const int q = (int)(t - img * per);                       // float4 position in a plane
         const float4* src = reinterpret_cast<const float4*>(planar + img * 3 * (size_t)ppad);
         float4* dst = reinterpret_cast<float4*>(out + img * 4 * (size_t)ppad) + (size_t)(q >> 6) * 4 * kWave + (q & (kWave - 1));
-        const float4 first = plane0 ? reinterpret_cast<const float4*>(plane0 + img * (size_t)ppad)[q] : src[q];
+        float4 first = plane0 ? reinterpret_cast<const float4*>(plane0 + img * (size_t)ppad)[q] : src[q];
         float4 second = src[per + q];
         // a NaN in the replacement of channel 0 marks an inactive pixel: channel 1 carries the mark too, so that every
         // quantity of the pair is NaN there (no "on the discontinuity" verdict for a pixel that does not count)
@@ -821,10 +832,13 @@ interleave_kernel(const float* __restrict__ planar, const float* __restrict__ ch
         if (first.y != first.y) second.y = first.y;
         if (first.z != first.z) second.z = first.z;
         if (first.w != first.w) second.w = first.w;
+        // the prepared operands of ciede2000_fast<PREP = true>: L / 2 - 25 and C / 50
+        first = float4{fmaf(0.5f, first.x, -25.0f), fmaf(0.5f, first.y, -25.0f), fmaf(0.5f, first.z, -25.0f), fmaf(0.5f, first.w, -25.0f)};
         dst[0] = first;
         dst[kWave] = second;
         dst[2 * kWave] = src[2 * per + q];
-        dst[3 * kWave] = chroma ? reinterpret_cast<const float4*>(chroma + img * (size_t)ppad)[q] : float4{0.f, 0.f, 0.f, 0.f};
+        float4 ch = chroma ? reinterpret_cast<const float4*>(chroma + img * (size_t)ppad)[q] : float4{0.f, 0.f, 0.f, 0.f};
+        dst[3 * kWave] = float4{__fmul_rn(kChromaPrep, ch.x), __fmul_rn(kChromaPrep, ch.y), __fmul_rn(kChromaPrep, ch.z), __fmul_rn(kChromaPrep, ch.w)};
     }
 }
 
@@ -1022,13 +1036,14 @@ prune_limit_kernel(const float* __restrict__ seed_score, const uint8_t* __restri
 }
 
 // Replaces the fp32 term of every logged discontinuity pair by the fp64
-// reference-form value: scores[cell][cand] += (float)(exact - fast).
+// reference-form value: scores[cell][cand] += (float)(exact - fast).  `fast` must be, bit for bit, the term the
+// filter kernel added: prep != 0 when that kernel read the interleaved copies (prepared operands, interleave_kernel).
 __global__ void __launch_bounds__(kBlock)
 edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ cell_chroma,
                 const float* __restrict__ lib, const float* __restrict__ lib_chroma,
                 float* __restrict__ scores, int L, int ppad,
                 const EdgeEntry* __restrict__ edges, const unsigned int* __restrict__ edge_count,
-                unsigned int edge_cap, const HueEntry* __restrict__ hue_lut, Variants var)
+                unsigned int edge_cap, const HueEntry* __restrict__ hue_lut, Variants var, int prep)
 {
     __shared__ HueEntry lut[kHueLutEntries];
     load_hue_lut(lut, hue_lut);
@@ -1040,9 +1055,11 @@ edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ cell_
         const float* b = lib + (size_t)v * var.lib_stride + (size_t)en.cand * 3 * ppad + en.pixel;
         const PxF p{c[0], c[ppad], c[2 * (size_t)ppad]}, q{b[0], b[ppad], b[2 * (size_t)ppad]};
         bool edge;
-        const float fast = ciede2000_fast(p, q, cell_chroma[(size_t)en.cell * ppad + en.pixel],
-                                          lib_chroma[(size_t)v * var.chroma_stride + (size_t)en.cand * ppad + en.pixel],
-                                          lut, &edge);
+        const float cp = cell_chroma[(size_t)en.cell * ppad + en.pixel];
+        const float cq = lib_chroma[(size_t)v * var.chroma_stride + (size_t)en.cand * ppad + en.pixel];
+        const float fast = prep ? ciede2000_fast<true>(PxF{fmaf(0.5f, p.c0, -25.0f), p.c1, p.c2}, PxF{fmaf(0.5f, q.c0, -25.0f), q.c1, q.c2},
+                                                       __fmul_rn(kChromaPrep, cp), __fmul_rn(kChromaPrep, cq), lut, &edge)
+                                : ciede2000_fast(p, q, cp, cq, lut, &edge);
         const double exact = ciede2000(Px{p.c0, p.c1, p.c2}, Px{q.c0, q.c1, q.c2});
         atomicAdd(&scores[(size_t)en.cell * L + en.cand], (float)(exact - (double)fast));
     }
@@ -1212,7 +1229,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares, in.seeds, in.seeds ? in.n_seeds : 0, sort_groups);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
-                                                     edges, edge_count, edge_cap, in.hue_lut, in.var);
+                                                     edges, edge_count, edge_cap, in.hue_lut, in.var, il ? 1 : 0);
         return hipGetLastError();
     }
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
@@ -1240,7 +1257,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                 edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var);
             if ((code = hipGetLastError()) != hipSuccess) return code;
             edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
-                                                         edges, edge_count, edge_cap, in.hue_lut, in.var);
+                                                         edges, edge_count, edge_cap, in.hue_lut, in.var, 0);
         } else {
             auto kern = filter_lds_kernel<RGB_EUCLIDEAN>;
             if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1264,7 +1281,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             in.seeds, in.seeds ? in.n_seeds : 0, sort_groups);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
-                                                     edges, edge_count, edge_cap, in.hue_lut, in.var);
+                                                     edges, edge_count, edge_cap, in.hue_lut, in.var, il ? 1 : 0);
     } else {
         filter_kernel<RGB_EUCLIDEAN, kBlock, false, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN, kBlock, false, false>), blocks, kBlock, 0)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
