@@ -261,3 +261,21 @@ def test_visiting_order_of_the_groups_does_not_change_the_result(oracle, engine,
         assert tm["visited_groups"] > 0 and tm["bound_dropped"] > 0
     finally:
         engine.set_option("sort_groups", -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [16, 24, 32, 40, 48, 56, 64])
+@pytest.mark.parametrize("two_level", [1, 0])
+def test_stage_one_handles_every_group_count(oracle, engine, size, two_level):
+    """Stage 1 of the filter packs 64 / groups candidates into a wave pass (1, 3, 4, 7, 9, 13 and 16 groups of
+    256 positions for these cell sizes; tiles of 64 candidates leave a ragged last pass and the 150-image library
+    a ragged last tile): same grid as the single-stage form, the unpruned path, the fp64-only path and the oracle."""
+    t = Type.CIEDE2000
+    rows, cols = 4 * size + size // 2, 5 * size
+    img, lib = cases.inputs(rows, cols, size, 150, t, lattice=size)
+    try:
+        engine.set_option("two_level", two_level)
+        tm = run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(2, 300))
+        assert tm["bound_dropped"] > 0 and tm["band_alarms"] == 0
+    finally:
+        engine.set_option("two_level", 1)
