@@ -32,31 +32,30 @@ __device__ __forceinline__ float wave_sum_f(float v)
     return v;
 }
 
-// Wave-wide sum with DPP row rotations (no LDS crossbar): every lane of a 16-lane row
-// gets the row total after 4 rotate-adds, the 4 row totals are read with v_readlane.
-// ~11 short-latency instructions; used for the per-group exit test.  Uniform result.
-__device__ __forceinline__ float wave_sum_dpp(float v)
+// The per-group exit test "wave-wide sum of v, plus rest, exceeds limit" (uniform result) in eight VALU
+// instructions: four row rotations leave every lane of a 16-lane row with the row total, row_bcast:15 adds row 0's
+// total into row 1 and row 2's into row 3, row_bcast:31 adds rows 0 + 1 into row 3 -- lane 63 then holds
+// (r0 + r1) + (r2 + r3) -- and the comparison's bit 63 is the verdict.  Each step is ONE v_add_f32 with a DPP
+// operand (the compiler leaves a v_mov_b32_dpp + v_add_f32 pair per step and four v_readlane); the two wait
+// states a DPP read needs after the VALU write of its source are the s_nop 1 (inline asm is not hazard-checked).
+// All 64 lanes must be active.
+__device__ __forceinline__ bool wave_sum_exceeds(float v, float rest, float limit)
 {
-    auto ror = [](float x, const int ctrl_tag) {
-        int r;
-        switch (ctrl_tag) {
-        case 8: r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false); break;
-        case 4: r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false); break;
-        case 2: r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false); break;
-        default: r = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false); break;
-        }
-        return __builtin_bit_cast(float, r);
-    };
-    v += ror(v, 8);
-    v += ror(v, 4);
-    v += ror(v, 2);
-    v += ror(v, 1);
-    const int b = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-    return (r0 + r1) + (r2 + r3);
+    float t;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "=&v"(t) : "v"(v));
+    return (__builtin_amdgcn_ballot_w64(t + rest > limit) >> 63) != 0ull;
 }
 
 // One pair through the fp32 form.  For CIEDE2000 `edge` reports a pair on the
@@ -502,7 +501,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     // bound of what is still unvisited: sorted, lane `step` of the scan over the visiting order; else group
                     // `step` starts at block 4 step = the first block of lane (4 step) >> lane_shift
                     const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), by_group ? step : (4 * step) >> lane_shift)) : 0.0f;
-                    if (wave_sum_dpp(acc) + rest_j > limit) return true;
+                    if (wave_sum_exceeds(acc, rest_j, limit)) return true;
                 }
                 const int q = lane + kWave * j;
                 // byte offset of this lane's float4 in plane 0 of group j (interleaved: a group is 4 KB, planes 1 KB apart)
@@ -688,7 +687,7 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
             for (int j = 0; j < groups; ++j) {
                 if (j != 0) {
                     const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), (4 * j) >> lane_shift)) : 0.0f;
-                    if (wave_sum_dpp(acc) + rest_j > limit) { pruned = true; break; }
+                    if (wave_sum_exceeds(acc, rest_j, limit)) { pruned = true; break; }
                 }
                 const int q = lane + kWave * j;
                 const LibGroup cur = nxt;
