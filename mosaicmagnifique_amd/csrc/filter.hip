@@ -39,7 +39,7 @@ __device__ __forceinline__ float wave_sum_f(float v)
 // operand (the compiler leaves a v_mov_b32_dpp + v_add_f32 pair per step and four v_readlane); the two wait
 // states a DPP read needs after the VALU write of its source are the s_nop 1 (inline asm is not hazard-checked).
 // All 64 lanes must be active.
-__device__ __forceinline__ bool wave_sum_exceeds(float v, float rest, float limit)
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
 {
     float t;
     asm volatile("s_nop 1\n\t"
@@ -55,7 +55,34 @@ __device__ __forceinline__ bool wave_sum_exceeds(float v, float rest, float limi
                  "s_nop 1\n\t"
                  "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
                  : "=&v"(t) : "v"(v));
-    return (__builtin_amdgcn_ballot_w64(t + rest > limit) >> 63) != 0ull;
+    return t;       // lane 63: (r0 + r1) + (r2 + r3); the other lanes hold partial sums
+}
+
+__device__ __forceinline__ bool wave_sum_exceeds(float v, float rest, float limit)
+{
+    return (__builtin_amdgcn_ballot_w64(wave_sum_to_lane63(v) + rest > limit) >> 63) != 0ull;
+}
+
+// Wave-wide sum, uniform result (all 64 lanes active), by the same six DPP adds.
+__device__ __forceinline__ float wave_sum_all(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_to_lane63(v)), 63));
+}
+
+// Inclusive suffix sums inside each 16-lane row (lane i <- sum of lanes i .. 15 of its row): four DPP adds.
+// row_shl:n hands lane i the value of lane i + n; a lane whose source would lie outside the row keeps its value.
+__device__ __forceinline__ float row_suffix_sum(float v)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(v));
+    return v;
 }
 
 // One pair through the fp32 form.  For CIEDE2000 `edge` reports a pair on the
@@ -483,9 +510,13 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     if (lane >= 16) d = 0.0f;                                   // lanes 0..15: bounds in visiting order
                 }
                 // inclusive suffix scan over lanes (lane j <- sum of lanes >= j); group bounds fill lanes 0..15 only
-                for (int off = 1; off < (by_group ? 16 : kWave); off <<= 1) {
-                    const float up = __shfl_down(d, off, kWave);
-                    if (lane + off < kWave) d += up;
+                if (by_group) {
+                    d = row_suffix_sum(d);
+                } else {
+                    for (int off = 1; off < kWave; off <<= 1) {
+                        const float up = __shfl_down(d, off, kWave);
+                        if (lane + off < kWave) d += up;
+                    }
                 }
                 rest = d;
                 pruned = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), 0)) > limit;
@@ -562,7 +593,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             if (!two_level) n_groups_all += (unsigned int)groups;
             n_bound_dropped += (pruned && visited == 0) ? 1u : 0u;
         }
-        acc = wave_sum_f(acc + acc_edge);
+        acc = wave_sum_all(acc + acc_edge);
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }
     }   // next item
