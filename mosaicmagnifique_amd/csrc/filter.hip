@@ -20,9 +20,15 @@ constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
 // Waves per SIMD the dominant kernel is compiled for: 5 -> at most 96 VGPRs (the 16 KB hue table and
-// the block statistics leave room for six workgroups per CU).  Overridable for experiments.
+// the block statistics leave room for five workgroups per CU).  Overridable for experiments.
 #ifndef MM_FILTER_WAVES
 #define MM_FILTER_WAVES 5
+#endif
+// ... and seed_score_kernel, which carries the fp64 form inline for pairs on the hue discontinuity: 3 -> 167 VGPRs,
+// no spills (left alone the compiler takes 171 = 2 waves; at 4 and 5 the pixel loop spills: 1.78 / 1.41 / 2.06 / 3.57 ms
+// for config D's seeds at 2 / 3 / 4 / 5).
+#ifndef MM_SEED_WAVES
+#define MM_SEED_WAVES 3
 #endif
 
 __device__ __forceinline__ float wave_sum_f(float v)
@@ -774,7 +780,7 @@ __device__ __forceinline__ float pair_seed(const PxF& p, const PxF& q, float cp,
 // limit): one wave per (cell, slot), no early exit; same values as filter_kernel +
 // edge_fix_kernel produce, up to fp32 summation order.
 template <int TYPE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MM_SEED_WAVES, MM_SEED_WAVES)))
 seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
                   const float* __restrict__ cell_chroma, const float* __restrict__ lib,
                   const float* __restrict__ lib_chroma, const int32_t* __restrict__ seeds,
@@ -784,15 +790,18 @@ seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long w = (long long)blockIdx.x * (kBlock / kWave) + wave;
+    const float* const lib_base = lib;
+    const float* const lib_chroma_base = lib_chroma;
+    // grid-stride over the (cell, slot) pairs: the hue table is loaded once per workgroup, not once per four pairs
+    for (long long w = (long long)blockIdx.x * (kBlock / kWave) + wave; w < (long long)n_cells * M;
+         w += (long long)gridDim.x * (kBlock / kWave)) {
     const int cell = (int)(w / M);
-    if (cell >= n_cells) return;
     const int l = seeds[w];
-    if (l < 0) { if (lane == 0) seed_score[w] = __builtin_huge_valf(); return; }
+    if (l < 0) { if (lane == 0) seed_score[w] = __builtin_huge_valf(); continue; }
     const int v = var.cell_var[cell];
     const int groups = var.groups[v];
-    lib += (size_t)v * var.lib_stride;
-    lib_chroma += (size_t)v * var.chroma_stride;
+    lib = lib_base + (size_t)v * var.lib_stride;
+    lib_chroma = lib_chroma_base + (size_t)v * var.chroma_stride;
     const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
     const float4* c1 = c0 + ppad / 4;
     const float4* c2 = c1 + ppad / 4;
@@ -824,6 +833,7 @@ seed_score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ c
         // the seed IS a filter score of this (cell, candidate): deposited in the score row; filter_kernel looks the
         // candidate up in the cell's seed list and leaves it alone instead of scoring it a second time
         if (scores) scores[(size_t)cell * L + l] = acc;
+    }
     }
 }
 
@@ -1364,13 +1374,14 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
     if (M > 256 || M < K || (size_t)L * sizeof(float) > 100 * 1024) return hipErrorInvalidValue;
     const size_t lds = (size_t)L * sizeof(float);
     const long long waves = (long long)n_cells * M;
+    const unsigned score_blocks = (unsigned)std::min<long long>((waves + 3) / 4, 8192);   // grid-stride: the hue table once per workgroup
     if (type == CIEDE2000) {
         seed_kernel<CIEDE2000><<<n_cells, kBlock, lds, stream>>>(in.cells, in.cmask, lib_means, L, ppad, M, seeds, in.hue_lut);
-        seed_score_kernel<CIEDE2000><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(
+        seed_score_kernel<CIEDE2000><<<score_blocks, kBlock, 0, stream>>>(
             in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut, in.var, scores, L);
     } else {
         seed_kernel<RGB_EUCLIDEAN><<<n_cells, kBlock, lds, stream>>>(in.cells, in.cmask, lib_means, L, ppad, M, seeds, in.hue_lut);
-        seed_score_kernel<RGB_EUCLIDEAN><<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(
+        seed_score_kernel<RGB_EUCLIDEAN><<<score_blocks, kBlock, 0, stream>>>(
             in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, seeds, seed_score, n_cells, M, ppad, in.hue_lut, in.var, scores, L);
     }
     hipError_t code = hipGetLastError();
