@@ -134,3 +134,58 @@ def test_random_scenario_large_library(oracle, engine, seed):
     ok = picks >= 0
     tol = 1e-4 if t == Type.CIEDE2000 else 1e-12
     assert (np.abs(score[pos[ok, 0], pos[ok, 1]] - scores[ok]) <= tol * np.abs(scores[ok]) + 1e-300).all()
+
+
+OPTION_SETS = [
+    {"interleave": 0},                              # planar images: filter_kernel<.., IL = false> (raw operands of the fp32 form)
+    {"xcd_aware": 0},                               # one item counter for the whole launch
+    {"tile": 16, "xcd_cells": 16},                  # small items, small XCD sub-groups
+    {"tile": 64, "xcd_cells": 200},                 # the largest tile of the two-stage form, ragged sub-groups
+    {"tile": 128},                                  # tiles above 64 candidates: single-stage bound
+    {"two_level": 0, "sort_groups": 0},             # per-candidate bound, plane-order visits
+    {"lds_filter": 1, "tile": 64},                  # the LDS-resident cell tile, interleaved operands
+    {"lds_filter": 1, "interleave": 0},             # ... and planar ones
+    {"seeds": 0},                                   # no extra seeds: the limit rests on K proxies only
+    {"spec_k": 2},                                  # short speculative lists: cells get deepened
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", OPTION_SETS, ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()))
+def test_tuning_options_do_not_change_the_result(oracle, engine, opts):
+    """Every tuning option of the filter (mm_set_option) is a pure performance knob: on a scenario with >= 512 cells
+    (per-XCD shares), a ragged hexagon-ish mask, 260 images and a repeat penalty the grid and the fp64 scores equal the
+    default's bit for bit; the default's grid is checked against the oracle cell by cell."""
+    import os
+    rng = np.random.default_rng(4242)
+    size = 48
+    shape = random_shape(rng, size)
+    t, rep, n_lib = Type.CIEDE2000, (2, 300), 260
+    rows = cols = 23 * max(shape.rowSpacing, shape.colSpacing, shape.alternateRowSpacing, shape.alternateColSpacing) + 17
+    img = synth.preprocess(synth.target_u8(rows, cols, lattice=64, seed=0x7A6 + 77), t)
+    lib = synth.preprocess(synth.library_u8(n_lib, size, seed=0x11B + 77), t)
+    group = CellGroup(shape)
+    state = G.getGridState(group, rows, cols)[0]
+    cells = G.cell_records(group, state, rows, cols)
+    assert len(cells) >= 512
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    defaults = {"interleave": 1, "xcd_aware": 1, "tile": 0, "xcd_cells": 0, "two_level": 1, "sort_groups": -1,
+                "lds_filter": -1, "seeds": 14, "spec_k": 4}
+    try:
+        for name, value in opts.items():
+            engine.set_option(name, value)
+        got, got_score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+        tm = engine.timing()
+    finally:
+        for name in opts:
+            engine.set_option(name, defaults[name])
+    assert np.array_equal(got, best) and np.array_equal(got_score[state >= 0], score[state >= 0])
+    assert tm["band_alarms"] == 0
+    if opts == OPTION_SETS[0]:                      # the oracle once
+        grid = np.where(best < n_lib, best, -1)
+        pos = np.stack([cells["grid_y"], cells["grid_x"]], axis=1)
+        picks, _ = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), rep[0], rep[1], grid, pos,
+                                           threads=min(16, len(os.sched_getaffinity(0))))
+        mine = best[pos[:, 0], pos[:, 1]]
+        assert np.array_equal(np.where(mine == n_lib, -1, mine), picks)
