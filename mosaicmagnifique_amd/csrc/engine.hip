@@ -50,7 +50,7 @@ struct mm_engine {
     // per-call workspaces (grown on demand, kept)
     DevBuf recs, cells, cmask, scores, cand_i, cand_s, grid, best, counter, scratch;
     // two-tier scoring workspaces
-    DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, dense_s, sentinel;
+    DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, sentinel;
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut, lib_il, cells_il;
     DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
@@ -534,7 +534,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
 
     std::vector<uint8_t> flags_host;
     std::vector<mm_cell> dense_cells;
-    std::vector<int> dense_slots;
+    std::vector<int> dense_slots, dense_rows;
     for (int done = 0; done < n; done += batch) {
         if (cancel && *cancel) return MM_CANCELLED;
         const int b = std::min(batch, n - done);
@@ -645,23 +645,21 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         }
         if (!dense_cells.empty()) {
             const int nd = (int)dense_cells.size();
+            // the selection kernel writes each cell's list straight into its row of the caller's arrays (row map on the device)
+            dense_rows.resize((size_t)nd);
+            for (int i = 0; i < nd; ++i)
+                dense_rows[(size_t)i] = row_map_host ? row_map_host[dense_slots[(size_t)i]] : dense_slots[(size_t)i];
             if ((st = ensure(e, e->dense_recs, (size_t)nd * sizeof(mm_cell), "Failed to allocate cell records")) ||
-                (st = ensure(e, e->dense_i, (size_t)nd * KW * sizeof(int32_t), "Failed to allocate candidates")) ||
-                (st = ensure(e, e->dense_s, (size_t)nd * KW * sizeof(double), "Failed to allocate candidates")))
+                (st = ensure(e, e->dense_i, (size_t)nd * sizeof(int), "Failed to allocate row map")))
                 return st;
             HIP_TRY(e, hipMemcpyAsync(e->dense_recs.p, dense_cells.data(), (size_t)nd * sizeof(mm_cell),
                                       hipMemcpyHostToDevice, e->stream), "Failed to copy cell records to device");
+            HIP_TRY(e, hipMemcpyAsync(e->dense_i.p, dense_rows.data(), (size_t)nd * sizeof(int),
+                                      hipMemcpyHostToDevice, e->stream), "Failed to copy row map to device");
             HIP_TRY(e, hipEventRecord(e->ev[10], e->stream), "event");
-            if ((st = dense_batch(e, (const mm_cell*)e->dense_recs.p, nd, diff_type, K, KW, (int32_t*)e->dense_i.p,
-                                  (double*)e->dense_s.p, nullptr, nullptr, nullptr)))
+            if ((st = dense_batch(e, (const mm_cell*)e->dense_recs.p, nd, diff_type, K, KW, cand_i_dev, cand_s_dev,
+                                  (const int*)e->dense_i.p, nullptr, nullptr)))
                 return st;
-            for (int i = 0; i < nd; ++i) {
-                const size_t r = row_map_host ? (size_t)row_map_host[dense_slots[(size_t)i]] : (size_t)dense_slots[(size_t)i];
-                HIP_TRY(e, hipMemcpyAsync(cand_i_dev + r * KW, (int32_t*)e->dense_i.p + (size_t)i * KW,
-                                          (size_t)KW * sizeof(int32_t), hipMemcpyDeviceToDevice, e->stream), "scatter");
-                HIP_TRY(e, hipMemcpyAsync(cand_s_dev + r * KW, (double*)e->dense_s.p + (size_t)i * KW,
-                                          (size_t)KW * sizeof(double), hipMemcpyDeviceToDevice, e->stream), "scatter");
-            }
             HIP_TRY(e, hipEventRecord(e->ev[11], e->stream), "event");
             HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
             e->timing.rescore_ms += elapsed(e->ev[10], e->ev[11]);
@@ -925,7 +923,7 @@ void mm_destroy(mm_engine* e)
     for (DevBuf* b : { &e->lib, &e->masks, &e->target, &e->recs, &e->cells, &e->cmask, &e->scores,
                        &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter, &e->scratch,
                        &e->cont_i, &e->cont_f, &e->cont_s, &e->flags, &e->edges, &e->edge_count,
-                       &e->dense_recs, &e->dense_i, &e->dense_s, &e->lib_means, &e->seeds,
+                       &e->dense_recs, &e->dense_i, &e->lib_means, &e->seeds,
                        &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
