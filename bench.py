@@ -400,13 +400,17 @@ def main():
             insts = pmc["SQ_INSTS_VALU_per_launch"] * scale
             roof["valu_wave_insts_per_launch"] = insts
             roof["visited_groups_vs_pmc_run"] = scale
+            # instructions per unit of useful work (a visited group = 256 pixel pairs): what kernel work lowers;
+            # `frac` below is issue-rate use, which FALLS when instructions are removed at the same cycles per instruction
+            roof["valu_wave_insts_per_visited_group"] = insts / visited_per_launch if visited_per_launch else None
         if insts and per_launch_s > 0:
             rate = insts / per_launch_s
             roof["achieved"] = rate * 128 / 1e12
             roof["frac"] = rate / VALU_PEAK_WAVE_INSTS
             roof["note"] = ("VALU wave-instructions per second x 128 (fma-equivalent flop per wave64 instruction) against "
                             "the fp32 vector peak = 1024 SIMDs x 2.4 GHz / 2 cycles; transcendentals (10 of ~104 per "
-                            "pixel pair) issue at quarter rate, so the mix's own ceiling is below 1")
+                            "pixel pair) issue at quarter rate, so the mix's own ceiling is below 1 (~0.57); frac is issue-rate use, not "
+                            "progress: removing instructions at the same cycles per instruction lowers it while cells/s rises")
         else:
             roof["achieved"] = None
             roof["frac"] = None
