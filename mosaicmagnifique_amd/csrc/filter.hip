@@ -142,7 +142,7 @@ __device__ __forceinline__ LibGroup load_lib_group(const float4* b0, const float
 // Lower bound of  sum over a block's pixel pairs of dE00  from the seven statistics of the cell's block (c_*) and the
 // library image's block (l_*): sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma, hue arc
 // centre (offset from 275 deg) and half-width (group_sums_kernel).  The derivation is in filter_kernel's comment.
-// slack: what the fp32 rounding of the two sums can hide (1e-2 for 64-term sums of values <= ~128, 5e-2 for 256 terms).
+// slack: what the fp32 rounding of the two sums can hide (1e-2 for the 64-term sums of values <= ~128 of a block).
 __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa, float c_sb, float c_cmax, float c_hc, float c_hw,
                                              float l_sl, float l_dev, float l_sa, float l_sb, float l_cmax, float l_hc, float l_hw,
                                              float slack)
@@ -241,7 +241,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     __shared__ int seed_ids[256];           // the cell's seeds: their scores are in the row already (launch_prune_limits)
     // stage 1 -> stage 2: the bound of every 256-position group of the tile's candidates (<= 64 per tile, <= 16 groups)
     __shared__ float cand_gb[TYPE == CIEDE2000 ? 64 : 1][TYPE == CIEDE2000 ? 16 : 1];
-    __shared__ unsigned int alive_mask[2];  // candidates of the tile that passed the group-level bound (<= 64 per tile)
+    __shared__ unsigned int alive_mask[2];  // candidates of the tile that passed the bound in stage 1 (<= 64 per tile)
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
     __shared__ unsigned int next_item;      // ... and workgroups pull (cell, tile) items: the hue table is loaded once
     __shared__ int item_share;              // the XCD share next_item belongs to (-1: none left)
@@ -1222,11 +1222,15 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
 {
     const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
     // Candidates per item and cells per XCD sub-group, measured at 32 / 48 / 64 x 32 / 64 / 128: small cells (config E's
-    // 48 x 48: 9 groups) gain 7 % of the launch from 64-candidate items (the two-level bound's survivor mask holds 64)
+    // 48 x 48: 9 groups) gain 7 % of the launch from 64-candidate items (the survivor mask of the bound's stage 1 holds 64)
     // and 128-cell sub-groups; 64 x 64 cells run the same within 1 % either way, but the larger working set costs
     // 40 % more fabric traffic (303 GB instead of 217 GB per launch), so they keep 32 / 64.
     const bool small_cells = groups < 12;
-    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : (small_cells ? 64 : 32), cell_group = 512;
+    // ... rounded down to whole rounds of stage 1: a pass judges 64 / groups candidates, four waves share a tile
+    // (48 x 48 cells: 7 per pass -> 56-candidate items, two passes per wave, instead of 64 = 2.3)
+    const int round_of = 4 * (kWave / std::max(groups, 1));
+    const int small_tile = round_of <= 64 ? 64 / round_of * round_of : 64;
+    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : (small_cells ? small_tile : 32), cell_group = 512;
     // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited), times two
     // so a finishing workgroup's slot refills at once
     auto persistent_grid = [&](const void* kern, long long items, int threads, size_t dyn_lds) -> unsigned {

@@ -101,7 +101,7 @@ def test_random_scenario_with_size_steps(oracle, seed):
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MOSAIC_FUZZ_LARGE", "24"))))     # soak: MOSAIC_FUZZ_LARGE=300
 def test_random_scenario_large_library(oracle, engine, seed):
     """Scenarios the small ones above cannot reach: hundreds of library images (so most candidates are NOT seeds
-    and go through the two-level bound, the bound-ordered visits and the early exit), 48 / 56 / 64 px cells with
+    and go through the two stages of the bound, the bound-ordered visits and the early exit), 48 / 56 / 64 px cells with
     random masks, and at least 512 cells (so the persistent workgroups split the cells into per-XCD shares).
     Every cell is checked by the oracle as the reference's raster loop reaches it, given the engine's earlier
     picks (oracle_ffi.picks_given_grid: equality on the whole raster = equality with the sequential run)."""

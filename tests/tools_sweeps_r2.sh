@@ -13,7 +13,7 @@ tune)      # candidates per item x cells per XCD sub-group, seeds, waves per SIM
   for w in 4 6; do tests/tools_build_variant.sh w$w -DMM_FILTER_WAVES=$w >/dev/null 2>&1 && { echo "== waves $w"; MOSAIC_HIP_LIB=gpurun_out/w$w.so $B 2>/dev/null | g; rm -f gpurun_out/w$w.so; }; done ;;
 order)     # how many of the largest-bound groups are visited first
   for c in D E8 C; do for m in 0 1 2 3 4 6 8 16; do echo "== $c sort_groups=$m"; $B --config $c --opt sort_groups=$m 2>/dev/null | g; done; done ;;
-level)     # the group-level first stage of the bound, the interleaved image copies
+level)     # the bound's stage 1 (several candidates per wave pass) against the per-candidate form, the interleaved image copies
   for c in D E8 C; do for o in 1 0; do echo "== $c two_level=$o"; $B --config $c --opt two_level=$o 2>/dev/null | g; done; done
   echo "== D interleave=0"; $B --opt interleave=0 2>/dev/null | g ;;
 lds)       # the LDS-resident cell tile
