@@ -323,3 +323,24 @@ def test_config_e_one_rank_shard_48px_cells_l10000(oracle, engine):
     for r, i, s in zip(cells[:2], idx[:2, 0], sc[:2, 0]):
         assert i == want[r["grid_y"], r["grid_x"]]
         assert abs(s - want_score[r["grid_y"], r["grid_x"]]) <= 1e-4 * s
+
+
+def test_config_e_whole_grid_same_on_every_path(engine):
+    """BASELINE config 5 as stated, whole, on one GPU: 8192 x 8192 target, 48 x 48 cells, 171 x 171 grid with the
+    clipped last row / column (29 241 cells), 10 000 images, CIEDE2000 -- staged as bench.py --config E stages it
+    (u8 images converted on the device).  Default path == early exit off == fp64 only: every best fit, every score."""
+    import bench
+    w = bench.build_workload("E", 1, "strong")
+    assert len(w["cells"]) == 171 * 171 and w["L"] == 10000
+    bench.stage(engine, w)
+    cells, gw, gh, t, rep = w["cells"], w["grid_w"], w["grid_h"], w["t"], w["rep"]
+    run = lambda: engine.generate(cells, gw, gh, int(t), *rep)
+    best, score = run()
+    tm = engine.timing()
+    assert tm["seed_ms"] > 0 and tm["rescore_ms"] > 0 and tm["band_alarms"] == 0
+    pos = (cells["grid_y"], cells["grid_x"])
+    assert (best[pos] < w["L"]).all()
+    for options in ({"prune": 0}, {"filter": 0}):
+        b2, s2 = with_options(engine, options, run)
+        assert np.array_equal(b2, best), (options, int((b2 != best).sum()))
+        assert np.array_equal(s2[pos], score[pos]), options
