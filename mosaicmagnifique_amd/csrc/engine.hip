@@ -418,9 +418,8 @@ mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_typ
     if (after_gather) HIP_TRY(e, hipEventRecord(after_gather, e->stream), "event");
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long blocks = (long long)b * n_tiles;
-    if (blocks > 0x7fffffffLL) { set_err(e, "score grid too large"); return MM_INVALID_ARGUMENT; }
     by_type(diff_type, [&](auto T) {
-        mm::score_kernel<decltype(T)::value><<<dim3((unsigned)blocks), mm::kBlock, 0, e->stream>>>(
+        mm::score_kernel<decltype(T)::value><<<dim3((unsigned)std::min(blocks, mm::kMaxBlocks256)), mm::kBlock, 0, e->stream>>>(
             (const float*)e->cells.p, (const uint8_t*)e->cmask.p, (const float*)e->lib.p,
             (double*)e->scores.p, b, L, ppad, cand_per_block, cell_group, var);
         return MM_OK;

@@ -646,19 +646,23 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
     float4* sc = s2 + pq;
 
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
-    const long long bid = blockIdx.x;
+    const float* const lib_base = lib;
+    const float* const lib_chroma_base = lib_chroma;
+    // a grid may not exceed 2^32 threads: the launch is capped and the workgroups stride over the (cell, tile) items
+    for (long long bid = blockIdx.x; bid < (long long)n_cells * n_tiles; bid += gridDim.x) {
+    if (bid != (long long)blockIdx.x) __syncthreads();        // the previous item is done with the staged cell
     const long long per_group = (long long)cell_group * n_tiles;
     const int group = (int)(bid / per_group);
     const long long rem = bid - (long long)group * per_group;
     const int cells_here = min(cell_group, n_cells - group * cell_group);
     const int tile = (int)(rem / cells_here);
     const int cell = group * cell_group + (int)(rem - (long long)tile * cells_here);
-    if (tile >= n_tiles || cell >= n_cells) return;           // whole workgroup: uniform
+    if (tile >= n_tiles || cell >= n_cells) continue;         // whole workgroup: uniform
 
     const int v = var.cell_var[cell];
     const int groups = var.groups[v];
-    lib += (size_t)v * var.lib_stride;
-    lib_chroma += (size_t)v * var.chroma_stride;
+    lib = lib_base + (size_t)v * var.lib_stride;
+    lib_chroma = lib_chroma_base + (size_t)v * var.chroma_stride;
 
     // stage the hue table and the cell (active groups only)
     if constexpr (TYPE == CIEDE2000)
@@ -761,6 +765,7 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
         }
         acc = wave_sum_f(acc + acc_edge);
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
+    }
     }
 }
 
@@ -1291,12 +1296,11 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         const int cpb = 64;
         const long long tiles = (L + cpb - 1) / cpb;
         const long long nblk = (long long)n_cells * tiles;
-        if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
         if (type == CIEDE2000) {
             auto kern = filter_lds_kernel<CIEDE2000>;
             if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes)) != hipSuccess) return code;
-            kern<<<dim3((unsigned)nblk), kLdsBlock, lds_bytes, stream>>>(
+            kern<<<dim3((unsigned)std::min<long long>(nblk, (1ll << 22) - 1)), kLdsBlock, lds_bytes, stream>>>(
                 in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
                 edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var);
             if ((code = hipGetLastError()) != hipSuccess) return code;
@@ -1306,7 +1310,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             auto kern = filter_lds_kernel<RGB_EUCLIDEAN>;
             if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes)) != hipSuccess) return code;
-            kern<<<dim3((unsigned)nblk), kLdsBlock, lds_bytes, stream>>>(
+            kern<<<dim3((unsigned)std::min<long long>(nblk, (1ll << 22) - 1)), kLdsBlock, lds_bytes, stream>>>(
                 in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
                 edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var);
         }

@@ -384,6 +384,9 @@ gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ 
     if (cells_f0) cells_f0[(size_t)blockIdx.y * ppad + k] = m ? v0 : __builtin_nanf("");
 }
 
+// Largest grid of kBlock-thread workgroups HIP launches whole: gridDim x blockDim stays below 2^32.
+constexpr long long kMaxBlocks256 = (1ll << 24) - 1;
+
 // ---------------------------------------------------------------------------
 // score kernel (the dominant kernel): base score of every (cell, candidate)
 // ---------------------------------------------------------------------------
@@ -405,19 +408,22 @@ score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
              int n_cells, int L, int ppad, int cand_per_block, int cell_group, Variants var)
 {
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
-    const long long bid = blockIdx.x;
+    const float* const lib_base = lib;
+    // a grid may not exceed 2^32 threads (n_cells x n_tiles x 256 does for 29 241 cells x 10 000 images): the launch
+    // is capped (score_grid) and the workgroups stride over the (cell, tile) items
+    for (long long bid = blockIdx.x; bid < (long long)n_cells * n_tiles; bid += gridDim.x) {
     const long long per_group = (long long)cell_group * n_tiles;
     const int group = (int)(bid / per_group);
     const long long rem = bid - (long long)group * per_group;
     const int cells_here = min(cell_group, n_cells - group * cell_group);
     const int tile = (int)(rem / cells_here);
     const int cell = group * cell_group + (int)(rem - (long long)tile * cells_here);
-    if (tile >= n_tiles || cell >= n_cells) return;
+    if (tile >= n_tiles || cell >= n_cells) continue;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int v = var.cell_var[cell];
     const int groups = var.groups[v];                 // float4 groups per lane holding active pixels
-    lib += (size_t)v * var.lib_stride;
+    lib = lib_base + (size_t)v * var.lib_stride;
     const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
     const float4* c1 = c0 + ppad / 4;
     const float4* c2 = c1 + ppad / 4;
@@ -442,6 +448,7 @@ score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
         }
         acc = wave_sum(acc);
         if (lane == 0) scores[(size_t)cell * L + l] = acc;
+    }
     }
 }
 

@@ -325,15 +325,20 @@ def test_config_e_one_rank_shard_48px_cells_l10000(oracle, engine):
         assert abs(s - want_score[r["grid_y"], r["grid_x"]]) <= 1e-4 * s
 
 
-def test_config_e_whole_grid_same_on_every_path(engine):
+@pytest.mark.parametrize("t", [Type.CIEDE2000, Type.RGB_EUCLIDEAN], ids=["ciede2000", "rgb"])
+def test_config_e_whole_grid_same_on_every_path(engine, t):
     """BASELINE config 5 as stated, whole, on one GPU: 8192 x 8192 target, 48 x 48 cells, 171 x 171 grid with the
     clipped last row / column (29 241 cells), 10 000 images, CIEDE2000 -- staged as bench.py --config E stages it
-    (u8 images converted on the device).  Default path == early exit off == fp64 only: every best fit, every score."""
+    (u8 images converted on the device) -- and the same images as RGB.  Default path == early exit off == fp64 only:
+    every best fit, every score.  (One batch of 29 241 cells x 10 000 images is also where a (cell, tile) grid passes
+    2^32 threads: 18.3 M workgroups of the fp64 kernel, 4.6 M 1024-thread ones of the RGB filter.)"""
     import bench
     w = bench.build_workload("E", 1, "strong")
     assert len(w["cells"]) == 171 * 171 and w["L"] == 10000
-    bench.stage(engine, w)
-    cells, gw, gh, t, rep = w["cells"], w["grid_w"], w["grid_h"], w["t"], w["rep"]
+    engine.set_library_u8(w["lib_u8"], int(t))
+    engine.set_target_u8(w["img_u8"], int(t))
+    engine.set_masks(w["shape"].masks4())
+    cells, gw, gh, rep = w["cells"], w["grid_w"], w["grid_h"], w["rep"]
     run = lambda: engine.generate(cells, gw, gh, int(t), *rep)
     best, score = run()
     tm = engine.timing()
