@@ -349,3 +349,30 @@ def test_config_e_whole_grid_same_on_every_path(engine, t):
         b2, s2 = with_options(engine, options, run)
         assert np.array_equal(b2, best), (options, int((b2 != best).sum()))
         assert np.array_equal(s2[pos], score[pos]), options
+
+
+def test_more_cells_than_one_batch_holds(oracle, engine):
+    """53 248 cells (8 x 8 px on a 2048 x 1664 target) are more than the 32 768 a batch takes: two batches in the
+    two-tier path, one resolve over the whole grid with a repeat penalty that reaches across the batch boundary --
+    every cell checked by the oracle as the reference's raster loop reaches it; and equal to the fp64-only path."""
+    t, L, size = Type.CIEDE2000, 64, 8
+    shape = cases.square_shape(size)
+    rows, cols = 1664, 2048
+    img, lib = cases.inputs(rows, cols, size, L, t, lattice=32)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, rows, cols)[0]
+    cells = G.cell_records(group, state, rows, cols)
+    assert len(cells) == 208 * 256 > 32768
+    stage(engine, shape, img, lib)
+    rep = (2, 40)
+    run = lambda: engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    best, score = run()
+    assert engine.timing()["score_launches"] >= 2
+    b0, s0 = with_options(engine, {"filter": 0}, run)
+    assert np.array_equal(b0, best) and np.array_equal(s0[state >= 0], score[state >= 0])
+    grid = np.where(best < L, best, -1)
+    pos = np.stack([cells["grid_y"], cells["grid_x"]], axis=1)
+    picks, _ = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), rep[0], rep[1], grid, pos,
+                                       threads=host_threads())
+    got = best[pos[:, 0], pos[:, 1]]
+    assert np.array_equal(np.where(got == L, -1, got), picks)
