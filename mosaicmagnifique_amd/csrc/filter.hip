@@ -1234,7 +1234,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     // ... rounded down to whole rounds of stage 1: a pass judges 64 / groups candidates, four waves share a tile
     // (48 x 48 cells: 7 per pass -> 56-candidate items, two passes per wave, instead of 64 = 2.3)
     const int round_of = 4 * (kWave / std::max(groups, 1));
-    const int small_tile = round_of <= 64 ? 64 / round_of * round_of : 64;
+    const int small_tile = round_of > 0 && round_of <= 64 ? 64 / round_of * round_of : 64;
     const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : (small_cells ? small_tile : 32), cell_group = 512;
     // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited), times two
     // so a finishing workgroup's slot refills at once

@@ -279,3 +279,35 @@ def test_stage_one_handles_every_group_count(oracle, engine, size, two_level):
         assert tm["bound_dropped"] > 0 and tm["band_alarms"] == 0
     finally:
         engine.set_option("two_level", 1)
+
+
+@pytest.mark.parametrize("size", [160, 256])
+def test_cells_beyond_the_bound_s_reach(oracle, engine, size):
+    """Cells of more than 64 pixel groups (over 128 x 128) are outside what the early-exit bound's prelude holds in one
+    wave: they run with the plain partial-sum exit -- same grid as unpruned, fp64-only and the oracle."""
+    t = Type.CIEDE2000
+    rows, cols = 2 * size + size // 3, 2 * size + size // 2
+    img, lib = cases.inputs(rows, cols, size, 24, t, lattice=size // 2)
+    tm = run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(1, 300))
+    assert tm["band_alarms"] == 0
+
+
+@pytest.mark.parametrize("t", [Type.CIE76, Type.CIEDE2000])
+def test_library_too_large_for_the_seed_table(oracle, engine, t):
+    """More than 25 600 images: the per-cell proxy table of the seed selection no longer fits LDS, so the filter runs
+    without limits (no early exit) -- still the reference's picks, for the Lab-Euclidean and the CIEDE2000 form."""
+    size, n_lib = 8, 26000
+    img, lib = cases.inputs(4 * size, 6 * size, size, n_lib, t, lattice=8)
+    shape = cases.square_shape(size)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, img.shape[0], img.shape[1])[0]
+    cells = G.cell_records(group, state, img.shape[0], img.shape[1])
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), 2, 50)
+    tm = engine.timing()
+    assert tm["seed_ms"] < 0.05 and tm["bound_dropped"] == 0 and tm["rescore_ms"] > 0      # two-tier, but no seeds / limits
+    grid = np.where(best < n_lib, best, -1)
+    pos = np.stack([cells["grid_y"], cells["grid_x"]], axis=1)
+    picks, scores = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), 2, 50, grid, pos, threads=16)
+    got = best[pos[:, 0], pos[:, 1]]
+    assert np.array_equal(np.where(got == n_lib, -1, got), picks)
