@@ -459,3 +459,27 @@ def test_consistency_over_iterations(t, rep):
             assert np.array_equal(fits, last[0])
             assert np.array_equal(scores, last[1], equal_nan=True)         # bit-identical, not just close
         last = (fits, scores)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIEDE2000])
+@pytest.mark.parametrize("size,n_lib", [(1, 1), (1, 7), (2, 2), (3, 3), (5, 1), (2, 40)])
+def test_smallest_cells_and_libraries(oracle, t, size, n_lib):
+    """One-pixel cells, one-image libraries: every list is longer than the library, every plane is one padded group."""
+    shape = cases.square_shape(size)
+    img, lib = cases.inputs(7 * size + 1, 9 * size, size, n_lib, t, lattice=4)
+    for rep in ((0, 0), (1, 10), (3, 1000)):
+        compare(oracle, shape, img, lib, t, rep)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_filter", [1, 0], ids=["two_tier", "fp64_only"])
+def test_repeat_window_longer_than_the_seed_list(oracle, use_filter):
+    """Repeat range 12: a cell's window holds up to 312 earlier cells, more candidates than the 256 seeds the early exit
+    can take its limit from -- the filter runs without limits; the penalty is small against the score spread, so the
+    window actually pushes picks around."""
+    t, size, n_lib = Type.CIEDE2000, 16, 400
+    shape = cases.square_shape(size)
+    img, lib = cases.inputs(20 * size, 20 * size, size, n_lib, t, lattice=64)
+    gen = compare(oracle, shape, img, lib, t, (12, 60), use_filter)
+    assert gen.m_engine.candidates_per_cell(12, 60) > 256
