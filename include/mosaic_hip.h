@@ -286,8 +286,15 @@ mm_status mm_shrink_library_bgr(mm_engine *e, int factor);
  * chain takes over); "wave_resolve" / "row_pipeline" (default 1): the single-wave and the
  * row-pipelined forms of the chain.  "max_batch" (default 0 = sized
  * from free device memory): cap on the cells scored per device batch.  "spec_k" (default 4):
- * length of mm_generate's speculative short lists, 0 = always the full length.  Results are
- * identical whatever the options. */
+ * length of mm_generate's speculative short lists, 0 = always the full length.
+ * Tuning of the filter kernel (measured defaults): "tile" (candidates per work item, 0 = by cell
+ * size), "xcd_aware" (1) / "xcd_cells" (0 = by cell size): per-XCD item order; "interleave" (1): the [group][plane]
+ * image copies with prepared operands; "two_level" (1): the bound's stage 1, several candidates per wave pass;
+ * "sort_groups" (-1 = by cell size): how many of a candidate's pixel groups are visited by descending bound;
+ * "lds_filter" (-1 = RGB only): LDS-resident cell tile; "seeds" (14): proxy-chosen seeds beyond the list length;
+ * "band_guard" (64): every n-th cell carries a sentinel through the fp64 re-score (mm_timing.band_alarms);
+ * diagnostics only: "band_pct" (100, a deliberately wrong band), "lds_pad_kb".  Results are identical whatever the
+ * options (tests/test_gpu_fuzz.py::test_tuning_options_do_not_change_the_result). */
 mm_status mm_set_option(mm_engine *e, const char *name, int value);
 
 /* Timings of the last mm_generate / mm_score_cells (+ mm_resolve) on e. */
