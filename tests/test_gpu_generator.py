@@ -483,3 +483,28 @@ def test_repeat_window_longer_than_the_seed_list(oracle, use_filter):
     img, lib = cases.inputs(20 * size, 20 * size, size, n_lib, t, lattice=64)
     gen = compare(oracle, shape, img, lib, t, (12, 60), use_filter)
     assert gen.m_engine.candidates_per_cell(12, 60) > 256
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIEDE2000])
+@pytest.mark.parametrize("kind", ["empty", "one_pixel", "one_row", "flip_sensitive_corner"])
+def test_masks_with_next_to_nothing_in_them(oracle, t, kind):
+    """A mask with no active pixel at all (every candidate scores the bare repeat penalty: the lowest index, or the
+    least penalised, wins), one active pixel, one row, and a single corner pixel under flips (four different masks)."""
+    from mosaicmagnifique_amd.cellshape import CellShape
+    size = 24
+    mask = np.zeros((size, size), np.uint8)
+    if kind == "one_pixel":
+        mask[size // 2, size // 3] = 255
+    elif kind == "one_row":
+        mask[5, :] = 255
+    elif kind == "flip_sensitive_corner":
+        mask[0, 0] = 255
+    shape = CellShape(mask)
+    if kind == "flip_sensitive_corner":
+        shape.alternateColFlipHorizontal = True
+        shape.alternateRowFlipVertical = True
+    img, lib = cases.inputs(6 * size + 5, 7 * size, size, 60, t, lattice=16)
+    for rep in ((0, 0), (2, 25)):
+        for use_filter in (1, 0):
+            compare(oracle, shape, img, lib, t, rep, use_filter)
