@@ -508,3 +508,37 @@ def test_masks_with_next_to_nothing_in_them(oracle, t, kind):
     for rep in ((0, 0), (2, 25)):
         for use_filter in (1, 0):
             compare(oracle, shape, img, lib, t, rep, use_filter)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIE76, Type.CIEDE2000])
+@pytest.mark.parametrize("size", [16, 64])
+def test_flat_colour_content(oracle, t, size):
+    """Exactly constant colours on both sides -- black, white, greys, the saturated primaries, a blue at the hue where
+    R_T peaks, near-opposite hues -- and every library colour twice: scores that are exactly zero, exact ties between
+    duplicates (lowest index wins), blocks of zero chroma (open hue arcs) and of zero-width arcs in the bound."""
+    colours = np.array([[0, 0, 0], [255, 255, 255], [128, 128, 128], [127, 127, 127], [0, 0, 255], [0, 255, 0],
+                        [255, 0, 0], [255, 0, 40], [0, 255, 255], [255, 255, 0], [255, 0, 255], [1, 0, 0], [254, 255, 255],
+                        [200, 30, 30], [30, 30, 200], [60, 200, 60], [20, 20, 20], [235, 235, 235]], np.uint8)      # BGR
+    n = len(colours)
+    copies = 6                                                      # exact duplicates: ties at every score; 108 images,
+    lib_u8 = np.empty((copies * n, size, size, 3), np.uint8)        # so the short lists are shorter than the library
+    for i in range(copies * n):                                     # and the two-tier path with its early exit runs
+        lib_u8[i] = colours[i % n]
+    rows_c, cols_c = 9, 11
+    img_u8 = np.empty((rows_c * size, cols_c * size, 3), np.uint8)
+    rng = np.random.default_rng(12)
+    for gy in range(rows_c):
+        for gx in range(cols_c):
+            c = colours[rng.integers(n)].astype(int)
+            if (gy + gx) % 3 == 0:                                  # a colour nothing in the library matches exactly
+                c = np.clip(c + rng.integers(-3, 4, 3), 0, 255)
+            img_u8[gy * size:(gy + 1) * size, gx * size:(gx + 1) * size] = c
+    from mosaicmagnifique_amd import synth
+    img, lib = synth.preprocess(img_u8, t), synth.preprocess(lib_u8, t)
+    shape = cases.square_shape(size)
+    for rep in ((0, 0), (1, 5), (3, 100000)):
+        for use_filter in (1, 0):
+            gen = compare(oracle, shape, img, lib, t, rep, use_filter)
+            if use_filter and rep == (0, 0):
+                assert gen.timing()["rescore_ms"] > 0           # the two-tier path did run
