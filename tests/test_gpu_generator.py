@@ -542,3 +542,31 @@ def test_flat_colour_content(oracle, t, size):
             gen = compare(oracle, shape, img, lib, t, rep, use_filter)
             if use_filter and rep == (0, 0):
                 assert gen.timing()["rescore_ms"] > 0           # the two-tier path did run
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [48, 64])
+def test_smooth_content(oracle, size):
+    """Noise-free gradients on both sides (what photographs look like next to the synthetic library's +-32 of noise):
+    block statistics are tight, hue arcs narrow, the bound drops nearly every candidate in stage 1 and the survivors
+    are near-ties."""
+    t, n_lib = Type.CIEDE2000, 160
+    rng = np.random.default_rng(77)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64) / size
+    lib_u8 = np.empty((n_lib, size, size, 3), np.uint8)
+    for i in range(n_lib):
+        base = rng.uniform(20, 235, 3)
+        gy, gx = rng.uniform(-40, 40, 3), rng.uniform(-40, 40, 3)
+        lib_u8[i] = np.clip(base + yy[..., None] * gy + xx[..., None] * gx, 0, 255).round().astype(np.uint8)
+    rows, cols = 5 * size + size // 2, 6 * size
+    Y, X = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    img_u8 = np.stack([127 + 100 * np.sin(X / 210 + c) * np.cos(Y / 170 - c) for c in (0.0, 1.1, 2.3)], -1)
+    img_u8 = np.clip(img_u8, 0, 255).round().astype(np.uint8)
+    from mosaicmagnifique_amd import synth
+    img, lib = synth.preprocess(img_u8, t), synth.preprocess(lib_u8, t)
+    shape = cases.square_shape(size)
+    for rep in ((0, 0), (2, 200)):
+        gen = compare(oracle, shape, img, lib, t, rep)
+        tm = gen.timing()
+        assert tm["band_alarms"] == 0
+    assert tm["bound_dropped"] > 0
