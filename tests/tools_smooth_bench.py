@@ -25,7 +25,7 @@ state = G.getGridState(group, rows, cols)[0]
 cells = G.cell_records(group, state, rows, cols)
 e = Engine(0)
 e.set_library_u8(lib_u8, t); e.set_target_u8(img_u8, t); e.set_masks(shape.masks4())
-for name, opts in (("default", {}), ("prune=0", {"prune": 0})):
+for name, opts in (("default", {}), ("tile=64", {"tile": 64}), ("tile=16", {"tile": 16}), ("two_level=0", {"two_level": 0}), ("prune=0", {"prune": 0})):
     for k, v in opts.items():
         e.set_option(k, v)
     for i in range(3):
@@ -41,4 +41,4 @@ for name, opts in (("default", {}), ("prune=0", {"prune": 0})):
     else:
         print("same as default:", bool(np.array_equal(best, ref[0]) and np.array_equal(score[state >= 0], ref[1][state >= 0])))
     for k in opts:
-        e.set_option(k, 1)
+        e.set_option(k, {"tile": 0}.get(k, 1))
