@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-KEEP = ("filter_kernel", "filter_lds_kernel", "rescore_kernel", "seed_score_kernel", "seed_kernel", "contenders_kernel", "resolve_wave")
+KEEP = ("filter_kernel", "filter_lds_kernel", "rescore_kernel", "seed_score_kernel", "seed_kernel", "contenders_kernel", "resolve_wave", "score_kernel")
 
 
 def main():
@@ -20,7 +20,9 @@ def main():
     shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(HERE, "pmc_traffic.json"))
     shutil.copy(os.path.join(src, "kt", "d_kernel_stats.csv"), os.path.join(HERE, tag + "_configD_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "filter_resource_usage.txt"), os.path.join(HERE, tag + "_filter_resource_usage.txt"))
-    for c in "DCB":
+    for c in ("D", "C", "B", "E8", "E", "A"):
+        if not os.path.isdir(os.path.join(src, "pmc_" + c)):
+            continue
         for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"), ("SQ", "sq")):
             rows = list(csv.reader(open(os.path.join(src, "pmc_" + c, sub, "p_counter_collection.csv"))))
             keep = [rows[0]] + [r for r in rows[1:] if any(k in r[8] for k in KEEP)]

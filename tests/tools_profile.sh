@@ -1,5 +1,6 @@
 # Round profile of the bench commands on the GPU box: the rocprofv3 PMC passes (separate runs, as the
-# MI355X guide prescribes) that bench.py's roofline is priced from -- for configs D, C and B --, the
+# MI355X guide prescribes) that bench.py's roofline is priced from -- for configs D, C, B, E8, E and A
+# (CONFIGS="E8 E" bash tests/tools_profile.sh ... for a subset; ONLY=pmc skips the bench lines) --, the
 # kernel trace of the default command, and the bench lines of every configuration.
 # usage (on the box): bash tests/tools_profile.sh r02_v13        -> gpurun_out/r02_v13/
 set -x
@@ -7,7 +8,7 @@ V=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$V
 mkdir -p $O
-for c in D C B; do
+for c in ${CONFIGS:-D C B E8 E A}; do
   P=$O/pmc_$c
   mkdir -p $P
   CMD="python3 bench.py --config $c --steps 1 --warmup 0 --no-cpu"
@@ -17,6 +18,7 @@ for c in D C B; do
   python3 profiles/summarise_pmc.py $c $P > $P/pmc_summary.json
 done
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
+[ "$ONLY" = pmc ] && exit 0
 rocprofv3 --kernel-trace --stats -d $O/kt -o d --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $O/kt.log 2>&1
 python3 bench.py --steps 10 --warmup 2 > $O/bench_D.json 2> $O/bench_D.err
 for c in A B C E8; do python3 bench.py --config $c --steps 5 --warmup 2 > $O/bench_$c.json 2>/dev/null; done
