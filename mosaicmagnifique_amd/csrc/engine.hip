@@ -521,9 +521,9 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.xcd_aware = e->xcd_aware;
     fin.xcd_cells = e->xcd_cells;
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
-    // Early exit needs seeds: K <= M <= 256 of them, and the L proxy distances in LDS.
+    // Early exit needs seeds: K <= M <= 256 of them.
     const int M = std::min(L, std::min(256, round_up(K + e->extra_seeds, 4)));
-    const bool prune = two_tier && e->use_prune != 0 && K <= M && (size_t)L * sizeof(float) <= 100 * 1024;
+    const bool prune = two_tier && e->use_prune != 0 && K <= M;
     if (prune) {
         if ((st = ensure(e, e->seeds, (size_t)batch * M * sizeof(int32_t), "Failed to allocate seeds")) ||
             (st = ensure(e, e->seed_score, (size_t)batch * M * sizeof(float), "Failed to allocate seeds")) ||

@@ -402,9 +402,13 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 cand_gb[idx][g] = b;                        // (stage 2 reads the first `groups` entries only)
             }
             // sum over the candidate's lanes: a suffix scan that stops at the segment's end; its first lane gets the total
-            for (int off = 1; off < 16; off <<= 1) {
-                const float up = __shfl_down(b, off, kWave);
-                if (g + off < groups) b += up;
+            if (groups == 16) {
+                b = row_suffix_sum(b);                      // a candidate is a 16-lane row: four DPP adds
+            } else {
+                for (int off = 1; off < 16; off <<= 1) {
+                    const float up = __shfl_down(b, off, kWave);
+                    if (g + off < groups) b += up;
+                }
             }
             if (g == 0 && valid && !seed) {
                 if (b > limit) {
@@ -989,12 +993,17 @@ seed_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
             const float* __restrict__ lib_means, int L, int ppad, int M,
             int32_t* __restrict__ seeds, const HueEntry* __restrict__ hue_lut)
 {
-    extern __shared__ float proxy[];                 // [L]
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     __shared__ float red[4][kBlock / kWave];
     __shared__ float best_v[kBlock / kWave];
     __shared__ int best_i[kBlock / kWave];
+    // every thread keeps the two closest of its stripe of the library (l = t, t + 256, ...): the M seeds are then
+    // the M closest of those 512.  Exact up to 512 images; beyond, a third member of the true top M in one stripe
+    // is passed over for the next best -- ANY M distinct candidates give a valid limit (the K-th lowest of their
+    // true scores), the choice only has to be deterministic.  No table of L proxies: any library size.
+    __shared__ float cand_v[2 * kBlock];
+    __shared__ int cand_i[2 * kBlock];
     const float* c = cells + (size_t)blockIdx.x * 3 * ppad;
     const uint8_t* mk = cmask + (size_t)blockIdx.x * ppad;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, n = 0.f;
@@ -1009,18 +1018,25 @@ seed_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
     const float inv = 1.0f / fmaxf(t[3], 1.0f);
     const PxF mean{t[0] * inv, t[1] * inv, t[2] * inv};
     const float mean_c = chroma_of(mean.c1, mean.c2);
+    float v0 = __builtin_huge_valf(), v1 = __builtin_huge_valf();
+    int i0 = 0x7fffffff, i1 = 0x7fffffff;
     for (int l = threadIdx.x; l < L; l += kBlock) {
         bool e;
         const PxF lm{lib_means[3 * l], lib_means[3 * l + 1], lib_means[3 * l + 2]};
-        proxy[l] = pair_fast<TYPE>(mean, lm, mean_c, chroma_of(lm.c1, lm.c2), lut, &e);
+        const float d = pair_fast<TYPE>(mean, lm, mean_c, chroma_of(lm.c1, lm.c2), lut, &e);
+        if (d < v0) { v1 = v0; i1 = i0; v0 = d; i0 = l; }          // strict: the lower index stays ahead among equals
+        else if (d < v1) { v1 = d; i1 = l; }
     }
+    cand_v[threadIdx.x] = v0; cand_i[threadIdx.x] = i0;
+    cand_v[kBlock + threadIdx.x] = v1; cand_i[kBlock + threadIdx.x] = i1;
     __syncthreads();
     for (int r = 0; r < M; ++r) {
-        float v = __builtin_huge_valf();
-        int i = 0x7fffffff;
-        for (int l = threadIdx.x; l < L; l += kBlock) {
-            const float d = proxy[l];
-            if (d < v) { v = d; i = l; }                       // lowest index first within a thread
+        float v = cand_v[threadIdx.x];
+        int i = cand_i[threadIdx.x];
+        {
+            const float ov = cand_v[kBlock + threadIdx.x];
+            const int oi = cand_i[kBlock + threadIdx.x];
+            if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
         }
         for (int off = 32; off > 0; off >>= 1) {
             const float ov = __shfl_xor(v, off, kWave);
@@ -1033,7 +1049,11 @@ seed_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
             for (int w = 1; w < kBlock / kWave; ++w)
                 if (best_v[w] < v || (best_v[w] == v && best_i[w] < i)) { v = best_v[w]; i = best_i[w]; }
             seeds[(size_t)blockIdx.x * M + r] = (i == 0x7fffffff) ? -1 : i;
-            if (i != 0x7fffffff) proxy[i] = __builtin_huge_valf();       // taken
+            if (i != 0x7fffffff) {                                  // taken: its slot is the one of thread i % 256 that holds i
+                const int tq = i % kBlock;
+                if (cand_i[tq] == i) { cand_v[tq] = __builtin_huge_valf(); cand_i[tq] = 0x7fffffff; }
+                else { cand_v[kBlock + tq] = __builtin_huge_valf(); cand_i[kBlock + tq] = 0x7fffffff; }
+            }
         }
         __syncthreads();
     }
@@ -1379,8 +1399,8 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
                                int ppad, int M, int K, float px_abs, float rel, int32_t* seeds,
                                float* seed_score, float* limit, float* scores, hipStream_t stream)
 {
-    if (M > 256 || M < K || (size_t)L * sizeof(float) > 100 * 1024) return hipErrorInvalidValue;
-    const size_t lds = (size_t)L * sizeof(float);
+    if (M > 256 || M < K) return hipErrorInvalidValue;
+    const size_t lds = 0;
     const long long waves = (long long)n_cells * M;
     const unsigned score_blocks = (unsigned)std::min<long long>((waves + 3) / 4, 8192);   // grid-stride: the hue table once per workgroup
     if (type == CIEDE2000) {

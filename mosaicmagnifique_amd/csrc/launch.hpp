@@ -90,7 +90,8 @@ hipError_t launch_image_means(const float* planar, float* means, int n_images, i
 // contender.  seeds [n][M] i32, seed_score [n][M] f32, limit [n] f32 are workspaces /
 // outputs.  scores (the filter's f32 [n][L] rows): each seed's score is also left at its place there, so that
 // launch_filter, given the seed lists (FilterInputs::seeds), need not score those candidates again.
-// Requires K <= M <= 256 and L floats to fit LDS beside the hue table (L <= 25600).
+// Requires K <= M <= 256; any library size (the M seeds are the closest of the two best of each of 256 stripes of the
+// library: exact up to 512 images, a deterministic near-top-M beyond).
 hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* lib_means, int n_cells, int L,
                                int ppad, int M, int K, float px_abs, float rel, int32_t* seeds,
                                float* seed_score, float* limit, float* scores, hipStream_t stream);

@@ -293,9 +293,10 @@ def test_cells_beyond_the_bound_s_reach(oracle, engine, size):
 
 
 @pytest.mark.parametrize("t", [Type.CIE76, Type.CIEDE2000])
-def test_library_too_large_for_the_seed_table(oracle, engine, t):
-    """More than 25 600 images: the per-cell proxy table of the seed selection no longer fits LDS, so the filter runs
-    without limits (no early exit) -- still the reference's picks, for the Lab-Euclidean and the CIEDE2000 form."""
+def test_library_larger_than_any_table_in_lds(oracle, engine, t):
+    """26 000 images: the seed selection keeps no per-image table in LDS (two closest per thread stripe, then the M
+    closest of those 512), so the limits and the early exit work for any library size -- still the reference's picks,
+    for the Lab-Euclidean and the CIEDE2000 form."""
     size, n_lib = 8, 26000
     img, lib = cases.inputs(4 * size, 6 * size, size, n_lib, t, lattice=8)
     shape = cases.square_shape(size)
@@ -305,7 +306,7 @@ def test_library_too_large_for_the_seed_table(oracle, engine, t):
     engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
     best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), 2, 50)
     tm = engine.timing()
-    assert tm["seed_ms"] < 0.05 and tm["bound_dropped"] == 0 and tm["rescore_ms"] > 0      # two-tier, but no seeds / limits
+    assert tm["seed_ms"] > 0.02 and tm["rescore_ms"] > 0                    # two-tier, seeds and limits in place
     grid = np.where(best < n_lib, best, -1)
     pos = np.stack([cells["grid_y"], cells["grid_x"]], axis=1)
     picks, scores = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), 2, 50, grid, pos, threads=16)
