@@ -288,7 +288,7 @@ mm_status mm_shrink_library_bgr(mm_engine *e, int factor);
  * from free device memory): cap on the cells scored per device batch.  "spec_k" (default 4):
  * length of mm_generate's speculative short lists, 0 = always the full length.
  * Tuning of the filter kernel (measured defaults): "tile" (candidates per work item, 0 = by cell
- * size), "xcd_aware" (1) / "xcd_cells" (0 = by cell size): per-XCD item order; "interleave" (1): the [group][plane]
+ * size and by the share of candidates the bound dropped in the engine's last launch over the same library), "xcd_aware" (1) / "xcd_cells" (0 = by cell size): per-XCD item order; "interleave" (1): the [group][plane]
  * image copies with prepared operands; "two_level" (1): the bound's stage 1, several candidates per wave pass;
  * "sort_groups" (-1 = by cell size): how many of a candidate's pixel groups are visited by descending bound;
  * "lds_filter" (-1 = RGB only): LDS-resident cell tile; "seeds" (14): proxy-chosen seeds beyond the list length;
