@@ -189,3 +189,47 @@ def test_tuning_options_do_not_change_the_result(oracle, engine, opts):
                                            threads=min(16, len(os.sched_getaffinity(0))))
         mine = best[pos[:, 0], pos[:, 1]]
         assert np.array_equal(np.where(mine == n_lib, -1, mine), picks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MOSAIC_FUZZ_SMOOTH", "16"))))
+def test_random_scenario_graded_noise(oracle, engine, seed):
+    """Between the synthetic library's +-32 of per-channel noise and noise-free gradients: library images = a base colour
+    + a linear gradient + noise of a random amplitude (0 .. 24), target = smooth waves + noise (0 .. 12).  The bound then
+    drops anything from half to nearly all of the candidates, and the engine's item size follows (64-candidate items
+    after a launch that dropped >= 90 %): every cell against the oracle, given the engine's earlier picks."""
+    import os
+    rng = np.random.default_rng(31000 + seed)
+    size = int(rng.choice([32, 48, 64]))
+    shape = random_shape(rng, size)
+    t = Type.CIEDE2000
+    rep = (0, 0) if seed % 2 else (int(rng.integers(1, 4)), int(rng.choice([30, 400])))
+    n_lib = int(rng.integers(150, 320))
+    amp_lib, amp_img = float(rng.choice([0, 2, 8, 24])), float(rng.choice([0, 3, 12]))
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64) / size
+    base = rng.uniform(15, 240, (n_lib, 1, 1, 3))
+    gy, gx = rng.uniform(-45, 45, (n_lib, 1, 1, 3)), rng.uniform(-45, 45, (n_lib, 1, 1, 3))
+    lib_u8 = base + yy[None, ..., None] * gy + xx[None, ..., None] * gx + rng.uniform(-amp_lib, amp_lib, (n_lib, size, size, 3))
+    lib_u8 = np.clip(lib_u8, 0, 255).round().astype(np.uint8)
+    rows = cols = 23 * max(shape.rowSpacing, shape.colSpacing, shape.alternateRowSpacing, shape.alternateColSpacing) + int(rng.integers(0, size))
+    Y, X = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    img_u8 = np.stack([127 + 105 * np.sin(X / rng.uniform(90, 400) + c) * np.cos(Y / rng.uniform(90, 400) - c) for c in (0.0, 1.1, 2.3)], -1)
+    img_u8 = np.clip(img_u8 + rng.uniform(-amp_img, amp_img, img_u8.shape), 0, 255).round().astype(np.uint8)
+    img, lib = synth.preprocess(img_u8, t), synth.preprocess(lib_u8, t)
+    group = CellGroup(shape)
+    state = G.getGridState(group, rows, cols)[0]
+    cells = G.cell_records(group, state, rows, cols)
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    for call in range(2):                                   # the second call runs with the item size the first one's drop rate picks
+        best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+        tm = engine.timing()
+        assert tm["band_alarms"] == 0
+        if call == 0:
+            first = (best.copy(), score.copy())
+    assert np.array_equal(best, first[0]) and np.array_equal(score[state >= 0], first[1][state >= 0])
+    grid = np.where(best < n_lib, best, -1)
+    pos = np.stack([cells["grid_y"], cells["grid_x"]], axis=1)
+    picks, scores = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), rep[0], rep[1], grid, pos,
+                                            threads=min(16, len(os.sched_getaffinity(0))))
+    got = best[pos[:, 0], pos[:, 1]]
+    assert np.array_equal(np.where(got == n_lib, -1, got), picks), np.flatnonzero(np.where(got == n_lib, -1, got) != picks)[:5]
