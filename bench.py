@@ -73,6 +73,13 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def result_digest(best, score):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(best, dtype=np.int64).tobytes())
+    h.update(np.ascontiguousarray(np.nan_to_num(score, nan=-1.0), dtype=np.float64).tobytes())
+    return h.hexdigest()
+
+
 def build_workload(name, world, scaling="weak", mcs=None, mil=None):
     import cases
     from mosaicmagnifique_amd import GridUtility as G
@@ -215,8 +222,8 @@ def cpu_parity_rows(w, img, lib, best, n_cells):
 
 
 def pmc_record(w, opts):
-    """rocprofv3 PMC passes of this same command, summarised per launch of the dominant kernel by
-    profiles/summarise_pmc.py.  Only a record measured on exactly these kernel sources, this
+    """rocprofv3 PMC passes of this same command (tests/tools_profile.sh), summarised per launch of the dominant
+    kernel by profiles/summarise_pmc.py and copied into profiles/ by profiles/collect.py.  Only a record measured on exactly these kernel sources, this
     configuration and these engine options is used; anything else is reported as absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
@@ -308,10 +315,14 @@ def main():
     cells, gw, gh, t, rep = w["cells"], w["grid_w"], w["grid_h"], w["t"], w["rep"]
     sharded = ShardedBestFit(engine, rank, world) if use_dist else None
 
+    from mosaicmagnifique_amd.grid import CELL_DTYPE
+    cells = np.ascontiguousarray(cells, dtype=CELL_DTYPE)
+    out_arrays = (np.empty((gh, gw), dtype=np.int64), np.empty((gh, gw), dtype=np.float64))
+
     def step():
         if sharded is not None:
             return sharded.generate(cells, gw, gh, t, *rep)
-        return engine.generate(cells, gw, gh, t, *rep)
+        return engine.generate(cells, gw, gh, t, *rep, out=out_arrays)    # caller-owned result arrays, as a C++ host has
 
     def fence():
         if use_dist:
@@ -323,17 +334,36 @@ def main():
     fence()
     t0 = time.perf_counter()
     score_ms, launches, exact, visited, groups_all, dropped = 0.0, 0, 0, 0, 0, 0
+    raw = []
     for _ in range(args.steps):
         best, score = step()
-        tm = engine.timing()
-        score_ms += tm["score_ms"]
-        launches += tm["score_launches"]
-        exact += tm["exact_rescored"]
-        visited += tm["visited_groups"]
-        groups_all += tm["total_groups"]
-        dropped += tm["bound_dropped"]
+        raw.append(engine.timing_raw())          # one small ctypes call; summed up after the timed region
     fence()
     elapsed = time.perf_counter() - t0
+    for r in raw:
+        score_ms += r.score_ms
+        launches += r.score_launches
+        exact += r.exact_rescored
+        visited += r.visited_groups
+        groups_all += r.total_groups
+        dropped += r.bound_dropped
+    tm = raw[-1].as_dict() if raw else engine.timing()
+    if score_ms == 0.0 and sharded is None:
+        # a small job runs without events between its phases (option "phase_timing" -1: an event costs it more than a
+        # kernel): the dominant kernel's launch duration comes from three extra, untimed steps with the events on
+        engine.set_option("phase_timing", 1)
+        launches = 0
+        for _ in range(3):
+            step()
+            r = engine.timing_raw()
+            score_ms += r.score_ms
+            launches += r.score_launches
+        tm_phase = engine.timing()
+        engine.set_option("phase_timing", -1)
+        tm.update({k: tm_phase[k] for k in ("stage_ms", "seed_ms", "score_ms", "rescore_ms", "select_ms", "resolve_ms")})
+        launches_scale = args.steps / 3.0
+    else:
+        launches_scale = 1.0
     if world > 1:
         el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -356,15 +386,16 @@ def main():
     alg_bytes, total_pa = algorithmic_bytes(w, my_cells)
     launches = max(launches, 1)
     per_launch_s = (score_ms / 1e3) / launches
-    launches_per_step = launches / max(args.steps, 1)
+    launches_per_step = launches * launches_scale / max(args.steps, 1)
     alg_per_launch = alg_bytes / launches_per_step
-    visited_per_launch = visited / launches
+    visited_per_launch = visited / max(launches * launches_scale, 1)
     pairs_alg = total_pa * w["L"] / launches_per_step
     ciede = t == 2 and engine_uses_filter
 
     pmc, pmc_src = pmc_record(w, args.opt) if world == 1 else (None, "PMC records are single-GPU")
     roof = {
-        "kernel": "filter_kernel" if engine_uses_filter else "score_kernel",
+        # CIEDE2000: the persistent two-stage kernel; RGB-Euclidean / CIE76: the LDS-resident cell tile form
+        "kernel": ("filter_kernel" if t == 2 else "filter_lds_kernel") if engine_uses_filter else "score_kernel",
         "avg_launch_ms": per_launch_s * 1e3,
         "launches_per_step": launches_per_step,
         "effective_algorithmic_gbs": alg_per_launch / per_launch_s / 1e9 if per_launch_s > 0 else 0.0,
@@ -372,7 +403,7 @@ def main():
         "pair_evals_algorithmic_per_s": pairs_alg / per_launch_s if per_launch_s > 0 else 0.0,
         "visited_groups_per_launch": visited_per_launch,
         "visited_fraction_of_groups": visited / groups_all if groups_all else None,
-        "candidates_dropped_by_block_bound": dropped / max(launches, 1),
+        "candidates_dropped_by_block_bound": dropped / max(launches * launches_scale, 1),
         # a visited group = 256 pixel positions of one (cell, candidate): what was actually evaluated
         "pair_evals_visited_per_s": visited_per_launch * 256 / per_launch_s if per_launch_s > 0 and visited else None,
         "pmc_source": pmc_src,
@@ -452,6 +483,9 @@ def main():
         "stage_once_s": stage_s,
         "comm_init_s": comm_init_s,
         "exact_rescored_per_step": exact / max(args.steps, 1),
+        # sha256 over the best-fit grid (int64) and the scores (f64, NaN where the grid has no value) of the last step:
+        # what an N-rank run must reproduce bit for bit (tests/test_gpu_bench_ranks.py)
+        "result_digest": result_digest(best, score),
         "last_step_device_ms": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
     }
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2
 
 /* Return codes.  The reference returns bool and reports through a modal
  * CUDAErrMessageBox that separates "expected" errors (out of memory, bad
@@ -99,6 +99,10 @@ typedef struct mm_timing {
     int64_t bound_dropped;    /* candidates the block bound dropped before any pixel was read */
     int64_t band_alarms;      /* sampled cells where a candidate the fp32 band excluded beat a contender in fp64
                                * (must stay 0; such a cell is re-done fp64-only) */
+    int64_t filter_tile;      /* candidates per work item the last filter launch ran with (see "tile" / "item_auto") */
+    int64_t host_syncs;       /* times the host waited for the device during the call */
+    int64_t fast_path;        /* 1: the whole generate was ONE submission read back in one result block (option
+                               * "fast_path"); 0: the step-by-step path ran (or finished the call) */
 } mm_timing;
 
 /* Progress: called on the calling thread between device batches with
@@ -293,6 +297,12 @@ mm_status mm_shrink_library_bgr(mm_engine *e, int factor);
  * "sort_groups" (-1 = by cell size): how many of a candidate's pixel groups are visited by descending bound;
  * "lds_filter" (-1 = RGB only): LDS-resident cell tile; "seeds" (14): proxy-chosen seeds beyond the list length;
  * "band_guard" (64): every n-th cell carries a sentinel through the fp64 re-score (mm_timing.band_alarms);
+ * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
+ * dropped in the engine's PREVIOUS CIEDE2000 launch over the same library, so the TIME of a call (never its result)
+ * depends on the call history of the engine; 0 pins the size-by-cell default (mm_timing.filter_tile reports what ran).
+ * "fast_path" (1): mm_generate enqueues a whole generate and reads ONE result block back (one host wait) whenever the
+ * cells fit one batch, falling back to the step-by-step path when the block says a host decision was needed; "fused" (1):
+ * cell gather + chroma + interleave + block statistics in one launch and contenders + fp64 re-score + re-rank in one.
  * diagnostics only: "band_pct" (100, a deliberately wrong band), "lds_pad_kb".  Results are identical whatever the
  * options (tests/test_gpu_fuzz.py::test_tuning_options_do_not_change_the_result). */
 mm_status mm_set_option(mm_engine *e, const char *name, int value);

@@ -30,11 +30,14 @@ class MMTiming(ctypes.Structure):
                 ("spec_rounds", ctypes.c_int64), ("deepened_cells", ctypes.c_int64),
                 ("resolve_sweeps", ctypes.c_int64), ("visited_groups", ctypes.c_int64),
                 ("total_groups", ctypes.c_int64), ("bound_dropped", ctypes.c_int64),
-                ("band_alarms", ctypes.c_int64)]
+                ("band_alarms", ctypes.c_int64), ("filter_tile", ctypes.c_int64),
+                ("host_syncs", ctypes.c_int64), ("fast_path", ctypes.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
+
+ABI_VERSION = 2          # MM_ABI_VERSION of include/mosaic_hip.h
 
 PROGRESS_CB = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)
 
@@ -124,8 +127,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.mm_abi_version() != 1:
-        raise RuntimeError("libmosaic_hip.so ABI version %d != 1" % lib.mm_abi_version())
+    if lib.mm_abi_version() != ABI_VERSION:
+        raise RuntimeError("libmosaic_hip.so ABI version %d != %d" % (lib.mm_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -135,7 +138,8 @@ def ptr(a):
     if a is None:
         return None
     assert a.flags["C_CONTIGUOUS"]
-    return a.ctypes.data_as(ctypes.c_void_p)
+    # (the array interface is several times cheaper than a.ctypes.data_as: it matters to sub-millisecond calls)
+    return ctypes.c_void_p(a.__array_interface__["data"][0])
 
 
 def as_cells(records):

@@ -98,6 +98,27 @@ struct mm_engine {
                                  // guards; a negative value turns the band inside out: true contenders get excluded)
     int band_guard_every = 64;   // mm_set_option("band_guard", n): every n-th cell of a batch re-scores the best candidate the
                                  // filter band excluded in fp64 (0 = off); an excluded candidate that wins is a band failure
+    int item_auto = 1;           // mm_set_option("item_auto", 0): the filter's item size no longer follows the drop rate of the
+                                 // engine's previous CIEDE2000 launch (timing then does not depend on the call history)
+    int fused = 1;               // mm_set_option("fused", 0): separate gather / chroma / interleave / statistics and
+                                 // contenders / re-score / re-rank launches instead of the two fused kernels
+    int fast_path = 1;           // mm_set_option("fast_path", 0): mm_generate asks the host between its phases (step-by-step
+                                 // path) instead of enqueuing a whole generate and reading ONE result block back
+    DevBuf result;               // [ResultHeader][grid i64][scores f64] of the single-submission path
+    void* pinned = nullptr;      // page-locked host mirror of `result`
+    size_t pinned_bytes = 0;
+    // a score batch enqueued but not yet looked at by the host (single-submission path)
+    struct Pending { bool active = false, two_tier = false, prune = false, counted = false; int b = 0, diff_type = 0; unsigned int edge_cap = 0; } pend;
+    int64_t syncs = 0;           // stream synchronisations of the current call (mm_timing.host_syncs)
+    mm::ResultHeader* fast_hdr = nullptr;   // device header of the single-submission generate in flight (else null)
+    int phase_timing = -1;       // mm_set_option("phase_timing", n): events between the phases of a call (mm_timing's *_ms):
+                                 // 1 always, 0 never, -1 = only for calls of >= ~2e10 CIEDE2000 pixel pairs or ten times as many
+                                 // RGB ones (the nine events cost ~35 us per call)
+    bool phase_events = true;    // ... as decided for the current call
+    int fused_seed_cells = 2048; // mm_set_option("fused_seeds", n): batches of up to n cells pick seeds, score them and set the
+                                 // limit in ONE launch (0 = always the three separate kernels)
+    long long prune_min_pairs = -1;   // mm_set_option("prune_min_kpairs", n): below n thousand pixel pairs per batch the
+                                      // seeds / early exit are skipped (three launches cost more than they save); -1 = default
 
     mm_timing timing{};
 };
@@ -216,6 +237,12 @@ mm::CellResize cell_resize_of(const mm_engine* e)
     return r;
 }
 
+hipError_t sync_stream(mm_engine* e)
+{
+    e->syncs += 1;
+    return hipStreamSynchronize(e->stream);
+}
+
 float elapsed(hipEvent_t a, hipEvent_t b)
 {
     float ms = 0.f;
@@ -316,7 +343,7 @@ mm_status prepare_planes(mm_engine* e)
     if ((st = ensure(e, e->lib_il, (size_t)n_var * L * 4 * ppad * sizeof(float), "Failed to allocate interleaved library"))) return st;
     HIP_TRY(e, mm::launch_interleave((const float*)e->lib.p, (const float*)e->lib_chroma.p, nullptr, (float*)e->lib_il.p,
                                      (size_t)n_var * L, ppad, e->stream), "Error during library interleave kernel");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");   // host vectors go out of scope
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");   // host vectors go out of scope
     e->planes_dirty = false;
     return MM_OK;
 }
@@ -436,16 +463,88 @@ mm_status dense_batch(mm_engine* e, const mm_cell* recs_dev, int b, int diff_typ
     return MM_OK;
 }
 
+// Cells the filter could not vouch for (flags_host[i] != 0, or all of them after a discontinuity-log
+// overflow) go through the fp64-only path; their lists land in their rows of the caller's arrays.
+// `first` = index of flags_host[0] among the call's cells.
+mm_status redo_flagged_cells(mm_engine* e, const mm_cell* cells_host, int first, int b, const uint8_t* flags_host, bool all_dense,
+                             int diff_type, int K, int KW, int32_t* cand_i_dev, double* cand_s_dev, const int* row_map_host)
+{
+    std::vector<mm_cell> dense_cells;
+    std::vector<int> dense_rows;
+    for (int i = 0; i < b; ++i) {
+        if (flags_host[(size_t)i] & 4) e->timing.band_alarms += 1;
+        if (all_dense || flags_host[(size_t)i]) {
+            dense_cells.push_back(cells_host[first + i]);
+            dense_rows.push_back(row_map_host ? row_map_host[first + i] : first + i);
+        }
+    }
+    if (dense_cells.empty()) return MM_OK;
+    const int nd = (int)dense_cells.size();
+    mm_status st;
+    // the selection kernel writes each cell's list straight into its row of the caller's arrays (row map on the device)
+    if ((st = ensure(e, e->dense_recs, (size_t)nd * sizeof(mm_cell), "Failed to allocate cell records")) ||
+        (st = ensure(e, e->dense_i, (size_t)nd * sizeof(int), "Failed to allocate row map")))
+        return st;
+    HIP_TRY(e, hipMemcpyAsync(e->dense_recs.p, dense_cells.data(), (size_t)nd * sizeof(mm_cell),
+                              hipMemcpyHostToDevice, e->stream), "Failed to copy cell records to device");
+    HIP_TRY(e, hipMemcpyAsync(e->dense_i.p, dense_rows.data(), (size_t)nd * sizeof(int),
+                              hipMemcpyHostToDevice, e->stream), "Failed to copy row map to device");
+    HIP_TRY(e, hipEventRecord(e->ev[10], e->stream), "event");
+    if ((st = dense_batch(e, (const mm_cell*)e->dense_recs.p, nd, diff_type, K, KW, cand_i_dev, cand_s_dev,
+                          (const int*)e->dense_i.p, nullptr, nullptr)))
+        return st;
+    HIP_TRY(e, hipEventRecord(e->ev[11], e->stream), "event");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
+    e->timing.rescore_ms += elapsed(e->ev[10], e->ev[11]);
+    e->timing.dense_cells += nd;
+    return MM_OK;
+}
+
+// Phase times and work counters of a score batch whose events have completed.
+void account_score_batch(mm_engine* e, bool two_tier, bool prune, int diff_type, int b, unsigned int edge_n,
+                         const unsigned long long work[3])
+{
+    if (!two_tier) {
+        if (e->phase_events) {
+            e->timing.stage_ms += elapsed(e->ev[0], e->ev[1]);
+            e->timing.score_ms += elapsed(e->ev[1], e->ev[2]);
+            e->timing.select_ms += elapsed(e->ev[2], e->ev[3]);
+        }
+        e->timing.score_launches += 1;
+        return;
+    }
+    e->timing.visited_groups += (int64_t)work[0];
+    e->timing.total_groups += (int64_t)work[1];
+    e->timing.bound_dropped += (int64_t)work[2];
+    if (prune && diff_type == MM_CIEDE2000 && b > 0) {
+        e->drop_rate = (double)work[2] / ((double)b * (double)e->n_lib);
+        e->drop_rate_lib = e->n_lib; e->drop_rate_size = e->lib_size;
+    }
+    if (e->phase_events) {
+        e->timing.stage_ms += elapsed(e->ev[0], e->ev[1]);
+        e->timing.seed_ms += elapsed(e->ev[1], e->ev[4]);
+        e->timing.score_ms += elapsed(e->ev[4], e->ev[2]);
+        e->timing.select_ms += elapsed(e->ev[2], e->ev[3]) + elapsed(e->ev[8], e->ev[9]);
+        e->timing.rescore_ms += elapsed(e->ev[3], e->ev[8]);
+    }
+    e->timing.score_launches += 1;
+    e->timing.edge_pairs += edge_n;
+}
+
 // Scores `n` cells in batches and leaves the K lowest candidates per cell in rows of
 // cand_i_dev / cand_s_dev that are KW >= K entries wide (the rest of a row is emptied).
 // Cell i goes to row row_map_host[i] (null: row i).  cells_host = the same records on the
 // host (needed to re-run flagged cells through the fp64-only path).
+// defer: when the cells fit ONE batch, everything is enqueued and the function returns WITHOUT asking the
+// host anything (e->pend.active): the caller reads the cell flags and counters back later, in its own copy
+// (mm_generate's single-submission path), and calls account_score_batch / redo_flagged_cells itself.
 mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_cell* recs_dev, int n,
                              int diff_type, int K, int KW, int32_t* cand_i_dev, double* cand_s_dev,
                              const int* row_map_host,
-                             mm_progress_cb progress, void* user, volatile int* cancel)
+                             mm_progress_cb progress, void* user, volatile int* cancel, bool defer = false)
 {
     const int L = e->n_lib, size = e->lib_size, P = size * size, ppad = round_up(P, 256);
+    e->pend.active = false;
     mm_status stp = prepare_planes(e);
     if (stp) return stp;
     const int* row_map_dev = nullptr;
@@ -457,17 +556,27 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     }
     const bool two_tier = e->use_filter != 0 && K < L;
     const int Kc = two_tier ? std::min(L, round_up(K + 32, 4)) : 0;
+    // Early exit needs seeds: K <= M <= 256 of them.
+    const int M = std::min(L, std::min(256, round_up(K + e->extra_seeds, 4)));
+    // Seeds and the early exit pay three launches (one when fused) and ~M full scores per cell for the pixel pairs they
+    // save: below ~1e8 pairs of an RGB launch (~2e7 of CIEDE2000's, eight times the work per pair) the unpruned filter
+    // is over before the seeds would be
+    const double call_pairs = (double)std::min(n, 32768) * L * P;
+    const double min_pairs = e->prune_min_pairs >= 0 ? 1e3 * (double)e->prune_min_pairs : (diff_type == MM_CIEDE2000 ? 2e7 : 1e8);
+    const bool prune = two_tier && e->use_prune != 0 && K <= M && call_pairs >= min_pairs;
 
-    // Batch so that scores + gathered cells stay within a fixed budget.
-    const size_t per_cell = (size_t)L * sizeof(double) + (size_t)ppad * 17 + (size_t)Kc * 16 + 1;
+    // Batch so that every per-cell workspace stays within a budget: score row, the planar / NaN-marked / chroma /
+    // interleaved copies of the cell and its mask, block statistics, contenders, seeds, flags.
+    const size_t per_cell = (size_t)L * sizeof(double) + (size_t)ppad * (12 + 1 + (two_tier ? 4 + 4 + 16 : 0)) +
+                            (size_t)7 * (ppad / 64) * sizeof(float) + (size_t)Kc * 16 + (prune ? (size_t)M * 8 + 4 : 0) + 16;
     // hipMemGetInfo is a driver round trip: asked again only when this call needs more cells per batch than the
     // last budget allowed (the workspaces below are kept between calls)
     const int want_cells = std::min(n, 32768);
     if (e->batch_per_cell != per_cell || e->batch_capacity < want_cells) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(e, hipMemGetInfo(&free_b, &total_b), "Failed to query device memory");
-        const size_t budget = std::min<size_t>(free_b / 2 + e->scores.bytes + e->cells.bytes + e->cmask.bytes,
-                                               (size_t)6 << 30);
+        const size_t held = e->scores.bytes + e->cells.bytes + e->cmask.bytes + e->cells_il.bytes + e->cells_f0.bytes + e->cell_chroma.bytes;
+        const size_t budget = std::min<size_t>(free_b / 2 + held, (size_t)6 << 30);
         if (budget < per_cell) {
             set_err(e, "Not enough device memory: one cell needs %zu bytes of workspace, %zu free",
                     per_cell, free_b);
@@ -478,36 +587,53 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     }
     int batch = std::min(n, e->batch_capacity);
     if (e->max_batch_cells > 0) batch = std::min(batch, e->max_batch_cells);
-    mm_status st;
-    if ((st = ensure(e, e->cell_var, (size_t)batch, "Failed to allocate cell variants")) ||
-        (st = ensure(e, e->cell_full, (size_t)batch, "Failed to allocate cell flags")) ||
-        (st = ensure(e, e->cell_lsum, (size_t)7 * batch * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
-        (st = ensure(e, e->cells, (size_t)batch * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
-        (st = ensure(e, e->cmask, (size_t)batch * ppad, "Failed to allocate cell masks")) ||
-        (st = ensure(e, e->scores, (size_t)batch * L * sizeof(double), "Failed to allocate variants")))
-        return st;
     unsigned int edge_cap = 0;
-    if (two_tier) {
-        const double pairs = (double)batch * L * P;
-        edge_cap = (unsigned int)std::min<double>(64e6, std::max<double>(1e6, pairs / 2000.0));
-        if ((st = ensure(e, e->cont_i, (size_t)batch * Kc * sizeof(int32_t), "Failed to allocate contenders")) ||
-            (st = ensure(e, e->cont_f, (size_t)batch * Kc * sizeof(float), "Failed to allocate contenders")) ||
-            (st = ensure(e, e->cont_s, (size_t)batch * Kc * sizeof(double), "Failed to allocate contenders")) ||
-            (st = ensure(e, e->flags, (size_t)batch, "Failed to allocate cell flags")) ||
-            (st = ensure(e, e->sentinel, (size_t)batch * sizeof(int32_t), "Failed to allocate band guard slots")) ||
-            (st = ensure(e, e->edge_count, mm::kFilterCounterWords * sizeof(unsigned int), "Failed to allocate edge counter")) ||
-            (st = ensure(e, e->edges, (size_t)edge_cap * sizeof(mm::EdgeEntry), "Failed to allocate edge list")))
+    // Workspaces of a batch; a refused allocation (memory taken since the capacity was computed: a larger target, a
+    // second engine on the device) halves the batch instead of failing the call.
+    auto allocate = [&](int bt) -> mm_status {
+        mm_status st;
+        if ((st = ensure(e, e->cell_var, (size_t)bt, "Failed to allocate cell variants")) ||
+            (st = ensure(e, e->cell_full, (size_t)bt, "Failed to allocate cell flags")) ||
+            (st = ensure(e, e->cell_lsum, (size_t)7 * bt * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
+            (st = ensure(e, e->cells, (size_t)bt * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
+            (st = ensure(e, e->cmask, (size_t)bt * ppad, "Failed to allocate cell masks")) ||
+            (st = ensure(e, e->scores, (size_t)bt * L * sizeof(double), "Failed to allocate variants")))
             return st;
+        if (two_tier) {
+            const double pairs = (double)bt * L * P;
+            edge_cap = (unsigned int)std::min<double>(64e6, std::max<double>(1e6, pairs / 2000.0));
+            if ((st = ensure(e, e->cont_i, (size_t)bt * Kc * sizeof(int32_t), "Failed to allocate contenders")) ||
+                (st = ensure(e, e->cont_f, (size_t)bt * Kc * sizeof(float), "Failed to allocate contenders")) ||
+                (st = ensure(e, e->cont_s, (size_t)bt * Kc * sizeof(double), "Failed to allocate contenders")) ||
+                (st = ensure(e, e->flags, (size_t)bt, "Failed to allocate cell flags")) ||
+                (st = ensure(e, e->sentinel, (size_t)bt * sizeof(int32_t), "Failed to allocate band guard slots")) ||
+                (st = ensure(e, e->edge_count, mm::kFilterCounterWords * sizeof(unsigned int), "Failed to allocate edge counter")) ||
+                (st = ensure(e, e->edges, (size_t)edge_cap * sizeof(mm::EdgeEntry), "Failed to allocate edge list")) ||
+                (st = ensure_hue_lut(e)) ||
+                (st = ensure(e, e->cell_chroma, (size_t)bt * ppad * sizeof(float), "Failed to allocate cell chroma planes")) ||
+                (st = ensure(e, e->cells_f0, (size_t)bt * ppad * sizeof(float), "Failed to allocate cell planes")) ||
+                (st = ensure(e, e->cells_il, (size_t)bt * 4 * ppad * sizeof(float), "Failed to allocate interleaved cells")))
+                return st;
+        }
+        if (prune) {
+            if ((st = ensure(e, e->seeds, (size_t)bt * M * sizeof(int32_t), "Failed to allocate seeds")) ||
+                (st = ensure(e, e->seed_score, (size_t)bt * M * sizeof(float), "Failed to allocate seeds")) ||
+                (st = ensure(e, e->limits, (size_t)bt * sizeof(float), "Failed to allocate pruning limits")))
+                return st;
+        }
+        return MM_OK;
+    };
+    mm_status st;
+    while ((st = allocate(batch)) == MM_OUT_OF_MEMORY && batch > 1) {
+        for (DevBuf* bf : { &e->scores, &e->cells, &e->cmask, &e->cells_il, &e->cells_f0, &e->cell_chroma, &e->cont_s, &e->edges })
+            release(*bf);
+        batch = (batch + 1) / 2;
+        e->batch_capacity = batch;
     }
+    if (st) return st;
+
     const mm::FilterBand band = filter_band(diff_type, ppad, e->band_pct);
     const int ftype = diff_type == MM_CIEDE2000 ? mm::CIEDE2000 : mm::RGB_EUCLIDEAN;
-    if (two_tier) {
-        if ((st = ensure_hue_lut(e)) ||
-            (st = ensure(e, e->cell_chroma, (size_t)batch * ppad * sizeof(float), "Failed to allocate cell chroma planes")) ||
-            (st = ensure(e, e->cells_f0, (size_t)batch * ppad * sizeof(float), "Failed to allocate cell planes")) ||
-            (st = ensure(e, e->cells_il, (size_t)batch * 4 * ppad * sizeof(float), "Failed to allocate interleaved cells")))
-            return st;
-    }
     mm::FilterInputs fin{};
     fin.cells = (const float*)e->cells.p; fin.cmask = (const uint8_t*)e->cmask.p;
     fin.cells_f0 = (const float*)e->cells_f0.p;
@@ -523,57 +649,77 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.xcd_aware = e->xcd_aware;
     fin.xcd_cells = e->xcd_cells;
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
-    // Early exit needs seeds: K <= M <= 256 of them.
-    const int M = std::min(L, std::min(256, round_up(K + e->extra_seeds, 4)));
-    const bool prune = two_tier && e->use_prune != 0 && K <= M;
-    if (prune) {
-        if ((st = ensure(e, e->seeds, (size_t)batch * M * sizeof(int32_t), "Failed to allocate seeds")) ||
-            (st = ensure(e, e->seed_score, (size_t)batch * M * sizeof(float), "Failed to allocate seeds")) ||
-            (st = ensure(e, e->limits, (size_t)batch * sizeof(float), "Failed to allocate pruning limits")))
-            return st;
-    }
+    // the fused ranking kernel keeps a cell's contenders in LDS (16 bytes each)
+    // (config D, 4096 cells of CIEDE2000: the separate re-score balances the contenders better -- 2.21 + 0.15 ms against
+    // 2.53 fused; up to ~2000 cells the two launches saved weigh more)
+    const bool fused_rank = e->fused != 0 && (size_t)Kc * 16 <= 48 * 1024 && (diff_type != MM_CIEDE2000 || n <= 2048);
 
     std::vector<uint8_t> flags_host;
-    std::vector<mm_cell> dense_cells;
-    std::vector<int> dense_slots, dense_rows;
     for (int done = 0; done < n; done += batch) {
         if (cancel && *cancel) return MM_CANCELLED;
         const int b = std::min(batch, n - done);
         int32_t* ci = row_map_dev ? cand_i_dev : cand_i_dev + (size_t)done * KW;
         double* cs = row_map_dev ? cand_s_dev : cand_s_dev + (size_t)done * KW;
         const int* rmap = row_map_dev ? row_map_dev + done : nullptr;
-        HIP_TRY(e, hipEventRecord(e->ev[0], e->stream), "event");
+        const bool deferred = defer && n <= batch;
+        // single submission: the filter's counter block is the one inside the result header (zeroed by result_init_kernel)
+        mm::ResultHeader* const hdr = deferred ? e->fast_hdr : nullptr;
+        unsigned int* const counters_dev = hdr ? hdr->filter_counters : (unsigned int*)e->edge_count.p;
+        fin.counters_cleared = hdr ? 1 : 0;
+        // one launch for seeds + scores + limit where the batch is small: measured (round 3) config B 0.147 -> 0.129 ms, but
+        // config C (1694 cells of CIEDE2000, whose seed scores carry the fp64 form inline) 0.32 -> 0.47 ms: the separate
+        // score kernel spreads the (cell, seed) pairs over the device, the fused one keeps a cell's seeds on one CU
+        fin.fused_seeds = e->fused_seed_cells > 0 && b <= e->fused_seed_cells && (diff_type != MM_CIEDE2000 || (long long)b * M <= 4096);
+        if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream), "event");
         if (!two_tier) {
-            if ((st = dense_batch(e, recs_dev + done, b, diff_type, K, KW, ci, cs, rmap, e->ev[1], e->ev[2]))) return st;
-            HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
-            HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
-            e->timing.stage_ms += elapsed(e->ev[0], e->ev[1]);
-            e->timing.score_ms += elapsed(e->ev[1], e->ev[2]);
-            e->timing.select_ms += elapsed(e->ev[2], e->ev[3]);
-            e->timing.score_launches += 1;
+            if ((st = dense_batch(e, recs_dev + done, b, diff_type, K, KW, ci, cs, rmap, e->phase_events ? e->ev[1] : nullptr, e->phase_events ? e->ev[2] : nullptr))) return st;
+            if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
+            if (deferred) {
+                e->pend = mm_engine::Pending{true, false, false, false, b, diff_type, 0u};
+                return MM_OK;
+            }
+            HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
+            account_score_batch(e, false, false, diff_type, b, 0u, nullptr);
             if (progress) progress(done + b, user);
             continue;
         }
 
-        mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
-            recs_dev + done, (const float*)e->target.p, e->rows, e->cols, cell_resize_of(e), (const uint8_t*)e->masks.p,
-            (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
-            (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, (float*)e->cells_f0.p);
-        HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
-        if (diff_type == MM_CIEDE2000) {
-            HIP_TRY(e, mm::launch_chroma_planes((const float*)e->cells.p, (float*)e->cell_chroma.p, (size_t)b, ppad, e->stream),
-                    "Error during cell chroma kernel");
-            if (e->use_interleave)
-                HIP_TRY(e, mm::launch_interleave((const float*)e->cells.p, (const float*)e->cell_chroma.p, (const float*)e->cells_f0.p,
-                                                 (float*)e->cells_il.p, (size_t)b, ppad, e->stream), "Error during cell interleave kernel");
-        }
-        {
+        if (e->fused != 0) {
+            // one launch: planes, mask, NaN-marked channel 0, chroma plane, interleaved copy, block statistics
+            const dim3 grid((unsigned)(ppad / mm::kBlock), (unsigned)b);
+            const size_t stats_stride = e->cell_lsum.bytes / sizeof(float) / 7;
+            if (diff_type == MM_CIEDE2000)
+                mm::gather_prepare_kernel<true><<<grid, mm::kBlock, 0, e->stream>>>(
+                    recs_dev + done, (const float*)e->target.p, e->rows, e->cols, cell_resize_of(e), (const uint8_t*)e->masks.p,
+                    (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
+                    (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, (float*)e->cells_f0.p, (float*)e->cell_chroma.p,
+                    e->use_interleave ? (float*)e->cells_il.p : nullptr, (float*)e->cell_lsum.p, stats_stride, ppad / 64);
+            else
+                mm::gather_prepare_kernel<false><<<grid, mm::kBlock, 0, e->stream>>>(
+                    recs_dev + done, (const float*)e->target.p, e->rows, e->cols, cell_resize_of(e), (const uint8_t*)e->masks.p,
+                    (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
+                    (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, (float*)e->cells_f0.p, nullptr, nullptr,
+                    (float*)e->cell_lsum.p, stats_stride, ppad / 64);
+            HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
+        } else {
+            mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
+                recs_dev + done, (const float*)e->target.p, e->rows, e->cols, cell_resize_of(e), (const uint8_t*)e->masks.p,
+                (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
+                (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, (float*)e->cells_f0.p);
+            HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
+            if (diff_type == MM_CIEDE2000) {
+                HIP_TRY(e, mm::launch_chroma_planes((const float*)e->cells.p, (float*)e->cell_chroma.p, (size_t)b, ppad, e->stream),
+                        "Error during cell chroma kernel");
+                if (e->use_interleave)
+                    HIP_TRY(e, mm::launch_interleave((const float*)e->cells.p, (const float*)e->cell_chroma.p, (const float*)e->cells_f0.p,
+                                                     (float*)e->cells_il.p, (size_t)b, ppad, e->stream), "Error during cell interleave kernel");
+            }
             HIP_TRY(e, mm::launch_group_sums((const float*)e->cells.p, (const uint8_t*)e->cmask.p, (size_t)ppad,
                                              (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 7,
                                              (size_t)b, ppad, e->stream),
                     "Error during cell group-sum kernel");
         }
-        HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
+        if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
 
         // tier 1: fp32 filter score of every (cell, candidate), with early exit against a
         // per-cell limit obtained from a few proxy-chosen seeds
@@ -582,104 +728,107 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                                                M, K, band.px_abs, band.rel, (int32_t*)e->seeds.p,
                                                (float*)e->seed_score.p, (float*)e->limits.p, (float*)e->scores.p, e->stream),
                     "Error during seed / pruning limit kernels");
-        HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
+        if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
         fin.seeds = prune ? (const int32_t*)e->seeds.p : nullptr;
         fin.n_seeds = prune ? M : 0;
         // Item size by what the bound did last time on this library: where it drops nearly everything (photograph-like
         // content: 99 % at stage 1) an item is over in microseconds and its fixed latencies set the pace -- 64-candidate
         // items then run the filter in 0.6 of the time of 32-candidate ones; where half of the candidates survive (the
-        // synthetic benchmark) both run the same and the smaller item moves less data.  Results do not depend on it.
+        // synthetic benchmark) both run the same and the smaller item moves less data.  Results do not depend on it;
+        // the TIME of a call therefore depends on the engine's previous CIEDE2000 call over the same library
+        // (mm_set_option("item_auto", 0) turns the feedback off; mm_timing.filter_tile reports what was used).
         fin.tile_candidates = e->tile_candidates;
-        if (e->tile_candidates == 0 && prune && e->drop_rate >= 0.9 && e->drop_rate_lib == L && e->drop_rate_size == size)
+        if (e->tile_candidates == 0 && e->item_auto != 0 && prune && diff_type == MM_CIEDE2000 && e->drop_rate >= 0.9 &&
+            e->drop_rate_lib == L && e->drop_rate_size == size)
             fin.tile_candidates = 64;
+        int tile_used = 0;
         HIP_TRY(e, mm::launch_filter(ftype, fin, (float*)e->scores.p, b, L, ppad,
-                                     (mm::EdgeEntry*)e->edges.p, (unsigned int*)e->edge_count.p, edge_cap,
-                                     prune ? (const float*)e->limits.p : nullptr, e->stream),
+                                     (mm::EdgeEntry*)e->edges.p, counters_dev, edge_cap,
+                                     prune ? (const float*)e->limits.p : nullptr, e->stream, &tile_used),
                 "Error during filter colour difference kernel");
-        HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
+        e->timing.filter_tile = tile_used;
+        if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
 
-        mm::contenders_kernel<<<b, mm::kBlock, 0, e->stream>>>(
-            (const float*)e->scores.p, (const uint8_t*)e->cmask.p, L, ppad, K, Kc, band,
-            (int32_t*)e->cont_i.p, (float*)e->cont_f.p, (uint8_t*)e->flags.p, (int32_t*)e->sentinel.p, e->band_guard_every);
-        HIP_TRY(e, hipGetLastError(), "Error during contender selection kernel");
-        HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
+        if (fused_rank) {
+            // contenders, their fp64 reference-form scores and the K lowest of them in one launch
+            if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
+            by_type(diff_type, [&](auto T) {
+                mm::rank_kernel<decltype(T)::value><<<b, mm::kBlock, (size_t)Kc * 16, e->stream>>>(
+                    (const float*)e->scores.p, (const float*)e->cells.p, (const uint8_t*)e->cmask.p, (const float*)e->lib.p,
+                    L, ppad, K, Kc, band, kTieBand, ci, cs, (uint8_t*)e->flags.p, KW, rmap, e->band_guard_every, fin.var,
+                    hdr, K == KW ? 1 : 0);
+                return MM_OK;
+            });
+            HIP_TRY(e, hipGetLastError(), "Error during contender ranking kernel");
+            if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[8], e->stream), "event");
+            if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[9], e->stream), "event");
+        } else {
+            mm::contenders_kernel<<<b, mm::kBlock, 0, e->stream>>>(
+                (const float*)e->scores.p, (const uint8_t*)e->cmask.p, L, ppad, K, Kc, band,
+                (int32_t*)e->cont_i.p, (float*)e->cont_f.p, (uint8_t*)e->flags.p, (int32_t*)e->sentinel.p, e->band_guard_every);
+            HIP_TRY(e, hipGetLastError(), "Error during contender selection kernel");
+            if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
 
-        // tier 2: fp64 reference-form score of the contenders only
-        const long long waves = (long long)b * Kc;
-        by_type(diff_type, [&](auto T) {
-            mm::rescore_kernel<decltype(T)::value><<<(unsigned)((waves + 3) / 4), mm::kBlock, 0, e->stream>>>(
-                (const float*)e->cells.p, (const uint8_t*)e->cmask.p, (const float*)e->lib.p,
-                (const int32_t*)e->cont_i.p, (double*)e->cont_s.p, b, Kc, ppad, fin.var);
+            // tier 2: fp64 reference-form score of the contenders only
+            const long long waves = (long long)b * Kc;
+            by_type(diff_type, [&](auto T) {
+                mm::rescore_kernel<decltype(T)::value><<<(unsigned)((waves + 3) / 4), mm::kBlock, 0, e->stream>>>(
+                    (const float*)e->cells.p, (const uint8_t*)e->cmask.p, (const float*)e->lib.p,
+                    (const int32_t*)e->cont_i.p, (double*)e->cont_s.p, b, Kc, ppad, fin.var);
+                return MM_OK;
+            });
+            HIP_TRY(e, hipGetLastError(), "Error during contender re-score kernel");
+            if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[8], e->stream), "event");
+
+            mm::rerank_kernel<<<b, mm::kBlock, 0, e->stream>>>(
+                (const int32_t*)e->cont_i.p, (const float*)e->cont_f.p, (const double*)e->cont_s.p,
+                (const uint8_t*)e->cmask.p, Kc, K, ppad, band, kTieBand, ci, cs, (uint8_t*)e->flags.p, KW, rmap,
+                (const int32_t*)e->sentinel.p, L);
+            HIP_TRY(e, hipGetLastError(), "Error during re-rank kernel");
+            if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[9], e->stream), "event");
+        }
+        if (deferred) {
+            e->pend = mm_engine::Pending{true, true, prune, fused_rank && hdr != nullptr, b, diff_type, edge_cap};
             return MM_OK;
-        });
-        HIP_TRY(e, hipGetLastError(), "Error during contender re-score kernel");
-        HIP_TRY(e, hipEventRecord(e->ev[8], e->stream), "event");
-
-        mm::rerank_kernel<<<b, mm::kBlock, 0, e->stream>>>(
-            (const int32_t*)e->cont_i.p, (const float*)e->cont_f.p, (const double*)e->cont_s.p,
-            (const uint8_t*)e->cmask.p, Kc, K, ppad, band, kTieBand, ci, cs, (uint8_t*)e->flags.p, KW, rmap,
-            (const int32_t*)e->sentinel.p);
-        HIP_TRY(e, hipGetLastError(), "Error during re-rank kernel");
-        HIP_TRY(e, hipEventRecord(e->ev[9], e->stream), "event");
+        }
 
         flags_host.resize((size_t)b);
         unsigned int counters[8] = {0};          // [0] logged discontinuity pairs, [2..7] three u64 work counters
         HIP_TRY(e, hipMemcpyAsync(flags_host.data(), e->flags.p, (size_t)b, hipMemcpyDeviceToHost, e->stream), "flags");
         HIP_TRY(e, hipMemcpyAsync(counters, e->edge_count.p, sizeof counters, hipMemcpyDeviceToHost, e->stream), "edge count");
-        HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+        HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
         const unsigned int edge_n = counters[0];
-        {
-            unsigned long long work[3];
-            memcpy(work, counters + 2, sizeof work);
-            e->timing.visited_groups += (int64_t)work[0];
-            e->timing.total_groups += (int64_t)work[1];
-            e->timing.bound_dropped += (int64_t)work[2];
-            if (prune && diff_type == MM_CIEDE2000 && b > 0) {
-                e->drop_rate = (double)work[2] / ((double)b * (double)L);
-                e->drop_rate_lib = L; e->drop_rate_size = size;
-            }
-        }
-        e->timing.stage_ms += elapsed(e->ev[0], e->ev[1]);
-        e->timing.seed_ms += elapsed(e->ev[1], e->ev[4]);
-        e->timing.score_ms += elapsed(e->ev[4], e->ev[2]);
-        e->timing.select_ms += elapsed(e->ev[2], e->ev[3]) + elapsed(e->ev[8], e->ev[9]);
-        e->timing.rescore_ms += elapsed(e->ev[3], e->ev[8]);
-        e->timing.score_launches += 1;
-        e->timing.edge_pairs += edge_n;
-
+        unsigned long long work[3];
+        memcpy(work, counters + 2, sizeof work);
+        account_score_batch(e, true, prune, diff_type, b, edge_n, work);
         // cells the filter could not vouch for go through the fp64-only path
-        dense_cells.clear();
-        dense_slots.clear();
-        const bool all_dense = edge_n > edge_cap;        // discontinuity log overflowed
-        for (int i = 0; i < b; ++i) {
-            if (flags_host[(size_t)i] & 4) e->timing.band_alarms += 1;
-            if (all_dense || flags_host[(size_t)i]) { dense_cells.push_back(cells_host[done + i]); dense_slots.push_back(done + i); }
-        }
-        if (!dense_cells.empty()) {
-            const int nd = (int)dense_cells.size();
-            // the selection kernel writes each cell's list straight into its row of the caller's arrays (row map on the device)
-            dense_rows.resize((size_t)nd);
-            for (int i = 0; i < nd; ++i)
-                dense_rows[(size_t)i] = row_map_host ? row_map_host[dense_slots[(size_t)i]] : dense_slots[(size_t)i];
-            if ((st = ensure(e, e->dense_recs, (size_t)nd * sizeof(mm_cell), "Failed to allocate cell records")) ||
-                (st = ensure(e, e->dense_i, (size_t)nd * sizeof(int), "Failed to allocate row map")))
-                return st;
-            HIP_TRY(e, hipMemcpyAsync(e->dense_recs.p, dense_cells.data(), (size_t)nd * sizeof(mm_cell),
-                                      hipMemcpyHostToDevice, e->stream), "Failed to copy cell records to device");
-            HIP_TRY(e, hipMemcpyAsync(e->dense_i.p, dense_rows.data(), (size_t)nd * sizeof(int),
-                                      hipMemcpyHostToDevice, e->stream), "Failed to copy row map to device");
-            HIP_TRY(e, hipEventRecord(e->ev[10], e->stream), "event");
-            if ((st = dense_batch(e, (const mm_cell*)e->dense_recs.p, nd, diff_type, K, KW, cand_i_dev, cand_s_dev,
-                                  (const int*)e->dense_i.p, nullptr, nullptr)))
-                return st;
-            HIP_TRY(e, hipEventRecord(e->ev[11], e->stream), "event");
-            HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
-            e->timing.rescore_ms += elapsed(e->ev[10], e->ev[11]);
-            e->timing.dense_cells += nd;
-        }
+        if ((st = redo_flagged_cells(e, cells_host, done, b, flags_host.data(), edge_n > edge_cap /* log overflowed */,
+                                     diff_type, K, KW, cand_i_dev, cand_s_dev, row_map_host)))
+            return st;
         if (progress) progress(done + b, user);
     }
     return MM_OK;
+}
+
+// The arguments every resolve kernel takes, from the engine's resident state.
+mm::ResolveArgs resolve_args_of(const mm_engine* e, const mm_cell* recs_dev, int n, int grid_w, int grid_h,
+                                int range, int addition, int K, const int32_t* cand_i_dev, const double* cand_s_dev,
+                                long long* grid_dev, double* best_dev, const uint8_t* deep_dev, uint8_t* insufficient_dev, int k_fill)
+{
+    const int size = e->lib_size, P = size * size, ppad = round_up(P, 256);
+    mm::ResolveArgs a{};
+    a.recs = recs_dev; a.n_cells = n; a.grid_w = grid_w; a.grid_h = grid_h; a.L = e->n_lib;
+    a.repeat_range = range; a.repeat_addition = addition; a.K = K;
+    a.cand_index = cand_i_dev; a.cand_score = cand_s_dev;
+    a.grid = grid_dev; a.best_score = best_dev;
+    a.target = (const float*)e->target.p; a.rows = e->rows; a.cols = e->cols; a.cell_scale = cell_resize_of(e);
+    a.masks = (const uint8_t*)e->masks.p; a.lib = (const float*)e->lib.p;
+    a.lib_stride = (size_t)e->n_lib * 3 * ppad; a.inv_perm = (const int*)e->inv_perm.p;
+    for (int i = 0; i < 4; ++i) a.var_of_mask[i] = e->var_of_mask[i];
+    a.size = size; a.P = P; a.ppad = ppad;
+    a.tie_band = kTieBand;
+    a.deep = deep_dev; a.insufficient = insufficient_dev; a.k_fill = k_fill > 0 ? k_fill : K;
+    return a;
 }
 
 // deep_dev (may be null = every list is full): 1 where the list holds the full K; the
@@ -699,29 +848,18 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
         (st = ensure(e, e->counter, 2 * sizeof(unsigned long long), "Failed to allocate counter")))
         return st;
 
-    // Set best fits to max value (CUDAPhotomosaicGenerator.cpp:140-149), scores to NaN.
-    std::vector<long long> init(cells_total, (long long)e->n_lib);
-    std::vector<double> nan_init(cells_total, std::numeric_limits<double>::quiet_NaN());
-    HIP_TRY(e, hipMemcpyAsync(e->grid.p, init.data(), cells_total * sizeof(long long), hipMemcpyHostToDevice, e->stream),
-            "Failed to copy max best fit from host to device");
-    HIP_TRY(e, hipMemcpyAsync(e->best.p, nan_init.data(), cells_total * sizeof(double), hipMemcpyHostToDevice, e->stream),
-            "Failed to reset lowest variant");
+    // Set best fits to max value (CUDAPhotomosaicGenerator.cpp:140-149), scores to NaN: one fill kernel, nothing
+    // crosses PCIe and the host does not wait.
+    const unsigned fill_blocks = (unsigned)std::min<size_t>((cells_total + mm::kBlock - 1) / mm::kBlock, 1024);
+    auto fill_grid = [&]() -> hipError_t {
+        mm::grid_fill_kernel<<<fill_blocks, mm::kBlock, 0, e->stream>>>((long long*)e->grid.p, (double*)e->best.p, cells_total, (long long)e->n_lib);
+        return hipGetLastError();
+    };
+    HIP_TRY(e, fill_grid(), "Failed to copy max best fit from host to device");
     HIP_TRY(e, hipMemsetAsync(e->counter.p, 0, 2 * sizeof(unsigned long long), e->stream), "Failed to clear counter");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");   // host vectors go out of scope below
 
-    const int size = e->lib_size, P = size * size, ppad = round_up(P, 256);
-    mm::ResolveArgs a{};
-    a.recs = recs_dev; a.n_cells = n; a.grid_w = grid_w; a.grid_h = grid_h; a.L = e->n_lib;
-    a.repeat_range = range; a.repeat_addition = addition; a.K = K;
-    a.cand_index = cand_i_dev; a.cand_score = cand_s_dev;
-    a.grid = (long long*)e->grid.p; a.best_score = (double*)e->best.p;
-    a.target = (const float*)e->target.p; a.rows = e->rows; a.cols = e->cols; a.cell_scale = cell_resize_of(e);
-    a.masks = (const uint8_t*)e->masks.p; a.lib = (const float*)e->lib.p;
-    a.lib_stride = (size_t)e->n_lib * 3 * ppad; a.inv_perm = (const int*)e->inv_perm.p;
-    for (int i = 0; i < 4; ++i) a.var_of_mask[i] = e->var_of_mask[i];
-    a.size = size; a.P = P; a.ppad = ppad;
-    a.tie_band = kTieBand;
-    a.deep = deep_dev; a.insufficient = insufficient_dev; a.k_fill = k_fill > 0 ? k_fill : K;
+    mm::ResolveArgs a = resolve_args_of(e, recs_dev, n, grid_w, grid_h, range, addition, K, cand_i_dev, cand_s_dev,
+                                        (long long*)e->grid.p, (double*)e->best.p, deep_dev, insufficient_dev, k_fill);
     a.exact_count = (unsigned long long*)e->counter.p;
     a.dense_count = a.exact_count + 1;
 
@@ -740,7 +878,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
         HIP_TRY(e, hipGetLastError(), "Error during mark scan kernel");
         int marked = 0;
         HIP_TRY(e, hipMemcpyAsync(&marked, mark_count, sizeof(int), hipMemcpyDeviceToHost, e->stream), "mark count");
-        HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+        HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
         a.row_slot = marked > 0 ? slot : nullptr;      // no marks: skip the per-cell lookup
         if (marked > 0) {
             if ((st = ensure(e, e->dense_rows_buf, (size_t)marked * e->n_lib * sizeof(double), "Failed to allocate score rows")))
@@ -782,7 +920,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
                 HIP_TRY(e, hipGetLastError(), "Error during calculate repeats / find lowest kernel");
                 HIP_TRY(e, hipMemcpyAsync(host_counts.data(), counts + launched, (size_t)now * sizeof(unsigned int),
                                           hipMemcpyDeviceToHost, e->stream), "sweep counters");
-                HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+                HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
                 for (int i = 0; i < now && !swept; ++i)
                     if (host_counts[i] == 0) {
                         swept = true;
@@ -796,11 +934,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
             a.exact_count = exact_total_count;
             if (!swept) {                       // not converged: start the chain from a clean grid
                 e->timing.resolve_sweeps += launched;
-                HIP_TRY(e, hipMemcpyAsync(e->grid.p, init.data(), cells_total * sizeof(long long), hipMemcpyHostToDevice, e->stream),
-                        "Failed to copy max best fit from host to device");
-                HIP_TRY(e, hipMemcpyAsync(e->best.p, nan_init.data(), cells_total * sizeof(double), hipMemcpyHostToDevice, e->stream),
-                        "Failed to reset lowest variant");
-                HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+                HIP_TRY(e, fill_grid(), "Failed to copy max best fit from host to device");
             }
         }
         // whole grid + progress counters + per-wave exact buffers in LDS?
@@ -830,7 +964,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
             HIP_TRY(e, hipGetLastError(), "Error during calculate repeats / find lowest kernel");
             int stuck_host = 0;
             HIP_TRY(e, hipMemcpyAsync(&stuck_host, stuck, sizeof(int), hipMemcpyDeviceToHost, e->stream), "stuck flag");
-            HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+            HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
             if (stuck_host) { set_err(e, "row-pipelined resolve made no progress (internal error)"); return MM_DEVICE_ERROR; }
         } else {
             const int blocks = sequential ? 1 : std::max(1, std::min(n, 8192));
@@ -862,10 +996,115 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
                 "Error copying best scores to host");
     unsigned long long exact[2] = {0, 0};
     HIP_TRY(e, hipMemcpyAsync(exact, e->counter.p, sizeof exact, hipMemcpyDeviceToHost, e->stream), "counter");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     e->timing.resolve_ms += elapsed(e->ev[4], e->ev[5]);
     e->timing.exact_rescored += (int64_t)exact[0];
     e->timing.dense_rows += (int64_t)exact[1];
+    return MM_OK;
+}
+
+// Page-locked host mirror of the result block.
+mm_status ensure_pinned(mm_engine* e, size_t bytes)
+{
+    if (e->pinned && e->pinned_bytes >= bytes) return MM_OK;
+    if (e->pinned) { (void)hipHostFree(e->pinned); e->pinned = nullptr; e->pinned_bytes = 0; }
+    HIP_TRY(e, hipHostMalloc(&e->pinned, bytes, hipHostMallocDefault), "Failed to allocate page-locked result buffer");
+    e->pinned_bytes = bytes;
+    return MM_OK;
+}
+
+// Single submission, part 1 (before any scoring): the result block -- header, grid, scores -- allocated and
+// initialised on the device; the filter kernels count straight into the header from here on.
+mm_status begin_single_submission(mm_engine* e, int n, int grid_w, int grid_h, bool speculate)
+{
+    const size_t cells_total = (size_t)grid_w * grid_h;
+    const size_t block_bytes = sizeof(mm::ResultHeader) + cells_total * (sizeof(long long) + sizeof(double));
+    mm_status st;
+    if ((st = ensure(e, e->result, block_bytes, "Failed to allocate result block")) ||
+        (st = ensure_pinned(e, block_bytes)))
+        return st;
+    if (speculate &&
+        ((st = ensure(e, e->deep, (size_t)n, "Failed to allocate list flags")) ||
+         (st = ensure(e, e->insufficient, (size_t)n, "Failed to allocate list flags"))))
+        return st;
+    mm::ResultHeader* hdr = (mm::ResultHeader*)e->result.p;
+    long long* grid_dev = (long long*)((char*)e->result.p + sizeof(mm::ResultHeader));
+    double* best_dev = (double*)(grid_dev + cells_total);
+    const size_t work = std::max(cells_total, speculate ? (size_t)n : 0);
+    const unsigned fill_blocks = (unsigned)std::min<size_t>((work + mm::kBlock - 1) / mm::kBlock, 1024);
+    mm::result_init_kernel<<<std::max(fill_blocks, 1u), mm::kBlock, 0, e->stream>>>(
+        hdr, grid_dev, best_dev, cells_total, (long long)e->n_lib,
+        speculate ? (uint8_t*)e->deep.p : nullptr, speculate ? (uint8_t*)e->insufficient.p : nullptr, speculate ? n : 0);
+    HIP_TRY(e, hipGetLastError(), "Error during result initialisation kernel");
+    e->fast_hdr = hdr;
+    return MM_OK;
+}
+
+// Single submission, part 2 (after the lists were enqueued): the resolve -- a handful of sweeps when the repeat
+// penalty makes it order-dependent, ONE launch otherwise -- runs on the lists as they are, and header + grid
+// (+ scores) come back in ONE copy into page-locked memory; the host waits once.  Whether the state in the block
+// is final is for the caller to read off the header (all counters zero and a sweep that changed nothing).
+// Needs the wave form of the resolve (the caller checks).  counted: the ranking kernel counted flags and marks
+// into the header already; else two small kernels do it here.
+mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n, int grid_w, int grid_h,
+                                    int diff_type, int range, int addition, int K, int k_fill, bool speculate,
+                                    const int32_t* cand_i_dev, const double* cand_s_dev, bool want_scores,
+                                    const uint8_t* flags_dev, bool counted)
+{
+    const size_t cells_total = (size_t)grid_w * grid_h;
+    mm::ResultHeader* hdr = e->fast_hdr;
+    e->fast_hdr = nullptr;
+    long long* grid_dev = (long long*)((char*)e->result.p + sizeof(mm::ResultHeader));
+    double* best_dev = (double*)(grid_dev + cells_total);
+    mm_status st;
+    if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[10], e->stream), "event");
+    mm::ResolveArgs a = resolve_args_of(e, recs_dev, n, grid_w, grid_h, range, addition, K, cand_i_dev, cand_s_dev, grid_dev, best_dev,
+                                        speculate ? (const uint8_t*)e->deep.p : nullptr, speculate ? (uint8_t*)e->insufficient.p : nullptr, k_fill);
+    a.exact_count = &hdr->exact_plain;
+    a.dense_count = &hdr->dense_count;
+    a.row_slot = nullptr;                       // a mark voids the block; the step-by-step path then builds the rows
+    a.insufficient_count = speculate ? &hdr->n_insufficient : nullptr;
+    if (!counted) {
+        if ((st = ensure(e, e->row_slot, (size_t)n * sizeof(int) + sizeof(int), "Failed to allocate row slots"))) return st;
+        mm::mark_scan_kernel<<<std::min((n + mm::kBlock - 1) / mm::kBlock, 256), mm::kBlock, 0, e->stream>>>(
+            cand_i_dev, n, K, a.deep, (int*)e->row_slot.p, (int*)&hdr->n_marked);
+        HIP_TRY(e, hipGetLastError(), "Error during mark scan kernel");
+        if (flags_dev) {
+            mm::result_summary_kernel<<<1, mm::kBlock, 0, e->stream>>>(hdr, flags_dev, n);
+            HIP_TRY(e, hipGetLastError(), "Error during result summary kernel");
+        }
+    }
+    const int sequential = (range > 0 && addition != 0) ? 1 : 0;
+    const int blocks = std::max(1, std::min(n, 8192));
+    int sweeps = 0;
+    if (sequential) {
+        sweeps = std::min(e->max_sweeps, mm::kFastSweeps);
+        for (int i = 0; i < sweeps; ++i) {
+            a.sweep_changes = &hdr->sweep_changes[i];
+            a.exact_count = &hdr->sweep_exact[i];
+            a.insufficient_count = speculate ? &hdr->sweep_insufficient[i] : nullptr;
+            by_type(diff_type, [&](auto T) {
+                mm::resolve_wave_kernel<decltype(T)::value><<<blocks, mm::kWave, 0, e->stream>>>(a, 2);
+                return MM_OK;
+            });
+        }
+    } else {
+        by_type(diff_type, [&](auto T) {
+            mm::resolve_wave_kernel<decltype(T)::value><<<blocks, mm::kWave, 0, e->stream>>>(a, 0);
+            return MM_OK;
+        });
+    }
+    HIP_TRY(e, hipGetLastError(), "Error during calculate repeats / find lowest kernel");
+    if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[11], e->stream), "event");
+    const size_t back = sizeof(mm::ResultHeader) + cells_total * (sizeof(long long) + (want_scores ? sizeof(double) : 0));
+    HIP_TRY(e, hipMemcpyAsync(e->pinned, e->result.p, back, hipMemcpyDeviceToHost, e->stream), "Error copying best fits to host");
+    HIP_TRY(e, hipEventRecord(e->ev[7], e->stream), "event");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
+    mm::ResultHeader* h = (mm::ResultHeader*)e->pinned;
+    h->sweeps = (unsigned int)sweeps;
+    if (sequential && sweeps > 0) h->n_insufficient = h->sweep_insufficient[sweeps - 1];     // the final state's verdicts
+    h->edge_pairs = h->filter_counters[0];
+    memcpy(h->work, h->filter_counters + 2, sizeof h->work);
     return MM_OK;
 }
 
@@ -931,7 +1170,7 @@ void mm_destroy(mm_engine* e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->stream) (void)sync_stream(e);
     for (DevBuf* b : { &e->lib, &e->masks, &e->target, &e->recs, &e->cells, &e->cmask, &e->scores,
                        &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter, &e->scratch,
                        &e->cont_i, &e->cont_f, &e->cont_s, &e->flags, &e->edges, &e->edge_count,
@@ -940,8 +1179,9 @@ void mm_destroy(mm_engine* e)
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
                        &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0, &e->area_tab,
-                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il })
+                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il, &e->result })
         release(*b);
+    if (e->pinned) (void)hipHostFree(e->pinned);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -1060,7 +1300,7 @@ mm_status preprocess_u8(mm_engine* e, const uint8_t* bgr, size_t n_images, int r
         (const uint8_t*)e->stage_u8.p, (float*)dst.p, n_images, rows, cols, factor,
         diff_type != MM_RGB_EUCLIDEAN, (const double*)e->srgb_lut.p);
     HIP_TRY(e, hipGetLastError(), "Error during preprocessing kernel");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     return MM_OK;
 }
 
@@ -1127,7 +1367,7 @@ mm_status mm_set_library_u8_sized(mm_engine* e, const uint8_t* bgr, int n_images
             code = hipGetLastError();
         }
     }
-    if (code == hipSuccess) code = hipStreamSynchronize(e->stream);      // host vectors and temporaries go out of scope
+    if (code == hipSuccess) code = sync_stream(e);      // host vectors and temporaries go out of scope
     release(tab); release(small);
     if (code != hipSuccess) return hip_fail(e, code, "Error during library resize", __FILE__, __LINE__);
     e->planes_dirty = true;
@@ -1169,7 +1409,7 @@ mm_status mm_hue_rotate_u8(mm_engine* e, const uint8_t* bgr, int rows, int cols,
     mm::hue_rotate_u8_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(src, dst, n_px, degrees);
     HIP_TRY(e, hipGetLastError(), "Error during hue rotation kernel");
     HIP_TRY(e, hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, e->stream), "Failed to copy variant to host");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     return MM_OK;
 }
 
@@ -1192,7 +1432,7 @@ mm_status mm_shrink_library(mm_engine* e, int factor)
     mm::shrink_f32_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(
         (const float*)e->lib_hwc.p, (float*)e->shrink_tmp.p, e->n_lib, e->lib_size, factor);
     HIP_TRY(e, hipGetLastError(), "Error during library resize kernel");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     std::swap(e->lib_hwc, e->shrink_tmp);
     e->lib_size = so;
     e->planes_dirty = true;
@@ -1303,6 +1543,9 @@ mm_status mm_score_cells_partial(mm_engine* e, const mm_cell* cells, int n_cells
     if ((st = check_cells(e, cells, n_cells, 0, 0))) return st;
     HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
     e->timing = mm_timing{};
+    e->syncs = 0;
+    e->phase_events = e->phase_timing != 0;
+    e->fast_hdr = nullptr;
     if (n_cells == 0) return MM_OK;
 
     HIP_TRY(e, hipEventRecord(e->ev[6], e->stream), "event");
@@ -1328,9 +1571,10 @@ mm_status mm_score_cells_partial(mm_engine* e, const mm_cell* cells, int n_cells
                 "Error copying candidates to host");
     }
     HIP_TRY(e, hipEventRecord(e->ev[7], e->stream), "event");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
     e->timing.pair_evals = count_pair_evals(e, cells, n_cells);
+    e->timing.host_syncs = e->syncs;
     return MM_OK;
 }
 
@@ -1410,6 +1654,14 @@ mm_status mm_resolve(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w
 // few cells it could not vouch for to the full K and resolve again, until none is left.
 // Deep lists are sufficient by the counting argument, so the loop ends, and the result is
 // the one the full-K path gives.
+//
+// Single submission (option "fast_path", default on; cells that fit one batch): scoring, resolve and the copy of
+// ONE result block (header + grid + scores) are enqueued back to back and the host waits once.  The header says
+// whether anything the host would have acted on in between occurred -- a cell the filter could not vouch for, an
+// overflow mark, sweeps still changing picks, an unverified speculative pick; if so the call continues on the
+// step-by-step path from the first thing that cannot be trusted (lists, or the resolve only), so the result is the
+// same either way.  The reference's everyday jobs (~1000 cells, ~200 images) are bound by exactly these round
+// trips: the per-cell H2D / memset / sync sequence of CUDAPhotomosaicGenerator.cpp:176-229 is what they replace.
 mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_w, int grid_h, int diff_type,
                       int repeat_range, int repeat_addition, int64_t* best_fit_out, double* best_score_out,
                       mm_progress_cb progress, void* progress_user, volatile int* cancel)
@@ -1425,10 +1677,12 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     if ((st = check_cells(e, cells, n_cells, grid_w, grid_h))) return st;
     HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
     e->timing = mm_timing{};
+    e->syncs = 0;
 
     const int K = std::max(1, mm_candidates_per_cell(e->n_lib, repeat_range, repeat_addition));
     const int Ks = std::max(1, mm_speculative_candidates(e->n_lib, repeat_range, repeat_addition, e->spec_k));
     const bool speculate = Ks < K && n_cells > 0;
+    const size_t cells_total = (size_t)grid_w * grid_h;
     HIP_TRY(e, hipEventRecord(e->ev[6], e->stream), "event");
     if ((st = ensure(e, e->recs, (size_t)std::max(n_cells, 1) * sizeof(mm_cell), "Failed to allocate cell records")) ||
         (st = ensure(e, e->cand_i, (size_t)std::max(n_cells, 1) * K * sizeof(int32_t), "Failed to allocate candidates")) ||
@@ -1436,14 +1690,68 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
         return st;
     HIP_TRY(e, hipMemcpyAsync(e->recs.p, cells, (size_t)n_cells * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
             "Failed to copy cell records to device");
+    const bool sequential = repeat_range > 0 && repeat_addition != 0;
+    const size_t ring_bytes = sequential ? (size_t)(repeat_range + 1) * grid_w * sizeof(int) : 0;
+    const bool want_fast = e->fast_path != 0 && n_cells > 0 && e->use_wave_resolve != 0 && ring_bytes <= 120 * 1024 &&
+                           (!sequential || e->use_sweep_resolve != 0);
+    // events between the phases: worth their queue slots only where a phase outlasts them by far
+    // (measured on config A: ~35 us per call for the nine events, 0.081 -> 0.121 ms per step: on where that is below ~1 %)
+    e->phase_events = e->phase_timing > 0 ||
+                      (e->phase_timing < 0 && (double)n_cells * e->n_lib * e->lib_size * e->lib_size * (diff_type == MM_CIEDE2000 ? 1.0 : 0.1) >= 2e10);
+    e->fast_hdr = nullptr;
+    if (want_fast && (st = begin_single_submission(e, n_cells, grid_w, grid_h, speculate))) return st;
     if (n_cells > 0) {
         st = score_cells_device(e, cells, (const mm_cell*)e->recs.p, n_cells, diff_type, Ks, K, (int32_t*)e->cand_i.p,
-                                (double*)e->cand_s.p, nullptr, progress, progress_user, cancel);
-        if (st) return st;
+                                (double*)e->cand_s.p, nullptr, progress, progress_user, cancel, want_fast);
+        if (st) { e->fast_hdr = nullptr; return st; }
     }
-    if (cancel && *cancel) return MM_CANCELLED;
+    if (cancel && *cancel) { e->fast_hdr = nullptr; return MM_CANCELLED; }
 
     std::vector<uint8_t> deep, insufficient;
+    bool have_verdicts = false;            // the result block holds the final state of the lists as they are now
+    if (!e->pend.active) e->fast_hdr = nullptr;     // more than one batch: the step-by-step path
+    if (e->pend.active) {
+        const mm_engine::Pending pd = e->pend;
+        e->pend.active = false;
+        st = resolve_single_submission(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition,
+                                       K, Ks, speculate, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr,
+                                       pd.two_tier ? (const uint8_t*)e->flags.p : nullptr, pd.counted);
+        if (st) return st;
+        const mm::ResultHeader& h = *(const mm::ResultHeader*)e->pinned;
+        account_score_batch(e, pd.two_tier, pd.prune, pd.diff_type, pd.b, h.edge_pairs, h.work);
+        if (progress) progress(n_cells, progress_user);
+        const bool lists_ok = h.n_flagged == 0 && !(pd.two_tier && h.edge_pairs > pd.edge_cap);
+        int settled = -1;                  // first sweep that changed nothing
+        for (unsigned int i = 0; i < h.sweeps && settled < 0; ++i)
+            if (h.sweep_changes[i] == 0) settled = (int)i;
+        const bool resolved_ok = lists_ok && h.n_marked == 0 && (!sequential || settled >= 0);
+        if (!lists_ok) {
+            std::vector<uint8_t> flags_host((size_t)n_cells);
+            HIP_TRY(e, hipMemcpy(flags_host.data(), e->flags.p, (size_t)n_cells, hipMemcpyDeviceToHost), "flags");
+            if ((st = redo_flagged_cells(e, cells, 0, n_cells, flags_host.data(), h.edge_pairs > pd.edge_cap, diff_type,
+                                         Ks, K, (int32_t*)e->cand_i.p, (double*)e->cand_s.p, nullptr)))
+                return st;
+        }
+        if (resolved_ok) {
+            if (e->phase_events) e->timing.resolve_ms += elapsed(e->ev[10], e->ev[11]);
+            e->timing.resolve_sweeps += sequential ? settled + 1 : 0;
+            e->timing.exact_rescored += (int64_t)(sequential ? h.sweep_exact[settled] : h.exact_plain);
+            e->timing.dense_rows += (int64_t)h.dense_count;
+            const char* body = (const char*)e->pinned + sizeof(mm::ResultHeader);
+            memcpy(best_fit_out, body, cells_total * sizeof(int64_t));
+            if (best_score_out) memcpy(best_score_out, body + cells_total * sizeof(int64_t), cells_total * sizeof(double));
+            if (!speculate || h.n_insufficient == 0) {
+                e->timing.spec_rounds = 1;
+                e->timing.fast_path = 1;
+                e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
+                e->timing.pair_evals = count_pair_evals(e, cells, n_cells);
+                e->timing.host_syncs = e->syncs;
+                return MM_OK;
+            }
+            have_verdicts = true;          // only the unverified cells are left: straight to the deepening step
+        }
+    }
+
     std::vector<mm_cell> sub_cells;
     std::vector<int> sub_rows;
     if (speculate) {
@@ -1454,16 +1762,17 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
             return st;
     }
     for (int round = 0;; ++round) {
-        if (speculate) {
-            HIP_TRY(e, hipMemcpyAsync(e->deep.p, deep.data(), (size_t)n_cells, hipMemcpyHostToDevice, e->stream), "Failed to copy list flags");
-            HIP_TRY(e, hipMemsetAsync(e->insufficient.p, 0, (size_t)n_cells, e->stream), "Failed to clear list flags");
+        if (!(round == 0 && have_verdicts)) {
+            if (speculate) {
+                HIP_TRY(e, hipMemcpyAsync(e->deep.p, deep.data(), (size_t)n_cells, hipMemcpyHostToDevice, e->stream), "Failed to copy list flags");
+                HIP_TRY(e, hipMemsetAsync(e->insufficient.p, 0, (size_t)n_cells, e->stream), "Failed to clear list flags");
+            }
+            st = resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
+                                repeat_addition, K, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p,
+                                best_fit_out, best_score_out,
+                                speculate ? (const uint8_t*)e->deep.p : nullptr, speculate ? (uint8_t*)e->insufficient.p : nullptr, Ks);
+            if (st) return st;
         }
-        // resolve_device re-uploads the cell records it was given on the device already
-        st = resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
-                            repeat_addition, K, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p,
-                            best_fit_out, best_score_out,
-                            speculate ? (const uint8_t*)e->deep.p : nullptr, speculate ? (uint8_t*)e->insufficient.p : nullptr, Ks);
-        if (st) return st;
         e->timing.spec_rounds = round + 1;
         if (!speculate) break;
         HIP_TRY(e, hipMemcpy(insufficient.data(), e->insufficient.p, (size_t)n_cells, hipMemcpyDeviceToHost), "Error copying list flags to host");
@@ -1483,9 +1792,10 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
         e->timing.deepened_cells += ns;
     }
     HIP_TRY(e, hipEventRecord(e->ev[7], e->stream), "event");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
     e->timing.pair_evals = count_pair_evals(e, cells, n_cells);
+    e->timing.host_syncs = e->syncs;
     return MM_OK;
 }
 
@@ -1524,7 +1834,7 @@ mm_status mm_shrink_library_bgr(mm_engine* e, int factor)
     mm::shrink_u8_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(
         (const uint8_t*)e->lib_bgr.p, (uint8_t*)e->stage_u8.p, e->n_lib_bgr, e->lib_bgr_size, factor);
     HIP_TRY(e, hipGetLastError(), "Error during library resize kernel");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     std::swap(e->lib_bgr, e->stage_u8);
     e->lib_bgr_size = so;
     return MM_OK;
@@ -1607,7 +1917,7 @@ mm_status mm_build_photomosaic_step(mm_engine* e, const mm_cell* cells, int n_ce
         HIP_TRY(e, hipMemcpyAsync(mosaic_out, e->mosaic.p, n_pixels * 4, hipMemcpyDeviceToHost, e->stream),
                 "Error copying photomosaic to host");
     HIP_TRY(e, hipEventRecord(e->ev[7], e->stream), "event");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "Failed to synchronise stream");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     e->timing = mm_timing{};
     e->timing.build_ms = elapsed(e->ev[4], e->ev[5]);
     e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
@@ -1647,7 +1957,7 @@ mm_status mm_debug_stream_read(mm_engine* e, size_t bytes, int repeats, double* 
         mm::stream_read_kernel<<<blocks, mm::kBlock, 0, e->stream>>>((const float4*)src.p, n_vec, (float*)sink.p);
         if ((code = hipGetLastError()) != hipSuccess) break;
         if ((code = hipEventRecord(e->ev[5], e->stream)) != hipSuccess) break;
-        if ((code = hipStreamSynchronize(e->stream)) != hipSuccess) break;
+        if ((code = sync_stream(e)) != hipSuccess) break;
         if (r > 0) best_ms = std::min(best_ms, (double)elapsed(e->ev[4], e->ev[5]));
     }
     release(src); release(sink);
@@ -1675,7 +1985,7 @@ mm_status mm_debug_filter_band_sweep(mm_engine* e, int mode, uint64_t seed, uint
                                             (unsigned long long*)buf.p, e->stream);
     unsigned long long raw[6] = {0};
     if (code == hipSuccess) code = hipMemcpyAsync(raw, buf.p, sizeof raw, hipMemcpyDeviceToHost, e->stream);
-    if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
+    if (code == hipSuccess) code = sync_stream(e);
     release(buf);
     if (code != hipSuccess) return hip_fail(e, code, "Error during filter band sweep", __FILE__, __LINE__);
     for (int k = 0; k < 4; ++k) memcpy(&out[k], &raw[k], sizeof(double));
@@ -1705,6 +2015,12 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "xcd_aware") == 0) { e->xcd_aware = value != 0; return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "item_auto") == 0) { e->item_auto = value != 0; return MM_OK; }
+    if (strcmp(name, "fused") == 0) { e->fused = value != 0; return MM_OK; }
+    if (strcmp(name, "fast_path") == 0) { e->fast_path = value != 0; return MM_OK; }
+    if (strcmp(name, "phase_timing") == 0) { e->phase_timing = value < 0 ? -1 : (value != 0); return MM_OK; }
+    if (strcmp(name, "fused_seeds") == 0) { e->fused_seed_cells = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "prune_min_kpairs") == 0) { e->prune_min_pairs = value < 0 ? -1 : value; return MM_OK; }
     if (strcmp(name, "band_pct") == 0) { e->band_pct = std::min(1000, std::max(-1000, value)); return MM_OK; }
     set_err(e, "mm_set_option: unknown option '%s'", name);
     return MM_INVALID_ARGUMENT;
@@ -1745,7 +2061,7 @@ mm_status mm_colour_diff_batch(mm_engine* e, int diff_type, const float* first, 
         code = hipGetLastError();
     }
     if (code == hipSuccess) code = hipMemcpyAsync(out, o.p, n * sizeof(double), hipMemcpyDeviceToHost, e->stream);
-    if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
+    if (code == hipSuccess) code = sync_stream(e);
     release(a); release(b); release(o);
     if (code != hipSuccess) return hip_fail(e, code, "Error during colour difference kernel", __FILE__, __LINE__);
     return MM_OK;
@@ -1775,7 +2091,7 @@ mm_status mm_filter_diff_batch(mm_engine* e, int diff_type, const float* first, 
                                     (const float*)a.p, (const float*)b.p, n, (float*)o.p, 1,
                                     (const float2*)e->hue_lut.p, e->stream);
     if (code == hipSuccess) code = hipMemcpyAsync(out, o.p, n * sizeof(float), hipMemcpyDeviceToHost, e->stream);
-    if (code == hipSuccess) code = hipStreamSynchronize(e->stream);
+    if (code == hipSuccess) code = sync_stream(e);
     release(a); release(b); release(o);
     if (code != hipSuccess) return hip_fail(e, code, "Error during filter difference kernel", __FILE__, __LINE__);
     return MM_OK;

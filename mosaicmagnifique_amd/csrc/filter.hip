@@ -367,7 +367,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && groups > 0 && cand_per_block <= 64 && var.two_stage != 0;
     if (two_level && threadIdx.x < 2) alive_mask[threadIdx.x] = 0u;
     if (use_lb || CELL_LDS || n_seeds > 0) __syncthreads();   // workgroup-uniform
-    if (two_level) {
+    if constexpr (TYPE == CIEDE2000) if (two_level) {         // (the statistics arrays exist for CIEDE2000 only)
         // lanes (q, g): candidate q of the pass, group g < groups -- 64 / groups candidates per pass (four at 16 groups,
         // seven at the 9 groups of a 48 x 48 cell), packed so that no lane idles on a group the cell does not have
         const int per_pass = kWave / groups;
@@ -1059,6 +1059,157 @@ seed_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
     }
 }
 
+// seed_kernel + seed_score_kernel + prune_limit_kernel in ONE launch, one workgroup per cell, for batches small
+// enough that three dependent launches cost more than the balance they buy (the separate seed_score_kernel spreads
+// the (cell, seed) pairs over the whole device at its own occupancy; config D keeps it).  Same seeds (the same
+// selection code), the same per-seed arithmetic and lane assignment as seed_score_kernel, the same limit formula.
+template <int TYPE>
+__global__ void __launch_bounds__(kBlock)
+seed_fused_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
+                  const float* __restrict__ cell_chroma, const float* __restrict__ lib,
+                  const float* __restrict__ lib_chroma, const float* __restrict__ lib_means,
+                  int L, int ppad, int M, int K, float px_abs, float rel,
+                  int32_t* __restrict__ seeds, float* __restrict__ seed_score, float* __restrict__ limit,
+                  float* __restrict__ scores, const HueEntry* __restrict__ hue_lut, Variants var)
+{
+    __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
+    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
+    __shared__ float red[4][kBlock / kWave];
+    __shared__ float best_v[kBlock / kWave];
+    __shared__ int best_i[kBlock / kWave];
+    __shared__ float cand_v[2 * kBlock];
+    __shared__ int cand_i[2 * kBlock];
+    __shared__ int picked[256];              // the M seeds
+    __shared__ float picked_score[256];
+    const int cell = blockIdx.x;
+    const float* c = cells + (size_t)cell * 3 * ppad;
+    const uint8_t* mkb = cmask + (size_t)cell * ppad;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, n = 0.f;
+    for (int p = threadIdx.x; p < ppad; p += kBlock)
+        if (mkb[p]) { s0 += c[p]; s1 += c[ppad + p]; s2 += c[2 * (size_t)ppad + p]; n += 1.f; }
+    s0 = wave_sum_f(s0); s1 = wave_sum_f(s1); s2 = wave_sum_f(s2); n = wave_sum_f(n);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; red[3][wave] = n; }
+    __syncthreads();
+    float t[4];
+    for (int k = 0; k < 4; ++k) { t[k] = 0.f; for (int w = 0; w < kBlock / kWave; ++w) t[k] += red[k][w]; }
+    const float n_active = t[3];
+    const float inv = 1.0f / fmaxf(t[3], 1.0f);
+    const PxF mean{t[0] * inv, t[1] * inv, t[2] * inv};
+    const float mean_c = chroma_of(mean.c1, mean.c2);
+    float v0 = __builtin_huge_valf(), v1 = __builtin_huge_valf();
+    int i0 = 0x7fffffff, i1 = 0x7fffffff;
+    for (int l = threadIdx.x; l < L; l += kBlock) {
+        bool e;
+        const PxF lm{lib_means[3 * l], lib_means[3 * l + 1], lib_means[3 * l + 2]};
+        const float d = pair_fast<TYPE>(mean, lm, mean_c, chroma_of(lm.c1, lm.c2), lut, &e);
+        if (d < v0) { v1 = v0; i1 = i0; v0 = d; i0 = l; }
+        else if (d < v1) { v1 = d; i1 = l; }
+    }
+    cand_v[threadIdx.x] = v0; cand_i[threadIdx.x] = i0;
+    cand_v[kBlock + threadIdx.x] = v1; cand_i[kBlock + threadIdx.x] = i1;
+    __syncthreads();
+    for (int r = 0; r < M; ++r) {
+        float v = cand_v[threadIdx.x];
+        int i = cand_i[threadIdx.x];
+        {
+            const float ov = cand_v[kBlock + threadIdx.x];
+            const int oi = cand_i[kBlock + threadIdx.x];
+            if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off, kWave);
+            const int oi = __shfl_xor(i, off, kWave);
+            if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+        }
+        if (lane == 0) { best_v[wave] = v; best_i[wave] = i; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kBlock / kWave; ++w)
+                if (best_v[w] < v || (best_v[w] == v && best_i[w] < i)) { v = best_v[w]; i = best_i[w]; }
+            const int id = (i == 0x7fffffff) ? -1 : i;
+            seeds[(size_t)cell * M + r] = id;
+            picked[r] = id;
+            if (i != 0x7fffffff) {
+                const int tq = i % kBlock;
+                if (cand_i[tq] == i) { cand_v[tq] = __builtin_huge_valf(); cand_i[tq] = 0x7fffffff; }
+                else { cand_v[kBlock + tq] = __builtin_huge_valf(); cand_i[kBlock + tq] = 0x7fffffff; }
+            }
+        }
+        __syncthreads();
+    }
+
+    // the seeds' filter scores: one wave per seed (seed_score_kernel's loop)
+    {
+        const int v = var.cell_var[cell];
+        const int groups = var.groups[v];
+        const float* vlib = lib + (size_t)v * var.lib_stride;
+        const float* vchroma = lib_chroma + (size_t)v * var.chroma_stride;
+        const float4* c0 = reinterpret_cast<const float4*>(c);
+        const float4* c1 = c0 + ppad / 4;
+        const float4* c2 = c1 + ppad / 4;
+        const uint32_t* mk = reinterpret_cast<const uint32_t*>(mkb);
+        const float4* cc = reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
+        for (int slot = wave; slot < M; slot += kBlock / kWave) {
+            const int l = picked[slot];
+            float acc = __builtin_huge_valf();
+            if (l >= 0) {
+                const float4* b0 = reinterpret_cast<const float4*>(vlib + (size_t)l * 3 * ppad);
+                const float4* b1 = b0 + ppad / 4;
+                const float4* b2 = b1 + ppad / 4;
+                const float4* bc = reinterpret_cast<const float4*>(vchroma + (size_t)l * ppad);
+                acc = 0.0f;
+                for (int j = 0; j < groups; ++j) {
+                    const int q = lane + kWave * j;
+                    const uint32_t m = mk[q];
+                    if (m == 0) continue;
+                    const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
+                    const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
+                    float4 pc{0.f, 0.f, 0.f, 0.f}, qc{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (TYPE == CIEDE2000) { pc = cc[q]; qc = bc[q]; }
+                    const float w0 = pair_seed<TYPE>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut);
+                    const float w1 = pair_seed<TYPE>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut);
+                    const float w2 = pair_seed<TYPE>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut);
+                    const float w3 = pair_seed<TYPE>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut);
+                    acc += ((m & 0x000000ffu) ? w0 : 0.0f) + ((m & 0x0000ff00u) ? w1 : 0.0f)
+                         + ((m & 0x00ff0000u) ? w2 : 0.0f) + ((m & 0xff000000u) ? w3 : 0.0f);
+                }
+                acc = wave_sum_f(acc);
+            }
+            if (lane == 0) {
+                seed_score[(size_t)cell * M + slot] = acc;
+                picked_score[slot] = acc;
+                if (l >= 0 && scores) scores[(size_t)cell * L + l] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    // the limit: K-th lowest seed score + the band (prune_limit_kernel), by wave 0
+    if (wave == 0) {
+        float vv[4];
+        for (int k = 0; k < 4; ++k) vv[k] = (lane + kWave * k < M) ? picked_score[lane + kWave * k] : __builtin_huge_valf();
+        float kth = __builtin_huge_valf();
+        for (int r = 0; r < K; ++r) {
+            const float m = fminf(fminf(vv[0], vv[1]), fminf(vv[2], vv[3]));
+            float w = m;
+            for (int off = 32; off > 0; off >>= 1) w = fminf(w, __shfl_xor(w, off, kWave));
+            kth = w;
+            const unsigned long long holders = __ballot(m == w);
+            if (holders == 0) break;
+            if (lane == __ffsll((long long)holders) - 1) {
+                if (vv[0] == w) vv[0] = __builtin_huge_valf();
+                else if (vv[1] == w) vv[1] = __builtin_huge_valf();
+                else if (vv[2] == w) vv[2] = __builtin_huge_valf();
+                else vv[3] = __builtin_huge_valf();
+            }
+        }
+        if (lane == 0) {
+            const float err = n_active * px_abs + fabsf(kth) * rel;
+            limit[cell] = (kth + 2.0f * err) * 1.0001f + 1e-3f;
+        }
+    }
+}
+
 // Pruning limit of one cell from its seeds' filter scores: the K-th lowest seed score
 // is an upper bound on the cell's K-th lowest filter score v_K, so nothing scoring
 // above  it + 2*err  can be a contender (contenders_kernel keeps filter <= v_K + 2 err).
@@ -1243,7 +1394,7 @@ hipError_t launch_band_sweep(int mode, unsigned long long seed, unsigned long lo
 
 hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
-                         const float* prune_above, hipStream_t stream)
+                         const float* prune_above, hipStream_t stream, int* tile_used)
 {
     const int groups = std::max(std::max(in.var.groups[0], in.var.groups[1]), std::max(in.var.groups[2], in.var.groups[3]));
     // Candidates per item and cells per XCD sub-group, measured at 32 / 48 / 64 x 32 / 64 / 128: small cells (config E's
@@ -1282,11 +1433,12 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     if (type == CIEDE2000 && in.use_lds_form && prune_above != nullptr && groups <= kWave / 4 && (size_t)ppad * 12 <= 56 * 1024) {
         constexpr int kTileThreads = 640;
         const int cpb = in.tile_candidates > 0 ? in.tile_candidates : 64;
+        if (tile_used) *tile_used = cpb;
         const long long tiles = (L + cpb - 1) / cpb, items = (long long)n_cells * tiles;
         if (items <= 0 || items > 0x7fffffffLL) return hipErrorInvalidValue;
         const int shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
         const int sub = shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : 64) : 512;
-        hipError_t code = hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);
+        hipError_t code = in.counters_cleared ? hipSuccess : hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);
         if (code != hipSuccess) return code;
         auto kern = in.lib_il && in.cells_il ? filter_kernel<CIEDE2000, kTileThreads, true, true> : filter_kernel<CIEDE2000, kTileThreads, true, false>;
         const bool il = in.lib_il && in.cells_il;
@@ -1304,16 +1456,26 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     const long long n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const long long blocks = (long long)n_cells * n_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (tile_used) *tile_used = cand_per_block;
     // one share of the cells per XCD (8 on MI355X); small launches keep one share so no XCD idles on an empty one
     const int xcd_shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
     const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : (small_cells ? 128 : 64)) : cell_group;
     const int check_every = groups > 16 ? groups / 16 : 1;
-    hipError_t code = hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);  // + work counters, item counters
+    hipError_t code = in.counters_cleared ? hipSuccess
+                                          : hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);  // + work counters, item counters
     if (code != hipSuccess) return code;
     // LDS-resident form when the cell (4 planes + mask) fits beside the hue table
     const size_t lds_bytes = type == CIEDE2000 ? (size_t)kHueLutEntries * sizeof(HueEntry) + (size_t)ppad * 16 : (size_t)ppad * 12;
     if (in.use_lds_form && lds_bytes <= 156 * 1024) {
-        const int cpb = 64;
+        // Candidates per item: a workgroup stages the cell once per item, so the longer the item the less staging and
+        // the fewer barriers -- config B (1024 cells x 1000 images): 0.451 / 0.365 / 0.328 / 0.300 ms at 64 / 128 / 256 /
+        // 1000 -- as long as the launch still has a few items per workgroup slot of the device (2 x 256 CUs).
+        int cpb = in.tile_candidates;
+        if (cpb <= 0) {
+            const long long want = ((long long)L * n_cells / 2048 + 15) / 16 * 16;
+            cpb = (int)std::min<long long>(std::max<long long>(want, 64), std::max(L, 64));
+        }
+        if (tile_used) *tile_used = cpb;
         const long long tiles = (L + cpb - 1) / cpb;
         const long long nblk = (long long)n_cells * tiles;
         if (type == CIEDE2000) {
@@ -1400,6 +1562,15 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
                                float* seed_score, float* limit, float* scores, hipStream_t stream)
 {
     if (M > 256 || M < K) return hipErrorInvalidValue;
+    if (in.fused_seeds) {
+        if (type == CIEDE2000)
+            seed_fused_kernel<CIEDE2000><<<n_cells, kBlock, 0, stream>>>(in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, lib_means,
+                                                                         L, ppad, M, K, px_abs, rel, seeds, seed_score, limit, scores, in.hue_lut, in.var);
+        else
+            seed_fused_kernel<RGB_EUCLIDEAN><<<n_cells, kBlock, 0, stream>>>(in.cells, in.cmask, in.cell_chroma, in.lib, in.lib_chroma, lib_means,
+                                                                             L, ppad, M, K, px_abs, rel, seeds, seed_score, limit, scores, in.hue_lut, in.var);
+        return hipGetLastError();
+    }
     const size_t lds = 0;
     const long long waves = (long long)n_cells * M;
     const unsigned score_blocks = (unsigned)std::min<long long>((waves + 3) / 4, 8192);   // grid-stride: the hue table once per workgroup

@@ -21,6 +21,7 @@
 
 #include "../../include/mosaic_hip.h"
 #include "colour_diff.hpp"
+#include "colour_diff_fast.hpp"
 #include "launch.hpp"
 
 namespace mm {
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(kBlock)
 gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ target,
                     int rows, int cols, CellResize scale, const uint8_t* __restrict__ masks,
                     float* __restrict__ cells, uint8_t* __restrict__ cmask,
-                    int size, int P, int ppad, const int* __restrict__ perm, int4 var_of_mask,
+                    int size, int /*P*/, int ppad, const int* __restrict__ perm, int4 var_of_mask,
                     uint8_t* __restrict__ cell_var, uint8_t* __restrict__ cell_full,
                     float* __restrict__ cells_f0)
 {
@@ -382,6 +383,115 @@ gather_cells_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ 
     // active: every filter term of such a pixel comes out as max(NaN, 0) = 0, so the filter
     // kernels need no mask (filter.hip).
     if (cells_f0) cells_f0[(size_t)blockIdx.y * ppad + k] = m ? v0 : __builtin_nanf("");
+}
+
+// Angle in degrees wrapped into [-180, 180].
+__device__ __forceinline__ float wrap180_deg(float v) { return fmaf(-360.0f, rintf(v * (1.0f / 360.0f)), v); }
+
+// gather_cells_kernel and everything the fp32 filter wants of a cell, in ONE launch: one workgroup per
+// (cell, 256-position group), one wave per 64-position block of the plane order.  Beside the planes, the
+// active mask and the NaN-marked channel 0 it writes
+//   * the seven block statistics of the early-exit bound (what filter.hip group_sums_kernel computes for the
+//     library: sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma, hue arc centre
+//     and half-width; LAB = false: the three sums only, the rest is CIEDE2000's) -- a wave holds the block,
+//     so the statistics are wave reductions of values already in registers;
+//   * LAB: the chroma plane and the interleaved copy [group][plane][256] with the prepared operands
+//     L / 2 - 25, a, b, C / 50 and NaN in L and a at inactive pixels (filter.hip interleave_kernel).
+// Replaces four launches per batch (gather, chroma planes, interleave, group sums).  The statistics feed
+// a bound that carries its own slack for the fp32 summation order; nothing here decides a result.
+// Grid: (ppad / 256, cells) exactly -- every lane of every wave takes part in the reductions.
+template <bool LAB>
+__global__ void __launch_bounds__(kBlock)
+gather_prepare_kernel(const mm_cell* __restrict__ recs, const float* __restrict__ target,
+                      int rows, int cols, CellResize scale, const uint8_t* __restrict__ masks,
+                      float* __restrict__ cells, uint8_t* __restrict__ cmask,
+                      int size, int /*P*/, int ppad, const int* __restrict__ perm, int4 var_of_mask,
+                      uint8_t* __restrict__ cell_var, uint8_t* __restrict__ cell_full,
+                      float* __restrict__ cells_f0, float* __restrict__ cell_chroma,
+                      float* __restrict__ cells_il, float* __restrict__ stats, size_t stats_stride, int n_blocks)
+{
+    const int cell = blockIdx.y;
+    const mm_cell rec = recs[cell];
+    const int vm[4] = {var_of_mask.x, var_of_mask.y, var_of_mask.z, var_of_mask.w};
+    const int v = vm[rec.mask_id];
+    const int k = blockIdx.x * kBlock + threadIdx.x;     // position in the variant's pixel order (< ppad)
+    if (k == 0) {
+        cell_var[cell] = (uint8_t)v;
+        cell_full[cell] = rec.row_min == 0 && rec.col_min == 0 && rec.row_max == size && rec.col_max == size;
+    }
+    const int p = perm[(size_t)v * ppad + k];            // original pixel, < 0 = padding
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    bool m = false;
+    if (p >= 0) {
+        const int row = p / size, col = p - row * size;
+        if (row >= rec.row_min && row < rec.row_max && col >= rec.col_min && col < rec.col_max) {
+            float px[3];
+            cell_pixel(target, rows, cols, rec.y, rec.x, row, col, scale, px);
+            v0 = px[0]; v1 = px[1]; v2 = px[2];
+            m = masks[(size_t)rec.mask_id * ppad + p] != 0;
+        }
+    }
+    float* dst = cells + (size_t)cell * 3 * ppad + k;
+    dst[0] = v0;
+    dst[ppad] = v1;
+    dst[2 * (size_t)ppad] = v2;
+    cmask[(size_t)cell * ppad + k] = m ? 1 : 0;
+    const float nan = __builtin_nanf("");
+    const float f0 = m ? v0 : nan;
+    cells_f0[(size_t)cell * ppad + k] = f0;
+    float ch = 0.f;
+    if constexpr (LAB) {
+        ch = chroma_of(v1, v2);
+        cell_chroma[(size_t)cell * ppad + k] = ch;
+        if (cells_il) {
+            float* il = cells_il + (size_t)cell * 4 * ppad + (size_t)(k >> 8) * 1024 + (k & 255);
+            il[0] = fmaf(0.5f, f0, -25.0f);                          // NaN stays NaN
+            il[256] = m ? v1 : nan;
+            il[512] = v2;
+            il[768] = __fmul_rn(0.02f, ch);
+        }
+    }
+
+    // block statistics: this wave = block 4 * blockIdx.x + wave of the cell
+    float s0 = m ? v0 : 0.f, s1 = m ? v1 : 0.f, s2 = m ? v2 : 0.f;
+    float dev = m ? fabsf(v0 - 50.0f) : 0.f, cmax = m ? ch : 0.f;
+    int anywhere = (LAB && m && !(ch >= 1e-3f)) ? 1 : 0, any = m ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off, kWave); s1 += __shfl_xor(s1, off, kWave); s2 += __shfl_xor(s2, off, kWave);
+        if constexpr (LAB) {
+            dev = fmaxf(dev, __shfl_xor(dev, off, kWave));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, off, kWave));
+            anywhere |= __shfl_xor(anywhere, off, kWave);
+            any |= __shfl_xor(any, off, kWave);
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    float* o = stats + (size_t)cell * n_blocks + 4 * blockIdx.x + (threadIdx.x >> 6);
+    if constexpr (!LAB) {
+        if (lane == 0) { o[0] = s0; o[2 * stats_stride] = s1; o[3 * stats_stride] = s2; }
+    } else {
+        // every active pixel's hue (both ends of its (1 + G) range) against the direction of the block's sum
+        const float ref = atan2f(s2, s1) * 57.29577951308232f;
+        float dlo = 180.0f, dhi = -180.0f, far = 0.0f;
+        if (m) {
+            const float e1 = wrap180_deg(atan2f(v2, v1) * 57.29577951308232f - ref);
+            const float e2 = wrap180_deg(atan2f(v2, 1.5f * v1) * 57.29577951308232f - ref);
+            dlo = fminf(e1, e2); dhi = fmaxf(e1, e2);
+            far = fmaxf(fabsf(e1), fabsf(e2));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            dlo = fminf(dlo, __shfl_xor(dlo, off, kWave)); dhi = fmaxf(dhi, __shfl_xor(dhi, off, kWave));
+            far = fmaxf(far, __shfl_xor(far, off, kWave));
+        }
+        if (lane == 0) {
+            o[0] = s0; o[stats_stride] = dev; o[2 * stats_stride] = s1; o[3 * stats_stride] = s2; o[4 * stats_stride] = cmax;
+            const bool open = anywhere || !any || !(far <= 170.0f) || !(fmaf(s1, s1, s2 * s2) >= 1e-6f);
+            o[5 * stats_stride] = open ? 0.0f : wrap180_deg(ref + 0.5f * (dlo + dhi) - 275.0f);
+            o[6 * stats_stride] = open ? 180.0f : 0.5f * (dhi - dlo) + 0.02f;
+        }
+    }
 }
 
 // Largest grid of kBlock-thread workgroups HIP launches whole: gridDim x blockDim stays below 2^32.
@@ -664,7 +774,7 @@ rerank_kernel(const int32_t* __restrict__ cont_index, const float* __restrict__ 
               int Kc, int K, int ppad, FilterBand band, double tie_band,
               int32_t* __restrict__ cand_index, double* __restrict__ cand_score,
               uint8_t* __restrict__ flags, int KW, const int* __restrict__ row_map,
-              const int32_t* __restrict__ sentinel)
+              const int32_t* __restrict__ sentinel, int L)
 {
     __shared__ ScoreIdx sh[kBlock / kWave];
     __shared__ int n_active;
@@ -681,6 +791,16 @@ rerank_kernel(const int32_t* __restrict__ cont_index, const float* __restrict__ 
     for (int q = threadIdx.x; q < ppad / 4; q += kBlock) act += __popc(mk[q] & 0x01010101u);
     atomicAdd(&n_active, act);
     __syncthreads();
+    if (n_active == 0) {
+        // no active pixel: the cell scores exactly 0 against every image, in the reference's own sum too -- the list is
+        // the K lowest indices, exact, so neither an overflow mark nor the fp64-only re-run (see rank_kernel)
+        for (int t = threadIdx.x; t < K; t += kBlock) {
+            cand_index[out + t] = t < L ? t : -1;
+            cand_score[out + t] = t < L ? 0.0 : kInf;
+        }
+        if (threadIdx.x == 0) flags[blockIdx.x] = 0;
+        return;
+    }
 
     int bad = 0;
     for (int t = threadIdx.x; t < Kc; t += kBlock) {
@@ -728,6 +848,250 @@ rerank_kernel(const int32_t* __restrict__ cont_index, const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// one read-back per generate: the result block
+// ---------------------------------------------------------------------------
+//
+// mm_generate's single-submission path enqueues every kernel of a generate without asking the host anything
+// in between; whatever the host used to decide from (cells the filter could not vouch for, overflow marks,
+// sweeps that still changed picks, speculative picks left unverified) is counted into this header, which
+// comes back in the SAME copy as the best-fit grid and the scores that follow it in memory.  All zero (and
+// one sweep without a change) = the result is final; anything else sends the call down the step-by-step
+// path, which recomputes what the header says cannot be trusted.
+constexpr int kFastSweeps = 8;
+struct ResultHeader {
+    unsigned int n_flagged;              // cells with a filter flag (overflow, canary, band alarm)
+    unsigned int n_band_alarm;           // ... of which band alarms
+    unsigned int n_marked;               // full-length lists cut through a near-tie cluster
+    unsigned int n_insufficient;         // speculative picks the resolve could not prove (no-repeat resolve; sweeps: sweep_insufficient)
+    unsigned int edge_pairs;             // discontinuity pairs logged by the filter launch
+    unsigned int sweeps;                 // sweeps enqueued
+    unsigned int sweep_changes[kFastSweeps];
+    unsigned int pad[2];
+    unsigned long long work[3];          // filter work counters: groups visited, groups of a full visit, bound-dropped
+    unsigned long long exact_plain, dense_count, pad64;
+    unsigned long long sweep_exact[kFastSweeps];
+    unsigned int sweep_insufficient[kFastSweeps];   // unverified speculative picks per sweep (the last enqueued one counts)
+    // the filter launch's counter block (launch.hpp kFilterCounterWords), written by the filter kernels themselves
+    unsigned int filter_counters[kFilterCounterWords];
+};
+static_assert(sizeof(ResultHeader) % 16 == 0, "the grid follows the header, 8-byte aligned");
+
+// contenders_kernel + rescore_kernel + rerank_kernel in ONE launch, one workgroup per cell: the contender list
+// lives in LDS, the four waves share the contenders' fp64 re-scores (same lane / pixel assignment and summation
+// order as rescore_kernel, so the scores are bit-identical to the three-kernel form), then the K lowest are
+// ranked from LDS.  Saves two launches per batch and the (cell, empty slot) waves of the separate re-score.
+// A cell with NO active pixel (a sliver of an offset shape whose bound misses the mask) scores exactly 0
+// against every image, in the reference's own sum too (CPUPhotomosaicGenerator.cpp:143-161 adds nothing):
+// its list is the K lowest indices with score 0 -- exact, so no overflow mark and no fp64-only re-run.
+// Dynamic LDS: Kc * 16 bytes (f64 scores | i32 indices | f32 filter scores).
+template <int TYPE>
+__global__ void __launch_bounds__(kBlock)
+rank_kernel(const float* __restrict__ fscores, const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
+            const float* __restrict__ lib, int L, int ppad, int K, int Kc, FilterBand band, double tie_band,
+            int32_t* __restrict__ cand_index, double* __restrict__ cand_score, uint8_t* __restrict__ flags,
+            int KW, const int* __restrict__ row_map, int sample_every, Variants var,
+            ResultHeader* __restrict__ hdr, int count_marks)
+{
+    // hdr (may be null): flagged cells -- and, when the lists are final (count_marks), overflow marks -- are counted into
+    // the result block's header, so the single-submission path needs no summary launch
+    extern __shared__ double rank_lds[];
+    double* cs = rank_lds;                                        // [Kc]
+    int32_t* ci = reinterpret_cast<int32_t*>(cs + Kc);            // [Kc]
+    float* cf = reinterpret_cast<float*>(ci + Kc);                // [Kc]
+    __shared__ ScoreIdx sh[kBlock / kWave];
+    __shared__ int n_cont;
+    __shared__ int n_active;
+    const int cell = blockIdx.x;
+    const float* row = fscores + (size_t)cell * L;
+    const size_t out = (size_t)(row_map ? row_map[cell] : cell) * KW;
+    for (int t = K + threadIdx.x; t < KW; t += kBlock) { cand_index[out + t] = -1; cand_score[out + t] = kInf; }
+    if (threadIdx.x == 0) { n_cont = 0; n_active = 0; }
+    __syncthreads();
+    int act = 0;
+    const uint32_t* mk = reinterpret_cast<const uint32_t*>(cmask + (size_t)cell * ppad);
+    for (int q = threadIdx.x; q < ppad / 4; q += kBlock) act += __popc(mk[q] & 0x01010101u);
+    atomicAdd(&n_active, act);
+    __syncthreads();
+    if (n_active == 0) {
+        for (int t = threadIdx.x; t < K; t += kBlock) {
+            cand_index[out + t] = t < L ? t : -1;
+            cand_score[out + t] = t < L ? 0.0 : kInf;
+        }
+        if (threadIdx.x == 0) flags[cell] = 0;
+        return;
+    }
+
+    // K-th lowest filter score (ties by index)
+    double prev_s = -kInf;
+    int prev_i = -1;
+    for (int r = 0; r < K; ++r) {
+        ScoreIdx best{kInf, 0x7fffffff};
+        for (int l = threadIdx.x; l < L; l += kBlock) {
+            const double s = (double)row[l];
+            if (lex_less(prev_s, prev_i, s, l) && lex_less(s, l, best.s, best.i)) { best.s = s; best.i = l; }
+        }
+        best = block_min(best, sh);
+        if (best.i == 0x7fffffff) break;
+        prev_s = best.s;
+        prev_i = best.i;
+    }
+    const double err_k = (double)n_active * band.px_abs + fabs(prev_s) * band.rel;
+    const double thr = (prev_i < 0) ? kInf : prev_s + 2.0 * err_k;
+    for (int l = threadIdx.x; l < L; l += kBlock) {
+        const float s = row[l];
+        if ((double)s <= thr) {
+            const int slot = atomicAdd(&n_cont, 1);
+            if (slot < Kc) { ci[slot] = l; cf[slot] = s; }
+        }
+    }
+    __syncthreads();
+    const int n = n_cont;
+    int flag = n > Kc ? 1 : 0;
+    // band guard (sampled cells): the best candidate the band EXCLUDED rides along as a sentinel
+    int sent = -1;
+    if (sample_every > 0 && (unsigned)cell % (unsigned)sample_every == 0 && n < Kc) {
+        ScoreIdx best{kInf, 0x7fffffff};
+        for (int l = threadIdx.x; l < L; l += kBlock) {
+            const double sc = (double)row[l];
+            if (sc > thr && sc < kInf && lex_less(sc, l, best.s, best.i)) { best.s = sc; best.i = l; }
+        }
+        best = block_min(best, sh);
+        if (best.i != 0x7fffffff) {
+            sent = n;
+            if (threadIdx.x == 0) { ci[n] = best.i; cf[n] = (float)best.s; }
+        }
+    }
+    const int n_slots = min(n, Kc) + (sent >= 0 ? 1 : 0);
+    __syncthreads();
+
+    // fp64 reference-form score of every contender: one wave per slot
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int v = var.cell_var[cell];
+        const int groups = var.groups[v];
+        const float* vlib = lib + (size_t)v * var.lib_stride;
+        const float4* c0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
+        const float4* c1 = c0 + ppad / 4;
+        const float4* c2 = c1 + ppad / 4;
+        for (int t = wave; t < n_slots; t += kBlock / kWave) {
+            const int l = ci[t];
+            const float4* b0 = reinterpret_cast<const float4*>(vlib + (size_t)l * 3 * ppad);
+            const float4* b1 = b0 + ppad / 4;
+            const float4* b2 = b1 + ppad / 4;
+            double acc = 0.0;
+            for (int j = 0; j < groups; ++j) {
+                const int q = lane + kWave * j;
+                const uint32_t m = mk[q];
+                if (m == 0) continue;
+                const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
+                const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
+                if (m & 0x000000ffu) acc += colour_diff<TYPE>(Px{p0.x, p1.x, p2.x}, Px{q0.x, q1.x, q2.x});
+                if (m & 0x0000ff00u) acc += colour_diff<TYPE>(Px{p0.y, p1.y, p2.y}, Px{q0.y, q1.y, q2.y});
+                if (m & 0x00ff0000u) acc += colour_diff<TYPE>(Px{p0.z, p1.z, p2.z}, Px{q0.z, q1.z, q2.z});
+                if (m & 0xff000000u) acc += colour_diff<TYPE>(Px{p0.w, p1.w, p2.w}, Px{q0.w, q1.w, q2.w});
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) cs[t] = acc;
+        }
+    }
+    __syncthreads();
+
+    // canary: a contender whose filter score is further from its fp64 score than a quarter of the band
+    int bad = 0;
+    for (int t = threadIdx.x; t < n_slots; t += kBlock) {
+        const double err = (double)n_active * band.px_abs + fabs(cs[t]) * band.rel;
+        if (!(fabs((double)cf[t] - cs[t]) <= 0.25 * err)) bad = 1;     // also catches NaN
+    }
+    if (__syncthreads_or(bad)) flag |= 2;
+
+    // the K lowest (fp64 score, index), the overflow mark, the band guard's verdict
+    prev_s = -kInf;
+    prev_i = -1;
+    for (int r = 0; r <= K; ++r) {
+        ScoreIdx best{kInf, 0x7fffffff};
+        for (int t = threadIdx.x; t < n_slots; t += kBlock) {
+            if (t == sent) continue;
+            const int l = ci[t];
+            const double s = cs[t];
+            if (lex_less(prev_s, prev_i, s, l) && lex_less(s, l, best.s, best.i)) { best.s = s; best.i = l; }
+        }
+        best = block_min(best, sh);
+        const bool none = best.i == 0x7fffffff;
+        if (r < K && sent >= 0 && (none || (r == K - 1 && lex_less(cs[sent], ci[sent], best.s, best.i)))) flag |= 4;
+        if (r == K) {
+            if (!none && threadIdx.x == 0 && best.s <= prev_s + fabs(prev_s) * (4.0 * tie_band)) {
+                cand_index[out + K - 1] = -(prev_i + 2);
+                if (hdr && count_marks) atomicAdd(&hdr->n_marked, 1u);
+            }
+            break;
+        }
+        if (threadIdx.x == 0) {
+            cand_index[out + r] = none ? -1 : best.i;
+            cand_score[out + r] = none ? kInf : best.s;
+        }
+        if (none) {
+            for (int t = r + 1 + threadIdx.x; t < K; t += kBlock) {
+                cand_index[out + t] = -1;
+                cand_score[out + t] = kInf;
+            }
+            break;
+        }
+        prev_s = best.s;
+        prev_i = best.i;
+    }
+    if (threadIdx.x == 0) {
+        flags[cell] = (uint8_t)flag;
+        if (hdr && flag) { atomicAdd(&hdr->n_flagged, 1u); if (flag & 4) atomicAdd(&hdr->n_band_alarm, 1u); }
+    }
+}
+
+// Header zeroed (with it the filter kernels' counter block: no memset sits in the stream), grid filled with the
+// sentinel (CUDAPhotomosaicGenerator.cpp:140-149), scores with NaN; optional byte arrays cleared (list flags).
+__global__ void __launch_bounds__(kBlock)
+result_init_kernel(ResultHeader* __restrict__ hdr, long long* __restrict__ grid, double* __restrict__ best,
+                   size_t cells_total, long long sentinel, uint8_t* __restrict__ clear_a, uint8_t* __restrict__ clear_b, int clear_n)
+{
+    if (blockIdx.x == 0) {
+        unsigned int* w = reinterpret_cast<unsigned int*>(hdr);
+        for (int t = threadIdx.x; t < (int)(sizeof(ResultHeader) / 4); t += kBlock) w[t] = 0u;
+    }
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < clear_n; t += gridDim.x * kBlock) {
+        if (clear_a) clear_a[t] = 0;
+        if (clear_b) clear_b[t] = 0;
+    }
+    const double nan = __builtin_nan("");
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < cells_total; t += (size_t)gridDim.x * kBlock) {
+        grid[t] = sentinel;
+        best[t] = nan;
+    }
+}
+
+// Same fill for the step-by-step resolve (no header).
+__global__ void __launch_bounds__(kBlock)
+grid_fill_kernel(long long* __restrict__ grid, double* __restrict__ best, size_t cells_total, long long sentinel)
+{
+    const double nan = __builtin_nan("");
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < cells_total; t += (size_t)gridDim.x * kBlock) {
+        grid[t] = sentinel;
+        best[t] = nan;
+    }
+}
+
+// Filter flags folded into the header where the ranking kernel did not count them itself (option "fused" 0).
+__global__ void __launch_bounds__(kBlock)
+result_summary_kernel(ResultHeader* __restrict__ hdr, const uint8_t* __restrict__ flags, int n_cells)
+{
+    int nf = 0, na = 0;
+    for (int c = threadIdx.x; c < n_cells; c += kBlock) {
+        const uint8_t f = flags[c];
+        nf += f != 0;
+        na += (f & 4) != 0;
+    }
+    if (nf) atomicAdd(&hdr->n_flagged, (unsigned int)nf);
+    if (na) atomicAdd(&hdr->n_band_alarm, (unsigned int)na);
+}
+
+// ---------------------------------------------------------------------------
 // resolve: repeat penalty + argmin + exact tie-break, in the reference's order
 // ---------------------------------------------------------------------------
 
@@ -764,6 +1128,7 @@ struct ResolveArgs {
     const double* dense_rows;   // [marked][L]
     // sweep resolve (resolve_wave_kernel mode 2): picks changed by this sweep
     unsigned int* sweep_changes;
+    unsigned int* insufficient_count;   // (may be null) unverified speculative picks of this launch, counted
 };
 
 // Repeat value of library image `cand` at padded cell (px, py):
@@ -1186,7 +1551,10 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
                 const double b_last = nvalid > 0 ? __shfl(s0, nvalid - 1, kWave) : -kInf;
                 insuff = !(chosen != a.L && chosen_total + fabs(chosen_total) * a.tie_band < b_last);
             }
-            if (lane == 0) a.insufficient[c] = insuff ? 1 : 0;
+            if (lane == 0) {
+                a.insufficient[c] = insuff ? 1 : 0;
+                if (insuff && a.insufficient_count) atomicAdd(a.insufficient_count, 1u);
+            }
         }
         if (lane == 0) {
             const size_t pos = (size_t)py * gw + px;

@@ -50,6 +50,8 @@ struct FilterInputs {
                                 // plane order (cells up to 64 x 64); 0: plane order
     const float* lib_il;        // interleaved copies for filter_kernel<IL> (launch_interleave): [V][L][ppad/256][4][256] and
     const float* cells_il;      // [B][ppad/256][4][256] (plane 0 = cells_f0); null: the planar arrays are read
+    int counters_cleared;       // 1: the counter block was zeroed by an earlier kernel of the stream (no memset here)
+    int fused_seeds;            // 1: seeds, their scores and the limit in one launch (launch_prune_limits)
     const int32_t* seeds;       // [B][n_seeds] candidates launch_prune_limits scored already (their scores are in the
     int n_seeds;                // score rows): filter_kernel skips them.  null / 0: none.  n_seeds <= 256.
 };
@@ -64,9 +66,10 @@ constexpr int kFilterCounterWords = 32;
 // the capacity: the caller must then not trust the scores) and patched with the
 // fp64 form by a follow-up kernel on the same stream.  prune_above (may be null):
 // per-cell limit above which a candidate is abandoned and scored +inf.
+// tile_used (may be null): candidates per work item the launch ran with.
 hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
-                         const float* prune_above, hipStream_t stream);
+                         const float* prune_above, hipStream_t stream, int* tile_used = nullptr);
 
 // stats array k (block_stride floats apart), [img][ppad / 64] over plane positions [64 b, 64 b + 64):
 // masked sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma, hue range.

@@ -153,12 +153,19 @@ class Engine:
         return cb, (ctypes.byref(flag) if flag is not None else None)
 
     def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0,
-                 want_scores=True, progress=None, cancel=None):
+                 want_scores=True, progress=None, cancel=None, out=None):
         """mm_generate -> (best_fit int64 [grid_h][grid_w] with sentinel n_library,
-        best_score f64 [grid_h][grid_w] or None)."""
-        rec = _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
-        best = np.empty((grid_h, grid_w), dtype=np.int64)
-        score = np.empty((grid_h, grid_w), dtype=np.float64) if want_scores else None
+        best_score f64 [grid_h][grid_w] or None).  out = (best_fit, best_score) arrays to fill
+        instead of fresh ones."""
+        rec = cells if (isinstance(cells, np.ndarray) and cells.dtype == CELL_DTYPE and cells.flags["C_CONTIGUOUS"]) \
+            else _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
+        if out is not None:
+            best, score = out
+            assert best.shape == (grid_h, grid_w) and best.dtype == np.int64 and best.flags["C_CONTIGUOUS"]
+            assert score is None or (score.shape == (grid_h, grid_w) and score.dtype == np.float64 and score.flags["C_CONTIGUOUS"])
+        else:
+            best = np.empty((grid_h, grid_w), dtype=np.int64)
+            score = np.empty((grid_h, grid_w), dtype=np.float64) if want_scores else None
         cb, cflag = self._callbacks(progress, cancel)
         self._check(self._lib.mm_generate(
             self._h, _lib.ptr(rec), len(rec), grid_w, grid_h, int(diff_type),
@@ -262,9 +269,13 @@ class Engine:
         return dict(zip(("max_err", "max_abs_part", "band_share", "max_value", "handed_over", "measured"), list(out)))
 
     def timing(self):
+        return self.timing_raw().as_dict()
+
+    def timing_raw(self):
+        """mm_get_timing as the ctypes struct (cheap enough to call after every step of a timed loop)."""
         t = _lib.MMTiming()
         self._check(self._lib.mm_get_timing(self._h, ctypes.byref(t)))
-        return t.as_dict()
+        return t
 
     def colour_diff_batch(self, diff_type, first, second):
         """n pairs of f32 triplets -> f64 differences (first = main pixel, second = library pixel)."""

@@ -29,3 +29,29 @@ def engine():
     e = Engine(0)
     yield e
     e.close()
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _suite_engine_options():
+    """Engines of the suite run with the events between the phases on and the seeds / early exit at ANY job size
+    (defaults: both only above a work threshold, because they cost a small job more than they give): most scenarios
+    here are small, and the tests read phase times and work counters to see WHICH path ran.  The defaults themselves
+    are exercised by tests/test_gpu_small_jobs.py and the option matrix of tests/test_gpu_fuzz.py."""
+    try:
+        from mosaicmagnifique_amd import engine as E
+    except Exception:
+        yield
+        return
+    orig = E.Engine.__init__
+
+    def init(self, device=0):
+        orig(self, device)
+        self.set_option("phase_timing", 1)
+        self.set_option("prune_min_kpairs", 0)
+        self.options.clear()
+
+    E.Engine.__init__ = init
+    try:
+        yield
+    finally:
+        E.Engine.__init__ = orig

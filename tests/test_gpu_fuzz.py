@@ -146,7 +146,14 @@ OPTION_SETS = [
     {"lds_filter": 1, "tile": 64},                  # the LDS-resident cell tile, interleaved operands
     {"lds_filter": 1, "interleave": 0},             # ... and planar ones
     {"seeds": 0},                                   # no extra seeds: the limit rests on K proxies only
-    {"spec_k": 2},                                  # short speculative lists: cells get deepened
+    {"spec_k": 2},                                  # short speculative lists: cells get deepened (from the result block's verdicts)
+    {"fused": 0},                                   # separate gather / chroma / interleave / statistics and contenders / re-score / re-rank launches
+    {"fast_path": 0},                               # the step-by-step path: the host decides between the phases
+    {"fast_path": 0, "fused": 0, "spec_k": 2},      # ... as round 2 ran it, with deepening rounds
+    {"item_auto": 0},                               # item size pinned to the by-cell-size default
+    {"fused_seeds": 0},                             # seeds, their scores and the limit as three launches
+    {"prune_min_kpairs": -1, "phase_timing": -1},   # the engine's own defaults: no seeds / early exit and no phase events below a work threshold
+    {"prune_min_kpairs": 2000000000},               # never pruned
 ]
 
 
@@ -171,7 +178,8 @@ def test_tuning_options_do_not_change_the_result(oracle, engine, opts):
     engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
     best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
     defaults = {"interleave": 1, "xcd_aware": 1, "tile": 0, "xcd_cells": 0, "two_level": 1, "sort_groups": -1,
-                "lds_filter": -1, "seeds": 14, "spec_k": 4}
+                "lds_filter": -1, "seeds": 14, "spec_k": 4, "fused": 1, "fast_path": 1, "item_auto": 1,
+                "fused_seeds": 2048, "prune_min_kpairs": 0, "phase_timing": 1}
     try:
         for name, value in opts.items():
             engine.set_option(name, value)
@@ -182,6 +190,10 @@ def test_tuning_options_do_not_change_the_result(oracle, engine, opts):
             engine.set_option(name, defaults[name])
     assert np.array_equal(got, best) and np.array_equal(got_score[state >= 0], score[state >= 0])
     assert tm["band_alarms"] == 0
+    if opts.get("fast_path") == 0:
+        assert tm["fast_path"] == 0 and tm["host_syncs"] >= 3
+    elif "spec_k" not in opts:
+        assert tm["host_syncs"] >= 1
     if opts == OPTION_SETS[0]:                      # the oracle once
         grid = np.where(best < n_lib, best, -1)
         pos = np.stack([cells["grid_y"], cells["grid_x"]], axis=1)
