@@ -60,6 +60,9 @@ CONFIGS = {
     "D": (4096, 4096, 64, "square", 5000, 2, 4, 500, 8),
     "E": (8192, 8192, 48, "square", 10000, 2, 0, 0, 4),      # BASELINE config 5, the whole grid
     "E8": (8192, 8192, 48, "square", 10000, 2, 0, 0, 4),     # ... one rank's shard of it (first ceil(29 241 / 8) cells)
+    # reduced shapes of D and E for the rank rehearsals of tests/test_gpu_bench_ranks.py (not bench lines)
+    "Ds": (1024, 1024, 64, "square", 400, 2, 4, 500, 8),
+    "Es": (1000, 1000, 48, "square", 500, 2, 0, 0, 4),       # 21 x 21 cells, last row / column clipped to 40 px
 }
 TYPE_NAMES = {0: "RGB-Euclidean", 1: "CIE76", 2: "CIEDE2000"}
 
@@ -80,7 +83,7 @@ def result_digest(best, score):
     return h.hexdigest()
 
 
-def build_workload(name, world, scaling="weak", mcs=None, mil=None):
+def build_workload(name, world, scaling="weak", mcs=None, mil=None, bands=0):
     import cases
     from mosaicmagnifique_amd import GridUtility as G
     from mosaicmagnifique_amd import synth
@@ -117,9 +120,11 @@ def build_workload(name, world, scaling="weak", mcs=None, mil=None):
     if not big:
         w["img"] = synth.preprocess(img_u8, t)
         w["lib"] = synth.preprocess(lib_u8, t)
-    if world == 1 or scaling == "strong":
+    bands = bands or world
+    if bands == 1 or scaling == "strong":
         cells, grid_w, grid_h = cells1, state1.shape[1], state1.shape[0]
     else:
+        world = bands
         # weak scaling: `world` bands, each the single-GPU image; band b's cells read the
         # same target pixels (y unchanged) but sit `b * band_rows` grid rows lower.
         if shape_name != "square":
@@ -202,7 +207,28 @@ def cpu_baseline(w, img, lib):
     return grid, scores, done, dt
 
 
-def cpu_parity_rows(w, img, lib, best, n_cells):
+def parity_sample(w, my_cells):
+    """Which cells the all-cores parity leg checks.  With a repeat penalty: the first two full grid rows in raster
+    order (the window's rows-above half is exercised, and equality on a prefix is equality with the sequential run).
+    Without one the cells are independent: 64 of them drawn at random (seeded) from the whole workload -- for shapes
+    with clipped border cells (config C's hexagons) 64 unclipped + 16 clipped ones that hold active pixels."""
+    rep, size = w["rep"], w["size"]
+    if rep[0] > 0:
+        row_cells = int((my_cells["grid_y"] <= my_cells["grid_y"][0] + 1).sum())
+        return my_cells[:min(len(my_cells), max(row_cells, 16), 256)], "first %d valid cells in raster order (2 full grid rows: the repeat window's rows-above half is exercised)"
+    rng = np.random.default_rng(0xC0FFEE)
+    whole = (my_cells["row_min"] == 0) & (my_cells["row_max"] == size) & (my_cells["col_min"] == 0) & (my_cells["col_max"] == size)
+    masks = w["shape"].masks4() != 0
+    active = np.array([masks[c["mask_id"]][c["row_min"]:c["row_max"], c["col_min"]:c["col_max"]].any() for c in my_cells[~whole]], dtype=bool)
+    inner, clipped = np.flatnonzero(whole), np.flatnonzero(~whole)[active] if (~whole).any() else np.zeros(0, dtype=np.int64)
+    pick = np.concatenate([rng.choice(inner, size=min(64, len(inner)), replace=False),
+                           rng.choice(clipped, size=min(16, len(clipped)), replace=False)]).astype(np.int64)
+    pick.sort()
+    return my_cells[pick], "%%d cells drawn at random from the whole workload (%d unclipped + %d clipped with active pixels, seed 0xC0FFEE; no repeat penalty: cells are independent)" % (
+        min(64, len(inner)), min(16, len(clipped)))
+
+
+def cpu_parity_rows(w, img, lib, best, recs):
     """index parity where the repeat window is exercised -- the first `n_cells` valid
     cells in raster order (config D: 2 full rows), each evaluated by the oracle exactly as the
     reference's raster loop reaches it with the earlier cells at the engine's picks; equality on
@@ -210,7 +236,6 @@ def cpu_parity_rows(w, img, lib, best, n_cells):
     oracle_ffi.picks_given_grid).  One thread per host core: also the all-cores CPU rate."""
     import oracle_ffi
     o = oracle_ffi.load()
-    recs = w["cells_single"][:n_cells]
     pos = np.stack([recs["grid_y"], recs["grid_x"]], axis=1)
     grid = np.where(best < w["L"], best, -1)[:w["state_single"].shape[0]]
     cores = host_cores()
@@ -238,6 +263,73 @@ def pmc_record(w, opts):
     return entry, "profiles/pmc_traffic.json (rocprofv3 --pmc, separate passes: FETCH_SIZE x2 + WRITE_SIZE; SQ_INSTS_VALU)"
 
 
+def stage_bench(args, emit):
+    """--stage build | preprocess: the HBM-bound byte kernels either side of the hot path, on
+    the configuration's own sizes, priced against HBM peak with the bytes an ideal pass moves.
+      build       mm_build_photomosaic on the finished best-fit grid: owner map (atomicMax, 4 B written per covered
+                  pixel) + compose (4 B owner read + 3 B library read + 4 B BGRA written + 1 B coverage) -- 16 B per
+                  output pixel, plus the 4 B per pixel of clearing the owner map = 20 B;
+      preprocess  mm_set_target_u8 / mm_set_library_u8: 3 B read + 12 B written per pixel (u8 BGR -> f32 Lab / BGR),
+                  and mm_set_library_u8_sized at 75 % detail: the general INTER_AREA resize of the u8 library
+                  (3 B read per source pixel + 3 B written per detail pixel) followed by the conversion.
+    Kernel time = HIP events around the kernels on the engine's stream (mm_timing.build_ms / preprocess_ms), averaged
+    over --steps calls; `ms_per_step` is the whole call as the host sees it (staging copies included)."""
+    import torch  # noqa: F401  (one HIP runtime per process)
+    from mosaicmagnifique_amd.engine import Engine
+    w = build_workload(args.config, 1)
+    engine = Engine(0)
+    t, rows, cols, L, size = w["t"], w["rows"], w["cols"], w["L"], w["size"]
+    lines = []
+
+    def line(name, kernel_ms, call_ms, nbytes, note):
+        gbs = nbytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        lines.append({"stage": name, "kernel_ms": kernel_ms, "call_ms": call_ms, "algorithmic_bytes": nbytes,
+                      "achieved_gbs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "note": note})
+
+    if args.stage == "preprocess":
+        for name, fn, nbytes, note in (
+            ("preprocess_u8 target %dx%d" % (cols, rows), lambda: engine.set_target_u8(w["img_u8"], t), rows * cols * 15,
+             "3 B read + 12 B written per pixel"),
+            ("preprocess_u8 library %d x %dx%d" % (L, size, size), lambda: engine.set_library_u8(w["lib_u8"], t), L * size * size * 15,
+             "3 B read + 12 B written per pixel"),
+            ("resize_area_u8 + preprocess_u8 library at 75 %% detail (%d -> %d px)" % (size, size * 3 // 4),
+             lambda: engine.set_library_u8_sized(w["lib_u8"], t, size * 3 // 4),
+             L * (size * size * 3 + (size * 3 // 4) ** 2 * (3 + 3 + 12)),
+             "resize: 3 B per source pixel read + 3 B per detail pixel written; conversion: 3 B read + 12 B written per detail pixel"),
+        ):
+            for _ in range(args.warmup):
+                fn()
+            k_ms, t0 = 0.0, time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+                k_ms += engine.timing()["preprocess_ms"]
+            line(name, k_ms / args.steps, (time.perf_counter() - t0) / args.steps * 1e3, nbytes, note)
+    else:
+        stage(engine, w)
+        best, _ = engine.generate(w["cells"], w["grid_w"], w["grid_h"], t, *w["rep"])
+        engine.set_library_bgr(w["lib_u8"])
+        for _ in range(args.warmup):
+            engine.build_photomosaic(w["cells"], w["grid_w"], w["grid_h"], best, rows, cols, want_output=False)
+        k_ms, t0 = 0.0, time.perf_counter()
+        for _ in range(args.steps):
+            engine.build_photomosaic(w["cells"], w["grid_w"], w["grid_h"], best, rows, cols, want_output=False)
+            k_ms += engine.timing()["build_ms"]
+        line("buildPhotomosaic %dx%d, %d cells (owner map + compose)" % (cols, rows, len(w["cells"])), k_ms / args.steps,
+             (time.perf_counter() - t0) / args.steps * 1e3, rows * cols * 20,
+             "4 B owner cleared + 4 B owner raised (atomicMax) + 4 B owner read + 3 B library read + 4 B BGRA + 1 B coverage written per pixel")
+    head = lines[0] if args.stage == "build" else lines[1]
+    emit(json.dumps({
+        "metric": "achieved HBM GB/s of the %s stage" % args.stage, "value": head["achieved_gbs"], "unit": "GB/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["call_ms"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "config %s, stage %s: %s" % (w["name"], args.stage, head["stage"])},
+        "roofline": {"bound": "hbm", "achieved": head["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": head["frac_of_hbm_peak"], "traffic": None, "kernel_ms": head["kernel_ms"]},
+        "stages": lines,
+        "hbm_stream_read_measured_gbs": engine.stream_read_gbs(4 << 30, 5),
+    }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,9 +339,15 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="N > 1: weak = one config band per rank (default for D), strong = the fixed cell list "
                          "cut into N contiguous shards (default for E)")
+    ap.add_argument("--bands", type=int, default=0,
+                    help="weak scaling: bands of the config stacked into one mosaic (default: one per rank); with one rank it "
+                         "gives the single-GPU result an N-rank weak run must reproduce")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
     ap.add_argument("--mcs", default=None, help="cell shape from a MosaicMagnifique .mcs file (resized to the config's cell size)")
     ap.add_argument("--mil", default=None, help="library from a MosaicMagnifique .mil file (resized to the config's cell size)")
+    ap.add_argument("--stage", choices=("build", "preprocess"), default=None,
+                    help="time the byte kernels either side of the hot path instead of it (buildPhotomosaic / the u8 -> f32 "
+                         "pre-processing) and report their GB/s against HBM peak")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine tuning option (mm_set_option), for experiments")
     args = ap.parse_args()
@@ -265,6 +363,8 @@ def main():
         os.dup2(real_stdout, 1)
         print(line, flush=True)
 
+    if args.stage:
+        return stage_bench(args, emit)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -272,7 +372,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
-    scaling = args.scaling or ("strong" if args.config == "E" else "weak")
+    scaling = args.scaling or ("strong" if args.config in ("E", "Es") else "weak")
 
     import torch
     from mosaicmagnifique_amd.dist import ShardedBestFit
@@ -303,7 +403,8 @@ def main():
         dist.barrier()                          # builds the communicator before anything is timed
         comm_init_s = time.perf_counter() - t_comm
 
-    w = build_workload(args.config, world, scaling, args.mcs, args.mil)
+    bands = args.bands or world
+    w = build_workload(args.config, world, scaling, args.mcs, args.mil, bands)
     engine = Engine(local_rank)
     for item in args.opt:
         name, value = item.split("=")
@@ -382,7 +483,7 @@ def main():
         lo, hi = shard_range(n_cells, world, 0)
         my_cells = cells[lo:hi]
     else:
-        my_cells = w["cells_single"]
+        my_cells = w["cells_single"] if world > 1 else cells
     alg_bytes, total_pa = algorithmic_bytes(w, my_cells)
     launches = max(launches, 1)
     per_launch_s = (score_ms / 1e3) / launches
@@ -472,8 +573,8 @@ def main():
             os.path.basename(p) for p in (args.mcs, args.mil) if p),
         "config": {
             "workload": "config %s: %dx%d target%s, %dx%d %s cells, %d-image library, %s, repeat range %d (+%d)" % (
-                w["name"], w["cols"], w["rows"] * (world if scaling == "weak" else 1),
-                " (%d bands of %d rows)" % (world, w["rows"]) if world > 1 and scaling == "weak" else "",
+                w["name"], w["cols"], w["rows"] * (bands if scaling == "weak" else 1),
+                " (%d bands of %d rows)" % (bands, w["rows"]) if bands > 1 and scaling == "weak" else "",
                 w["size"], w["size"], w["shape_name"], w["L"], TYPE_NAMES[t], rep[0], rep[1]),
             "cells": n_cells,
             "library_images": w["L"],
@@ -506,20 +607,17 @@ def main():
         }
         out["speedup_vs_cpu"] = value / (done / dt)
         # parity where the repeat window is exercised + the all-cores rate: the first 2 grid rows
-        row_cells = int((my_cells["grid_y"] <= my_cells["grid_y"][0] + 1).sum())
-        n_par = min(len(my_cells), max(row_cells, 16) if rep[0] > 0 else 64, 256)
-        pos, picks, pscores, cores, dt_all = cpu_parity_rows(w, img, lib, best, n_par)
+        par_recs, par_text = parity_sample(w, my_cells)
+        n_par = len(par_recs)
+        pos, picks, pscores, cores, dt_all = cpu_parity_rows(w, img, lib, best, par_recs)
         got = best[pos[:, 0], pos[:, 1]]
         prel = np.abs(pscores - score[pos[:, 0], pos[:, 1]]) / np.maximum(pscores, 1e-300)
         out["parity_on_cpu_sample"] = {
             "indices_equal": bool(same and np.array_equal(picks, got)),
             "max_rel_score_err": float(max(rel, prel.max())),
             "cells": int(n_par),
-            "sample": "first %d valid cells in raster order (%s), each evaluated by the oracle as the reference's raster "
-                      "loop reaches it given the earlier picks -- equality on the prefix = equality with the sequential "
-                      "run; plus the %d cells of the sequential 1-thread leg" % (
-                          n_par, "2 full grid rows: the repeat window's rows-above half is exercised" if rep[0] > 0 else "no repeat penalty",
-                          done),
+            "sample": (par_text % n_par) + ", each evaluated by the oracle as the reference's raster loop reaches it given "
+                      "the earlier picks; plus the %d cells of the sequential 1-thread leg" % done,
         }
         out["cpu_baseline_all_cores"] = {
             "value": n_par / dt_all, "unit": "cells/s", "cores": cores, "kind": "port",

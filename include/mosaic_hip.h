@@ -103,6 +103,7 @@ typedef struct mm_timing {
     int64_t host_syncs;       /* times the host waited for the device during the call */
     int64_t fast_path;        /* 1: the whole generate was ONE submission read back in one result block (option
                                * "fast_path"); 0: the step-by-step path ran (or finished the call) */
+    double preprocess_ms;     /* mm_set_library_u8[_sized] / mm_set_target_u8: the resize + colour conversion kernels */
 } mm_timing;
 
 /* Progress: called on the calling thread between device batches with
@@ -280,6 +281,55 @@ mm_status mm_build_photomosaic_step(mm_engine *e, const mm_cell *cells, int n_ce
                                     const int64_t *best_fit, const uint8_t background[4], int rows, int cols,
                                     int step_index, uint8_t *mosaic_out);
 mm_status mm_shrink_library_bgr(mm_engine *e, int factor);
+
+/* ---- the entropy subdivision of the grid ------------------------
+ * GridGenerator::getGridState hands a cell of a size step that is not the last to the next (half-size) step when
+ * the grey-level entropy of the image under its bounded, flipped detail mask reaches 0.7 * MAX_ENTROPY
+ * (Grid/GridGenerator.cpp:143-189, Other/ImageUtility.cpp:189-242).  The host keeps the integer geometry and the
+ * bound merging (Grid/GridBounds.cpp); the per-cell image work -- resize of the visible part to the mask's size,
+ * BGR2GRAY, masked 256-bin histogram, entropy -- runs here, one workgroup per cell.
+ * mm_set_main_image_bgr: the main image as setMainImage receives it (u8 BGR [rows][cols][3]); kept on the device.
+ * mm_cell_entropy: cells = the step's cells inside an active bound, records as for mm_generate (x, y = rect origin
+ * of the NORMAL cell of normal_size pixels, the bound in DETAIL pixels, mask_id); the staged masks (mm_set_masks)
+ * must be the step's detail masks.  exceeded_out[n]: 1 = entropy >= 5.6 (split the cell); entropy_out optional. */
+mm_status mm_set_main_image_bgr(mm_engine *e, const uint8_t *bgr, int rows, int cols);
+mm_status mm_cell_entropy(mm_engine *e, const mm_cell *cells, int n_cells, int normal_size,
+                          uint8_t *exceeded_out, double *entropy_out);
+
+/* ---- one process, several GPUs ---------------------------------
+ * The reference drives one device (CUDAPhotomosaicGenerator(const int device), CUDA/CUDAPhotomosaicGenerator.h:31;
+ * the device list it chooses from: MainWindow.cpp:162-214).  A group holds one engine per listed device: the valid
+ * cells (raster order) are cut into contiguous shards of ceil(n / devices), inputs are replicated, every device
+ * scores its shard, ONE RCCL all-gather (ncclAllGather inside ncclGroupStart / End, one communicator per device
+ * from ncclCommInitAll) hands every device every candidate list, and every device runs the same verifying resolve;
+ * unverified speculative picks are deepened by their owners and gathered again.  The grid equals mm_generate's on
+ * one device, bit for bit.  RCCL refuses a device listed twice (what a one-GPU box can rehearse): such a group, or
+ * one whose communicator cannot be built, gathers through host memory instead -- same buffers, same resolve, same
+ * result (mm_group_uses_rccl).  Host threads: one per device inside the calls below; the calls themselves are
+ * blocking and not re-entrant per group. */
+typedef struct mm_group mm_group;
+mm_status mm_group_create(const int *devices, int n_devices, mm_group **out);
+void mm_group_destroy(mm_group *g);
+/* g == NULL: the last mm_group_create failure. */
+const char *mm_group_last_error(const mm_group *g);
+int mm_group_size(const mm_group *g);
+/* 1: the candidate lists travel by ncclAllGather; 0: through host memory (see above). */
+int mm_group_uses_rccl(const mm_group *g);
+/* The engine on devices[index] (owned by the group): for mm_get_timing, mm_set_cell_resize, mm_shrink_library,
+ * mm_build_photomosaic ... on one device. */
+mm_engine *mm_group_engine(mm_group *g, int index);
+/* Replicated staging: mm_set_library / mm_set_library_u8_sized / mm_set_masks / mm_set_target / mm_set_target_u8 /
+ * mm_set_option on every engine of the group (one host thread per device). */
+mm_status mm_group_set_library(mm_group *g, const float *images, int n_images, int size);
+mm_status mm_group_set_library_u8(mm_group *g, const uint8_t *bgr, int n_images, int size, int detail_size, int diff_type);
+mm_status mm_group_set_masks(mm_group *g, const uint8_t *masks, int size);
+mm_status mm_group_set_target(mm_group *g, const float *image, int rows, int cols);
+mm_status mm_group_set_target_u8(mm_group *g, const uint8_t *bgr, int rows, int cols, int diff_type);
+mm_status mm_group_set_option(mm_group *g, const char *name, int value);
+/* generateBestFits() for one size step over the group's devices; arguments and outputs as mm_generate. */
+mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int grid_w, int grid_h, int diff_type,
+                            int repeat_range, int repeat_addition, int64_t *best_fit_out, double *best_score_out,
+                            mm_progress_cb progress, void *progress_user, volatile int *cancel);
 
 /* Engine options.  "filter" (default 1): two-tier scoring -- an fp32 filter pass over
  * every (cell, candidate), then the fp64 reference-form score of each cell's

@@ -17,8 +17,12 @@ LIB = os.path.join(HERE, "libmosaic_hip.so")
 #  filter.hip  default contraction: the fp32 filter pass wants fused multiply-adds;
 #              -fno-slp-vectorize: on gfx950 a v_pk_*_f32 costs two issue slots, so SLP
 #              packing buys nothing and adds register-pairing moves (10 % of the kernel).
+#  group.hip   host code only (one process, several GPUs): the RCCL all-gather of the candidate lists.
 UNITS = [("engine.hip", ["-ffp-contract=off"]),
-         ("filter.hip", ["-ffp-contract=fast", "-fno-slp-vectorize"])]
+         ("filter.hip", ["-ffp-contract=fast", "-fno-slp-vectorize"]),
+         ("group.hip", [])]
+ROCM_LIB = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+LINK_FLAGS = ["-L" + ROCM_LIB, "-lrccl", "-Wl,-rpath," + ROCM_LIB, "-lpthread"]
 SOURCES = [os.path.join(CSRC, name) for name, _ in UNITS]
 HEADERS = [os.path.join(CSRC, h) for h in ("kernels.hpp", "colour_diff.hpp", "colour_diff_fast.hpp",
                                            "launch.hpp")] + \
@@ -50,7 +54,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(CSRC, name + ".o")
         _run([hipcc()] + HIPCC_FLAGS + extra + ["-c", os.path.join(CSRC, name), "-o", obj], verbose)
         objs.append(obj)
-    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs, verbose)
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs + LINK_FLAGS, verbose)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

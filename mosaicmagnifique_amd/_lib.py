@@ -31,7 +31,8 @@ class MMTiming(ctypes.Structure):
                 ("resolve_sweeps", ctypes.c_int64), ("visited_groups", ctypes.c_int64),
                 ("total_groups", ctypes.c_int64), ("bound_dropped", ctypes.c_int64),
                 ("band_alarms", ctypes.c_int64), ("filter_tile", ctypes.c_int64),
-                ("host_syncs", ctypes.c_int64), ("fast_path", ctypes.c_int64)]
+                ("host_syncs", ctypes.c_int64), ("fast_path", ctypes.c_int64),
+                ("preprocess_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -86,6 +87,22 @@ SIGNATURES = {
                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),
     "mm_shrink_library_bgr": (ctypes.c_int, [_VP, ctypes.c_int]),
     "mm_set_option": (ctypes.c_int, [_VP, ctypes.c_char_p, ctypes.c_int]),
+    "mm_set_main_image_bgr": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
+    "mm_cell_entropy": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _VP, _VP]),
+    "mm_group_create": (ctypes.c_int, [c_int_p, ctypes.c_int, ctypes.POINTER(_VP)]),
+    "mm_group_destroy": (None, [_VP]),
+    "mm_group_last_error": (ctypes.c_char_p, [_VP]),
+    "mm_group_size": (ctypes.c_int, [_VP]),
+    "mm_group_uses_rccl": (ctypes.c_int, [_VP]),
+    "mm_group_engine": (_VP, [_VP, ctypes.c_int]),
+    "mm_group_set_library": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
+    "mm_group_set_library_u8": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mm_group_set_masks": (ctypes.c_int, [_VP, _VP, ctypes.c_int]),
+    "mm_group_set_target": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
+    "mm_group_set_target_u8": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mm_group_set_option": (ctypes.c_int, [_VP, ctypes.c_char_p, ctypes.c_int]),
+    "mm_group_generate": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, _VP, _VP, _VP, _VP, _VP]),
     "mm_get_timing": (ctypes.c_int, [_VP, ctypes.POINTER(MMTiming)]),
     "mm_colour_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),
     "mm_filter_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),

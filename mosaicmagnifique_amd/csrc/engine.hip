@@ -55,6 +55,8 @@ struct mm_engine {
     DevBuf lib_chroma, cell_chroma, hue_lut, lib_il, cells_il;
     DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
     DevBuf stage_u8, srgb_lut, shrink_tmp, covered, cells_f0;
+    DevBuf main_bgr;   int main_rows = 0, main_cols = 0;      // mm_set_main_image_bgr: the u8 main image (entropy test)
+    DevBuf entropy_out, exceeded_out;
     int mosaic_rows = 0, mosaic_cols = 0;       // the mosaic kept between mm_build_photomosaic_step calls
     int cell_scale = 1;          // mm_set_cell_scale / mm_set_cell_resize: normal-cell pixels per detail pixel and
                                  // axis when that is a whole number, 0 = any ratio (area table in `area_tab`)
@@ -1179,7 +1181,7 @@ void mm_destroy(mm_engine* e)
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
                        &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0, &e->area_tab,
-                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il, &e->result })
+                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il, &e->result, &e->main_bgr, &e->entropy_out, &e->exceeded_out })
         release(*b);
     if (e->pinned) (void)hipHostFree(e->pinned);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1296,11 +1298,15 @@ mm_status preprocess_u8(mm_engine* e, const uint8_t* bgr, size_t n_images, int r
         return st;
     HIP_TRY(e, hipMemcpyAsync(e->stage_u8.p, bgr, in_bytes, hipMemcpyHostToDevice, e->stream), "Failed to copy u8 images to device");
     const unsigned blocks = (unsigned)std::min<size_t>((out_px + mm::kBlock - 1) / mm::kBlock, 65536);
+    HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
     mm::preprocess_u8_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(
         (const uint8_t*)e->stage_u8.p, (float*)dst.p, n_images, rows, cols, factor,
         diff_type != MM_RGB_EUCLIDEAN, (const double*)e->srgb_lut.p);
     HIP_TRY(e, hipGetLastError(), "Error during preprocessing kernel");
+    HIP_TRY(e, hipEventRecord(e->ev[5], e->stream), "event");
     HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
+    e->timing = mm_timing{};
+    e->timing.preprocess_ms = elapsed(e->ev[4], e->ev[5]);
     return MM_OK;
 }
 
@@ -1354,6 +1360,7 @@ mm_status mm_set_library_u8_sized(mm_engine* e, const uint8_t* bgr, int n_images
     if (code == hipSuccess) code = hipMemcpyAsync(base, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, e->stream);
     if (code == hipSuccess) code = hipMemcpyAsync(base + detail_size + 1, src.data(), n * sizeof(int), hipMemcpyHostToDevice, e->stream);
     if (code == hipSuccess) code = hipMemcpyAsync(base + detail_size + 1 + n, alpha.data(), n * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    if (code == hipSuccess) code = hipEventRecord(e->ev[4], e->stream);
     if (code == hipSuccess) {
         const mm::CellResize rs{0, base, base + detail_size + 1, (const float*)(base + detail_size + 1 + n)};
         const unsigned blocks = (unsigned)std::min<size_t>((out_px + mm::kBlock - 1) / mm::kBlock, 65536);
@@ -1367,9 +1374,12 @@ mm_status mm_set_library_u8_sized(mm_engine* e, const uint8_t* bgr, int n_images
             code = hipGetLastError();
         }
     }
+    if (code == hipSuccess) code = hipEventRecord(e->ev[5], e->stream);
     if (code == hipSuccess) code = sync_stream(e);      // host vectors and temporaries go out of scope
     release(tab); release(small);
     if (code != hipSuccess) return hip_fail(e, code, "Error during library resize", __FILE__, __LINE__);
+    e->timing = mm_timing{};
+    e->timing.preprocess_ms = elapsed(e->ev[4], e->ev[5]);
     e->planes_dirty = true;
     e->n_lib = n_images;
     e->lib_size = detail_size;
@@ -1921,6 +1931,68 @@ mm_status mm_build_photomosaic_step(mm_engine* e, const mm_cell* cells, int n_ce
     e->timing = mm_timing{};
     e->timing.build_ms = elapsed(e->ev[4], e->ev[5]);
     e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
+    return MM_OK;
+}
+
+mm_status mm_set_main_image_bgr(mm_engine* e, const uint8_t* bgr, int rows, int cols)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (!bgr || rows <= 0 || cols <= 0) {
+        set_err(e, "mm_set_main_image_bgr: need rows, cols > 0 (got %d, %d)", rows, cols);
+        return MM_INVALID_ARGUMENT;
+    }
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    const size_t bytes = (size_t)rows * cols * 3;
+    mm_status st = ensure(e, e->main_bgr, bytes, "Failed to allocate main image");
+    if (st) return st;
+    HIP_TRY(e, hipMemcpy(e->main_bgr.p, bgr, bytes, hipMemcpyHostToDevice), "Failed to copy main image to device");
+    e->main_rows = rows;
+    e->main_cols = cols;
+    return MM_OK;
+}
+
+// GridGenerator::findCellState's entropy test (Grid/GridGenerator.cpp:143-189) for a batch of cells of one size step.
+mm_status mm_cell_entropy(mm_engine* e, const mm_cell* cells, int n_cells, int normal_size, uint8_t* exceeded_out, double* entropy_out)
+{
+    if (!e) return MM_INVALID_ARGUMENT;
+    if (n_cells < 0 || (n_cells > 0 && (!cells || !exceeded_out)) || normal_size <= 0) { set_err(e, "mm_cell_entropy: bad arguments"); return MM_INVALID_ARGUMENT; }
+    if (!e->main_bgr.p || !e->masks.p) { set_err(e, "the u8 main image (mm_set_main_image_bgr) and the step's detail masks must be staged first"); return MM_NOT_READY; }
+    const int ds = e->mask_size;
+    if (ds > normal_size) { set_err(e, "mm_cell_entropy: detail masks of %d px against a normal cell of %d px", ds, normal_size); return MM_INVALID_ARGUMENT; }
+    for (int i = 0; i < n_cells; ++i) {
+        const mm_cell& c = cells[i];
+        const bool ok = c.row_min >= 0 && c.row_min < c.row_max && c.row_max <= ds && c.col_min >= 0 && c.col_min < c.col_max &&
+                        c.col_max <= ds && c.mask_id >= 0 && c.mask_id < 4 &&
+                        std::abs((long long)c.x) < (1LL << 28) && std::abs((long long)c.y) < (1LL << 28);
+        if (!ok) { set_err(e, "mm_cell_entropy: cell %d does not fit the %d px detail mask", i, ds); return MM_INVALID_ARGUMENT; }
+        // a shrink only: the visible part is never smaller than the bounded mask for detail <= 100 %
+        const long long vr = std::min<long long>(std::max<long long>((long long)c.y + normal_size, 0), e->main_rows) - std::min<long long>(std::max<long long>(c.y, 0), e->main_rows);
+        const long long vc = std::min<long long>(std::max<long long>((long long)c.x + normal_size, 0), e->main_cols) - std::min<long long>(std::max<long long>(c.x, 0), e->main_cols);
+        if (vr > 0 && vc > 0 && (vr < c.row_max - c.row_min || vc < c.col_max - c.col_min)) {
+            set_err(e, "mm_cell_entropy: cell %d would be ENLARGED (%lldx%lld visible pixels to a %dx%d mask): INTER_CUBIC is outside the hot path",
+                    i, vc, vr, c.col_max - c.col_min, c.row_max - c.row_min);
+            return MM_INVALID_ARGUMENT;
+        }
+    }
+    if (n_cells == 0) return MM_OK;
+    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    mm_status st;
+    if ((st = ensure(e, e->recs, (size_t)n_cells * sizeof(mm_cell), "Failed to allocate cell records")) ||
+        (st = ensure(e, e->exceeded_out, (size_t)n_cells, "Failed to allocate entropy verdicts")) ||
+        (st = ensure(e, e->entropy_out, (size_t)n_cells * sizeof(double), "Failed to allocate entropies")))
+        return st;
+    HIP_TRY(e, hipMemcpyAsync(e->recs.p, cells, (size_t)n_cells * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
+            "Failed to copy cell records to device");
+    const int ppad = round_up(ds * ds, 256);
+    mm::cell_entropy_kernel<<<n_cells, mm::kBlock, 0, e->stream>>>(
+        (const mm_cell*)e->recs.p, n_cells, (const uint8_t*)e->main_bgr.p, e->main_rows, e->main_cols, normal_size,
+        (const uint8_t*)e->masks.p, ds, ppad, (uint8_t*)e->exceeded_out.p, (double*)e->entropy_out.p);
+    HIP_TRY(e, hipGetLastError(), "Error during cell entropy kernel");
+    HIP_TRY(e, hipMemcpyAsync(exceeded_out, e->exceeded_out.p, (size_t)n_cells, hipMemcpyDeviceToHost, e->stream), "Error copying entropy verdicts to host");
+    if (entropy_out)
+        HIP_TRY(e, hipMemcpyAsync(entropy_out, e->entropy_out.p, (size_t)n_cells * sizeof(double), hipMemcpyDeviceToHost, e->stream),
+                "Error copying entropies to host");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     return MM_OK;
 }
 

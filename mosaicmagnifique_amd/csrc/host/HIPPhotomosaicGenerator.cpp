@@ -5,7 +5,6 @@
 #include <cmath>
 #include <cstdio>
 #include <stdexcept>
-#include <thread>
 
 #include <zlib.h>
 
@@ -104,6 +103,11 @@ std::vector<uint8_t> decodePngFirstChannel(const std::vector<uint8_t>& png, int&
         else if (t == "IEND") break;
     }
     if (channels == 0 || rows <= 0 || cols <= 0) throw std::runtime_error("PNG mask without a header");
+    // a cell mask is a few hundred pixels a side (the shipped ones: 512): a header asking for more than 16384 is a
+    // damaged or crafted file, not a reason to try a multi-gigabyte allocation; deflate cannot shrink by more than ~1032
+    if (rows > 16384 || cols > 16384) throw std::runtime_error("PNG mask larger than 16384 pixels a side");
+    if (idat.empty() || ((size_t)cols * channels + 1) * (size_t)rows / 1032 > idat.size() + 64)
+        throw std::runtime_error("PNG mask data too short for its header");
     const size_t stride = (size_t)cols * channels;
     std::vector<uint8_t> raw((stride + 1) * (size_t)rows);
     uLongf got = (uLongf)raw.size();
@@ -164,6 +168,7 @@ CellShape CellShape::loadFromFile(const std::string& path)
     else {
         r.u32();                                         // cv::Mat type
         rows = (int)r.u32(); cols = (int)r.u32();
+        if (rows <= 0 || cols <= 0 || rows > 16384 || cols > 16384) throw std::runtime_error("raw .mcs mask larger than 16384 pixels a side");
         mask = r.bytes(r.u32());
         if (mask.size() != (size_t)rows * cols) throw std::runtime_error("raw .mcs mask is not 8-bit single channel");
     }
@@ -454,22 +459,31 @@ HIPPhotomosaicGenerator::HIPPhotomosaicGenerator(int device) : HIPPhotomosaicGen
 HIPPhotomosaicGenerator::HIPPhotomosaicGenerator(const std::vector<int>& devices)
 {
     if (devices.empty()) throw std::invalid_argument("HIP engine: no device given");
-    for (int device : devices) {
+    if (devices.size() == 1) {
         mm_engine* e = nullptr;
-        if (mm_create(device, &e) != MM_OK) {
-            for (mm_engine* made : m_engines) mm_destroy(made);
-            throw std::runtime_error(std::string("HIP engine: ") + mm_last_error(nullptr));
-        }
+        if (mm_create(devices[0], &e) != MM_OK) throw std::runtime_error(std::string("HIP engine: ") + mm_last_error(nullptr));
         m_engines.push_back(e);
+    } else {
+        // several devices: the library's group (one engine per device, RCCL all-gather of the candidate lists)
+        if (mm_group_create(devices.data(), (int)devices.size(), &m_group) != MM_OK)
+            throw std::runtime_error(std::string("HIP engine group: ") + mm_group_last_error(nullptr));
+        for (int i = 0; i < mm_group_size(m_group); ++i) m_engines.push_back(mm_group_engine(m_group, i));
     }
     m_engine = m_engines.front();
 }
 
-HIPPhotomosaicGenerator::~HIPPhotomosaicGenerator() { for (mm_engine* e : m_engines) mm_destroy(e); }
+HIPPhotomosaicGenerator::~HIPPhotomosaicGenerator()
+{
+    if (m_group) mm_group_destroy(m_group);                 // (owns its engines)
+    else for (mm_engine* e : m_engines) mm_destroy(e);
+}
 
 bool HIPPhotomosaicGenerator::setEngineOption(const char* name, int value)
 {
-    if (std::string(name) == "spec_k") m_specK = value;
+    if (m_group) {
+        if (mm_group_set_option(m_group, name, value) != MM_OK) { m_lastError = mm_group_last_error(m_group); return false; }
+        return true;
+    }
     for (mm_engine* e : m_engines)
         if (mm_set_option(e, name, value) != MM_OK) { m_lastError = mm_last_error(e); return false; }
     return true;
@@ -746,74 +760,13 @@ bool HIPPhotomosaicGenerator::generateBestFits()
     return true;
 }
 
-// One size step over several engines: contiguous shards of ceil(n / engines) cells in raster order,
-// one host thread per engine (base scores of different cells are independent), the lists land in
-// ONE host array (the "gather"), then the verifying resolve on the first engine; cells whose short
-// list could not be vouched for are deepened by their owner and the resolve runs again -- the loop
-// of mm_generate (engine.hip), with the engines in place of the batches.
+// One size step over several devices: the library's group does the sharding, the ONE all-gather of the candidate
+// lists (RCCL; host memory where RCCL refuses the device list) and the verifying resolve (mm_group_generate).
 bool HIPPhotomosaicGenerator::generateStepSharded(const std::vector<mm_cell>& cells, int gridW, int gridH,
                                                   std::vector<int64_t>& bestFit)
 {
-    const int n = (int)cells.size(), type = (int)m_colourDiffType, engines = (int)m_engines.size();
-    const int K = std::max(1, mm_candidates_per_cell((int)m_libCount, m_repeatRange, m_repeatAddition));
-    const int Ks = std::max(1, mm_speculative_candidates((int)m_libCount, m_repeatRange, m_repeatAddition, m_specK));
-    const bool speculate = Ks < K && n > 0;
-    const int per = n > 0 ? (n + engines - 1) / engines : 0;
-    std::vector<int32_t> index((size_t)std::max(n, 1) * K, -1);
-    std::vector<double> score((size_t)std::max(n, 1) * K, 0.0);
-    std::vector<mm_status> status((size_t)engines, MM_OK);
-
-    // rows: cell numbers to score (empty = the engine's whole shard), fill = entries per list
-    auto scoreOn = [&](const std::vector<std::vector<int>>& rows, int fill) {
-        std::vector<std::thread> threads;
-        for (int g = 0; g < engines; ++g)
-            threads.emplace_back([&, g] {
-                const int lo = std::min(g * per, n), hi = std::min(lo + per, n);
-                if (rows.empty()) {
-                    if (hi > lo)
-                        status[(size_t)g] = mm_score_cells_partial(m_engines[(size_t)g], cells.data() + lo, hi - lo, type, K, fill,
-                                                                   index.data() + (size_t)lo * K, score.data() + (size_t)lo * K, 0,
-                                                                   nullptr, nullptr, &m_wasCanceled);
-                    return;
-                }
-                const std::vector<int>& mine = rows[(size_t)g];
-                if (mine.empty()) return;
-                std::vector<mm_cell> sub;
-                for (int c : mine) sub.push_back(cells[(size_t)c]);
-                std::vector<int32_t> si(mine.size() * (size_t)K);
-                std::vector<double> ss(mine.size() * (size_t)K);
-                status[(size_t)g] = mm_score_cells_partial(m_engines[(size_t)g], sub.data(), (int)sub.size(), type, K, fill,
-                                                           si.data(), ss.data(), 0, nullptr, nullptr, &m_wasCanceled);
-                if (status[(size_t)g] != MM_OK) return;
-                for (size_t r = 0; r < mine.size(); ++r) {
-                    std::copy(si.begin() + r * K, si.begin() + (r + 1) * K, index.begin() + (size_t)mine[r] * K);
-                    std::copy(ss.begin() + r * K, ss.begin() + (r + 1) * K, score.begin() + (size_t)mine[r] * K);
-                }
-            });
-        for (std::thread& t : threads) t.join();
-        for (int g = 0; g < engines; ++g)
-            if (status[(size_t)g] != MM_OK) {
-                if (status[(size_t)g] != MM_CANCELLED) m_lastError = mm_last_error(m_engines[(size_t)g]);
-                return false;
-            }
-        return true;
-    };
-
-    if (!scoreOn({}, Ks)) return false;
-    std::vector<uint8_t> deep((size_t)std::max(n, 1), 0), insufficient((size_t)std::max(n, 1), 0);
-    for (;;) {
-        if (m_wasCanceled) return false;
-        const mm_status st = mm_resolve_verify(m_engine, cells.data(), n, gridW, gridH, type, m_repeatRange, m_repeatAddition,
-                                               K, Ks, index.data(), score.data(), 0,
-                                               speculate ? deep.data() : nullptr, speculate ? insufficient.data() : nullptr,
-                                               bestFit.data(), nullptr);
-        if (st != MM_OK) { m_lastError = mm_last_error(m_engine); return false; }
-        if (!speculate) return true;
-        std::vector<std::vector<int>> todo((size_t)engines);
-        bool any = false;
-        for (int c = 0; c < n; ++c)
-            if (insufficient[(size_t)c] && !deep[(size_t)c]) { todo[(size_t)std::min(c / per, engines - 1)].push_back(c); deep[(size_t)c] = 1; any = true; }
-        if (!any) return true;
-        if (!scoreOn(todo, K)) return false;            // the owners deepen their unverified cells to the full length
-    }
+    const mm_status st = mm_group_generate(m_group, cells.data(), (int)cells.size(), gridW, gridH, (int)m_colourDiffType,
+                                           m_repeatRange, m_repeatAddition, bestFit.data(), nullptr, nullptr, nullptr, &m_wasCanceled);
+    if (st != MM_OK && st != MM_CANCELLED) m_lastError = mm_group_last_error(m_group);
+    return st == MM_OK;
 }

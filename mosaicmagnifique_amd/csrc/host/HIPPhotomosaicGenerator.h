@@ -130,11 +130,12 @@ class HIPPhotomosaicGenerator {
 public:
     explicit HIPPhotomosaicGenerator(int device = 0);
     // Several GPUs from ONE process (the reference's generator is single-device,
-    // CUDA/CUDAPhotomosaicGenerator.h:31): one engine per entry of `devices` (an id may be listed more
-    // than once), library / masks / target replicated, the valid cells of a step cut into contiguous
-    // shards scored concurrently by one host thread per engine (mm_score_cells_partial), the candidate
-    // lists merged on the host, and ONE verifying resolve (mm_resolve_verify) on the first engine --
-    // the same speculate-and-verify loop as mm_generate, so the grid equals the single-device one.
+    // CUDA/CUDAPhotomosaicGenerator.h:31): the library's mm_group -- one engine per entry of `devices`,
+    // library / masks / target replicated, the valid cells of a step cut into contiguous shards, ONE RCCL
+    // all-gather of the candidate lists, the same verifying resolve on every device (mm_group_generate); a
+    // device id listed more than once gathers through host memory (RCCL refuses it).  The grid equals
+    // the single-device one.
+    bool usesRccl() const { return m_group && mm_group_uses_rccl(m_group) != 0; }
     explicit HIPPhotomosaicGenerator(const std::vector<int>& devices);
     ~HIPPhotomosaicGenerator();
     size_t deviceCount() const { return m_engines.size(); }
@@ -179,7 +180,7 @@ public:
 private:
     mm_engine* m_engine = nullptr;          // m_engines[0]: the one that resolves and paints
     std::vector<mm_engine*> m_engines;
-    int m_specK = 4;                        // speculative short lists of the multi-engine path (option "spec_k")
+    mm_group* m_group = nullptr;            // several devices: owns m_engines
     bool generateStepSharded(const std::vector<mm_cell>& cells, int gridW, int gridH, std::vector<int64_t>& bestFit);
     Image m_img;
     std::vector<Image> m_lib;

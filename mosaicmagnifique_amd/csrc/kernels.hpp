@@ -1888,6 +1888,129 @@ shrink_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int
 }
 
 // ---------------------------------------------------------------------------
+// entropy subdivision of the grid (GridGenerator::findCellState, Grid/GridGenerator.cpp:143-189)
+// ---------------------------------------------------------------------------
+//
+// A cell of a size step that is not the last is handed to the next (half-size) step when the grey-level
+// entropy of the image under its (bounded, flipped) detail mask reaches 0.7 * MAX_ENTROPY = 5.6 bits:
+//   visible part of the u8 main image under the cell rect  ->  resizeImage(EXACT) to the bounded mask's size
+//   (Other/ImageUtility.cpp:34-61: INTER_AREA for a shrink)  ->  BGR2GRAY  ->  256-bin histogram under the mask
+//   ->  entropy = -sum p log2 p  (Other/ImageUtility.cpp:189-242).
+// One workgroup per cell: every thread resizes its share of the destination pixels straight from the resident
+// image, the histogram lives in LDS, thread 0 sums the 256 terms in index order in fp64.
+// OpenCV is absent from the reference checkout, so the resize arithmetic is the SPECIFIED one of this repository
+// (imageutil.resize_area_u8; the CPU checker of the test suite restates it independently): same size -> copy; both axes shrunk by the same
+// whole factor f -> (sum + 2) >> 2 for f = 2, rint(float(sum) * (1.f / (f f))) above; anything else ->
+// computeResizeAreaTab per axis (entries generated here on the fly, in fp64 as cv::resize does) with f32
+// accumulators: buf = ((0 + S a0) + S a1) + ... along each contributing source row, sum = b0 buf0, sum += b1 buf1 ...,
+// cvRound, saturate.  BGR2GRAY on u8 is (B 1868 + G 9617 + R 4899 + 2^13) >> 14.
+
+// Source cells and weights under destination index d of an axis shrunk from ssize to dsize.
+struct AreaSpan {
+    int first, count;        // source indices first .. first + count - 1
+    float head, mid, tail;   // weights: entry 0 (if has_head), the full ones, the last (if has_tail)
+    bool has_head, has_tail;
+    __device__ __forceinline__ float weight(int k) const
+    {
+        if (has_head && k == 0) return head;
+        if (has_tail && k == count - 1) return tail;
+        return mid;
+    }
+};
+
+__device__ __forceinline__ AreaSpan area_span(int ssize, int dsize, int d)
+{
+    const double scale = 1.0 / ((double)dsize / ssize);
+    const double fsx1 = d * scale, fsx2 = fsx1 + scale;
+    const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    if (sx2 > ssize - 1) sx2 = ssize - 1;
+    if (sx1 > sx2) sx1 = sx2;
+    AreaSpan sp;
+    sp.has_head = sx1 - fsx1 > 1e-3;
+    sp.has_tail = fsx2 - sx2 > 1e-3;
+    sp.first = sp.has_head ? sx1 - 1 : sx1;
+    sp.count = (sp.has_head ? 1 : 0) + (sx2 - sx1) + (sp.has_tail ? 1 : 0);
+    sp.head = (float)((sx1 - fsx1) / cell);
+    sp.mid = (float)(1.0 / cell);
+    double w = fsx2 - sx2;
+    if (w > 1.0) w = 1.0;
+    if (w > cell) w = cell;
+    sp.tail = (float)(w / cell);
+    return sp;
+}
+
+__global__ void __launch_bounds__(kBlock)
+cell_entropy_kernel(const mm_cell* __restrict__ recs, int n_cells, const uint8_t* __restrict__ image, int rows, int cols,
+                    int normal_size, const uint8_t* __restrict__ masks, int detail_size, int ppad,
+                    uint8_t* __restrict__ exceeded, double* __restrict__ entropy_out)
+{
+    __shared__ unsigned int hist[256];
+    const int cell = blockIdx.x;
+    if (cell >= n_cells) return;
+    const mm_cell rec = recs[cell];
+    hist[threadIdx.x] = 0u;                                   // kBlock == 256 bins
+    __syncthreads();
+    // visible part of the image under the normal cell's rect, and the bounded detail mask it is resized to
+    const int y0 = min(max(rec.y, 0), rows), y1 = min(max(rec.y + normal_size, 0), rows);
+    const int x0 = min(max(rec.x, 0), cols), x1 = min(max(rec.x + normal_size, 0), cols);
+    const int vr = y1 - y0, vc = x1 - x0;
+    const int bh = rec.row_max - rec.row_min, bw = rec.col_max - rec.col_min;
+    const uint8_t* mask = masks + (size_t)rec.mask_id * ppad + (size_t)rec.row_min * detail_size + rec.col_min;
+    if (vr > 0 && vc > 0) {
+        const bool same = vr == bh && vc == bw;
+        const bool whole = !same && vr % bh == 0 && vc % bw == 0 && vr / bh == vc / bw;
+        const int f = whole ? vr / bh : 1;
+        for (int p = threadIdx.x; p < bh * bw; p += kBlock) {
+            const int r = p / bw, c = p - r * bw;
+            if (mask[(size_t)r * detail_size + c] == 0) continue;          // (the value is needed under the mask only)
+            int px[3];
+            if (same || whole) {
+                int sum[3] = {0, 0, 0};
+                for (int i = 0; i < f; ++i)
+                    for (int j = 0; j < f; ++j) {
+                        const uint8_t* q = image + ((size_t)(y0 + r * f + i) * cols + (x0 + c * f + j)) * 3;
+                        sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2];
+                    }
+                const float scale = 1.0f / (float)(f * f);
+                for (int k = 0; k < 3; ++k)
+                    px[k] = f == 1 ? sum[k] : (f == 2 ? (sum[k] + 2) >> 2 : min(255, max(0, __float2int_rn((float)sum[k] * scale))));
+            } else {
+                const AreaSpan ys = area_span(vr, bh, r), xs = area_span(vc, bw, c);
+                float t[3] = {0.f, 0.f, 0.f};
+                for (int ky = 0; ky < ys.count; ++ky) {
+                    const uint8_t* row = image + ((size_t)(y0 + ys.first + ky) * cols + x0) * 3;
+                    const float beta = ys.weight(ky);
+                    float b[3] = {0.f, 0.f, 0.f};
+                    for (int kx = 0; kx < xs.count; ++kx) {
+                        const uint8_t* q = row + (size_t)(xs.first + kx) * 3;
+                        const float al = xs.weight(kx);
+                        b[0] = b[0] + (float)q[0] * al; b[1] = b[1] + (float)q[1] * al; b[2] = b[2] + (float)q[2] * al;
+                    }
+                    if (ky == 0) { t[0] = beta * b[0]; t[1] = beta * b[1]; t[2] = beta * b[2]; }
+                    else { t[0] = t[0] + beta * b[0]; t[1] = t[1] + beta * b[1]; t[2] = t[2] + beta * b[2]; }
+                }
+                for (int k = 0; k < 3; ++k) px[k] = min(255, max(0, __float2int_rn(t[k])));
+            }
+            const int gray = (px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + (1 << 13)) >> 14;
+            atomicAdd(&hist[gray & 255], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long count = 0;
+        for (int i = 0; i < 256; ++i) count += hist[i];
+        double entropy = 0.0;
+        for (int i = 0; i < 256; ++i) {
+            const double prob = (double)hist[i] / (double)count;        // count == 0: NaN, "> 0" is false, entropy stays 0
+            if (prob > 0) entropy -= prob * log2(prob);
+        }
+        exceeded[cell] = entropy >= 8.0 * 0.7 ? 1 : 0;                  // MAX_ENTROPY * 0.7 (ImageUtility.h:69)
+        if (entropy_out) entropy_out[cell] = entropy;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // calibration: what a plain coalesced read stream reaches on this device
 // ---------------------------------------------------------------------------
 

@@ -251,6 +251,21 @@ class Engine:
         """batchResizeMat on the u8 library between the size steps of buildPhotomosaic."""
         self._check(self._lib.mm_shrink_library_bgr(self._h, int(factor)))
 
+    def set_main_image_bgr(self, image):
+        """The u8 BGR main image as setMainImage receives it, kept on the device for ``cell_entropy``."""
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("image must be [rows][cols][3]")
+        self._check(self._lib.mm_set_main_image_bgr(self._h, _lib.ptr(a), a.shape[0], a.shape[1]))
+
+    def cell_entropy(self, cells, normal_size, want_entropy=False):
+        """mm_cell_entropy -> u8 [n] (1 = the cell's entropy reaches 0.7 * MAX_ENTROPY), and the entropies if wanted."""
+        rec = _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
+        exceeded = np.zeros(len(rec), dtype=np.uint8)
+        entropy = np.zeros(len(rec), dtype=np.float64) if want_entropy else None
+        self._check(self._lib.mm_cell_entropy(self._h, _lib.ptr(rec), len(rec), int(normal_size), _lib.ptr(exceeded), _lib.ptr(entropy)))
+        return (exceeded, entropy) if want_entropy else exceeded
+
     def set_option(self, name, value):
         """mm_set_option: "filter" 1 (default, two-tier fp32 filter + fp64 re-score) or 0 (fp64 only)."""
         self._check(self._lib.mm_set_option(self._h, name.encode(), int(value)))
@@ -296,3 +311,85 @@ class Engine:
         self._check(self._lib.mm_filter_diff_batch(self._h, int(diff_type), _lib.ptr(a), _lib.ptr(b),
                                                    a.shape[0], _lib.ptr(out)))
         return out
+
+
+class EngineGroup:
+    """mm_group_*: one process, one engine per listed device, the cell-sharded generate with ONE RCCL all-gather of
+    the candidate lists behind the C ABI (host merge when RCCL refuses the device list, e.g. one device twice)."""
+
+    def __init__(self, devices):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        st = self._lib.mm_group_create(devs, len(devices), ctypes.byref(self._h))
+        if st != _lib.MM_OK:
+            raise EngineError(st, (self._lib.mm_group_last_error(None) or b"").decode())
+        self.devices = [int(d) for d in devices]
+        self.n_library = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mm_group_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, st):
+        if st == _lib.MM_OK:
+            return
+        msg = (self._lib.mm_group_last_error(self._h) or b"").decode()
+        raise (Cancelled if st == _lib.MM_CANCELLED else EngineError)(st, msg)
+
+    @property
+    def uses_rccl(self):
+        return bool(self._lib.mm_group_uses_rccl(self._h))
+
+    def __len__(self):
+        return self._lib.mm_group_size(self._h)
+
+    def timing(self, index=0):
+        t = _lib.MMTiming()
+        st = self._lib.mm_get_timing(self._lib.mm_group_engine(self._h, int(index)), ctypes.byref(t))
+        self._check(st)
+        return t.as_dict()
+
+    def set_library(self, images):
+        a = np.ascontiguousarray(images, dtype=np.float32)
+        self._check(self._lib.mm_group_set_library(self._h, _lib.ptr(a), a.shape[0], a.shape[1]))
+        self.n_library = a.shape[0]
+
+    def set_library_u8(self, images, diff_type, detail_size=None):
+        a = np.ascontiguousarray(images, dtype=np.uint8)
+        self._check(self._lib.mm_group_set_library_u8(self._h, _lib.ptr(a), a.shape[0], a.shape[1],
+                                                      int(detail_size or a.shape[1]), int(diff_type)))
+        self.n_library = a.shape[0]
+
+    def set_masks(self, masks):
+        a = np.ascontiguousarray(masks, dtype=np.uint8)
+        self._check(self._lib.mm_group_set_masks(self._h, _lib.ptr(a), a.shape[1]))
+
+    def set_target(self, image):
+        a = np.ascontiguousarray(image, dtype=np.float32)
+        self._check(self._lib.mm_group_set_target(self._h, _lib.ptr(a), a.shape[0], a.shape[1]))
+
+    def set_target_u8(self, image, diff_type):
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        self._check(self._lib.mm_group_set_target_u8(self._h, _lib.ptr(a), a.shape[0], a.shape[1], int(diff_type)))
+
+    def set_option(self, name, value):
+        self._check(self._lib.mm_group_set_option(self._h, name.encode(), int(value)))
+
+    def generate(self, cells, grid_w, grid_h, diff_type, repeat_range=0, repeat_addition=0, want_scores=True):
+        rec = _lib.as_cells(np.asarray(cells, dtype=CELL_DTYPE))
+        best = np.empty((grid_h, grid_w), dtype=np.int64)
+        score = np.empty((grid_h, grid_w), dtype=np.float64) if want_scores else None
+        self._check(self._lib.mm_group_generate(self._h, _lib.ptr(rec), len(rec), grid_w, grid_h, int(diff_type),
+                                                int(repeat_range), int(repeat_addition), _lib.ptr(best), _lib.ptr(score),
+                                                None, None, None))
+        return best, score

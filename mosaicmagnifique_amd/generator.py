@@ -92,7 +92,10 @@ class HIPPhotomosaicGenerator:
         self._inputs_version += 1
 
     def setCellGroup(self, cellGroup):
-        self.m_cells = cellGroup
+        """A COPY, as the reference's setter takes one (PhotomosaicGeneratorBase.cpp:72-75 assigns the CellGroup by
+        value): a shape swapped into the caller's group afterwards does not reach masks already staged."""
+        import copy
+        self.m_cells = copy.deepcopy(cellGroup)
         self._inputs_version += 1
 
     def invalidate(self):
@@ -101,6 +104,16 @@ class HIPPhotomosaicGenerator:
 
     def getCellGroup(self):
         return self.m_cells
+
+    def gridStateOnDevice(self):
+        """GridGenerator::getGridState(cellGroup, mainImage) with the entropy test of every size step on this
+        generator's device (mm_cell_entropy); needs the u8 BGR main image and the cell group."""
+        if self.m_img is None or self.m_img.dtype != np.uint8:
+            raise ValueError("the entropy subdivision needs the u8 BGR main image")
+        state = GridUtility.getGridState(self.m_cells, self.m_img.shape[0], self.m_img.shape[1], mainImage=self.m_img,
+                                         engine=self.m_engine)
+        self._masks_key = None              # the engine now holds some step's detail masks
+        return state
 
     def setGridState(self, gridState):
         self.m_bestFits = [np.array(s, dtype=np.int64) for s in gridState]

@@ -158,11 +158,54 @@ def findCellState(cellGroup, mainImage, x, y, bounds, step):
     return 0, False
 
 
-def getGridState(cellGroup, imageRows, imageCols, mainImage=None):
+def _grid_state_on_device(cellGroup, mainImage, engine):
+    """getGridState's step loop with the per-cell image work (resize of the visible part, BGR2GRAY, masked
+    histogram, entropy) on the device: ``engine.cell_entropy`` over all cells of a step that lie inside an active
+    bound; the integer geometry, the bounds and their merging stay here, vectorised."""
+    imageRows, imageCols = mainImage.shape[0], mainImage.shape[1]
+    engine.set_main_image_bgr(mainImage)
+    gridState = []
+    active = [Rect(0, 0, imageCols, imageRows)]
+    steps = cellGroup.getSizeSteps()
+    for step in range(steps + 1):
+        if not active:
+            break
+        shape = cellGroup.getCell(step)
+        gw, gh = calculateGridSize(shape, imageCols, imageRows)
+        gx, gy = np.meshgrid(np.arange(gw, dtype=np.int64) - PAD_GRID, np.arange(gh, dtype=np.int64) - PAD_GRID)
+        r = getRectAt(shape, gx, gy)
+        inside = np.zeros(gx.shape, dtype=bool)
+        for b in active:                                     # findCellState's in-bounds test, :124-140
+            y0, y1 = np.clip(r.y, b.y, b.y + b.height), np.clip(r.y + r.height, b.y, b.y + b.height)
+            x0, x1 = np.clip(r.x, b.x, b.x + b.width), np.clip(r.x + r.width, b.x, b.x + b.width)
+            inside |= (y0 != y1) & (x0 != x1)
+        state = np.where(inside, 0, NULLOPT).astype(np.int64)
+        nxt = []
+        if step < steps and inside.any():
+            detail = cellGroup.getCell(step, True)
+            engine.set_masks(detail.masks4())
+            recs = cell_records(cellGroup, state, imageRows, imageCols, step)
+            split = engine.cell_entropy(recs, shape.getSize()) != 0
+            state[recs["grid_y"][split], recs["grid_x"][split]] = NULLOPT
+            for c in recs[split]:                            # raster order, as the reference adds them (:77-103)
+                y0, y1 = min(max(int(c["y"]), 0), imageRows), min(max(int(c["y"]) + shape.getSize(), 0), imageRows)
+                x0, x1 = min(max(int(c["x"]), 0), imageCols), min(max(int(c["x"]) + shape.getSize(), 0), imageCols)
+                if y0 != y1 and x0 != x1:
+                    nxt.append(Rect(x0, y0, x1 - x0, y1 - y0))
+        gridState.append(state)
+        active = mergeBounds(nxt) if nxt else []
+    return gridState
+
+
+def getGridState(cellGroup, imageRows, imageCols, mainImage=None, engine=None):
     """GridGenerator::getGridState (GridGenerator.cpp:29-110): one StepBestFit per size step;
     a cell whose masked grey-level entropy reaches 0.7 * MAX_ENTROPY is handed to the next
     (half-size) step.  ``mainImage``: u8 BGR, needed only with size steps > 0; without it
-    (or with size steps 0) a cell is valid iff its rect meets the image."""
+    (or with size steps 0) a cell is valid iff its rect meets the image.  ``engine``: an Engine
+    whose ``cell_entropy`` does the per-cell image work on the device (it leaves the LAST step's
+    detail masks staged on that engine)."""
+    if engine is not None and mainImage is not None and cellGroup.getSizeSteps() > 0 and not cellGroup.getCell(0).empty():
+        return _grid_state_on_device(cellGroup, np.asarray(mainImage), engine)
     if cellGroup.getCell(0).empty():
         return []
     if mainImage is not None:

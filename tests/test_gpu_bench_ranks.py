@@ -1,7 +1,11 @@
 """bench.py's N > 1 code path on a one-GPU box: the ranks share GPU 0 and the collective runs over gloo
-(MOSAIC_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device).  The timings of such a run are void; what
-is checked is that the launch contract holds: torch.distributed.run with N ranks, ONE JSON line from rank 0,
-whole-job cell counts, the scaling mode."""
+(MOSAIC_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device).  The timings of such a run are void; what is
+checked is (a) the launch contract -- torch.distributed.run with N ranks, ONE JSON line from rank 0, whole-job cell
+counts, the scaling mode -- and (b) the RESULT: the sha256 of the best-fit grid and the scores an N-rank run of the
+real engine through mosaicmagnifique_amd/dist.py ends with (`result_digest`) equals the one-GPU run's, for weak
+bands and strong shards, with the deepening rounds forced (spec_k = 2).  A GPU box admits six processes on its
+card (this process holds it too), so the rank counts here are 2, 3 and 4; eight shards run in ONE process through the C ABI's group
+(tests/test_gpu_group.py)."""
 import json
 import os
 import subprocess
@@ -19,34 +23,69 @@ def free_port():
         return so.getsockname()[1]
 
 
-def run_ranks(n, port, *extra):
-    port = free_port()                                  # (the argument is kept for readability of the call sites)
+def last_json(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, stdout[-2000:]              # one JSON line, nothing else on stdout
+    return json.loads(lines[0])
+
+
+def run_single(*extra):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu", *extra],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return last_json(p.stdout)
+
+
+def run_ranks(n, *extra):
     env = dict(os.environ, MOSAIC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(n), "--steps", "2", "--warmup", "1", *extra]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]            # one JSON line, nothing else on stdout
-    return json.loads(lines[0])
+    return last_json(p.stdout)
 
 
 @pytest.mark.gpu
 def test_two_ranks_weak_bands_of_config_b():
-    single = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "B", "--steps", "1",
-                                        "--warmup", "0", "--no-cpu"], cwd=ROOT, capture_output=True, text=True,
-                                       timeout=300, check=True).stdout.strip().splitlines()[-1])
-    out = run_ranks(2, 29541, "--config", "B")       # weak bands need square cells: B (config D is the same path, 25 s)
+    single = run_single("--config", "B", "--bands", "2")          # the same 2-band mosaic on one GPU
+    out = run_ranks(2, "--config", "B")       # weak bands need square cells: B (config D is the same path, 25 s)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 2
-    assert out["config"]["cells"] == 2 * single["config"]["cells"]          # one band per rank
+    assert out["config"]["cells"] == single["config"]["cells"] == 2 * 1024          # one band per rank
     assert "REHEARSAL" in out["data"] and out["value"] > 0
     assert out["last_step_device_ms"]["band_alarms"] == 0
+    assert out["result_digest"] == single["result_digest"]
 
 
 @pytest.mark.gpu
 def test_three_ranks_strong_shards_of_config_c():
-    out = run_ranks(3, 29542, "--config", "C", "--scaling", "strong")
+    single = run_single("--config", "C")
+    out = run_ranks(3, "--config", "C", "--scaling", "strong")
     assert out["n_gpus"] == 3 and out["scaling"] == "strong"
     assert "x3 (strong)" in out["config"]["parallelism"]
     assert out["value"] > 0
+    assert out["result_digest"] == single["result_digest"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_weak_bands_with_the_repeat_penalty_and_forced_deepening(n):
+    """The reduced shape of config D (64 x 64 cells, CIEDE2000, repeat range 4 + 500): the repeat window reaches across
+    the band seams, the short lists of 2 leave picks unverified, their owners deepen them and the lists are gathered
+    again -- and the N-band grid equals the one a single GPU gives for the same mosaic."""
+    single = run_single("--config", "Ds", "--bands", str(n), "--opt", "spec_k=2")
+    out = run_ranks(n, "--config", "Ds", "--opt", "spec_k=2")
+    assert out["n_gpus"] == n and out["scaling"] == "weak"
+    assert out["config"]["cells"] == single["config"]["cells"] == n * 256
+    assert out["result_digest"] == single["result_digest"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4])
+def test_strong_shards_of_the_reduced_config_e(n):
+    """The reduced shape of config E (48 x 48 cells, last row / column clipped, no repeat penalty): ceil(441 / N)
+    contiguous shards, the last one short."""
+    single = run_single("--config", "Es")
+    out = run_ranks(n, "--config", "Es")           # E-shaped configs default to strong scaling
+    assert out["config"]["cells"] == single["config"]["cells"] == 441
+    assert out["result_digest"] == single["result_digest"]

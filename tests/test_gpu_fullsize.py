@@ -182,6 +182,22 @@ def test_config_c_ciede2000_2048_hexagon_l1000(oracle, engine):
     # interior (unclipped) and clipped cells both present in the prefix? check one clipped cell explicitly
     clipped = cells[(cells["row_max"] - cells["row_min"] < 64) | (cells["col_max"] - cells["col_min"] < 64)]
     assert len(clipped) > 100
+    # ... and at the benchmarked size against the ORACLE, not only against the engine's other paths: 64 unclipped and
+    # 16 clipped cells drawn at random from the whole grid (the sample bench.py --config C reports parity on)
+    random_cells_against_the_oracle(oracle, engine, shape, img, lib, t, cells, best, score, L)
+
+
+def random_cells_against_the_oracle(oracle, engine, shape, img, lib, t, cells, best, score, L, rel_tol=1e-4):
+    import bench
+    sample, _ = bench.parity_sample(dict(rep=(0, 0), size=shape.getSize(), shape=shape), cells)
+    assert len(sample) >= 64
+    pos = np.stack([sample["grid_y"], sample["grid_x"]], axis=1)
+    grid = np.where(best < L, best, -1)
+    picks, scores = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), 0, 0, grid, pos, threads=host_threads())
+    got = best[pos[:, 0], pos[:, 1]]
+    assert np.array_equal(np.where(got == L, -1, got), picks), np.flatnonzero(np.where(got == L, -1, got) != picks)
+    ok = picks >= 0
+    assert (np.abs(score[pos[ok, 0], pos[ok, 1]] - scores[ok]) <= rel_tol * np.abs(scores[ok]) + 1e-300).all()
 
 
 def test_config_c_whole_grid_same_on_every_path(engine):
@@ -326,7 +342,7 @@ def test_config_e_one_rank_shard_48px_cells_l10000(oracle, engine):
 
 
 @pytest.mark.parametrize("t", [Type.CIEDE2000, Type.RGB_EUCLIDEAN], ids=["ciede2000", "rgb"])
-def test_config_e_whole_grid_same_on_every_path(engine, t):
+def test_config_e_whole_grid_same_on_every_path(oracle, engine, t):
     """BASELINE config 5 as stated, whole, on one GPU: 8192 x 8192 target, 48 x 48 cells, 171 x 171 grid with the
     clipped last row / column (29 241 cells), 10 000 images, CIEDE2000 -- staged as bench.py --config E stages it
     (u8 images converted on the device) -- and the same images as RGB.  Default path == early exit off == fp64 only:
@@ -349,6 +365,11 @@ def test_config_e_whole_grid_same_on_every_path(engine, t):
         b2, s2 = with_options(engine, options, run)
         assert np.array_equal(b2, best), (options, int((b2 != best).sum()))
         assert np.array_equal(s2[pos], score[pos]), options
+    # 64 cells drawn at random from the whole grid (clipped last row / column included) against the ORACLE, on the arrays
+    # the engine holds (the sample bench.py --config E reports parity on)
+    img, lib = engine.get_target(w["rows"], w["cols"]), engine.get_library()
+    random_cells_against_the_oracle(oracle, engine, w["shape"], img, lib, t, cells, best, score, w["L"],
+                                    rel_tol=1e-4 if t == Type.CIEDE2000 else 1e-12)
 
 
 def test_more_cells_than_one_batch_holds(oracle, engine):

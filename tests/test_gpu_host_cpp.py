@@ -155,12 +155,12 @@ def test_host_cpp_colour_scheme(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices,spec_k", [("0,0", None), ("0,0,0", "2")])
+@pytest.mark.parametrize("devices,spec_k", [("0,0", None), ("0,0,0", "2"), ("0,0,0,0,0,0,0,0", "2")])
 def test_host_cpp_several_engines_in_one_process(oracle, tmp_path, devices, spec_k):
     """The single-process multi-GPU path of the C++ host (HIPPhotomosaicGenerator(devices)): one engine
-    per listed device -- two / three engines on device 0 here, as one GPU is what the box has --, the
-    cells of a step cut into contiguous shards scored by one host thread per engine, lists merged on the
-    host, ONE verifying resolve.  The grid must equal the oracle's sequential run; spec_k = 2 forces
+    per listed device -- two / three / eight engines on device 0 here, as one GPU is what the box has --, through
+    the library's mm_group: contiguous shards, ONE gather of the candidate lists (through host memory, since RCCL
+    refuses a device listed twice; ncclAllGather on distinct devices), the same verifying resolve on every engine.  The grid must equal the oracle's sequential run; spec_k = 2 forces
     the deepening rounds (short lists that the repeat penalty outruns) through the sharded path too."""
     from mosaicmagnifique_amd import synth
     shape, t, rep = cases.hexagon_shape(), Type.CIEDE2000, (2, 300)

@@ -61,7 +61,7 @@ def test_config_a_is_one_submission(oracle, default_engine):
     want, want_score, n = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), 0, 0)
     assert n == 256 and np.array_equal(np.where(best < L, best, -1), want)
     valid = want >= 0
-    assert np.array_equal(score[valid], want_score[valid])          # RGB: the same bits
+    assert (np.abs(score[valid] - want_score[valid]) <= 1e-12 * want_score[valid]).all()     # parallel vs sequential fp64 sum
 
 
 @pytest.mark.parametrize("t,rep", [(Type.CIEDE2000, (0, 0)), (Type.CIEDE2000, (3, 400)), (Type.CIE76, (2, 150)),
