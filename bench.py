@@ -330,6 +330,114 @@ def stage_bench(args, emit):
     }))
 
 
+def sweep_bench(args, emit):
+    """--sweep: the shape of the reference's own benchmark harness (Benchmark/Benchmark_Generator.h:107-183) on
+    synthetic inputs: a 5000 x 4000 main image (its "edgar-perez" photograph), a 214-image library (the count of
+    Library/lib-images.txt) at the cell size, square cells; one parameter varied per block from the harness's
+    defaults (CIE76, detail 20 %, size steps 0, cell size 128): colour difference x3, detail {25, 50, 75, 100} (and the
+    default 20), size steps {0, 1, 2}, cell size {128, 64, 32, 16, 8}.  Per line, wall-clock ms of
+      first   generateBestFits() of a freshly set-up generator -- what the harness's timer brackets: pre-processing of
+              image and library (on the device here), staging, the best-fit pass over every size step;
+      warm    the same call again (inputs resident: the hot path alone);
+      grid    GridGenerator::getGridState (entropy subdivision on the device when size steps > 0);
+      build   buildPhotomosaic incl. the copy of the BGRA mosaic to the host;
+      cpu     the CPU oracle (port of CPUPhotomosaicGenerator, 1 thread, early exit on) on the same pre-processed
+              arrays -- the whole grid when that is below ~8 s, else a raster-order prefix scaled up (marked ~)."""
+    import torch  # noqa: F401
+    import oracle_ffi
+    import cases
+    from mosaicmagnifique_amd import GridUtility as G
+    from mosaicmagnifique_amd import HIPPhotomosaicGenerator, synth
+    from mosaicmagnifique_amd.cellshape import CellGroup
+    orc = oracle_ffi.load()
+    rows, cols, n_lib = 4000, 5000, 214
+    img = synth.target_u8(rows, cols, lattice=64)
+    ns_per_pair = {0: 6.0, 1: 6.0, 2: 200.0}
+    libs = {}
+    lines = []
+
+    def one(block, t, detail, steps, cell):
+        if cell not in libs:
+            libs[cell] = synth.library_u8(n_lib, cell)
+        lib = libs[cell]
+        group = CellGroup(cases.square_shape(cell))
+        group.setDetail(detail)
+        group.setSizeSteps(steps)
+        gen = HIPPhotomosaicGenerator(0)
+        gen.setMainImage(img); gen.setLibrary(lib); gen.setColourDifference(t); gen.setCellGroup(group)
+        t0 = time.perf_counter()
+        state = gen.gridStateOnDevice() if steps > 0 else G.getGridState(group, rows, cols)
+        grid_ms = (time.perf_counter() - t0) * 1e3
+        gen.setGridState(state)
+        t0 = time.perf_counter()
+        ok = gen.generateBestFits()
+        first_ms = (time.perf_counter() - t0) * 1e3
+        if not ok:
+            raise SystemExit("sweep: generateBestFits failed: " + gen.lastError)
+        fits, scores = gen.getBestFits(), gen.getBestScores()
+        gen.setGridState(state)
+        t0 = time.perf_counter()
+        gen.generateBestFits()
+        warm_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        mosaic = gen.buildPhotomosaic((0, 0, 0, 0))
+        build_ms = (time.perf_counter() - t0) * 1e3
+        cells = [int((s >= 0).sum()) for s in state]
+        # the CPU oracle on the same arrays, step by step
+        gen2_main = gen.preprocessMainImage()
+        lib_f = gen.preprocessLibraryImages()
+        cpu_ms, estimated, same = 0.0, False, True
+        for step in range(len(state)):
+            if step > 0:
+                lib_f = orc.shrink_library_f32(lib_f, 2)
+            d = group.getCell(step, True)
+            dsize = d.getSize()
+            pairs_per_cell = n_lib * dsize * dsize
+            budget_cells = int(8e9 / (len(state) * max(pairs_per_cell * ns_per_pair[int(t)], 1.0)))
+            n_valid = cells[step]
+            max_cells = -1 if budget_cells >= n_valid else max(budget_cells, 16)
+            t0 = time.perf_counter()
+            want, want_score, done = orc.generate_step(oracle_ffi.shape_of(group.getCell(step)), dsize, group.getDetail(), gen2_main,
+                                                       lib_f, d.masks4(), int(t), 0, 0, state=state[step], max_cells=max_cells)
+            dt = (time.perf_counter() - t0) * 1e3
+            if done < n_valid:
+                estimated = True
+                dt *= n_valid / max(done, 1)
+            cpu_ms += dt
+            checked = G.cell_records(group, state[step], rows, cols, step)[:done]
+            same = same and bool((fits[step][checked["grid_y"], checked["grid_x"]] == want[checked["grid_y"], checked["grid_x"]]).all())
+        line = {"block": block, "diff_type": TYPE_NAMES[int(t)], "detail_percent": detail, "size_steps": steps, "cell_size": cell,
+                "detail_cell": group.getCellSize(0, True), "cells_per_step": cells, "grid_ms": grid_ms, "first_ms": first_ms,
+                "warm_ms": warm_ms, "build_ms": build_ms, "cpu_ms": cpu_ms, "cpu_estimated_from_prefix": estimated,
+                "speedup_first": cpu_ms / first_ms, "speedup_warm": cpu_ms / warm_ms, "indices_equal_on_cpu_cells": same,
+                "mosaic_alpha_covered": float((mosaic[..., 3] == 255).mean())}
+        lines.append(line)
+        sys.stderr.write("%-12s %-13s detail %3d%% steps %d cell %3d (%2d px) cells %-22s grid %8.1f first %8.1f warm %8.2f build %7.1f cpu %s%10.0f ms  x%-8.0f %s\n" % (
+            block, TYPE_NAMES[int(t)], detail, steps, cell, line["detail_cell"], cells, grid_ms, first_ms, warm_ms, build_ms,
+            "~" if estimated else " ", cpu_ms, line["speedup_first"], "ok" if same else "MISMATCH"))
+        del gen
+
+    for t in (0, 1, 2):
+        one("colour diff", t, 20, 0, 128)
+    for detail in (25, 50, 75, 100):
+        one("detail", 1, detail, 0, 128)
+    # (detail 25 % here: at the harness's 20 % the detail cell is 25 px and the reference's own per-step sizes drift apart --
+    # batchResizeMat halves the library to round(12.5) = 13 px against a detail cell of int(64 * 0.2) = 12 px)
+    for steps in (0, 1, 2):
+        one("size steps", 1, 25, steps, 128)
+    for cell in (128, 64, 32, 16, 8):
+        one("cell size", 1, 20, 0, cell)
+    base = lines[1]
+    emit(json.dumps({
+        "metric": "ms per generateBestFits, reference harness defaults (5000x4000, 214 images, cell 128, detail 20 %, CIE76), cold call",
+        "value": base["first_ms"], "unit": "ms", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": base["first_ms"],
+        "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32 filter + f64 arbiter", "data": "synthetic",
+        "config": {"workload": "sweep after Benchmark/Benchmark_Generator.h:107-183: 5000x4000 target, 214-image library, square cells; "
+                               "colour difference x3 | detail 25..100 | size steps 0..2 | cell size 128..8"},
+        "sweep": lines,
+    }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,6 +456,9 @@ def main():
     ap.add_argument("--stage", choices=("build", "preprocess"), default=None,
                     help="time the byte kernels either side of the hot path instead of it (buildPhotomosaic / the u8 -> f32 "
                          "pre-processing) and report their GB/s against HBM peak")
+    ap.add_argument("--sweep", action="store_true",
+                    help="the reference's benchmark harness shape (Benchmark/Benchmark_Generator.h): end-to-end ms per "
+                         "generateBestFits beside the CPU oracle's over colour difference / detail / size steps / cell size")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine tuning option (mm_set_option), for experiments")
     args = ap.parse_args()
@@ -365,6 +476,8 @@ def main():
 
     if args.stage:
         return stage_bench(args, emit)
+    if args.sweep:
+        return sweep_bench(args, emit)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -239,6 +239,16 @@ mm::CellResize cell_resize_of(const mm_engine* e)
     return r;
 }
 
+// The engine's device made current, and the calling thread's sticky HIP error cleared: the kernel launches below are
+// checked with hipGetLastError(), which would otherwise report an error some OTHER library left behind on this thread
+// (RCCL probing peer access while it builds a communicator leaves hipErrorInvalidDevice, for one).
+hipError_t select_device(mm_engine* e)
+{
+    const hipError_t code = hipSetDevice(e->device);
+    (void)hipGetLastError();
+    return code;
+}
+
 hipError_t sync_stream(mm_engine* e)
 {
     e->syncs += 1;
@@ -361,7 +371,7 @@ mm::Variants variants_of(const mm_engine* e)
     v.lib_stats = (const float*)e->lib_lsum.p;
     v.cell_stats = (const float*)e->cell_lsum.p;
     v.lib_stats_stride = (size_t)e->n_var * e->n_lib * (ppad / 64);
-    v.cell_stats_stride = e->cell_lsum.bytes / sizeof(float) / 7;
+    v.cell_stats_stride = e->cell_lsum.bytes / sizeof(float) / 8;
     v.n_blocks = ppad / 64;
     v.cell_full = (const uint8_t*)e->cell_full.p;
     v.two_stage = e->two_level;
@@ -570,7 +580,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     // Batch so that every per-cell workspace stays within a budget: score row, the planar / NaN-marked / chroma /
     // interleaved copies of the cell and its mask, block statistics, contenders, seeds, flags.
     const size_t per_cell = (size_t)L * sizeof(double) + (size_t)ppad * (12 + 1 + (two_tier ? 4 + 4 + 16 : 0)) +
-                            (size_t)7 * (ppad / 64) * sizeof(float) + (size_t)Kc * 16 + (prune ? (size_t)M * 8 + 4 : 0) + 16;
+                            (size_t)8 * (ppad / 64) * sizeof(float) + (size_t)Kc * 16 + (prune ? (size_t)M * 8 + 4 : 0) + 16;
     // hipMemGetInfo is a driver round trip: asked again only when this call needs more cells per batch than the
     // last budget allowed (the workspaces below are kept between calls)
     const int want_cells = std::min(n, 32768);
@@ -596,7 +606,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         mm_status st;
         if ((st = ensure(e, e->cell_var, (size_t)bt, "Failed to allocate cell variants")) ||
             (st = ensure(e, e->cell_full, (size_t)bt, "Failed to allocate cell flags")) ||
-            (st = ensure(e, e->cell_lsum, (size_t)7 * bt * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
+            (st = ensure(e, e->cell_lsum, (size_t)8 * bt * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
             (st = ensure(e, e->cells, (size_t)bt * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
             (st = ensure(e, e->cmask, (size_t)bt * ppad, "Failed to allocate cell masks")) ||
             (st = ensure(e, e->scores, (size_t)bt * L * sizeof(double), "Failed to allocate variants")))
@@ -689,7 +699,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         if (e->fused != 0) {
             // one launch: planes, mask, NaN-marked channel 0, chroma plane, interleaved copy, block statistics
             const dim3 grid((unsigned)(ppad / mm::kBlock), (unsigned)b);
-            const size_t stats_stride = e->cell_lsum.bytes / sizeof(float) / 7;
+            const size_t stats_stride = e->cell_lsum.bytes / sizeof(float) / 8;
             if (diff_type == MM_CIEDE2000)
                 mm::gather_prepare_kernel<true><<<grid, mm::kBlock, 0, e->stream>>>(
                     recs_dev + done, (const float*)e->target.p, e->rows, e->cols, cell_resize_of(e), (const uint8_t*)e->masks.p,
@@ -717,7 +727,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                                                      (float*)e->cells_il.p, (size_t)b, ppad, e->stream), "Error during cell interleave kernel");
             }
             HIP_TRY(e, mm::launch_group_sums((const float*)e->cells.p, (const uint8_t*)e->cmask.p, (size_t)ppad,
-                                             (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 7,
+                                             (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 8,
                                              (size_t)b, ppad, e->stream),
                     "Error during cell group-sum kernel");
         }
@@ -1198,7 +1208,7 @@ mm_status mm_set_library(mm_engine* e, const float* images, int n_images, int si
         set_err(e, "mm_set_library: need n_images > 0 and 0 < size <= 4096 (got %d, %d)", n_images, size);
         return MM_INVALID_ARGUMENT;
     }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     const size_t bytes = (size_t)n_images * size * size * 3 * sizeof(float);
     mm_status st = ensure(e, e->lib_hwc, bytes, "Failed to allocate library images");
     if (st) return st;
@@ -1216,7 +1226,7 @@ mm_status mm_set_masks(mm_engine* e, const uint8_t* masks, int size)
         set_err(e, "mm_set_masks: need 0 < size <= 4096 (got %d)", size);
         return MM_INVALID_ARGUMENT;
     }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     const int P = size * size, ppad = round_up(P, 256);
     std::vector<uint8_t> padded((size_t)4 * ppad, 0);
     for (int m = 0; m < 4; ++m) memcpy(padded.data() + (size_t)m * ppad, masks + (size_t)m * P, (size_t)P);
@@ -1237,7 +1247,7 @@ mm_status mm_set_target(mm_engine* e, const float* image, int rows, int cols)
         set_err(e, "mm_set_target: need rows, cols > 0 (got %d, %d)", rows, cols);
         return MM_INVALID_ARGUMENT;
     }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     const size_t bytes = (size_t)rows * cols * 3 * sizeof(float);
     mm_status st = ensure(e, e->target, bytes, "Failed to allocate main image");
     if (st) return st;
@@ -1320,7 +1330,7 @@ mm_status mm_set_library_u8(mm_engine* e, const uint8_t* bgr, int n_images, int 
                    "(got %d, %d, %d, %d)", n_images, size, shrink, diff_type);
         return MM_INVALID_ARGUMENT;
     }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     mm_status st = preprocess_u8(e, bgr, (size_t)n_images, size, size, shrink, diff_type, e->lib_hwc);
     if (st) return st;
     e->planes_dirty = true;
@@ -1338,7 +1348,7 @@ mm_status mm_set_library_u8_sized(mm_engine* e, const uint8_t* bgr, int n_images
         return MM_INVALID_ARGUMENT;
     }
     if (size % detail_size == 0) return mm_set_library_u8(e, bgr, n_images, size, size / detail_size, diff_type);
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     // INTER_AREA by a ratio that is not whole, on the u8 images (the reference resizes before it
     // converts, PhotomosaicGeneratorBase.cpp:262-271), then the usual colour conversion
     std::vector<int> first, src;
@@ -1393,7 +1403,7 @@ mm_status mm_set_target_u8(mm_engine* e, const uint8_t* bgr, int rows, int cols,
         set_err(e, "mm_set_target_u8: need rows, cols > 0 and a known type (got %d, %d, %d)", rows, cols, diff_type);
         return MM_INVALID_ARGUMENT;
     }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     mm_status st = preprocess_u8(e, bgr, 1, rows, cols, 1, diff_type, e->target);
     if (st) return st;
     e->rows = rows;
@@ -1408,7 +1418,7 @@ mm_status mm_hue_rotate_u8(mm_engine* e, const uint8_t* bgr, int rows, int cols,
         set_err(e, "mm_hue_rotate_u8: need rows, cols > 0 and 0 <= degrees < 360 (got %d, %d, %g)", rows, cols, (double)degrees);
         return MM_INVALID_ARGUMENT;
     }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     const size_t n_px = (size_t)rows * cols, bytes = n_px * 3;
     mm_status st;
     if ((st = ensure(e, e->stage_u8, 2 * bytes, "Failed to allocate u8 staging"))) return st;
@@ -1433,7 +1443,7 @@ mm_status mm_shrink_library(mm_engine* e, int factor)
         return MM_INVALID_ARGUMENT;
     }
     if (factor == 1) return MM_OK;
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     const int so = e->lib_size / factor;
     const size_t out_px = (size_t)e->n_lib * so * so;
     mm_status st = ensure(e, e->shrink_tmp, out_px * 3 * sizeof(float), "Failed to allocate library images");
@@ -1461,7 +1471,7 @@ mm_status mm_set_cell_resize(mm_engine* e, int normal_size, int detail_size)
         set_err(e, "mm_set_cell_resize: detail size %d differs from the library's %d", detail_size, e->lib_size);
         return MM_INVALID_ARGUMENT;
     }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     std::vector<int> first, src;
     std::vector<float> alpha;
     build_area_table(normal_size, detail_size, first, src, alpha);
@@ -1491,7 +1501,7 @@ mm_status mm_get_library(mm_engine* e, float* out)
 {
     if (!e || !out) return MM_INVALID_ARGUMENT;
     if (!e->lib_hwc.p || e->n_lib <= 0) { set_err(e, "mm_get_library: no library staged"); return MM_NOT_READY; }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     HIP_TRY(e, hipMemcpy(out, e->lib_hwc.p, (size_t)e->n_lib * e->lib_size * e->lib_size * 3 * sizeof(float),
                          hipMemcpyDeviceToHost), "Error copying library to host");
     return MM_OK;
@@ -1501,7 +1511,7 @@ mm_status mm_get_target(mm_engine* e, float* out)
 {
     if (!e || !out) return MM_INVALID_ARGUMENT;
     if (!e->target.p || e->rows <= 0) { set_err(e, "mm_get_target: no main image staged"); return MM_NOT_READY; }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     HIP_TRY(e, hipMemcpy(out, e->target.p, (size_t)e->rows * e->cols * 3 * sizeof(float), hipMemcpyDeviceToHost),
             "Error copying main image to host");
     return MM_OK;
@@ -1551,7 +1561,7 @@ mm_status mm_score_cells_partial(mm_engine* e, const mm_cell* cells, int n_cells
     mm_status st = check_ready(e);
     if (st) return st;
     if ((st = check_cells(e, cells, n_cells, 0, 0))) return st;
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     e->timing = mm_timing{};
     e->syncs = 0;
     e->phase_events = e->phase_timing != 0;
@@ -1612,7 +1622,7 @@ mm_status mm_resolve_verify(mm_engine* e, const mm_cell* cells, int n_cells, int
     mm_status st = check_ready(e);
     if (st) return st;
     if ((st = check_cells(e, cells, n_cells, grid_w, grid_h))) return st;
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     if ((st = ensure(e, e->recs, (size_t)std::max(n_cells, 1) * sizeof(mm_cell), "Failed to allocate cell records"))) return st;
     HIP_TRY(e, hipMemcpyAsync(e->recs.p, cells, (size_t)n_cells * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
             "Failed to copy cell records to device");
@@ -1685,7 +1695,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     mm_status st = check_ready(e);
     if (st) return st;
     if ((st = check_cells(e, cells, n_cells, grid_w, grid_h))) return st;
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     e->timing = mm_timing{};
     e->syncs = 0;
 
@@ -1816,7 +1826,7 @@ mm_status mm_set_library_bgr(mm_engine* e, const uint8_t* images, int n_images, 
         set_err(e, "mm_set_library_bgr: need n_images > 0 and 0 < size <= 4096 (got %d, %d)", n_images, size);
         return MM_INVALID_ARGUMENT;
     }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     const size_t bytes = (size_t)n_images * size * size * 3;
     mm_status st = ensure(e, e->lib_bgr, bytes, "Failed to allocate library images");
     if (st) return st;
@@ -1835,7 +1845,7 @@ mm_status mm_shrink_library_bgr(mm_engine* e, int factor)
         return MM_INVALID_ARGUMENT;
     }
     if (factor == 1) return MM_OK;
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     const int so = e->lib_bgr_size / factor;
     const size_t out_px = (size_t)e->n_lib_bgr * so * so;
     mm_status st = ensure(e, e->stage_u8, out_px * 3, "Failed to allocate library images");
@@ -1890,7 +1900,7 @@ mm_status mm_build_photomosaic_step(mm_engine* e, const mm_cell* cells, int n_ce
                         c.grid_x >= 0 && c.grid_x < grid_w && c.grid_y >= 0 && c.grid_y < grid_h;
         if (!ok) { set_err(e, "mm_build_photomosaic: cell %d does not fit the %dx%d image / %dx%d grid", i, cols, rows, grid_w, grid_h); return MM_INVALID_ARGUMENT; }
     }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     const size_t n_pixels = (size_t)rows * cols, grid_cells = (size_t)grid_w * grid_h;
     mm_status st;
     if ((st = ensure(e, e->recs, (size_t)std::max(n_cells, 1) * sizeof(mm_cell), "Failed to allocate cell records")) ||
@@ -1941,7 +1951,7 @@ mm_status mm_set_main_image_bgr(mm_engine* e, const uint8_t* bgr, int rows, int 
         set_err(e, "mm_set_main_image_bgr: need rows, cols > 0 (got %d, %d)", rows, cols);
         return MM_INVALID_ARGUMENT;
     }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     const size_t bytes = (size_t)rows * cols * 3;
     mm_status st = ensure(e, e->main_bgr, bytes, "Failed to allocate main image");
     if (st) return st;
@@ -1975,7 +1985,7 @@ mm_status mm_cell_entropy(mm_engine* e, const mm_cell* cells, int n_cells, int n
         }
     }
     if (n_cells == 0) return MM_OK;
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     mm_status st;
     if ((st = ensure(e, e->recs, (size_t)n_cells * sizeof(mm_cell), "Failed to allocate cell records")) ||
         (st = ensure(e, e->exceeded_out, (size_t)n_cells, "Failed to allocate entropy verdicts")) ||
@@ -2012,7 +2022,7 @@ mm_status mm_debug_visit_counters(mm_engine* e, unsigned long long out[3])
 mm_status mm_debug_stream_read(mm_engine* e, size_t bytes, int repeats, double* gb_per_s)
 {
     if (!e || !gb_per_s || bytes < (1u << 20) || repeats < 1) return MM_INVALID_ARGUMENT;
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     const size_t n_vec = bytes / 16;
     const int blocks = 256 * 16;                                  // 16 workgroups of 4 waves per CU
     DevBuf src, sink;
@@ -2046,7 +2056,7 @@ mm_status mm_debug_stream_read(mm_engine* e, size_t bytes, int repeats, double* 
 mm_status mm_debug_filter_band_sweep(mm_engine* e, int mode, uint64_t seed, uint64_t n_pairs, double out[6])
 {
     if (!e || !out || (mode != 0 && mode != 1) || n_pairs == 0) return MM_INVALID_ARGUMENT;
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     mm_status st = ensure_hue_lut(e);
     if (st) return st;
     DevBuf buf;
@@ -2112,7 +2122,7 @@ mm_status mm_colour_diff_batch(mm_engine* e, int diff_type, const float* first, 
     if (!known_type(diff_type)) { set_err(e, "No function for given type %d", diff_type); return MM_INVALID_ARGUMENT; }
     if (n == 0) return MM_OK;
     if (!first || !second || !out) { set_err(e, "mm_colour_diff_batch: null pointer"); return MM_INVALID_ARGUMENT; }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     DevBuf a, b, o;
     mm_status st;
     if ((st = ensure(e, a, n * 3 * sizeof(float), "Failed to allocate pairs")) ||
@@ -2146,7 +2156,7 @@ mm_status mm_filter_diff_batch(mm_engine* e, int diff_type, const float* first, 
     if (!known_type(diff_type)) { set_err(e, "No function for given type %d", diff_type); return MM_INVALID_ARGUMENT; }
     if (n == 0) return MM_OK;
     if (!first || !second || !out) { set_err(e, "mm_filter_diff_batch: null pointer"); return MM_INVALID_ARGUMENT; }
-    HIP_TRY(e, hipSetDevice(e->device), "Failed to select device");
+    HIP_TRY(e, select_device(e), "Failed to select device");
     DevBuf a, b, o;
     mm_status st;
     if ((st = ensure(e, a, n * 3 * sizeof(float), "Failed to allocate pairs")) ||

@@ -246,7 +246,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     __shared__ unsigned int next_item;      // ... and workgroups pull (cell, tile) items: the hue table is loaded once
     __shared__ int item_share;              // the XCD share next_item belongs to (-1: none left)
     // block statistics of the cell (early-exit bound), up to 4 blocks per lane
-    __shared__ __attribute__((aligned(16))) float cell_st[TYPE == CIEDE2000 ? 7 : 1][TYPE == CIEDE2000 ? (CELL_LDS ? kWave : 4 * kWave) : 1];
+    // (row 7: 1 where the block's mask pixels are all active in this cell, else 0 -- a clipped cell's bound counts only such blocks)
+    __shared__ __attribute__((aligned(16))) float cell_st[TYPE == CIEDE2000 ? 8 : 1][TYPE == CIEDE2000 ? (CELL_LDS ? kWave : 4 * kWave) : 1];
     extern __shared__ float4 cell_tile[];   // CELL_LDS: [3][ppad / 4] -- channel 0 (NaN = inactive), a, b
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
@@ -338,8 +339,9 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // over the pixels.  Lane g holds group g's bound; a suffix scan turns it into "bound
     // of groups >= j".  The candidate is dropped once
     //   (trusted partial sum of groups < j) + (bound of groups >= j) > limit.
-    // Valid only for cells whose active set is the whole mask (unclipped): the library's
-    // group sums are over the mask's pixels.  Clipped cells use the plain partial-sum exit.
+    // The library's block statistics are over the mask's pixels, so a block counts only where the cell's active pixels
+    // ARE the mask's (statistic 7 of the cell, gather_prepare_kernel): all blocks of an unclipped cell, the blocks wholly
+    // inside the bound of a clipped one -- its other blocks contribute 0, which every sum of non-negative terms exceeds.
     // Terms of pairs flagged for the fp64 patch (hue discontinuity) are summed apart and
     // never enter the exit test: only terms with a proven error bound may prune.
     const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
@@ -348,9 +350,12 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= (CELL_LDS ? kWave / 4 : kWave);     // workgroup-uniform
         if (use_lb) {
             // the cell's seven numbers per block (group_sums_kernel) wait in LDS: read per candidate, no registers held
-            for (int t = threadIdx.x; t < 4 * groups; t += THREADS)
+            const bool clipped = var.cell_full[cell] == 2;
+            for (int t = threadIdx.x; t < 4 * groups; t += THREADS) {
                 for (int k = 0; k < 7; ++k)
                     cell_st[k][t] = var.cell_stats[(size_t)k * var.cell_stats_stride + (size_t)cell * var.n_blocks + t];
+                cell_st[7][t] = clipped ? var.cell_stats[(size_t)7 * var.cell_stats_stride + (size_t)cell * var.n_blocks + t] : 1.0f;
+            }
         }
     }
     // blocks per lane in the bound's prelude: 1, 2 or 4 (a power of two, so groups start on lane boundaries)
@@ -391,8 +396,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 for (int k = 0; k < 7; ++k) ls[k] = *reinterpret_cast<const float4*>(st + k * bs);
                 auto block = [&](int i, float l0, float l1, float l2, float l3, float l4, float l5, float l6) {
                     const int blk = 4 * g + i;
-                    b += stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
-                                     l0, l1, l2, l3, l4, l5, l6, 1e-2f);
+                    b += cell_st[7][blk] * stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
+                                                       l0, l1, l2, l3, l4, l5, l6, 1e-2f);
                     __builtin_amdgcn_sched_barrier(0);  // one block at a time: four interleaved evaluations do not fit the registers
                 };
                 block(0, ls[0].x, ls[1].x, ls[2].x, ls[3].x, ls[4].x, ls[5].x, ls[6].x);
@@ -472,8 +477,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                         if (blk >= n_blk) break;
                         const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + blk;
                         const size_t bs = var.lib_stats_stride;
-                        d += stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
-                                         st[0], st[bs], st[2 * bs], st[3 * bs], st[4 * bs], st[5 * bs], st[6 * bs], 1e-2f);
+                        d += cell_st[7][blk] * stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
+                                                           st[0], st[bs], st[2 * bs], st[3 * bs], st[4 * bs], st[5 * bs], st[6 * bs], 1e-2f);
                     }
                 }
                 if (sorted) {
@@ -695,6 +700,7 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
     // Only for unclipped cells (the library's sums are over the mask's pixels).
     bool use_lb = false;
     if constexpr (TYPE != CIEDE2000) use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;
+    const bool clipped = var.cell_full[cell] == 2;
     const int lane_shift = groups <= 16 ? 0 : (groups <= 32 ? 1 : 2), per_lane = 1 << lane_shift;
     const int l_end = min((tile + 1) * cand_per_block, L);
     for (int l = tile * cand_per_block + wave; l < l_end; l += kLdsBlock / kWave) {
@@ -717,7 +723,8 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
                 const float d0 = fmaxf(fabsf(ct[0] - st[0]) - 2e-2f, 0.0f);
                 const float d1 = fmaxf(fabsf(ct[2 * cs] - st[2 * bs]) - 2e-2f, 0.0f);
                 const float d2 = fmaxf(fabsf(ct[3 * cs] - st[3 * bs]) - 2e-2f, 0.0f);
-                d += 0.9999f * fsqrt(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
+                // (a clipped cell: only blocks whose mask pixels are all inside its bound -- statistic 7 -- count)
+                d += (clipped ? ct[7 * cs] : 1.0f) * 0.9999f * fsqrt(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
             }
             for (int off = 1; off < kWave; off <<= 1) {       // inclusive suffix scan over lanes
                 const float up = __shfl_down(d, off, kWave);

@@ -170,6 +170,7 @@ mm_status mm_group_create(const int* devices, int n_devices, mm_group** out)
     if (distinct) {
         std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
         const ncclResult_t res = ncclCommInitAll(comms.data(), n_devices, devices);
+        (void)hipGetLastError();         // (RCCL's probing of peer access may leave a sticky HIP error on this thread)
         if (res == ncclSuccess) {
             for (int i = 0; i < n_devices; ++i) g->members[(size_t)i].comm = comms[(size_t)i];
             g->rccl = true;
@@ -187,7 +188,7 @@ void mm_group_destroy(mm_group* g)
     for (Member& m : g->members) {
         (void)hipSetDevice(m.device);
         if (m.stream) (void)hipStreamSynchronize(m.stream);
-        if (m.comm) (void)ncclCommDestroy(m.comm);
+        if (m.comm) { (void)ncclCommDestroy(m.comm); (void)hipGetLastError(); }
         for (void* p : { m.send, m.recv, m.idx_all, m.score_all }) if (p) (void)hipFree(p);
         if (m.stream) (void)hipStreamDestroy(m.stream);
         if (m.engine) mm_destroy(m.engine);
@@ -327,6 +328,7 @@ mm_status mm_group_generate(mm_group* g, const mm_cell* cells, int n_cells, int 
                 res = ncclAllGather(m.send, m.recv, total, ncclUint8, m.comm, m.stream);
             }
             const ncclResult_t end = ncclGroupEnd();
+            (void)hipGetLastError();
             if (res == ncclSuccess) res = end;
             if (res != ncclSuccess) { set_err(g, "ncclAllGather: %s", ncclGetErrorString(res)); return MM_DEVICE_ERROR; }
         } else {

@@ -394,7 +394,8 @@ __device__ __forceinline__ float wrap180_deg(float v) { return fmaf(-360.0f, rin
 //   * the seven block statistics of the early-exit bound (what filter.hip group_sums_kernel computes for the
 //     library: sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma, hue arc centre
 //     and half-width; LAB = false: the three sums only, the rest is CIEDE2000's) -- a wave holds the block,
-//     so the statistics are wave reductions of values already in registers;
+//     so the statistics are wave reductions of values already in registers -- and an eighth: whether the
+//     block's mask pixels are all active in this cell (a clipped cell's bound counts only such blocks);
 //   * LAB: the chroma plane and the interleaved copy [group][plane][256] with the prepared operands
 //     L / 2 - 25, a, b, C / 50 and NaN in L and a at inactive pixels (filter.hip interleave_kernel).
 // Replaces four launches per batch (gather, chroma planes, interleave, group sums).  The statistics feed
@@ -417,18 +418,21 @@ gather_prepare_kernel(const mm_cell* __restrict__ recs, const float* __restrict_
     const int k = blockIdx.x * kBlock + threadIdx.x;     // position in the variant's pixel order (< ppad)
     if (k == 0) {
         cell_var[cell] = (uint8_t)v;
-        cell_full[cell] = rec.row_min == 0 && rec.col_min == 0 && rec.row_max == size && rec.col_max == size;
+        // 1: the active set is the whole mask; 2: clipped -- the early-exit bound then counts only the blocks whose
+        // active pixels are ALL inside the cell's bound (statistic 7 below)
+        cell_full[cell] = (rec.row_min == 0 && rec.col_min == 0 && rec.row_max == size && rec.col_max == size) ? 1 : 2;
     }
     const int p = perm[(size_t)v * ppad + k];            // original pixel, < 0 = padding
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-    bool m = false;
+    bool m = false, in_mask = false;
     if (p >= 0) {
         const int row = p / size, col = p - row * size;
+        in_mask = masks[(size_t)rec.mask_id * ppad + p] != 0;
         if (row >= rec.row_min && row < rec.row_max && col >= rec.col_min && col < rec.col_max) {
             float px[3];
             cell_pixel(target, rows, cols, rec.y, rec.x, row, col, scale, px);
             v0 = px[0]; v1 = px[1]; v2 = px[2];
-            m = masks[(size_t)rec.mask_id * ppad + p] != 0;
+            m = in_mask;
         }
     }
     float* dst = cells + (size_t)cell * 3 * ppad + k;
@@ -468,6 +472,10 @@ gather_prepare_kernel(const mm_cell* __restrict__ recs, const float* __restrict_
     }
     const int lane = threadIdx.x & 63;
     float* o = stats + (size_t)cell * n_blocks + 4 * blockIdx.x + (threadIdx.x >> 6);
+    // statistic 7: 1 where every mask pixel of the block is active in this cell (the library's block statistics are
+    // over the mask's pixels: only then do both sides of the bound speak of the same pixel set), else 0
+    const bool whole_block = __builtin_amdgcn_ballot_w64(in_mask && !m) == 0ull;
+    if (lane == 0) o[7 * stats_stride] = whole_block ? 1.0f : 0.0f;
     if constexpr (!LAB) {
         if (lane == 0) { o[0] = s0; o[2 * stats_stride] = s1; o[3 * stats_stride] = s2; }
     } else {

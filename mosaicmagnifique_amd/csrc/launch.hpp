@@ -24,10 +24,11 @@ struct Variants {
     // lower bound of the filter's early exit (filter.hip): seven statistics per image and
     // 64-position block over the mask's active positions (group_sums_kernel), as seven arrays
     const float* lib_stats;     // 7 x [V][L][n_blocks], lib_stats_stride floats apart
-    const float* cell_stats;    // 7 x [B][n_blocks], cell_stats_stride floats apart
+    const float* cell_stats;    // 8 x [B][n_blocks], cell_stats_stride floats apart (7: block wholly active in the cell, 1 / 0)
     size_t lib_stats_stride, cell_stats_stride;
     int n_blocks;               // ppad / 64
-    const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask (not clipped)
+    const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask; 2 = clipped, with a per-block flag (cell statistic 7)
+                                // saying which blocks still are whole; 0 = clipped, no flags (separate gather kernels): no bound
     int two_stage;              // 1: the bound is evaluated four candidates per wave pass ahead of the pixel loops (filter_kernel)
 };
 
