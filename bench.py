@@ -246,7 +246,7 @@ def cpu_parity_rows(w, img, lib, best, recs):
     return pos, picks, scores, cores, dt
 
 
-def pmc_record(w, opts):
+def pmc_record(w, opts, tile=None):
     """rocprofv3 PMC passes of this same command (tests/tools_profile.sh), summarised per launch of the dominant
     kernel by profiles/summarise_pmc.py and copied into profiles/ by profiles/collect.py.  Only a record measured on exactly these kernel sources, this
     configuration and these engine options is used; anything else is reported as absent."""
@@ -260,6 +260,9 @@ def pmc_record(w, opts):
         return None, "PMC record is for kernel sources %s, this build is %s" % (entry.get("kernel_src_sha16"), kernel_source_hash())
     if sorted(entry.get("options", [])) != sorted(opts):
         return None, "PMC record was taken with options %s" % entry.get("options")
+    if tile is not None and entry.get("filter_tile") not in (None, tile):
+        # (the item size can follow the engine's call history -- option "item_auto" -- so the record names the one it ran with)
+        return None, "PMC record was taken with %s-candidate items, this run used %s" % (entry.get("filter_tile"), tile)
     return entry, "profiles/pmc_traffic.json (rocprofv3 --pmc, separate passes: FETCH_SIZE x2 + WRITE_SIZE; SQ_INSTS_VALU)"
 
 
@@ -417,6 +420,8 @@ def sweep_bench(args, emit):
             "~" if estimated else " ", cpu_ms, line["speedup_first"], "ok" if same else "MISMATCH"))
         del gen
 
+    one("(warm-up)", 1, 20, 0, 128)            # device initialisation and code loading stay out of the first line
+    del lines[:]
     for t in (0, 1, 2):
         one("colour diff", t, 20, 0, 128)
     for detail in (25, 50, 75, 100):
@@ -606,7 +611,7 @@ def main():
     pairs_alg = total_pa * w["L"] / launches_per_step
     ciede = t == 2 and engine_uses_filter
 
-    pmc, pmc_src = pmc_record(w, args.opt) if world == 1 else (None, "PMC records are single-GPU")
+    pmc, pmc_src = pmc_record(w, args.opt, tm.get("filter_tile")) if world == 1 else (None, "PMC records are single-GPU")
     roof = {
         # CIEDE2000: the persistent two-stage kernel; RGB-Euclidean / CIE76: the LDS-resident cell tile form
         "kernel": ("filter_kernel" if t == 2 else "filter_lds_kernel") if engine_uses_filter else "score_kernel",

@@ -94,6 +94,8 @@ typedef struct mm_timing {
     int64_t spec_rounds;      /* resolve passes of the speculate-and-verify loop (1 = no cell needed deepening) */
     int64_t deepened_cells;   /* cells whose short candidate list had to be extended to the full length */
     int64_t resolve_sweeps;   /* parallel sweeps the repeat-penalty resolve took to reach its fix point */
+    /* the next three: counted by the CIEDE2000 filter kernel only (RGB-Euclidean / CIE76 run the LDS-tile kernel, which
+     * neither counts nor skips the seeds: the fields stay 0 there) */
     int64_t visited_groups;   /* 256-pixel groups the filter kernel evaluated (always-on counter) */
     int64_t total_groups;     /* groups a full evaluation of every (cell, candidate) would take */
     int64_t bound_dropped;    /* candidates the block bound dropped before any pixel was read */

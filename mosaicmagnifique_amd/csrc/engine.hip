@@ -94,6 +94,7 @@ struct mm_engine {
     int use_interleave = 1;      // mm_set_option("interleave", 0): the filter kernel reads the planar arrays (eight bases per pair)
     int xcd_aware = 1;           // mm_set_option("xcd_aware", 0): one item order for the whole device
     int xcd_cells = 0;           // mm_set_option("xcd_cells", n): cells per sub-group of an XCD's share (0 = default)
+    int item_chunk = 0;          // mm_set_option("item_chunk", n): work items per global atomic of the filter's persistent workgroups (0 = by launch size)
     size_t batch_per_cell = 0;   // workspace bytes per cell the batch capacity below was computed for
     int batch_capacity = 0;      // cells per device batch the last hipMemGetInfo allowed (0 = not asked yet)
     int band_pct = 100;          // mm_set_option("band_pct", n): diagnostics -- trust only n % of the filter band (tests of the
@@ -660,6 +661,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.sort_groups = e->sort_groups;
     fin.xcd_aware = e->xcd_aware;
     fin.xcd_cells = e->xcd_cells;
+    fin.item_chunk = e->item_chunk;
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     // the fused ranking kernel keeps a cell's contenders in LDS (16 bytes each)
     // (config D, 4096 cells of CIEDE2000: the separate re-score balances the contenders better -- 2.21 + 0.15 ms against
@@ -2095,6 +2097,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "sort_groups") == 0) { e->sort_groups = std::min(16, std::max(-1, value)); return MM_OK; }
     if (strcmp(name, "interleave") == 0) { e->use_interleave = value != 0; return MM_OK; }
     if (strcmp(name, "xcd_aware") == 0) { e->xcd_aware = value != 0; return MM_OK; }
+    if (strcmp(name, "item_chunk") == 0) { e->item_chunk = std::max(0, value); return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }
     if (strcmp(name, "item_auto") == 0) { e->item_auto = value != 0; return MM_OK; }

@@ -235,7 +235,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
               EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
               unsigned int edge_cap, const float* __restrict__ prune_above, int check_every,
               const HueEntry* __restrict__ hue_lut, Variants var, int xcd_shares,
-              const int32_t* __restrict__ seeds, int n_seeds, int sort_groups)
+              const int32_t* __restrict__ seeds, int n_seeds, int sort_groups, int item_chunk)
 {
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     __shared__ int seed_ids[256];           // the cell's seeds: their scores are in the row already (launch_prune_limits)
@@ -256,6 +256,12 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     unsigned int* const item_counter = edge_count + kItemCounters;
     const int my_share = xcd_shares > 1 ? xcc_id() % xcd_shares : 0;
     int first_live = 0;                     // thread 0: shares before my_share + first_live (cyclically) are exhausted
+    // thread 0: items are taken `item_chunk` at a time -- one global atomic (a ~2 us round trip the whole workgroup sits
+    // out) per chunk instead of per item; consecutive item numbers are neighbouring cells on the same candidate tile
+    // (kept in LDS, not in registers of thread 0: the kernel sits exactly at its 96-VGPR budget)
+    __shared__ unsigned int chunk_next;
+    __shared__ int chunk_left, chunk_share;
+    if (threadIdx.x == 0) chunk_left = 0;
     unsigned int n_visited = 0, n_groups_all = 0, n_bound_dropped = 0;     // work counters, per lane (a wave's share of a launch fits 32 bits)
     // Persistent workgroups: as many as the device holds at once, each taking the next item of the
     // launch order from a global counter.  A 33 KB table per 32-candidate tile was
@@ -266,12 +272,22 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     if (threadIdx.x == 0) {
         int share = -1;
         unsigned int item = 0;
-        for (int k = first_live; k < xcd_shares; ++k) {
-            const int sh = (my_share + k) % xcd_shares;
-            const long long lo = (long long)n_cells * sh / xcd_shares, hi = (long long)n_cells * (sh + 1) / xcd_shares;
-            const unsigned int it = atomicAdd(item_counter + sh, 1u);
-            if ((long long)it < (hi - lo) * n_tiles) { share = sh; item = it; break; }
-            first_live = k + 1;             // that share is exhausted for good
+        if (chunk_left > 0) {
+            share = chunk_share; item = chunk_next; chunk_next = item + 1u; chunk_left = chunk_left - 1;
+        } else {
+            for (int k = first_live; k < xcd_shares; ++k) {
+                const int sh = (my_share + k) % xcd_shares;
+                const long long lo = (long long)n_cells * sh / xcd_shares, hi = (long long)n_cells * (sh + 1) / xcd_shares;
+                const long long total = (hi - lo) * n_tiles;
+                const unsigned int it = atomicAdd(item_counter + sh, (unsigned int)item_chunk);
+                if ((long long)it < total) {
+                    share = sh; item = it;
+                    chunk_share = sh; chunk_next = it + 1u;
+                    chunk_left = (int)min((long long)item_chunk, total - (long long)it) - 1;
+                    break;
+                }
+                first_live = k + 1;             // that share is exhausted for good
+            }
         }
         next_item = item;
         item_share = share;
@@ -1454,7 +1470,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             return code;
         kern<<<dim3(persistent_grid(reinterpret_cast<const void*>(kern), items, kTileThreads, dyn)), kTileThreads, dyn, stream>>>(
             in.cells, il ? in.cells_il : in.cells_f0, in.cell_chroma, il ? in.lib_il : in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, sub,
-            edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares, in.seeds, in.seeds ? in.n_seeds : 0, sort_groups);
+            edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares, in.seeds, in.seeds ? in.n_seeds : 0, sort_groups, 1);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var, il ? 1 : 0);
@@ -1468,6 +1484,12 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     const int xcd_shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
     const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : (small_cells ? 128 : 64)) : cell_group;
     const int check_every = groups > 16 ? groups / 16 : 1;
+    // items per global atomic.  Measured (round 3, one box): taking several items at a time is SLOWER -- config C 3.53 /
+    // 3.64 / 3.70 / 3.91 ms per step at 1 / 2 / 4 / 8, config E's shard 31.8 / 33.3 / 34.0 at 1 / 4 / 8, config D 46.6 / 47.7 /
+    // 49.1 at 1 / 2 / 4: the atomic's round trip is hidden behind the other workgroups of the CU, while a workgroup that
+    // holds a run of neighbouring cells keeps them from the other workgroups of its XCD (tail imbalance, less sharing of
+    // the candidate tile in L2).  One item per atomic stays the default; the option remains for experiments.
+    const int item_chunk = in.item_chunk > 0 ? std::min(in.item_chunk, 64) : 1;
     hipError_t code = in.counters_cleared ? hipSuccess
                                           : hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);  // + work counters, item counters
     if (code != hipSuccess) return code;
@@ -1515,7 +1537,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             il ? nullptr : in.cells, il ? in.cells_il : in.cells_f0, il ? nullptr : in.cell_chroma, il ? in.lib_il : in.lib,
             il ? nullptr : in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares,
-            in.seeds, in.seeds ? in.n_seeds : 0, sort_groups);
+            in.seeds, in.seeds ? in.n_seeds : 0, sort_groups, item_chunk);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var, il ? 1 : 0);
@@ -1523,7 +1545,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         filter_kernel<RGB_EUCLIDEAN, kBlock, false, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN, kBlock, false, false>), blocks, kBlock, 0)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares,
-            in.seeds, in.seeds ? in.n_seeds : 0, sort_groups);
+            in.seeds, in.seeds ? in.n_seeds : 0, sort_groups, item_chunk);
     }
     return hipGetLastError();
 }

@@ -51,6 +51,7 @@ struct FilterInputs {
                                 // plane order (cells up to 64 x 64); 0: plane order
     const float* lib_il;        // interleaved copies for filter_kernel<IL> (launch_interleave): [V][L][ppad/256][4][256] and
     const float* cells_il;      // [B][ppad/256][4][256] (plane 0 = cells_f0); null: the planar arrays are read
+    int item_chunk;             // work items a persistent workgroup takes per global atomic (0 = by launch size)
     int counters_cleared;       // 1: the counter block was zeroed by an earlier kernel of the stream (no memset here)
     int fused_seeds;            // 1: seeds, their scores and the limit in one launch (launch_prune_limits)
     const int32_t* seeds;       // [B][n_seeds] candidates launch_prune_limits scored already (their scores are in the

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 passes of tests/tools_profile.sh (all of the SAME command,
-`python3 bench.py --config X --steps 1 --warmup 0 --no-cpu`, separate runs as the MI355X guide
+`python3 bench.py --config X --steps 1 --warmup 1 --no-cpu` (a warm-up step first: the item size of a CIEDE2000
+launch can follow the engine's previous launch, so the counted launches are steady-state ones), separate runs as the MI355X guide
 prescribes: --pmc FETCH_SIZE, --pmc WRITE_SIZE, --pmc SQ_*) into the per-launch record of the
 dominant kernel that bench.py prices its roofline with (profiles/pmc_traffic.json).
 
@@ -60,7 +61,7 @@ def main():
         "WRITE_SIZE_KiB_per_launch": wv / wn,
         "fetch_correction": 2.0,
         "traffic_bytes_per_launch": (2.0 * fv / fn + wv / wn) * 1024.0,
-        "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> -- python3 bench.py --config %s --steps 1 --warmup 0 --no-cpu %s" % (
+        "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> -- python3 bench.py --config %s --steps 1 --warmup 1 --no-cpu %s" % (
             config, " ".join("--opt " + o for o in opts)),
     }
     if name in sq:
@@ -72,6 +73,7 @@ def main():
         doc = json.loads(line)
         entry["visited_groups_per_launch"] = doc["roofline"]["visited_groups_per_launch"]
         entry["avg_launch_ms_under_pmc"] = doc["roofline"]["avg_launch_ms"]
+        entry["filter_tile"] = doc["last_step_device_ms"].get("filter_tile")     # candidates per work item the passes ran with
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     doc = json.load(open(path)) if os.path.exists(path) else {}
     doc[config] = entry

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 C=${1:-E8}; shift
 O=gpurun_out/pmc_$C; mkdir -p $O
-CMD="python3 bench.py --config $C --steps 1 --warmup 0 --no-cpu $*"
+CMD="python3 bench.py --config $C --steps 1 --warmup 1 --no-cpu $*"
 timeout -k 10 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE -d $O/sq -o p --output-format csv -- $CMD > $O/sq.log 2>&1
 timeout -k 10 240 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD -d $O/lds -o p --output-format csv -- $CMD > $O/lds.log 2>&1
 timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- $CMD > $O/fetch.log 2>&1

@@ -4,14 +4,14 @@
 # kernel trace of the default command, and the bench lines of every configuration.
 # usage (on the box): bash tests/tools_profile.sh r02_v13        -> gpurun_out/r02_v13/
 set -x
-V=${1:-r02}
+V=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$V
 mkdir -p $O
 for c in ${CONFIGS:-D C B E8 E A}; do
   P=$O/pmc_$c
   mkdir -p $P
-  CMD="python3 bench.py --config $c --steps 1 --warmup 0 --no-cpu"
+  CMD="python3 bench.py --config $c --steps 1 --warmup 1 --no-cpu"
   rocprofv3 --pmc FETCH_SIZE -d $P/fetch -o p --output-format csv -- $CMD > $P/fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -d $P/write -o p --output-format csv -- $CMD > $P/write.log 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE -d $P/sq -o p --output-format csv -- $CMD > $P/bench_sq.json 2> $P/sq.log
