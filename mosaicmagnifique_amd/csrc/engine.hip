@@ -101,6 +101,8 @@ struct mm_engine {
                                  // guards; a negative value turns the band inside out: true contenders get excluded)
     int band_guard_every = 64;   // mm_set_option("band_guard", n): every n-th cell of a batch re-scores the best candidate the
                                  // filter band excluded in fp64 (0 = off); an excluded candidate that wins is a band failure
+    int tiny_path = 1;           // mm_set_option("tiny", 0): detail cells of <= 64 pixels go through the general path too
+    DevBuf lib_tiny;             // position-major library copy [variant][64][3][L] for tiny_cells_kernel
     int item_auto = 1;           // mm_set_option("item_auto", 0): the filter's item size no longer follows the drop rate of the
                                  // engine's previous CIEDE2000 launch (timing then does not depend on the call history)
     int fused = 1;               // mm_set_option("fused", 0): separate gather / chroma / interleave / statistics and
@@ -356,6 +358,14 @@ mm_status prepare_planes(mm_engine* e)
     if ((st = ensure(e, e->lib_il, (size_t)n_var * L * 4 * ppad * sizeof(float), "Failed to allocate interleaved library"))) return st;
     HIP_TRY(e, mm::launch_interleave((const float*)e->lib.p, (const float*)e->lib_chroma.p, nullptr, (float*)e->lib_il.p,
                                      (size_t)n_var * L, ppad, e->stream), "Error during library interleave kernel");
+    if (P <= mm::kTinyPositions) {
+        // position-major copy for tiny_cells_kernel: [variant][position < 64][channel][image]
+        const size_t n = (size_t)n_var * mm::kTinyPositions * 3 * L;
+        if ((st = ensure(e, e->lib_tiny, n * sizeof(float), "Failed to allocate the position-major library"))) return st;
+        mm::transpose_tiny_kernel<<<(unsigned)std::min<size_t>((n + mm::kBlock - 1) / mm::kBlock, 65536), mm::kBlock, 0, e->stream>>>(
+            (const float*)e->lib.p, (float*)e->lib_tiny.p, n_var, L, ppad, mm::kTinyPositions);
+        HIP_TRY(e, hipGetLastError(), "Error during library transpose kernel");
+    }
     HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");   // host vectors go out of scope
     e->planes_dirty = false;
     return MM_OK;
@@ -567,7 +577,9 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                 "Failed to copy row map to device");
         row_map_dev = (const int*)e->row_map.p;
     }
-    const bool two_tier = e->use_filter != 0 && K < L;
+    // detail cells of up to 64 pixels: one wave per cell from the image to the list (tiny_cells_kernel), fp64 throughout
+    const bool tiny = e->tiny_path != 0 && P <= mm::kTinyPositions && e->lib_tiny.p != nullptr;
+    const bool two_tier = !tiny && e->use_filter != 0 && K < L;
     const int Kc = two_tier ? std::min(L, round_up(K + 32, 4)) : 0;
     // Early exit needs seeds: K <= M <= 256 of them.
     const int M = std::min(L, std::min(256, round_up(K + e->extra_seeds, 4)));
@@ -605,6 +617,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     // second engine on the device) halves the batch instead of failing the call.
     auto allocate = [&](int bt) -> mm_status {
         mm_status st;
+        if (tiny) return ensure(e, e->scores, (size_t)bt * L * sizeof(double), "Failed to allocate variants");
         if ((st = ensure(e, e->cell_var, (size_t)bt, "Failed to allocate cell variants")) ||
             (st = ensure(e, e->cell_full, (size_t)bt, "Failed to allocate cell flags")) ||
             (st = ensure(e, e->cell_lsum, (size_t)8 * bt * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
@@ -685,6 +698,29 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         // score kernel spreads the (cell, seed) pairs over the device, the fused one keeps a cell's seeds on one CU
         fin.fused_seeds = e->fused_seed_cells > 0 && b <= e->fused_seed_cells && (diff_type != MM_CIEDE2000 || (long long)b * M <= 4096);
         if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[0], e->stream), "event");
+        if (tiny) {
+            if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
+            by_type(diff_type, [&](auto T) {
+                mm::tiny_cells_kernel<decltype(T)::value><<<(unsigned)((b + 3) / 4), mm::kBlock, 0, e->stream>>>(
+                    recs_dev + done, b, (const float*)e->target.p, e->rows, e->cols, cell_resize_of(e), (const uint8_t*)e->masks.p,
+                    size, ppad, (const int*)e->perm.p, vom, (const float*)e->lib_tiny.p, L, (double*)e->scores.p,
+                    K, kTieBand, ci, cs, KW, rmap);
+                return MM_OK;
+            });
+            HIP_TRY(e, hipGetLastError(), "Error during tiny-cell kernel");
+            if (e->phase_events) {
+                HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
+                HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
+            }
+            if (deferred) {
+                e->pend = mm_engine::Pending{true, false, false, false, b, diff_type, 0u};
+                return MM_OK;
+            }
+            HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
+            account_score_batch(e, false, false, diff_type, b, 0u, nullptr);
+            if (progress) progress(done + b, user);
+            continue;
+        }
         if (!two_tier) {
             if ((st = dense_batch(e, recs_dev + done, b, diff_type, K, KW, ci, cs, rmap, e->phase_events ? e->ev[1] : nullptr, e->phase_events ? e->ev[2] : nullptr))) return st;
             if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
@@ -1193,7 +1229,7 @@ void mm_destroy(mm_engine* e)
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
                        &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0, &e->area_tab,
-                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il, &e->result, &e->main_bgr, &e->entropy_out, &e->exceeded_out })
+                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il, &e->result, &e->main_bgr, &e->entropy_out, &e->exceeded_out, &e->lib_tiny })
         release(*b);
     if (e->pinned) (void)hipHostFree(e->pinned);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -2100,6 +2136,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "item_chunk") == 0) { e->item_chunk = std::max(0, value); return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "tiny") == 0) { e->tiny_path = value != 0; return MM_OK; }
     if (strcmp(name, "item_auto") == 0) { e->item_auto = value != 0; return MM_OK; }
     if (strcmp(name, "fused") == 0) { e->fused = value != 0; return MM_OK; }
     if (strcmp(name, "fast_path") == 0) { e->fast_path = value != 0; return MM_OK; }

@@ -624,6 +624,125 @@ select_kernel(const double* __restrict__ scores, int L, int K, double tie_band,
     }
 }
 
+// ---------------------------------------------------------------------------
+// tiny cells: detail cells of at most 64 pixels (the reference's harness runs cell sizes down to 8 at detail
+// 20 %, Benchmark/Benchmark_Generator.h:163-171: detail cells of 6, 3 and 1 pixels)
+// ---------------------------------------------------------------------------
+//
+// The general path gives every (cell, candidate) a wave and every cell several workgroups; with a handful of
+// pixels per cell that is all overhead.  Here ONE WAVE owns a cell from the image to its candidate list:
+//   lane k fetches pixel k of the cell straight from the target (getCellAt on the device, as gather_cells_kernel);
+//   the candidates are spread over the lanes (l = lane, lane + 64, ...), each lane summing ITS candidate's
+//   differences over the active pixels in fp64, reference form, in plane order -- which for cells of up to 8 x 8 is
+//   the reference's own row-major order --, the cell's pixel broadcast per step with v_readlane;
+//   K + 1 rounds of a wave-wide lexicographic minimum over the row pick the list and the overflow mark
+//   (select_kernel's rule), or the whole row in index order when K >= L (full_list_kernel's).
+// The library is read from a position-major copy [variant][position][channel][image] (transpose_tiny_kernel), so the
+// 64 lanes of a load are 64 consecutive floats.  No filter tier, no seeds: the work is too small to prune.
+__global__ void __launch_bounds__(kBlock)
+transpose_tiny_kernel(const float* __restrict__ planar, float* __restrict__ out, int n_var, int L, int ppad, int n_pos)
+{
+    const size_t total = (size_t)n_var * n_pos * 3 * L;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const int l = (int)(t % L);
+        size_t r = t / L;
+        const int c = (int)(r % 3); r /= 3;
+        const int k = (int)(r % n_pos);
+        const int v = (int)(r / n_pos);
+        out[t] = planar[(((size_t)v * L + l) * 3 + c) * ppad + k];
+    }
+}
+
+constexpr int kTinyPositions = 64;
+
+template <int TYPE>
+__global__ void __launch_bounds__(kBlock)
+tiny_cells_kernel(const mm_cell* __restrict__ recs, int n_cells, const float* __restrict__ target, int rows, int cols,
+                  CellResize scale, const uint8_t* __restrict__ masks, int size, int ppad, const int* __restrict__ perm,
+                  int4 var_of_mask, const float* __restrict__ lib_tiny, int L, double* __restrict__ scores,
+                  int K, double tie_band, int32_t* __restrict__ cand_index, double* __restrict__ cand_score,
+                  int KW, const int* __restrict__ row_map)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * (kBlock / kWave) + wave;
+    if (cell >= n_cells) return;
+    const mm_cell rec = recs[cell];
+    const int vm[4] = {var_of_mask.x, var_of_mask.y, var_of_mask.z, var_of_mask.w};
+    const int v = vm[rec.mask_id];
+    // lane k: pixel at plane position k of the cell's mask variant (active pixels first)
+    const int p = perm[(size_t)v * ppad + lane];
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    bool m = false;
+    if (p >= 0) {
+        const int row = p / size, col = p - row * size;
+        if (row >= rec.row_min && row < rec.row_max && col >= rec.col_min && col < rec.col_max &&
+            masks[(size_t)rec.mask_id * ppad + p] != 0) {
+            float px[3];
+            cell_pixel(target, rows, cols, rec.y, rec.x, row, col, scale, px);
+            v0 = px[0]; v1 = px[1]; v2 = px[2];
+            m = true;
+        }
+    }
+    const unsigned long long active = __builtin_amdgcn_ballot_w64(m);
+    double* row_scores = scores + (size_t)cell * L;
+    const float* lt = lib_tiny + (size_t)v * kTinyPositions * 3 * L;
+    for (int base = 0; base < L; base += kWave) {
+        const int l = base + lane;
+        double acc = 0.0;
+        for (unsigned long long left = active; left != 0ull; left &= left - 1ull) {
+            const int k = __builtin_ctzll(left);                                 // wave-uniform
+            const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), k));
+            const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v1), k));
+            const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v2), k));
+            if (l < L) {
+                const float* q = lt + (size_t)k * 3 * L + l;
+                acc += colour_diff<TYPE>(Px{c0, c1, c2}, Px{q[0], q[L], q[2 * (size_t)L]});
+            }
+        }
+        if (l < L) row_scores[l] = acc;
+    }
+    // the list: rows of the output are KW wide (K <= KW filled, the rest empty); row_map scatters
+    const size_t out = (size_t)(row_map ? row_map[cell] : cell) * KW;
+    for (int t = K + lane; t < KW; t += kWave) { cand_index[out + t] = -1; cand_score[out + t] = kInf; }
+    if (K >= L) {                        // the whole row, in index order (full_list_kernel)
+        for (int k = lane; k < K; k += kWave) {
+            cand_index[out + k] = k < L ? k : -1;
+            cand_score[out + k] = k < L ? row_scores[k] : kInf;
+        }
+        return;
+    }
+    // (the row was written by this wave's own lanes: visible to them again after the wave-wide exchanges below
+    // only through memory, so make it so)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double prev_s = -kInf;
+    int prev_i = -1;
+    for (int r = 0; r <= K; ++r) {
+        ScoreIdx best{kInf, 0x7fffffff};
+        for (int l = lane; l < L; l += kWave) {
+            const double sc = row_scores[l];
+            if (lex_less(prev_s, prev_i, sc, l) && lex_less(sc, l, best.s, best.i)) { best.s = sc; best.i = l; }
+        }
+        best = wave_min(best);
+        const bool none = best.i == 0x7fffffff;
+        if (r == K) {        // one past the list: does it belong to the last entry's cluster?
+            if (!none && lane == 0 && best.s <= prev_s + fabs(prev_s) * (4.0 * tie_band))
+                cand_index[out + K - 1] = -(prev_i + 2);
+            break;
+        }
+        if (lane == 0) {
+            cand_index[out + r] = none ? -1 : best.i;
+            cand_score[out + r] = none ? kInf : best.s;
+        }
+        if (none) {
+            for (int t = r + 1 + lane; t < K; t += kWave) { cand_index[out + t] = -1; cand_score[out + t] = kInf; }
+            break;
+        }
+        prev_s = best.s;
+        prev_i = best.i;
+    }
+}
+
 // K >= L (a negative repeat "penalty" can promote any candidate): the list is the whole
 // row, in index order; nothing to select.
 __global__ void __launch_bounds__(kBlock)

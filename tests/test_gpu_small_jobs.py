@@ -122,3 +122,41 @@ def test_cells_without_an_active_pixel_stay_on_the_device(oracle, default_engine
             total = score[cells[i]["grid_y"], cells[i]["grid_x"]]
             assert total == 0 if rep[1] == 0 else total % rep[1] == 0
         check_against_oracle(oracle, shape, img, lib, t, rep, cells, best, score, L)
+
+
+@pytest.mark.parametrize("size,t,rep", [(8, Type.CIEDE2000, (2, 300)), (8, Type.RGB_EUCLIDEAN, (0, 0)), (6, Type.CIE76, (3, 40)),
+                                        (3, Type.CIEDE2000, (0, 0)), (1, Type.CIE76, (1, 25)), (5, Type.RGB_EUCLIDEAN, (4, -30))])
+def test_tiny_detail_cells_one_wave_per_cell(oracle, default_engine, size, t, rep):
+    """Detail cells of <= 64 pixels (the reference's harness goes down to cell size 8 at detail 20 %: ONE pixel,
+    Benchmark/Benchmark_Generator.h:163-171) take the one-wave-per-cell path: every cell against the oracle, the general
+    path (option "tiny" 0) gives the same grid and the same score bits up to the summation order; a negative addition
+    asks for the whole row (K = L)."""
+    e = default_engine
+    L = 150
+    yy, xx = np.mgrid[0:size, 0:size]
+    mask = np.where((xx + yy) % 5 != 4, 255, 0).astype(np.uint8) if size >= 5 else np.full((size, size), 255, np.uint8)
+    from mosaicmagnifique_amd.cellshape import CellShape
+    shape = CellShape(mask)
+    if size >= 5:
+        shape.alternateRowOffset = 2                       # offset rows: clipped slivers at the borders
+        shape.alternateColFlipHorizontal = True
+    rows, cols = 37 * max(size, 2) + 3, 41 * max(size, 2) + 1
+    img, lib = cases.inputs(rows, cols, size, L, t, lattice=max(4 * size, 8))
+    group = cases.group_of(shape)
+    state = G.getGridState(group, rows, cols)[0]
+    cells = G.cell_records(group, state, rows, cols)
+    assert len(cells) > 1000
+    e.set_library(lib); e.set_masks(shape.masks4()); e.set_target(img)
+    e.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    best, score = e.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    tm = e.timing()
+    assert tm["rescore_ms"] == 0 and tm["seed_ms"] == 0           # neither filter tier nor seeds ran
+    check_against_oracle(oracle, shape, img, lib, t, rep, cells, best, score, L)
+    e.set_option("tiny", 0)
+    try:
+        gbest, gscore = e.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    finally:
+        e.set_option("tiny", 1)
+    valid = state >= 0
+    assert np.array_equal(gbest, best)
+    assert (np.abs(gscore[valid] - score[valid]) <= 1e-12 * np.abs(score[valid]) + 1e-300).all()
