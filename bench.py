@@ -341,7 +341,8 @@ def sweep_bench(args, emit):
     default 20), size steps {0, 1, 2}, cell size {128, 64, 32, 16, 8}.  Per line, wall-clock ms of
       first   generateBestFits() of a freshly set-up generator -- what the harness's timer brackets: pre-processing of
               image and library (on the device here), staging, the best-fit pass over every size step;
-      warm    the same call again (inputs resident: the hot path alone);
+      warm    the same call again (inputs resident: the hot path alone, incl. the Python host's per-cell geometry;
+              `last_step_device_ms` = mm_generate's own first-launch-to-results time for the last size step);
       grid    GridGenerator::getGridState (entropy subdivision on the device when size steps > 0);
       build   buildPhotomosaic incl. the copy of the BGRA mosaic to the host;
       cpu     the CPU oracle (port of CPUPhotomosaicGenerator, 1 thread, early exit on) on the same pre-processed
@@ -382,6 +383,7 @@ def sweep_bench(args, emit):
         t0 = time.perf_counter()
         gen.generateBestFits()
         warm_ms = (time.perf_counter() - t0) * 1e3
+        device_ms = gen.timing()["total_ms"]             # mm_generate of the LAST size step, first launch to results on the host
         t0 = time.perf_counter()
         mosaic = gen.buildPhotomosaic((0, 0, 0, 0))
         build_ms = (time.perf_counter() - t0) * 1e3
@@ -411,12 +413,12 @@ def sweep_bench(args, emit):
             same = same and bool((fits[step][checked["grid_y"], checked["grid_x"]] == want[checked["grid_y"], checked["grid_x"]]).all())
         line = {"block": block, "diff_type": TYPE_NAMES[int(t)], "detail_percent": detail, "size_steps": steps, "cell_size": cell,
                 "detail_cell": group.getCellSize(0, True), "cells_per_step": cells, "grid_ms": grid_ms, "first_ms": first_ms,
-                "warm_ms": warm_ms, "build_ms": build_ms, "cpu_ms": cpu_ms, "cpu_estimated_from_prefix": estimated,
+                "warm_ms": warm_ms, "last_step_device_ms": device_ms, "build_ms": build_ms, "cpu_ms": cpu_ms, "cpu_estimated_from_prefix": estimated,
                 "speedup_first": cpu_ms / first_ms, "speedup_warm": cpu_ms / warm_ms, "indices_equal_on_cpu_cells": same,
                 "mosaic_alpha_covered": float((mosaic[..., 3] == 255).mean())}
         lines.append(line)
-        sys.stderr.write("%-12s %-13s detail %3d%% steps %d cell %3d (%2d px) cells %-22s grid %8.1f first %8.1f warm %8.2f build %7.1f cpu %s%10.0f ms  x%-8.0f %s\n" % (
-            block, TYPE_NAMES[int(t)], detail, steps, cell, line["detail_cell"], cells, grid_ms, first_ms, warm_ms, build_ms,
+        sys.stderr.write("%-12s %-13s detail %3d%% steps %d cell %3d (%2d px) cells %-22s grid %8.1f first %8.1f warm %8.2f (device %6.2f) build %7.1f cpu %s%10.0f ms  x%-8.0f %s\n" % (
+            block, TYPE_NAMES[int(t)], detail, steps, cell, line["detail_cell"], cells, grid_ms, first_ms, warm_ms, device_ms, build_ms,
             "~" if estimated else " ", cpu_ms, line["speedup_first"], "ok" if same else "MISMATCH"))
         del gen
 

@@ -76,7 +76,7 @@ struct mm_engine {
     int use_sweep_resolve = 1;   // mm_set_option("sweep_resolve", 0): raster-order chain instead of parallel sweeps
     int max_sweeps = 48;         // mm_set_option("max_sweeps", n): sweeps before falling back to the chain
     int use_lds_filter = -1;     // mm_set_option("lds_filter", 0/1); -1 = auto (Euclid only: it is the L2-bound one)
-    int extra_seeds = 14;        // mm_set_option("seeds", n): proxy-chosen seeds beyond the list length (10..30 measured: flat within 1 %)
+    int extra_seeds = -1;        // mm_set_option("seeds", n): proxy-chosen seeds beyond the list length; -1 = 14 for CIEDE2000, 2 for RGB / CIE76
     int lds_pad_kb = 0;          // mm_set_option("lds_pad_kb", n): diagnostics -- extra LDS per filter workgroup (lowers occupancy)
     int tile_candidates = 0;     // mm_set_option("tile", n): candidates per filter workgroup (0 = default)
     double drop_rate = -1.0;     // share of the candidates the bound dropped in the last CIEDE2000 filter launch over ...
@@ -582,21 +582,29 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     const bool two_tier = !tiny && e->use_filter != 0 && K < L;
     const int Kc = two_tier ? std::min(L, round_up(K + 32, 4)) : 0;
     // Early exit needs seeds: K <= M <= 256 of them.
-    const int M = std::min(L, std::min(256, round_up(K + e->extra_seeds, 4)));
+    // (extra seeds tighten the CIEDE2000 limit -- 10..30 measured flat within 1 % of the filter time -- but buy the RGB /
+    // CIE76 filter nothing: config B's kernel runs 0.315 ms at 0, 2, 6, 10 or 14 extra seeds while the seed phase grows from
+    // 0.042 to 0.129 ms, so the Euclidean forms take two)
+    const int extra_seeds = e->extra_seeds >= 0 ? e->extra_seeds : (diff_type == MM_CIEDE2000 ? 14 : 2);
+    const int M = std::min(L, std::min(256, round_up(K + extra_seeds, 4)));
     // Seeds and the early exit pay three launches (one when fused) and ~M full scores per cell for the pixel pairs they
     // save: below ~1e8 pairs of an RGB launch (~2e7 of CIEDE2000's, eight times the work per pair) the unpruned filter
     // is over before the seeds would be
-    const double call_pairs = (double)std::min(n, 32768) * L * P;
+    const double call_pairs = (double)std::min(n, 32768) * L * P;     // (irrelevant to tiny cells: they neither seed nor prune)
     const double min_pairs = e->prune_min_pairs >= 0 ? 1e3 * (double)e->prune_min_pairs : (diff_type == MM_CIEDE2000 ? 2e7 : 1e8);
     const bool prune = two_tier && e->use_prune != 0 && K <= M && call_pairs >= min_pairs;
 
     // Batch so that every per-cell workspace stays within a budget: score row, the planar / NaN-marked / chroma /
     // interleaved copies of the cell and its mask, block statistics, contenders, seeds, flags.
-    const size_t per_cell = (size_t)L * sizeof(double) + (size_t)ppad * (12 + 1 + (two_tier ? 4 + 4 + 16 : 0)) +
-                            (size_t)8 * (ppad / 64) * sizeof(float) + (size_t)Kc * 16 + (prune ? (size_t)M * 8 + 4 : 0) + 16;
+    const size_t per_cell = tiny ? (size_t)L * sizeof(double) + 16
+                                 : (size_t)L * sizeof(double) + (size_t)ppad * (12 + 1 + (two_tier ? 4 + 4 + 16 : 0)) +
+                                   (size_t)8 * (ppad / 64) * sizeof(float) + (size_t)Kc * 16 + (prune ? (size_t)M * 8 + 4 : 0) + 16;
     // hipMemGetInfo is a driver round trip: asked again only when this call needs more cells per batch than the
     // last budget allowed (the workspaces below are kept between calls)
-    const int want_cells = std::min(n, 32768);
+    // (a batch is a grid dimension of the general path's kernels: 32768; tiny cells have no such bound, and a job of theirs
+    // is hundreds of thousands of cells -- 312 500 for the reference harness's cell size 8 on a 5000 x 4000 image)
+    const int cell_cap = tiny ? (1 << 22) : 32768;
+    const int want_cells = std::min(n, cell_cap);
     if (e->batch_per_cell != per_cell || e->batch_capacity < want_cells) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(e, hipMemGetInfo(&free_b, &total_b), "Failed to query device memory");
@@ -608,7 +616,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             return MM_OUT_OF_MEMORY;
         }
         e->batch_per_cell = per_cell;
-        e->batch_capacity = (int)std::min<size_t>(budget / per_cell, 32768);
+        e->batch_capacity = (int)std::min<size_t>(budget / per_cell, (size_t)cell_cap);
     }
     int batch = std::min(n, e->batch_capacity);
     if (e->max_batch_cells > 0) batch = std::min(batch, e->max_batch_cells);
@@ -2125,7 +2133,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "max_sweeps") == 0) { if (value < 1 || value > 4096) return MM_INVALID_ARGUMENT; e->max_sweeps = value; return MM_OK; }
     if (strcmp(name, "lds_filter") == 0) { e->use_lds_filter = value < 0 ? -1 : (value != 0); return MM_OK; }
     if (strcmp(name, "spec_k") == 0) { e->spec_k = std::max(0, value); return MM_OK; }
-    if (strcmp(name, "seeds") == 0) { e->extra_seeds = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "seeds") == 0) { e->extra_seeds = std::max(-1, value); return MM_OK; }
     if (strcmp(name, "lds_pad_kb") == 0) { e->lds_pad_kb = std::min(120, std::max(0, value)); return MM_OK; }
     if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }
     if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }

@@ -304,9 +304,15 @@ def test_library_larger_than_any_table_in_lds(oracle, engine, t):
     state = G.getGridState(group, img.shape[0], img.shape[1])[0]
     cells = G.cell_records(group, state, img.shape[0], img.shape[1])
     engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
-    best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), 2, 50)
+    engine.set_option("tiny", 0)            # (8 x 8 cells would take the one-wave-per-cell path: this test is about the seeds)
+    try:
+        best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), 2, 50)
+    finally:
+        engine.set_option("tiny", 1)
     tm = engine.timing()
     assert tm["seed_ms"] > 0.02 and tm["rescore_ms"] > 0                    # two-tier, seeds and limits in place
+    tiny_best, tiny_score = engine.generate(cells, state.shape[1], state.shape[0], int(t), 2, 50)     # ... and the tiny path agrees
+    assert np.array_equal(tiny_best, best) and engine.timing()["seed_ms"] == 0
     grid = np.where(best < n_lib, best, -1)
     pos = np.stack([cells["grid_y"], cells["grid_x"]], axis=1)
     picks, scores = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), 2, 50, grid, pos, threads=16)

@@ -178,7 +178,7 @@ def test_tuning_options_do_not_change_the_result(oracle, engine, opts):
     engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
     best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
     defaults = {"interleave": 1, "xcd_aware": 1, "tile": 0, "xcd_cells": 0, "two_level": 1, "sort_groups": -1,
-                "lds_filter": -1, "seeds": 14, "spec_k": 4, "fused": 1, "fast_path": 1, "item_auto": 1,
+                "lds_filter": -1, "seeds": -1, "spec_k": 4, "fused": 1, "fast_path": 1, "item_auto": 1,
                 "fused_seeds": 2048, "prune_min_kpairs": 0, "phase_timing": 1}
     try:
         for name, value in opts.items():
