@@ -352,6 +352,12 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
  * dropped in the engine's PREVIOUS CIEDE2000 launch over the same library, so the TIME of a call (never its result)
  * depends on the call history of the engine; 0 pins the size-by-cell default (mm_timing.filter_tile reports what ran).
+ * "stage0" (1): one whole-image bound per candidate ahead of the block bound; "item_chunk" (0 = 1): work items a persistent
+ * filter workgroup takes per global atomic; "tiny" (1): detail cells of <= 64 pixels take the one-wave-per-cell path;
+ * "fused_seeds" (2048): batches of up to n cells pick seeds, score them and set the limit in one launch;
+ * "prune_min_kpairs" (-1 = 1e5 for RGB / CIE76, 2e4 for CIEDE2000): below n thousand pixel pairs per call the seeds and the
+ * early exit are skipped (they would cost a small job more than they save); "phase_timing" (-1): events between the phases of
+ * a call -- the *_ms fields of mm_timing -- 1 always, 0 never, -1 only for calls large enough not to notice their ~35 us.
  * "fast_path" (1): mm_generate enqueues a whole generate and reads ONE result block back (one host wait) whenever the
  * cells fit one batch, falling back to the step-by-step path when the block says a host decision was needed; "fused" (1):
  * cell gather + chroma + interleave + block statistics in one launch and contenders + fp64 re-score + re-rank in one.

@@ -101,6 +101,8 @@ struct mm_engine {
                                  // guards; a negative value turns the band inside out: true contenders get excluded)
     int band_guard_every = 64;   // mm_set_option("band_guard", n): every n-th cell of a batch re-scores the best candidate the
                                  // filter band excluded in fp64 (0 = off); an excluded candidate that wins is a band failure
+    int stage0 = 1;              // mm_set_option("stage0", 0): no whole-image bound ahead of the block bound (filter_kernel stage 0)
+    int var_active[4] = {0, 0, 0, 0}; // active pixels of each mask variant
     int tiny_path = 1;           // mm_set_option("tiny", 0): detail cells of <= 64 pixels go through the general path too
     DevBuf lib_tiny;             // position-major library copy [variant][64][3][L] for tiny_cells_kernel
     int item_auto = 1;           // mm_set_option("item_auto", 0): the filter's item size no longer follows the drop rate of the
@@ -179,6 +181,8 @@ void release(DevBuf& b)
 constexpr double kTieBand = 1e-9;
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// Slots per image of the block statistics: the ppad / 64 blocks, the whole-image slot, padding to a float4 (launch.hpp Variants).
+inline int stat_slots(int ppad) { return ppad / 64 + 4; }
 
 
 inline bool known_type(int t) { return t == MM_RGB_EUCLIDEAN || t == MM_CIE76 || t == MM_CIEDE2000; }
@@ -318,6 +322,7 @@ mm_status prepare_planes(mm_engine* e)
         for (int p : walk) if (mk[p] != 0) { perm[(size_t)v * ppad + k] = p; inv[(size_t)v * P + p] = k; ++k; }
         for (int a = 0; a < k; ++a) pos_mask[(size_t)v * ppad + a] = 1;
         e->var_groups[v] = (k + 255) / 256;
+        e->var_active[v] = k;
         for (int p : walk) if (mk[p] == 0) { perm[(size_t)v * ppad + k] = p; inv[(size_t)v * P + p] = k; ++k; }
     }
     for (int v = n_var; v < 4; ++v) e->var_groups[v] = 0;
@@ -330,7 +335,7 @@ mm_status prepare_planes(mm_engine* e)
         (st = ensure(e, e->lib_chroma, (size_t)n_var * L * ppad * sizeof(float), "Failed to allocate library chroma planes")) ||
         (st = ensure(e, e->lib_means, (size_t)L * 3 * sizeof(float), "Failed to allocate library means")) ||
         (st = ensure(e, e->pos_mask, pos_mask.size(), "Failed to allocate position masks")) ||
-        (st = ensure(e, e->lib_lsum, (size_t)7 * n_var * L * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")))
+        (st = ensure(e, e->lib_lsum, (size_t)7 * n_var * L * stat_slots(ppad) * sizeof(float), "Failed to allocate block statistics")))
         return st;
     HIP_TRY(e, hipMemcpyAsync(e->pos_mask.p, pos_mask.data(), pos_mask.size(), hipMemcpyHostToDevice, e->stream),
             "Failed to copy position masks to device");
@@ -346,8 +351,8 @@ mm_status prepare_planes(mm_engine* e)
         HIP_TRY(e, hipGetLastError(), "Error during library plane kernel");
         HIP_TRY(e, mm::launch_group_sums((const float*)e->lib.p + (size_t)v * L * 3 * ppad,
                                          (const uint8_t*)e->pos_mask.p + (size_t)v * ppad, 0,
-                                         (float*)e->lib_lsum.p + (size_t)v * L * (ppad / 64),
-                                         (size_t)n_var * L * (ppad / 64), (size_t)L, ppad, e->stream),
+                                         (float*)e->lib_lsum.p + (size_t)v * L * stat_slots(ppad),
+                                         (size_t)n_var * L * stat_slots(ppad), (size_t)L, ppad, stat_slots(ppad), e->stream),
                 "Error during library group-sum kernel");
     }
     HIP_TRY(e, mm::launch_chroma_planes((const float*)e->lib.p, (float*)e->lib_chroma.p, (size_t)n_var * L, ppad, e->stream),
@@ -358,6 +363,11 @@ mm_status prepare_planes(mm_engine* e)
     if ((st = ensure(e, e->lib_il, (size_t)n_var * L * 4 * ppad * sizeof(float), "Failed to allocate interleaved library"))) return st;
     HIP_TRY(e, mm::launch_interleave((const float*)e->lib.p, (const float*)e->lib_chroma.p, nullptr, (float*)e->lib_il.p,
                                      (size_t)n_var * L, ppad, e->stream), "Error during library interleave kernel");
+    // whole-image statistics for stage 0 of the filter's bound (the blocks holding active pixels, joined), into slot ppad / 64
+    for (int v = 0; v < n_var; ++v)
+        HIP_TRY(e, mm::launch_image_stats((float*)e->lib_lsum.p + (size_t)v * L * stat_slots(ppad), (size_t)n_var * L * stat_slots(ppad),
+                                          stat_slots(ppad), ppad / 64, (e->var_active[v] + 63) / 64, (size_t)L, e->stream),
+                "Error during library image-statistics kernel");
     if (P <= mm::kTinyPositions) {
         // position-major copy for tiny_cells_kernel: [variant][position < 64][channel][image]
         const size_t n = (size_t)n_var * mm::kTinyPositions * 3 * L;
@@ -381,11 +391,11 @@ mm::Variants variants_of(const mm_engine* e)
     for (int i = 0; i < 4; ++i) v.groups[i] = e->var_groups[i];
     v.lib_stats = (const float*)e->lib_lsum.p;
     v.cell_stats = (const float*)e->cell_lsum.p;
-    v.lib_stats_stride = (size_t)e->n_var * e->n_lib * (ppad / 64);
+    v.lib_stats_stride = (size_t)e->n_var * e->n_lib * stat_slots(ppad);
     v.cell_stats_stride = e->cell_lsum.bytes / sizeof(float) / 8;
-    v.n_blocks = ppad / 64;
+    v.n_blocks = stat_slots(ppad);
     v.cell_full = (const uint8_t*)e->cell_full.p;
-    v.two_stage = e->two_level;
+    v.two_stage = e->two_level ? 1 : 0;     // (bit 1, stage 0, is set per batch once the cells' image statistics exist)
     return v;
 }
 
@@ -598,7 +608,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     // interleaved copies of the cell and its mask, block statistics, contenders, seeds, flags.
     const size_t per_cell = tiny ? (size_t)L * sizeof(double) + 16
                                  : (size_t)L * sizeof(double) + (size_t)ppad * (12 + 1 + (two_tier ? 4 + 4 + 16 : 0)) +
-                                   (size_t)8 * (ppad / 64) * sizeof(float) + (size_t)Kc * 16 + (prune ? (size_t)M * 8 + 4 : 0) + 16;
+                                   (size_t)8 * stat_slots(ppad) * sizeof(float) + (size_t)Kc * 16 + (prune ? (size_t)M * 8 + 4 : 0) + 16;
     // hipMemGetInfo is a driver round trip: asked again only when this call needs more cells per batch than the
     // last budget allowed (the workspaces below are kept between calls)
     // (a batch is a grid dimension of the general path's kernels: 32768; tiny cells have no such bound, and a job of theirs
@@ -628,7 +638,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         if (tiny) return ensure(e, e->scores, (size_t)bt * L * sizeof(double), "Failed to allocate variants");
         if ((st = ensure(e, e->cell_var, (size_t)bt, "Failed to allocate cell variants")) ||
             (st = ensure(e, e->cell_full, (size_t)bt, "Failed to allocate cell flags")) ||
-            (st = ensure(e, e->cell_lsum, (size_t)8 * bt * (ppad / 64) * sizeof(float), "Failed to allocate block statistics")) ||
+            (st = ensure(e, e->cell_lsum, (size_t)8 * bt * stat_slots(ppad) * sizeof(float), "Failed to allocate block statistics")) ||
             (st = ensure(e, e->cells, (size_t)bt * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
             (st = ensure(e, e->cmask, (size_t)bt * ppad, "Failed to allocate cell masks")) ||
             (st = ensure(e, e->scores, (size_t)bt * L * sizeof(double), "Failed to allocate variants")))
@@ -751,13 +761,13 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                     recs_dev + done, (const float*)e->target.p, e->rows, e->cols, cell_resize_of(e), (const uint8_t*)e->masks.p,
                     (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
                     (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, (float*)e->cells_f0.p, (float*)e->cell_chroma.p,
-                    e->use_interleave ? (float*)e->cells_il.p : nullptr, (float*)e->cell_lsum.p, stats_stride, ppad / 64);
+                    e->use_interleave ? (float*)e->cells_il.p : nullptr, (float*)e->cell_lsum.p, stats_stride, stat_slots(ppad));
             else
                 mm::gather_prepare_kernel<false><<<grid, mm::kBlock, 0, e->stream>>>(
                     recs_dev + done, (const float*)e->target.p, e->rows, e->cols, cell_resize_of(e), (const uint8_t*)e->masks.p,
                     (float*)e->cells.p, (uint8_t*)e->cmask.p, size, P, ppad, (const int*)e->perm.p, vom,
                     (uint8_t*)e->cell_var.p, (uint8_t*)e->cell_full.p, (float*)e->cells_f0.p, nullptr, nullptr,
-                    (float*)e->cell_lsum.p, stats_stride, ppad / 64);
+                    (float*)e->cell_lsum.p, stats_stride, stat_slots(ppad));
             HIP_TRY(e, hipGetLastError(), "Error launching cell gather kernel");
         } else {
             mm::gather_cells_kernel<<<dim3((ppad + mm::kBlock - 1) / mm::kBlock, b), mm::kBlock, 0, e->stream>>>(
@@ -774,9 +784,15 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             }
             HIP_TRY(e, mm::launch_group_sums((const float*)e->cells.p, (const uint8_t*)e->cmask.p, (size_t)ppad,
                                              (float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 8,
-                                             (size_t)b, ppad, e->stream),
+                                             (size_t)b, ppad, stat_slots(ppad), e->stream),
                     "Error during cell group-sum kernel");
         }
+        // stage 0 of the bound wants the cells' statistics joined over the whole image too (one thread per cell)
+        const bool stage0 = e->stage0 != 0 && prune && diff_type == MM_CIEDE2000;
+        if (stage0)
+            HIP_TRY(e, mm::launch_image_stats((float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 8, stat_slots(ppad), ppad / 64,
+                                              (e->var_active[0] + 63) / 64, (size_t)b, e->stream), "Error during cell image-statistics kernel");
+        fin.var.two_stage = (e->two_level ? 1 : 0) | (stage0 ? 2 : 0);
         if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
 
         // tier 1: fp32 filter score of every (cell, candidate), with early exit against a
@@ -2144,6 +2160,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "item_chunk") == 0) { e->item_chunk = std::max(0, value); return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "stage0") == 0) { e->stage0 = value != 0; return MM_OK; }
     if (strcmp(name, "tiny") == 0) { e->tiny_path = value != 0; return MM_OK; }
     if (strcmp(name, "item_auto") == 0) { e->item_auto = value != 0; return MM_OK; }
     if (strcmp(name, "fused") == 0) { e->fused = value != 0; return MM_OK; }

@@ -242,6 +242,10 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // stage 1 -> stage 2: the bound of every 256-position group of the tile's candidates (<= 64 per tile, <= 16 groups)
     __shared__ float cand_gb[TYPE == CIEDE2000 ? 64 : 1][TYPE == CIEDE2000 ? 16 : 1];
     __shared__ unsigned int alive_mask[2];  // candidates of the tile that passed the bound in stage 1 (<= 64 per tile)
+    // stage 0 -> stage 1: the tile's candidates that passed the whole-image bound (and are no seeds), compacted
+    __shared__ unsigned char surv_idx[TYPE == CIEDE2000 ? 64 : 1];
+    __shared__ int n_surv;
+    __shared__ float cell_ist[TYPE == CIEDE2000 ? 7 : 1];
     __shared__ int next_candidate;          // waves pull candidates: early exits make their cost uneven
     __shared__ unsigned int next_item;      // ... and workgroups pull (cell, tile) items: the hue table is loaded once
     __shared__ int item_share;              // the XCD share next_item belongs to (-1: none left)
@@ -385,22 +389,63 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // mask of the survivors.  Stage 2: the waves pull survivors from the mask; a survivor's prelude is then a read of its
     // group bounds, the visiting order and a scan -- ~60 instructions instead of ~300 -- before the pixel loop.
     bool two_level = false;
-    if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && groups > 0 && cand_per_block <= 64 && var.two_stage != 0;
+    if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && groups > 0 && cand_per_block <= 64 && (var.two_stage & 1) != 0;
     if (two_level && threadIdx.x < 2) alive_mask[threadIdx.x] = 0u;
+    // Stage 0: ONE bound per candidate from the statistics of the two WHOLE images (the triangle inequality holds for any
+    // partition of the pixels, the one-block partition included).  Weaker than the block bound, but 1 / 64 of its cost, and it
+    // drops a third of config D's candidates (more on smoother content) before stage 1 spends 64 block evaluations on them.
+    // Unclipped cells only (the image statistics are over the whole mask).
+    bool stage0 = false;
+    if constexpr (TYPE == CIEDE2000) {
+        stage0 = two_level && (var.two_stage & 2) != 0 && var.cell_full[cell] == 1;
+        // (the image-level statistics sit in slot ppad / 64 of each image's block statistics: no arguments of their own)
+        if (stage0 && threadIdx.x < 7)
+            cell_ist[threadIdx.x] = var.cell_stats[(size_t)threadIdx.x * var.cell_stats_stride + (size_t)cell * var.n_blocks + ppad / 64];
+    }
     if (use_lb || CELL_LDS || n_seeds > 0) __syncthreads();   // workgroup-uniform
+    if constexpr (TYPE == CIEDE2000) if (stage0) {
+        if (wave == 0) {
+            const int l = l_base + lane;
+            const bool valid = lane < n_here;
+            bool seed = false;
+            if (valid)
+                for (int t = 0; t < n_seeds; ++t) seed = seed || seed_ids[t] == l;
+            bool keep = valid && !seed;
+            if (keep) {
+                const float* is = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + ppad / 64;
+                const size_t ss = var.lib_stats_stride;
+                // slack 1: the fp32 rounding of a 4096-term sum of values <= 128 kept in fp64 until its one rounding (0.03),
+                // plus what the 64 block sums behind it carry (64 x 1e-2)
+                const float b0 = stats_bound(cell_ist[0], cell_ist[1], cell_ist[2], cell_ist[3], cell_ist[4], cell_ist[5], cell_ist[6],
+                                             is[0], is[ss], is[2 * ss], is[3 * ss], is[4 * ss], is[5 * ss], is[6 * ss], 1.0f);
+                n_groups_all += (unsigned int)groups;
+                if (b0 > limit) {
+                    scores[(size_t)cell * L + l] = __builtin_huge_valf();
+                    n_bound_dropped += 1;
+                    keep = false;
+                }
+            }
+            const unsigned long long kept = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) surv_idx[__builtin_popcountll(kept & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+            if (lane == 0) n_surv = __builtin_popcountll(kept);
+        }
+        __syncthreads();
+    }
     if constexpr (TYPE == CIEDE2000) if (two_level) {         // (the statistics arrays exist for CIEDE2000 only)
+        const int n_stage1 = stage0 ? n_surv : n_here;
         // lanes (q, g): candidate q of the pass, group g < groups -- 64 / groups candidates per pass (four at 16 groups,
         // seven at the 9 groups of a 48 x 48 cell), packed so that no lane idles on a group the cell does not have
         const int per_pass = kWave / groups;
         const int q = lane / groups, g = lane - q * groups;
-        for (int first = per_pass * wave; first < n_here; first += per_pass * (THREADS / kWave)) {
-            const int idx = first + q;
+        for (int first = per_pass * wave; first < n_stage1; first += per_pass * (THREADS / kWave)) {
+            const bool valid = q < per_pass && first + q < n_stage1;
+            const int idx = stage0 ? (valid ? (int)surv_idx[first + q] : 0) : first + q;      // stage 0 left a compacted list
             const int l = l_base + idx;
-            const bool valid = q < per_pass && idx < n_here;
             float b = 0.0f;
             // scored already as a seed: not a survivor.  The candidate's lanes share the seed list out; one ballot gathers the hits
+            // (stage 0 has taken the seeds out already)
             bool hit = false;
-            if (valid)
+            if (valid && !stage0)
                 for (int t = g; t < n_seeds; t += groups) hit = hit || seed_ids[t] == l;
             const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
             const bool seed = ((hits >> (q * groups)) & ((1ull << groups) - 1ull)) != 0ull;     // (q * groups < 64 where it matters: valid lanes)
@@ -438,7 +483,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 } else {
                     atomicOr(&alive_mask[idx >> 5], 1u << (idx & 31));
                 }
-                n_groups_all += (unsigned int)groups;
+                if (!stage0) n_groups_all += (unsigned int)groups;     // (stage 0 counted its candidates itself)
             }
         }
         if (threadIdx.x == 0) next_candidate = 0;           // stage 2 counts survivors from 0
@@ -984,6 +1029,46 @@ group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ 
         const bool open = anywhere || !any || !(far <= 170.0f) || !(fmaf(s1, s1, s2 * s2) >= 1e-6f);
         o[5 * block_stride] = open ? 0.0f : wrap180(ref + 0.5f * (dlo + dhi) - 275.0f);
         o[6 * block_stride] = open ? 180.0f : 0.5f * (dhi - dlo) + 0.02f;
+    }
+}
+
+// Whole-image statistics from the block statistics (see launch.hpp launch_image_stats): one WAVE per image -- lane b holds
+// block b, b + 64, ... (coalesced) --, written into the image's own slot `image_slot` of the same seven arrays.
+__global__ void __launch_bounds__(kBlock)
+image_stats_kernel(float* __restrict__ stats, size_t block_stride, int slots_per_image, int image_slot, int active_blocks, size_t n_images)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t img = (size_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (img >= n_images) return;
+    float* st = stats + img * slots_per_image;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    float dev = 0.f, cmax = 0.f;
+    for (int b = lane; b < active_blocks; b += kWave) {
+        s0 += (double)st[b]; s1 += (double)st[2 * block_stride + b]; s2 += (double)st[3 * block_stride + b];
+        dev = fmaxf(dev, st[block_stride + b]);
+        cmax = fmaxf(cmax, st[4 * block_stride + b]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off, kWave); s1 += __shfl_xor(s1, off, kWave); s2 += __shfl_xor(s2, off, kWave);
+        dev = fmaxf(dev, __shfl_xor(dev, off, kWave)); cmax = fmaxf(cmax, __shfl_xor(cmax, off, kWave));
+    }
+    // the blocks' hue arcs (centre as an offset from 275 deg, half-width) joined around the direction of the summed (a, b)
+    const float ref = atan2f((float)s2, (float)s1) * 57.29577951308232f;
+    float lo = 180.0f, hi = -180.0f;
+    bool open = false;
+    for (int b = lane; b < active_blocks; b += kWave) {
+        const float c = st[5 * block_stride + b], w = st[6 * block_stride + b];
+        const float off = wrap180(c + 275.0f - ref);
+        open = open || !(fabsf(off) + w <= 170.0f);
+        lo = fminf(lo, off - w); hi = fmaxf(hi, off + w);
+    }
+    for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, kWave)); hi = fmaxf(hi, __shfl_xor(hi, off, kWave)); }
+    open = __builtin_amdgcn_ballot_w64(open) != 0ull || active_blocks <= 0 || !(s1 * s1 + s2 * s2 >= 1e-6);
+    if (lane == 0) {
+        float* o = st + image_slot;
+        o[0] = (float)s0; o[block_stride] = dev; o[2 * block_stride] = (float)s1; o[3 * block_stride] = (float)s2; o[4 * block_stride] = cmax;
+        o[5 * block_stride] = open ? 0.0f : wrap180(ref + 0.5f * (lo + hi) - 275.0f);
+        o[6 * block_stride] = open ? 180.0f : 0.5f * (hi - lo) + 0.02f;
     }
 }
 
@@ -1561,13 +1646,22 @@ hipError_t launch_interleave(const float* planar, const float* chroma, const flo
 }
 
 hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
-                             size_t block_stride, size_t n_images, int ppad, hipStream_t stream)
+                             size_t block_stride, size_t n_images, int ppad, int slots_per_image, hipStream_t stream)
 {
-    const int n_groups = ppad / 256, n_blocks = ppad / 64;
+    const int n_groups = ppad / 256, n_blocks = slots_per_image;
     const size_t waves = n_images * (size_t)n_groups;
     if (waves == 0) return hipSuccess;
     group_sums_kernel<<<(unsigned)((waves + 3) / 4), kBlock, 0, stream>>>(planar, mask, mask_stride, stats, block_stride,
                                                                             n_images, n_groups, n_blocks, ppad);
+    return hipGetLastError();
+}
+
+hipError_t launch_image_stats(float* stats, size_t block_stride, int slots_per_image, int image_slot, int active_blocks,
+                              size_t n_images, hipStream_t stream)
+{
+    if (n_images == 0) return hipSuccess;
+    image_stats_kernel<<<(unsigned)((n_images + kBlock / kWave - 1) / (kBlock / kWave)), kBlock, 0, stream>>>(stats, block_stride, slots_per_image, image_slot,
+                                                                                             active_blocks, n_images);
     return hipGetLastError();
 }
 

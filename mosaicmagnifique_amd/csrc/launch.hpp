@@ -23,13 +23,16 @@ struct Variants {
     int groups[4];
     // lower bound of the filter's early exit (filter.hip): seven statistics per image and
     // 64-position block over the mask's active positions (group_sums_kernel), as seven arrays
+    // Per image n_blocks = ppad / 64 + 4 slots: the blocks, then (slot ppad / 64) the same statistic over the WHOLE image
+    // (image_stats_kernel; stage 0 of the bound), then padding that keeps every image's slots 16-byte aligned.
     const float* lib_stats;     // 7 x [V][L][n_blocks], lib_stats_stride floats apart
     const float* cell_stats;    // 8 x [B][n_blocks], cell_stats_stride floats apart (7: block wholly active in the cell, 1 / 0)
     size_t lib_stats_stride, cell_stats_stride;
-    int n_blocks;               // ppad / 64
+    int n_blocks;               // slots per image: ppad / 64 + 4
     const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask; 2 = clipped, with a per-block flag (cell statistic 7)
                                 // saying which blocks still are whole; 0 = clipped, no flags (separate gather kernels): no bound
-    int two_stage;              // 1: the bound is evaluated four candidates per wave pass ahead of the pixel loops (filter_kernel)
+    int two_stage;              // bit 0: the bound is evaluated several candidates per wave pass ahead of the pixel loops (filter_kernel
+                                // stage 1); bit 1: the whole-image bound ahead of that (stage 0; needs the image slots filled)
 };
 
 // Device inputs of the fp32 filter kernels.
@@ -75,8 +78,15 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
 
 // stats array k (block_stride floats apart), [img][ppad / 64] over plane positions [64 b, 64 b + 64):
 // masked sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma, hue range.
+// (slots_per_image: floats between two images' statistics, >= ppad / 64)
 hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
-                             size_t block_stride, size_t n_images, int ppad, hipStream_t stream);
+                             size_t block_stride, size_t n_images, int ppad, int slots_per_image, hipStream_t stream);
+
+// Whole-image statistics from the block statistics, written into each image's slot ppad / 64 of the same arrays: sums added
+// up (in fp64), maxima taken, the hue arcs of the first `active_blocks` blocks joined into one arc around the direction of
+// the image's summed (a, b) (the whole circle if a block's arc is open or reaches further than 170 deg from that direction).
+hipError_t launch_image_stats(float* stats, size_t block_stride, int slots_per_image, int image_slot, int active_blocks,
+                              size_t n_images, hipStream_t stream);
 
 // Interleaved copy of n planar images (+ chroma, + optional replacement of channel 0): [n][ppad/256][4][256].
 hipError_t launch_interleave(const float* planar, const float* chroma, const float* plane0, float* out,

@@ -25,7 +25,7 @@ state = G.getGridState(group, rows, cols)[0]
 cells = G.cell_records(group, state, rows, cols)
 e = Engine(0)
 e.set_library_u8(lib_u8, t); e.set_target_u8(img_u8, t); e.set_masks(shape.masks4())
-for name, opts in (("default", {}), ("tile=64", {"tile": 64}), ("tile=16", {"tile": 16}), ("two_level=0", {"two_level": 0}), ("prune=0", {"prune": 0})):
+for name, opts in (("default", {}), ("stage0=0", {"stage0": 0}), ("tile=64", {"tile": 64}), ("tile=16", {"tile": 16}), ("two_level=0", {"two_level": 0}), ("prune=0", {"prune": 0})):
     for k, v in opts.items():
         e.set_option(k, v)
     for i in range(3):
