@@ -94,8 +94,7 @@ typedef struct mm_timing {
     int64_t spec_rounds;      /* resolve passes of the speculate-and-verify loop (1 = no cell needed deepening) */
     int64_t deepened_cells;   /* cells whose short candidate list had to be extended to the full length */
     int64_t resolve_sweeps;   /* parallel sweeps the repeat-penalty resolve took to reach its fix point */
-    /* the next three: counted by the CIEDE2000 filter kernel only (RGB-Euclidean / CIE76 run the LDS-tile kernel, which
-     * neither counts nor skips the seeds: the fields stay 0 there) */
+    /* the next three: the filter kernels' always-on work counters (0 when the call ran without the early exit) */
     int64_t visited_groups;   /* 256-pixel groups the filter kernel evaluated (always-on counter) */
     int64_t total_groups;     /* groups a full evaluation of every (cell, candidate) would take */
     int64_t bound_dropped;    /* candidates the block bound dropped before any pixel was read */
@@ -352,7 +351,8 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
  * dropped in the engine's PREVIOUS CIEDE2000 launch over the same library, so the TIME of a call (never its result)
  * depends on the call history of the engine; 0 pins the size-by-cell default (mm_timing.filter_tile reports what ran).
- * "stage0" (1): one whole-image bound per candidate ahead of the block bound; "item_chunk" (0 = 1): work items a persistent
+ * "stage0" (1): one whole-image bound per candidate ahead of the block bound; "euclid_stage1" (1): the RGB / CIE76 filter
+ * judges the block bound one candidate per lane before any wave is spent on a candidate; "item_chunk" (0 = 1): work items a persistent
  * filter workgroup takes per global atomic; "tiny" (1): detail cells of <= 64 pixels take the one-wave-per-cell path;
  * "fused_seeds" (2048): batches of up to n cells pick seeds, score them and set the limit in one launch;
  * "prune_min_kpairs" (-1 = 1e5 for RGB / CIE76, 2e4 for CIEDE2000): below n thousand pixel pairs per call the seeds and the

@@ -101,6 +101,8 @@ struct mm_engine {
                                  // guards; a negative value turns the band inside out: true contenders get excluded)
     int band_guard_every = 64;   // mm_set_option("band_guard", n): every n-th cell of a batch re-scores the best candidate the
                                  // filter band excluded in fp64 (0 = off); an excluded candidate that wins is a band failure
+    int euclid_stage1 = 1;       // mm_set_option("euclid_stage1", 0): the RGB / CIE76 filter gives every candidate a wave from the start
+    DevBuf lib_stats_t;          // [V][3][ppad / 64][L]: the library's channel sums per block, candidate-fastest (filter_lds_kernel stage 1)
     int stage0 = 1;              // mm_set_option("stage0", 0): no whole-image bound ahead of the block bound (filter_kernel stage 0)
     int var_active[4] = {0, 0, 0, 0}; // active pixels of each mask variant
     int tiny_path = 1;           // mm_set_option("tiny", 0): detail cells of <= 64 pixels go through the general path too
@@ -368,6 +370,12 @@ mm_status prepare_planes(mm_engine* e)
         HIP_TRY(e, mm::launch_image_stats((float*)e->lib_lsum.p + (size_t)v * L * stat_slots(ppad), (size_t)n_var * L * stat_slots(ppad),
                                           stat_slots(ppad), ppad / 64, (e->var_active[v] + 63) / 64, (size_t)L, e->stream),
                 "Error during library image-statistics kernel");
+    // ... and the three channel sums per block once more, candidate-fastest, for the Euclid filter's stage 1
+    if ((st = ensure(e, e->lib_stats_t, (size_t)n_var * 3 * (ppad / 64) * L * sizeof(float), "Failed to allocate transposed block sums"))) return st;
+    for (int v = 0; v < n_var; ++v)
+        HIP_TRY(e, mm::launch_transpose_stats((const float*)e->lib_lsum.p + (size_t)v * L * stat_slots(ppad), (size_t)n_var * L * stat_slots(ppad),
+                                              stat_slots(ppad), ppad / 64, (float*)e->lib_stats_t.p + (size_t)v * 3 * (ppad / 64) * L, (size_t)L,
+                                              e->stream), "Error during block-sum transpose kernel");
     if (P <= mm::kTinyPositions) {
         // position-major copy for tiny_cells_kernel: [variant][position < 64][channel][image]
         const size_t n = (size_t)n_var * mm::kTinyPositions * 3 * L;
@@ -693,6 +701,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.xcd_aware = e->xcd_aware;
     fin.xcd_cells = e->xcd_cells;
     fin.item_chunk = e->item_chunk;
+    fin.lib_stats_t = e->euclid_stage1 != 0 && diff_type != MM_CIEDE2000 ? (const float*)e->lib_stats_t.p : nullptr;
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     // the fused ranking kernel keeps a cell's contenders in LDS (16 bytes each)
     // (config D, 4096 cells of CIEDE2000: the separate re-score balances the contenders better -- 2.21 + 0.15 ms against
@@ -1253,7 +1262,7 @@ void mm_destroy(mm_engine* e)
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
                        &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
                        &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0, &e->area_tab,
-                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il, &e->result, &e->main_bgr, &e->entropy_out, &e->exceeded_out, &e->lib_tiny })
+                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il, &e->result, &e->main_bgr, &e->entropy_out, &e->exceeded_out, &e->lib_tiny, &e->lib_stats_t })
         release(*b);
     if (e->pinned) (void)hipHostFree(e->pinned);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -2160,6 +2169,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "item_chunk") == 0) { e->item_chunk = std::max(0, value); return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "euclid_stage1") == 0) { e->euclid_stage1 = value != 0; return MM_OK; }
     if (strcmp(name, "stage0") == 0) { e->stage0 = value != 0; return MM_OK; }
     if (strcmp(name, "tiny") == 0) { e->tiny_path = value != 0; return MM_OK; }
     if (strcmp(name, "item_auto") == 0) { e->item_auto = value != 0; return MM_OK; }

@@ -30,6 +30,12 @@ constexpr int kWave = 64;
 #ifndef MM_SEED_WAVES
 #define MM_SEED_WAVES 3
 #endif
+#ifndef MM_EUCLID_PREFETCH
+#define MM_EUCLID_PREFETCH 0
+#endif
+#ifndef MM_EUCLID_WAVES
+#define MM_EUCLID_WAVES 8
+#endif
 
 __device__ __forceinline__ float wave_sum_f(float v)
 {
@@ -697,27 +703,37 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
 // filter_kernel; used whenever the cell fits LDS beside the hue table.
 constexpr int kLdsBlock = 1024;
 
+// (RGB / CIE76: two 16-wave workgroups per CU need 8 waves per SIMD, i.e. at most 64 VGPRs -- left alone the compiler takes 80
+// and one workgroup per CU stays resident)
 template <int TYPE>
-__global__ void __launch_bounds__(kLdsBlock)
+__global__ void __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(TYPE == CIEDE2000 ? 4 : MM_EUCLID_WAVES, TYPE == CIEDE2000 ? 4 : 8)))
 filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
                   const float* __restrict__ cell_chroma, const float* __restrict__ lib,
                   const float* __restrict__ lib_chroma, float* __restrict__ scores,
                   int n_cells, int L, int ppad, int cand_per_block, int cell_group,
                   EdgeEntry* __restrict__ edges, unsigned int* __restrict__ edge_count,
                   unsigned int edge_cap, const float* __restrict__ prune_above,
-                  const HueEntry* __restrict__ hue_lut, Variants var)
+                  const HueEntry* __restrict__ hue_lut, Variants var, const float* __restrict__ lib_stats_t)
 {
+    // lib_stats_t (Euclid; may be null): the three channel sums per block, candidate-fastest: [variant][3][ppad / 64][L]
     extern __shared__ float4 smem[];
+    __shared__ int n_surv;
+    __shared__ unsigned int wg_counts[3];
     HueEntry* lut = reinterpret_cast<HueEntry*>(smem);              // [kHueLutEntries] (CIEDE2000), 16-byte multiple
     float4* s0 = smem + (TYPE == CIEDE2000 ? kHueLutEntries / 2 : 0);  // cell planes, ppad/4 float4 each
     const int pq = ppad / 4;
     float4* s1 = s0 + pq;
     float4* s2 = s1 + pq;
     float4* sc = s2 + pq;
+    // Euclid with the early exit: behind the three planes the cell's block sums + weights [4][ppad / 64] and the tile's survivors
+    float* cst = reinterpret_cast<float*>(s2 + pq);
+    int* surv = reinterpret_cast<int*>(cst + 4 * (ppad / 64));
+    if (threadIdx.x < 3) wg_counts[threadIdx.x] = 0u;
 
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
     const float* const lib_base = lib;
     const float* const lib_chroma_base = lib_chroma;
+    unsigned int n_visited = 0, n_groups_all = 0, n_bound_dropped = 0;     // work counters (per lane; as filter_kernel's)
     // a grid may not exceed 2^32 threads: the launch is capped and the workgroups stride over the (cell, tile) items
     for (long long bid = blockIdx.x; bid < (long long)n_cells * n_tiles; bid += gridDim.x) {
     if (bid != (long long)blockIdx.x) __syncthreads();        // the previous item is done with the staged cell
@@ -749,10 +765,64 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
             if constexpr (TYPE == CIEDE2000) sc[q] = gc[q];
         }
     }
+    // Stage 1 (Euclid, early exit on): on the synthetic benchmark content the block bound ALONE drops 98 % of config B's
+    // candidates, so it is evaluated one candidate per LANE -- each lane walks the blocks of its own candidate through the
+    // candidate-fastest copy of the library's block sums (coalesced), ~12 instructions per block and candidate -- before any
+    // wave is spent on a candidate; the few survivors go into an LDS list and get the wave-per-candidate treatment below.
+    const int nb = ppad / 64;
+    bool staged1 = false;
+    if constexpr (TYPE != CIEDE2000) {
+        staged1 = lib_stats_t != nullptr && prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;
+        if (staged1) {
+            const bool clip1 = var.cell_full[cell] == 2;
+            const float* ct = var.cell_stats + (size_t)cell * var.n_blocks;
+            const size_t cs = var.cell_stats_stride;
+            for (int t = threadIdx.x; t < 4 * groups; t += kLdsBlock) {
+                cst[t] = ct[t]; cst[nb + t] = ct[2 * cs + t]; cst[2 * nb + t] = ct[3 * cs + t];
+                cst[3 * nb + t] = clip1 ? ct[7 * cs + t] : 1.0f;
+            }
+            if (threadIdx.x == 0) n_surv = 0;
+        }
+    }
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
+    const int l_first = tile * cand_per_block;
+    if constexpr (TYPE != CIEDE2000) if (staged1) {
+        const int n_here = min(cand_per_block, L - l_first);
+        const float* st_v = lib_stats_t + (size_t)v * 3 * nb * L;
+        for (int idx = threadIdx.x; idx < n_here; idx += kLdsBlock) {
+            const int l = l_first + idx;
+            float b = 0.0f;
+            // four blocks' sums in flight at a time (12 independent loads): the loop is latency, not arithmetic
+            for (int blk0 = 0; blk0 < 4 * groups; blk0 += 4) {      // (4 * groups is a multiple of 4)
+                float q0[4], q1[4], q2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    q0[u] = st_v[(size_t)(blk0 + u) * L + l];
+                    q1[u] = st_v[((size_t)nb + blk0 + u) * L + l];
+                    q2[u] = st_v[((size_t)2 * nb + blk0 + u) * L + l];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int blk = blk0 + u;
+                    const float d0 = fmaxf(fabsf(cst[blk] - q0[u]) - 2e-2f, 0.0f);
+                    const float d1 = fmaxf(fabsf(cst[nb + blk] - q1[u]) - 2e-2f, 0.0f);
+                    const float d2 = fmaxf(fabsf(cst[2 * nb + blk] - q2[u]) - 2e-2f, 0.0f);
+                    b += cst[3 * nb + blk] * 0.9999f * fsqrt(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
+                }
+            }
+            if (b > limit) {
+                scores[(size_t)cell * L + l] = __builtin_huge_valf();
+                n_bound_dropped += 1;
+                n_groups_all += (unsigned int)groups;
+            } else {
+                surv[atomicAdd(&n_surv, 1)] = idx;
+            }
+        }
+        __syncthreads();
+    }
     // Euclidean differences: the lower bound on the unvisited pixels needs no constants at all --
     // by the triangle inequality of the Euclidean norm over a block's pixels
     //   sum_block sqrt(d0^2 + d1^2 + d2^2) >= sqrt((sum d0)^2 + (sum d1)^2 + (sum d2)^2),
@@ -764,7 +834,9 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
     const bool clipped = var.cell_full[cell] == 2;
     const int lane_shift = groups <= 16 ? 0 : (groups <= 32 ? 1 : 2), per_lane = 1 << lane_shift;
     const int l_end = min((tile + 1) * cand_per_block, L);
-    for (int l = tile * cand_per_block + wave; l < l_end; l += kLdsBlock / kWave) {
+    const int n_todo = staged1 ? n_surv : l_end - l_first;
+    for (int turn = wave; turn < n_todo; turn += kLdsBlock / kWave) {
+        const int l = l_first + (staged1 ? surv[turn] : turn);
         const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * 3 * ppad);
         const float4* b1 = b0 + pq;
         const float4* b2 = b1 + pq;
@@ -795,16 +867,21 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
             pruned = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), 0)) > limit;
         }
         float acc = 0.0f, acc_edge = 0.0f;
+        int visited = 0;
         if (!pruned && groups > 0) {
+            // (the library group one iteration ahead of its use -- CIEDE2000 only: the Euclidean form is held to 64 VGPRs for
+            // two workgroups per CU, and the second register set is what would spill)
+            constexpr bool kAhead = TYPE == CIEDE2000 || MM_EUCLID_PREFETCH;
             LibGroup nxt = load_lib_group<TYPE>(b0, b1, b2, bc, lane);
             for (int j = 0; j < groups; ++j) {
                 if (j != 0) {
                     const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), (4 * j) >> lane_shift)) : 0.0f;
                     if (wave_sum_exceeds(acc, rest_j, limit)) { pruned = true; break; }
                 }
+                visited += 1;
                 const int q = lane + kWave * j;
-                const LibGroup cur = nxt;
-                if (j + 1 < groups) nxt = load_lib_group<TYPE>(b0, b1, b2, bc, q + kWave);   // one group ahead
+                const LibGroup cur = (kAhead || j == 0) ? nxt : load_lib_group<TYPE>(b0, b1, b2, bc, q);
+                if (kAhead && j + 1 < groups) nxt = load_lib_group<TYPE>(b0, b1, b2, bc, q + kWave);   // one group ahead
                 const float4 p0 = s0[q], p1 = s1[q], p2 = s2[q];
                 float4 pc{0.f, 0.f, 0.f, 0.f};
                 if constexpr (TYPE == CIEDE2000) pc = sc[q];
@@ -836,8 +913,31 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
             }
         }
         acc = wave_sum_f(acc + acc_edge);
-        if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
+        if (lane == 0) {
+            scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
+            n_visited += (unsigned int)visited;
+            n_groups_all += (unsigned int)groups;
+            n_bound_dropped += (pruned && visited == 0) ? 1u : 0u;
+        }
     }
+    }
+    // work counters: summed over the workgroup in LDS, then ONE set of global atomics per workgroup (a set per wave is
+    // 10^5 atomics on three addresses in a 0.3 ms launch: it quadrupled config B's kernel time when it was tried)
+    for (int off = 32; off > 0; off >>= 1) {
+        n_visited += __shfl_xor(n_visited, off, kWave);
+        n_groups_all += __shfl_xor(n_groups_all, off, kWave);
+        n_bound_dropped += __shfl_xor(n_bound_dropped, off, kWave);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&wg_counts[0], n_visited); atomicAdd(&wg_counts[1], n_groups_all); atomicAdd(&wg_counts[2], n_bound_dropped);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* c = reinterpret_cast<unsigned long long*>(edge_count + kCounterBase);
+        atomicAdd(c, (unsigned long long)wg_counts[0]);
+        atomicAdd(c + 1, (unsigned long long)wg_counts[1]);
+        atomicAdd(c + 2, (unsigned long long)wg_counts[2]);
     }
 }
 
@@ -1069,6 +1169,22 @@ image_stats_kernel(float* __restrict__ stats, size_t block_stride, int slots_per
         o[0] = (float)s0; o[block_stride] = dev; o[2 * block_stride] = (float)s1; o[3 * block_stride] = (float)s2; o[4 * block_stride] = cmax;
         o[5 * block_stride] = open ? 0.0f : wrap180(ref + 0.5f * (lo + hi) - 275.0f);
         o[6 * block_stride] = open ? 180.0f : 0.5f * (hi - lo) + 0.02f;
+    }
+}
+
+// Candidate-fastest copy of the three channel sums per block (statistics 0, 2, 3) for filter_lds_kernel's stage 1:
+// out[(k * n_blocks + blk) * n_images + img].
+__global__ void __launch_bounds__(kBlock)
+transpose_stats_kernel(const float* __restrict__ stats, size_t block_stride, int slots_per_image, int n_blocks,
+                       float* __restrict__ out, size_t n_images)
+{
+    const size_t total = (size_t)3 * n_blocks * n_images;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const size_t img = t % n_images;
+        const size_t r = t / n_images;
+        const int blk = (int)(r % n_blocks), k = (int)(r / n_blocks);
+        const int stat = k == 0 ? 0 : k + 1;                      // 0, 2, 3
+        out[t] = stats[(size_t)stat * block_stride + img * slots_per_image + blk];
     }
 }
 
@@ -1579,7 +1695,9 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                                           : hipMemsetAsync(edge_count, 0, kCounterWords * sizeof(unsigned int), stream);  // + work counters, item counters
     if (code != hipSuccess) return code;
     // LDS-resident form when the cell (4 planes + mask) fits beside the hue table
-    const size_t lds_bytes = type == CIEDE2000 ? (size_t)kHueLutEntries * sizeof(HueEntry) + (size_t)ppad * 16 : (size_t)ppad * 12;
+    // (Euclid: + the cell's block sums and weights, + the survivor list of a tile of up to 2048 candidates)
+    const size_t lds_bytes = type == CIEDE2000 ? (size_t)kHueLutEntries * sizeof(HueEntry) + (size_t)ppad * 16
+                                               : (size_t)ppad * 12 + (size_t)4 * (ppad / 64) * 4 + 2048 * 4;
     if (in.use_lds_form && lds_bytes <= 156 * 1024) {
         // Candidates per item: a workgroup stages the cell once per item, so the longer the item the less staging and
         // the fewer barriers -- config B (1024 cells x 1000 images): 0.451 / 0.365 / 0.328 / 0.300 ms at 64 / 128 / 256 /
@@ -1589,6 +1707,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             const long long want = ((long long)L * n_cells / 2048 + 15) / 16 * 16;
             cpb = (int)std::min<long long>(std::max<long long>(want, 64), std::max(L, 64));
         }
+        // with stage 1 (one candidate per lane) a tile should give all 1024 threads a candidate: whole multiples of 1024 up to L
+        if (in.tile_candidates <= 0 && in.lib_stats_t != nullptr && prune_above != nullptr && L >= 1024) cpb = std::max(cpb, 1024);
+        if (in.tile_candidates <= 0 && in.lib_stats_t != nullptr && prune_above != nullptr && L < 1024) cpb = std::max(cpb, (L + 63) / 64 * 64);
+        cpb = std::min(cpb, 2048);              // (the survivor list of a tile)
         if (tile_used) *tile_used = cpb;
         const long long tiles = (L + cpb - 1) / cpb;
         const long long nblk = (long long)n_cells * tiles;
@@ -1596,9 +1718,9 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             auto kern = filter_lds_kernel<CIEDE2000>;
             if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes)) != hipSuccess) return code;
-            kern<<<dim3((unsigned)std::min<long long>(nblk, (1ll << 22) - 1)), kLdsBlock, lds_bytes, stream>>>(
+            kern<<<dim3((unsigned)std::min<long long>(nblk, 8192)), kLdsBlock, lds_bytes, stream>>>(
                 in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
-                edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var);
+                edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, nullptr);
             if ((code = hipGetLastError()) != hipSuccess) return code;
             edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                          edges, edge_count, edge_cap, in.hue_lut, in.var, 0);
@@ -1606,9 +1728,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             auto kern = filter_lds_kernel<RGB_EUCLIDEAN>;
             if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes)) != hipSuccess) return code;
-            kern<<<dim3((unsigned)std::min<long long>(nblk, (1ll << 22) - 1)), kLdsBlock, lds_bytes, stream>>>(
+            // (at most 8192 workgroups stride over the items: 16 rounds of what the device holds at once)
+            kern<<<dim3((unsigned)std::min<long long>(nblk, 8192)), kLdsBlock, lds_bytes, stream>>>(
                 in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
-                edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var);
+                edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, in.lib_stats_t);
         }
         return hipGetLastError();
     }
@@ -1662,6 +1785,16 @@ hipError_t launch_image_stats(float* stats, size_t block_stride, int slots_per_i
     if (n_images == 0) return hipSuccess;
     image_stats_kernel<<<(unsigned)((n_images + kBlock / kWave - 1) / (kBlock / kWave)), kBlock, 0, stream>>>(stats, block_stride, slots_per_image, image_slot,
                                                                                              active_blocks, n_images);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose_stats(const float* stats, size_t block_stride, int slots_per_image, int n_blocks, float* out,
+                                  size_t n_images, hipStream_t stream)
+{
+    const size_t total = (size_t)3 * n_blocks * n_images;
+    if (total == 0) return hipSuccess;
+    transpose_stats_kernel<<<(unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 65536), kBlock, 0, stream>>>(
+        stats, block_stride, slots_per_image, n_blocks, out, n_images);
     return hipGetLastError();
 }
 

@@ -54,6 +54,8 @@ struct FilterInputs {
                                 // plane order (cells up to 64 x 64); 0: plane order
     const float* lib_il;        // interleaved copies for filter_kernel<IL> (launch_interleave): [V][L][ppad/256][4][256] and
     const float* cells_il;      // [B][ppad/256][4][256] (plane 0 = cells_f0); null: the planar arrays are read
+    const float* lib_stats_t;   // Euclid LDS kernel's stage 1: the library's three channel sums per block, candidate-fastest
+                                // [variant][3][ppad / 64][L] (launch_transpose_stats); null: one wave per candidate from the start
     int item_chunk;             // work items a persistent workgroup takes per global atomic (0 = by launch size)
     int counters_cleared;       // 1: the counter block was zeroed by an earlier kernel of the stream (no memset here)
     int fused_seeds;            // 1: seeds, their scores and the limit in one launch (launch_prune_limits)
@@ -87,6 +89,10 @@ hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t ma
 // the image's summed (a, b) (the whole circle if a block's arc is open or reaches further than 170 deg from that direction).
 hipError_t launch_image_stats(float* stats, size_t block_stride, int slots_per_image, int image_slot, int active_blocks,
                               size_t n_images, hipStream_t stream);
+
+// Candidate-fastest copy of the three channel sums (statistics 0, 2, 3) of n images: out [3][n_blocks][n_images].
+hipError_t launch_transpose_stats(const float* stats, size_t block_stride, int slots_per_image, int n_blocks, float* out,
+                                  size_t n_images, hipStream_t stream);
 
 // Interleaved copy of n planar images (+ chroma, + optional replacement of channel 0): [n][ppad/256][4][256].
 hipError_t launch_interleave(const float* planar, const float* chroma, const float* plane0, float* out,

@@ -160,3 +160,28 @@ def test_tiny_detail_cells_one_wave_per_cell(oracle, default_engine, size, t, re
     valid = state >= 0
     assert np.array_equal(gbest, best)
     assert (np.abs(gscore[valid] - score[valid]) <= 1e-12 * np.abs(score[valid]) + 1e-300).all()
+
+
+@pytest.mark.parametrize("t,rep", [(Type.RGB_EUCLIDEAN, (0, 0)), (Type.CIE76, (3, 120))])
+def test_euclid_filter_stage_1_one_candidate_per_lane(oracle, engine, t, rep):
+    """The RGB / CIE76 filter judges the block bound one candidate per lane before it spends a wave on a candidate (on
+    benchmark-like content the bound alone drops nearly all of them): hexagon cells (clipped border cells use the bound on
+    their whole blocks), 700 images, every cell against the oracle; option euclid_stage1 = 0 gives the same grid and bits."""
+    L = 700
+    shape = cases.hexagon_shape()
+    img, lib = cases.inputs(900, 1100, 64, L, t, lattice=96)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, img.shape[0], img.shape[1])[0]
+    cells = G.cell_records(group, state, img.shape[0], img.shape[1])
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    tm = engine.timing()
+    assert tm["bound_dropped"] > 0.5 * len(cells) * L and tm["visited_groups"] > 0 and tm["band_alarms"] == 0
+    check_against_oracle(oracle, shape, img, lib, t, rep, cells, best, score, L)
+    engine.set_option("euclid_stage1", 0)
+    try:
+        b2, s2 = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+    finally:
+        engine.set_option("euclid_stage1", 1)
+    valid = state >= 0
+    assert np.array_equal(b2, best) and np.array_equal(s2[valid], score[valid])

@@ -8,6 +8,7 @@ mkdir -p gpurun_out/var_$name
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Iinclude"
 hipcc $F -ffp-contract=off -c $C/engine.hip -o gpurun_out/var_$name/engine.o
 hipcc $F -ffp-contract=fast -fno-slp-vectorize "$@" -c $C/filter.hip -o gpurun_out/var_$name/filter.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_out/$name.so gpurun_out/var_$name/engine.o gpurun_out/var_$name/filter.o
+hipcc $F -c $C/group.hip -o gpurun_out/var_$name/group.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_out/$name.so gpurun_out/var_$name/engine.o gpurun_out/var_$name/filter.o gpurun_out/var_$name/group.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -lpthread
 rm -rf gpurun_out/var_$name
 echo gpurun_out/$name.so

@@ -11,6 +11,6 @@ python3 - $O <<'PY'
 import csv, glob, sys
 for path in sorted(glob.glob(sys.argv[1] + '/*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(path)):
-        if 'filter_kernel' in r['Kernel_Name']:
+        if 'filter_kernel' in r['Kernel_Name'] or 'filter_lds_kernel' in r['Kernel_Name']:
             print(path.split('/')[2], r['Counter_Name'], '%.4g' % float(r['Counter_Value']), 'ms %.2f' % ((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6))
 PY
