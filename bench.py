@@ -60,6 +60,10 @@ CONFIGS = {
     "D": (4096, 4096, 64, "square", 5000, 2, 4, 500, 8),
     "E": (8192, 8192, 48, "square", 10000, 2, 0, 0, 4),      # BASELINE config 5, the whole grid
     "E8": (8192, 8192, 48, "square", 10000, 2, 0, 0, 4),     # ... one rank's shard of it (first ceil(29 241 / 8) cells)
+    # the reference GUI's defaults -- cell size 128 (CellShape.h:36), detail 100 %, the first colour difference of the combo box
+    # (MainWindow.cpp:60,150,157) -- on a 4096 x 4096 target with a 1000-image library, and the same shape as CIEDE2000
+    "F": (4096, 4096, 128, "square", 1000, 0, 0, 0, 16),
+    "G": (4096, 4096, 128, "square", 1000, 2, 0, 0, 2),
     # reduced shapes of D and E for the rank rehearsals of tests/test_gpu_bench_ranks.py (not bench lines)
     "Ds": (1024, 1024, 64, "square", 400, 2, 4, 500, 8),
     "Es": (1000, 1000, 48, "square", 500, 2, 0, 0, 4),       # 21 x 21 cells, last row / column clipped to 40 px

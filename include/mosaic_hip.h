@@ -353,7 +353,7 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * depends on the call history of the engine; 0 pins the size-by-cell default (mm_timing.filter_tile reports what ran).
  * "stage0" (1): one whole-image bound per candidate ahead of the block bound; "euclid_stage1" (1): the RGB / CIE76 filter
  * judges the block bound one candidate per lane before any wave is spent on a candidate; "item_chunk" (0 = 1): work items a persistent
- * filter workgroup takes per global atomic; "tiny" (1): detail cells of <= 64 pixels take the one-wave-per-cell path;
+ * filter workgroup takes per global atomic; "cell_order" (1): the CIEDE2000 filter takes each XCD share's clipped cells (long items) first; "tiny" (1): detail cells of <= 64 pixels take the one-wave-per-cell path;
  * "fused_seeds" (2048): batches of up to n cells pick seeds, score them and set the limit in one launch;
  * "prune_min_kpairs" (-1 = 1e5 for RGB / CIE76, 2e4 for CIEDE2000): below n thousand pixel pairs per call the seeds and the
  * early exit are skipped (they would cost a small job more than they save); "phase_timing" (-1): events between the phases of

@@ -68,7 +68,7 @@ struct mm_engine {
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
     // per distinct mask in that mask's active-pixels-first order whenever either changes
-    DevBuf lib_hwc, perm, inv_perm, cell_var, cell_full, pos_mask, lib_lsum, cell_lsum;
+    DevBuf lib_hwc, perm, inv_perm, cell_var, cell_full, cell_order, pos_mask, lib_lsum, cell_lsum;
     std::vector<uint8_t> masks_host;
     bool planes_dirty = true;
     int n_var = 0, var_of_mask[4] = {0, 0, 0, 0}, var_groups[4] = {0, 0, 0, 0};
@@ -94,6 +94,8 @@ struct mm_engine {
     int use_interleave = 1;      // mm_set_option("interleave", 0): the filter kernel reads the planar arrays (eight bases per pair)
     int xcd_aware = 1;           // mm_set_option("xcd_aware", 0): one item order for the whole device
     int xcd_cells = 0;           // mm_set_option("xcd_cells", n): cells per sub-group of an XCD's share (0 = default)
+    bool any_clipped = false;        // the cells of the call in flight: does any of them carry a bound short of the whole cell? (check_cells)
+    bool long_items_first = true;    // mm_set_option("cell_order", 0 / 1): filter_kernel takes the clipped cells of each XCD's share first
     int item_chunk = 0;          // mm_set_option("item_chunk", n): work items per global atomic of the filter's persistent workgroups (0 = by launch size)
     size_t batch_per_cell = 0;   // workspace bytes per cell the batch capacity below was computed for
     int batch_capacity = 0;      // cells per device batch the last hipMemGetInfo allowed (0 = not asked yet)
@@ -213,8 +215,10 @@ mm_status check_ready(mm_engine* e)
 mm_status check_cells(mm_engine* e, const mm_cell* cells, int n, int grid_w, int grid_h)
 {
     const int size = e->lib_size;
+    e->any_clipped = false;
     for (int i = 0; i < n; ++i) {
         const mm_cell& c = cells[i];
+        e->any_clipped = e->any_clipped || c.row_min != 0 || c.col_min != 0 || c.row_max != size || c.col_max != size;
         const bool ok =
             c.row_min >= 0 && c.row_min < c.row_max && c.row_max <= size &&
             c.col_min >= 0 && c.col_min < c.col_max && c.col_max <= size &&
@@ -616,7 +620,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     // interleaved copies of the cell and its mask, block statistics, contenders, seeds, flags.
     const size_t per_cell = tiny ? (size_t)L * sizeof(double) + 16
                                  : (size_t)L * sizeof(double) + (size_t)ppad * (12 + 1 + (two_tier ? 4 + 4 + 16 : 0)) +
-                                   (size_t)8 * stat_slots(ppad) * sizeof(float) + (size_t)Kc * 16 + (prune ? (size_t)M * 8 + 4 : 0) + 16;
+                                   (size_t)8 * stat_slots(ppad) * sizeof(float) + (size_t)Kc * 16 + (prune ? (size_t)M * 8 + 4 : 0) + 20;
     // hipMemGetInfo is a driver round trip: asked again only when this call needs more cells per batch than the
     // last budget allowed (the workspaces below are kept between calls)
     // (a batch is a grid dimension of the general path's kernels: 32768; tiny cells have no such bound, and a job of theirs
@@ -646,6 +650,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         if (tiny) return ensure(e, e->scores, (size_t)bt * L * sizeof(double), "Failed to allocate variants");
         if ((st = ensure(e, e->cell_var, (size_t)bt, "Failed to allocate cell variants")) ||
             (st = ensure(e, e->cell_full, (size_t)bt, "Failed to allocate cell flags")) ||
+            (st = ensure(e, e->cell_order, (size_t)bt * sizeof(int32_t), "Failed to allocate the cell order")) ||
             (st = ensure(e, e->cell_lsum, (size_t)8 * bt * stat_slots(ppad) * sizeof(float), "Failed to allocate block statistics")) ||
             (st = ensure(e, e->cells, (size_t)bt * 3 * ppad * sizeof(float), "Failed to allocate cell images")) ||
             (st = ensure(e, e->cmask, (size_t)bt * ppad, "Failed to allocate cell masks")) ||
@@ -701,6 +706,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.xcd_aware = e->xcd_aware;
     fin.xcd_cells = e->xcd_cells;
     fin.item_chunk = e->item_chunk;
+    fin.cell_order = e->long_items_first && e->any_clipped ? (int32_t*)e->cell_order.p : nullptr;     // (no clipped cell: nothing to move)
     fin.lib_stats_t = e->euclid_stage1 != 0 && diff_type != MM_CIEDE2000 ? (const float*)e->lib_stats_t.p : nullptr;
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
     // the fused ranking kernel keeps a cell's contenders in LDS (16 bytes each)
@@ -1260,7 +1266,7 @@ void mm_destroy(mm_engine* e)
                        &e->dense_recs, &e->dense_i, &e->lib_means, &e->seeds,
                        &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
                        &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
-                       &e->cell_var, &e->cell_full, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
+                       &e->cell_var, &e->cell_full, &e->cell_order, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
                        &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0, &e->area_tab,
                        &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il, &e->result, &e->main_bgr, &e->entropy_out, &e->exceeded_out, &e->lib_tiny, &e->lib_stats_t })
         release(*b);
@@ -2085,6 +2091,13 @@ mm_status mm_debug_visit_counters(mm_engine* e, unsigned long long out[3])
     unsigned int raw[8] = {0};
     HIP_TRY(e, hipMemcpy(raw, e->edge_count.p, sizeof raw, hipMemcpyDeviceToHost), "counters");
     memcpy(out, raw + 2, 3 * sizeof(unsigned long long));
+#ifdef MM_FILTER_STAMPS
+    {   // instrumented build: the cycle accounts of filter_kernel (words 24..31, units of 1024 cycles)
+        unsigned int st[8] = {0};
+        HIP_TRY(e, hipMemcpy(st, (unsigned int*)e->edge_count.p + 24, sizeof st, hipMemcpyDeviceToHost), "stamps");
+        fprintf(stderr, "stamps wait %u fetch %u stats %u stage0 %u stage1 %u stage2 %u longest lifetime %u sum of lifetimes / 16 %u\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+    }
+#endif
     return MM_OK;
 }
 
@@ -2166,6 +2179,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "sort_groups") == 0) { e->sort_groups = std::min(16, std::max(-1, value)); return MM_OK; }
     if (strcmp(name, "interleave") == 0) { e->use_interleave = value != 0; return MM_OK; }
     if (strcmp(name, "xcd_aware") == 0) { e->xcd_aware = value != 0; return MM_OK; }
+    if (strcmp(name, "cell_order") == 0) { e->long_items_first = value != 0; return MM_OK; }
     if (strcmp(name, "item_chunk") == 0) { e->item_chunk = std::max(0, value); return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }

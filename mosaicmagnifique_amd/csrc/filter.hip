@@ -200,6 +200,10 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 //   +0,1  u64  256-pixel groups visited          +2,3  u64  groups a full visit of every candidate would take
 //   +4,5  u64  candidates dropped by the block bound alone (no pixel touched)
 //   +6    u32  unused                            +8 .. +15  u32  next item of XCD 0 .. 7 (persistent workgroups)
+#ifndef MM_LONG_SPLIT
+#define MM_LONG_SPLIT 0.8f
+#endif
+constexpr float kLongSplit = MM_LONG_SPLIT;   // stage 2 of filter_kernel: candidates whose block bound is below this share of the limit go first
 constexpr int kCounterBase = 2;
 constexpr int kItemCounters = 16;
 constexpr int kCounterWords = 32;        // words cleared per launch (edge count, work counters, item counters)
@@ -247,7 +251,11 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     __shared__ int seed_ids[256];           // the cell's seeds: their scores are in the row already (launch_prune_limits)
     // stage 1 -> stage 2: the bound of every 256-position group of the tile's candidates (<= 64 per tile, <= 16 groups)
     __shared__ float cand_gb[TYPE == CIEDE2000 ? 64 : 1][TYPE == CIEDE2000 ? 16 : 1];
-    __shared__ unsigned int alive_mask[2];  // candidates of the tile that passed the bound in stage 1 (<= 64 per tile)
+    // candidates of the tile that passed the bound in stage 1 (<= 64 per tile), in two classes: [0, 1] those whose bound is
+    // below kLongSplit of the limit -- the likely contenders, which walk most of their groups -- and [2, 3] the others.
+    // Stage 2 hands out the first class first: the waves of an item meet at a barrier, and a long candidate drawn last
+    // keeps the other three waiting for it
+    __shared__ unsigned int alive_mask[4];
     // stage 0 -> stage 1: the tile's candidates that passed the whole-image bound (and are no seeds), compacted
     __shared__ unsigned char surv_idx[TYPE == CIEDE2000 ? 64 : 1];
     __shared__ int n_surv;
@@ -272,6 +280,20 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     __shared__ unsigned int chunk_next;
     __shared__ int chunk_left, chunk_share;
     if (threadIdx.x == 0) chunk_left = 0;
+#ifdef MM_FILTER_STAMPS
+    // Instrumented build (tests/tools_r3_stamps.sh): where a wave's cycles go inside an item, summed over the launch
+    // into words 24..31 of the counters (units of 1024 cycles): 0 waiting for the workgroup's slowest wave, 1 item fetch
+    // (the global atomic), 2 statistics / seeds into LDS, 3 stage 0, 4 stage 1, 5 stage 2; 6 the longest workgroup lifetime, 7 the sum of the lifetimes / 16
+    __shared__ unsigned int stamp_acc[8];
+    if (threadIdx.x < 8) stamp_acc[threadIdx.x] = 0u;
+    unsigned long long stamp_t = __builtin_readcyclecounter();
+    const unsigned long long stamp_begin = stamp_t;
+    unsigned int stamp_items = 0;
+#define MM_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&stamp_acc[k], (unsigned int)((now_ - stamp_t) >> 4)); stamp_t = now_; } while (0)
+#else
+#define MM_STAMP(k) do { } while (0)
+#endif
     unsigned int n_visited = 0, n_groups_all = 0, n_bound_dropped = 0;     // work counters, per lane (a wave's share of a launch fits 32 bits)
     // Persistent workgroups: as many as the device holds at once, each taking the next item of the
     // launch order from a global counter.  A 33 KB table per 32-candidate tile was
@@ -279,6 +301,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // at every workgroup start.
     for (;;) {
     __syncthreads();                        // the previous item is done with next_candidate / cell_st
+    MM_STAMP(0);
     if (threadIdx.x == 0) {
         int share = -1;
         unsigned int item = 0;
@@ -304,6 +327,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         next_candidate = THREADS / kWave;
     }
     __syncthreads();
+    MM_STAMP(1);
     // read back as scalars: everything derived from them (cell, tile, plane addresses) stays in SGPRs
     const int share = __builtin_amdgcn_readfirstlane(item_share);
     if (share < 0) break;
@@ -315,8 +339,10 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     const long long rem = bid - (long long)group * per_group;
     const int cells_here = min(cell_group, share_cells - group * cell_group);
     const int tile = (int)(rem / cells_here);
-    const int cell = share_lo + group * cell_group + (int)(rem - (long long)tile * cells_here);
-    if (tile >= n_tiles || cell >= n_cells) continue;
+    const int cell_at = share_lo + group * cell_group + (int)(rem - (long long)tile * cells_here);
+    if (tile >= n_tiles || cell_at >= n_cells) continue;
+    // (long items first: launch_filter's order of the share's cells; a scalar load, the cell number stays in an SGPR)
+    const int cell = var.cell_order ? __builtin_amdgcn_readfirstlane(var.cell_order[cell_at]) : cell_at;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int v = var.cell_var[cell];
@@ -396,7 +422,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // group bounds, the visiting order and a scan -- ~60 instructions instead of ~300 -- before the pixel loop.
     bool two_level = false;
     if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && groups > 0 && cand_per_block <= 64 && (var.two_stage & 1) != 0;
-    if (two_level && threadIdx.x < 2) alive_mask[threadIdx.x] = 0u;
+    if (two_level && threadIdx.x < 4) alive_mask[threadIdx.x] = 0u;
     // Stage 0: ONE bound per candidate from the statistics of the two WHOLE images (the triangle inequality holds for any
     // partition of the pixels, the one-block partition included).  Weaker than the block bound, but 1 / 64 of its cost, and it
     // drops a third of config D's candidates (more on smoother content) before stage 1 spends 64 block evaluations on them.
@@ -409,6 +435,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             cell_ist[threadIdx.x] = var.cell_stats[(size_t)threadIdx.x * var.cell_stats_stride + (size_t)cell * var.n_blocks + ppad / 64];
     }
     if (use_lb || CELL_LDS || n_seeds > 0) __syncthreads();   // workgroup-uniform
+    MM_STAMP(2);
     if constexpr (TYPE == CIEDE2000) if (stage0) {
         if (wave == 0) {
             const int l = l_base + lane;
@@ -437,6 +464,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         __syncthreads();
     }
+    MM_STAMP(3);
     if constexpr (TYPE == CIEDE2000) if (two_level) {         // (the statistics arrays exist for CIEDE2000 only)
         const int n_stage1 = stage0 ? n_surv : n_here;
         // lanes (q, g): candidate q of the pass, group g < groups -- 64 / groups candidates per pass (four at 16 groups,
@@ -487,7 +515,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     scores[(size_t)cell * L + l] = __builtin_huge_valf();
                     n_bound_dropped += 1;       // (per lane; summed over the wave's lanes at the end)
                 } else {
-                    atomicOr(&alive_mask[idx >> 5], 1u << (idx & 31));
+                    atomicOr(&alive_mask[(b < kLongSplit * limit ? 0 : 2) + (idx >> 5)], 1u << (idx & 31));
                 }
                 if (!stage0) n_groups_all += (unsigned int)groups;     // (stage 0 counted its candidates itself)
             }
@@ -495,8 +523,10 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         if (threadIdx.x == 0) next_candidate = 0;           // stage 2 counts survivors from 0
         __syncthreads();
     }
-    const unsigned long long survivors = two_level ? ((unsigned long long)alive_mask[1] << 32) | alive_mask[0] : 0ull;
-    const int n_todo = two_level ? __builtin_popcountll(survivors) : n_here;
+    MM_STAMP(4);
+    // (the masks are read from LDS again per candidate: four more SGPRs held across the pixel loop cost more in spills)
+    const int n_long = two_level ? __builtin_popcount(alive_mask[0]) + __builtin_popcount(alive_mask[1]) : 0;
+    const int n_todo = two_level ? n_long + __builtin_popcount(alive_mask[2]) + __builtin_popcount(alive_mask[3]) : n_here;
     for (int turn = two_level ? 0 : wave; ;) {
         if (two_level) {                                    // the next survivor not yet taken by any wave
             int nxt = 0;
@@ -505,8 +535,11 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         if (turn >= n_todo) break;
         int idx = turn;
-        if (two_level) {                                    // the turn-th set bit of the mask
-            const bool mine = ((survivors >> lane) & 1ull) != 0 && __builtin_popcountll(survivors & ((1ull << lane) - 1ull)) == turn;
+        if (two_level) {                                    // the turn-th set bit of the masks, the long class first
+            const int cls = turn < n_long ? 0 : 2;
+            const unsigned long long survivors = ((unsigned long long)alive_mask[cls + 1] << 32) | alive_mask[cls];
+            const int nth = turn < n_long ? turn : turn - n_long;
+            const bool mine = ((survivors >> lane) & 1ull) != 0 && __builtin_popcountll(survivors & ((1ull << lane) - 1ull)) == nth;
             idx = __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine));
         }
         const int l = l_base + idx;
@@ -678,7 +711,20 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         acc = wave_sum_all(acc + acc_edge);
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }
+    MM_STAMP(5);
+#ifdef MM_FILTER_STAMPS
+    stamp_items += 1;
+#endif
     }   // next item
+#ifdef MM_FILTER_STAMPS
+    __syncthreads();
+    if (threadIdx.x < 6) atomicAdd(edge_count + 24 + threadIdx.x, stamp_acc[threadIdx.x] >> 6);
+    if (threadIdx.x == 0 && stamp_items > 0) {      // 6: the longest workgroup lifetime, 7: the sum of the lifetimes (workgroups that took an item)
+        const unsigned int life = (unsigned int)((__builtin_readcyclecounter() - stamp_begin) >> 10);
+        atomicMax(edge_count + 30, life);
+        atomicAdd(edge_count + 31, life >> 4);
+    }
+#endif
     {   // one set of atomics per wave and launch
         for (int off = 32; off > 0; off >>= 1) {
             n_visited += __shfl_xor(n_visited, off, kWave);
@@ -705,7 +751,11 @@ constexpr int kLdsBlock = 1024;
 
 // (RGB / CIE76: two 16-wave workgroups per CU need 8 waves per SIMD, i.e. at most 64 VGPRs -- left alone the compiler takes 80
 // and one workgroup per CU stays resident)
-template <int TYPE>
+// CELL_GLOBAL (RGB / CIE76 only): cells whose planes do not fit LDS (128 x 128: 196 KB -- the reference GUI's default cell
+// size at its default detail of 100 %) keep everything else of this kernel -- the cell's block sums in LDS, stage 1 with one
+// candidate per lane, the survivor list -- and the few survivors' waves read the cell's pixels from global memory (L2: the
+// sixteen waves of the workgroup walk the same 196 KB).
+template <int TYPE, bool CELL_GLOBAL = false>
 __global__ void __launch_bounds__(kLdsBlock) __attribute__((amdgpu_waves_per_eu(TYPE == CIEDE2000 ? 4 : MM_EUCLID_WAVES, TYPE == CIEDE2000 ? 4 : 8)))
 filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
                   const float* __restrict__ cell_chroma, const float* __restrict__ lib,
@@ -726,7 +776,7 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
     float4* s2 = s1 + pq;
     float4* sc = s2 + pq;
     // Euclid with the early exit: behind the three planes the cell's block sums + weights [4][ppad / 64] and the tile's survivors
-    float* cst = reinterpret_cast<float*>(s2 + pq);
+    float* cst = CELL_GLOBAL ? reinterpret_cast<float*>(smem) : reinterpret_cast<float*>(s2 + pq);
     int* surv = reinterpret_cast<int*>(cst + 4 * (ppad / 64));
     if (threadIdx.x < 3) wg_counts[threadIdx.x] = 0u;
 
@@ -753,9 +803,9 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
     // stage the hue table and the cell (active groups only)
     if constexpr (TYPE == CIEDE2000)
         for (int i = threadIdx.x; i < kHueLutEntries; i += kLdsBlock) lut[i] = hue_lut[i];
-    {
-        const float4* g0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
-        const float4* gf = reinterpret_cast<const float4*>(cells_f0 + (size_t)cell * ppad);     // NaN = inactive
+    const float4* const g0 = reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad);
+    const float4* const gf = reinterpret_cast<const float4*>(cells_f0 + (size_t)cell * ppad);     // NaN = inactive
+    if constexpr (!CELL_GLOBAL) {
         const float4* gc = reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
         const int nq = groups * kWave;
         for (int q = threadIdx.x; q < nq; q += kLdsBlock) {
@@ -882,7 +932,7 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
                 const int q = lane + kWave * j;
                 const LibGroup cur = (kAhead || j == 0) ? nxt : load_lib_group<TYPE>(b0, b1, b2, bc, q);
                 if (kAhead && j + 1 < groups) nxt = load_lib_group<TYPE>(b0, b1, b2, bc, q + kWave);   // one group ahead
-                const float4 p0 = s0[q], p1 = s1[q], p2 = s2[q];
+                const float4 p0 = CELL_GLOBAL ? gf[q] : s0[q], p1 = CELL_GLOBAL ? g0[pq + q] : s1[q], p2 = CELL_GLOBAL ? g0[2 * pq + q] : s2[q];
                 float4 pc{0.f, 0.f, 0.f, 0.f};
                 if constexpr (TYPE == CIEDE2000) pc = sc[q];
                 const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, qc = cur.qc;
@@ -1616,6 +1666,37 @@ hipError_t launch_band_sweep(int mode, unsigned long long seed, unsigned long lo
     return hipGetLastError();
 }
 
+// Launch order of filter_kernel's cells: the persistent workgroups take the items of an XCD's share front to back, and a
+// launch ends when the last item does.  Clipped cells (cell_full != 1: a bound on their whole blocks only, or none) make
+// items several times as long as the others; left where the raster order puts them -- the last rows and columns of the grid
+// -- they are the tail of the launch (config C: the workgroups were resident 87 % of the longest one's lifetime).  So
+// each share's cells are partitioned, stably: long ones first.  One workgroup per share, a contiguous run of cells per thread.
+__global__ void __launch_bounds__(kBlock)
+cell_order_kernel(const uint8_t* __restrict__ cell_full, int n_cells, int shares, int32_t* __restrict__ order)
+{
+    __shared__ int n_long[kBlock + 1], n_short[kBlock + 1];
+    const int sh = blockIdx.x, t = threadIdx.x;
+    const int lo = (int)((long long)n_cells * sh / shares), hi = (int)((long long)n_cells * (sh + 1) / shares);
+    const int per = (hi - lo + kBlock - 1) / kBlock;
+    const int a = min(lo + t * per, hi), b = min(a + per, hi);
+    int longs = 0;
+    for (int i = a; i < b; ++i) longs += cell_full[i] != 1;
+    n_long[t + 1] = longs;
+    n_short[t + 1] = (b - a) - longs;
+    __syncthreads();
+    if (t == 0) {
+        n_long[0] = 0;
+        n_short[0] = 0;
+        for (int k = 1; k <= kBlock; ++k) { n_long[k] += n_long[k - 1]; n_short[k] += n_short[k - 1]; }
+    }
+    __syncthreads();
+    int at_long = lo + n_long[t], at_short = lo + n_long[kBlock] + n_short[t];
+    for (int i = a; i < b; ++i) {
+        if (cell_full[i] != 1) order[at_long++] = i;
+        else order[at_short++] = i;
+    }
+}
+
 hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream, int* tile_used)
@@ -1698,7 +1779,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     // (Euclid: + the cell's block sums and weights, + the survivor list of a tile of up to 2048 candidates)
     const size_t lds_bytes = type == CIEDE2000 ? (size_t)kHueLutEntries * sizeof(HueEntry) + (size_t)ppad * 16
                                                : (size_t)ppad * 12 + (size_t)4 * (ppad / 64) * 4 + 2048 * 4;
-    if (in.use_lds_form && lds_bytes <= 156 * 1024) {
+    // RGB / CIE76 cells too large for LDS (up to 64 groups: 128 x 128) with the bound available: the same kernel, the cell read from L2
+    const bool cell_global = type != CIEDE2000 && in.use_lds_form && lds_bytes > 156 * 1024 && groups <= kWave &&
+                             in.lib_stats_t != nullptr && prune_above != nullptr;
+    if (cell_global || (in.use_lds_form && lds_bytes <= 156 * 1024)) {
         // Candidates per item: a workgroup stages the cell once per item, so the longer the item the less staging and
         // the fewer barriers -- config B (1024 cells x 1000 images): 0.451 / 0.365 / 0.328 / 0.300 ms at 64 / 128 / 256 /
         // 1000 -- as long as the launch still has a few items per workgroup slot of the device (2 x 256 CUs).
@@ -1725,11 +1809,12 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                          edges, edge_count, edge_cap, in.hue_lut, in.var, 0);
         } else {
-            auto kern = filter_lds_kernel<RGB_EUCLIDEAN>;
+            auto kern = cell_global ? filter_lds_kernel<RGB_EUCLIDEAN, true> : filter_lds_kernel<RGB_EUCLIDEAN, false>;
+            const size_t lds_used = cell_global ? (size_t)4 * (ppad / 64) * 4 + 2048 * 4 : lds_bytes;
             if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds_bytes)) != hipSuccess) return code;
+                                            (int)lds_used)) != hipSuccess) return code;
             // (at most 8192 workgroups stride over the items: 16 rounds of what the device holds at once)
-            kern<<<dim3((unsigned)std::min<long long>(nblk, 8192)), kLdsBlock, lds_bytes, stream>>>(
+            kern<<<dim3((unsigned)std::min<long long>(nblk, 8192)), kLdsBlock, lds_used, stream>>>(
                 in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
                 edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, in.lib_stats_t);
         }
@@ -1738,13 +1823,20 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     const bool il = in.lib_il && in.cells_il;
     if (type == CIEDE2000) {
         auto kern = il ? filter_kernel<CIEDE2000, kBlock, false, true> : filter_kernel<CIEDE2000, kBlock, false, false>;
+        Variants var = in.var;
+        var.cell_order = nullptr;
+        if (in.cell_order != nullptr && xcd_shares > 1 && prune_above != nullptr && var.cell_full != nullptr) {
+            cell_order_kernel<<<xcd_shares, kBlock, 0, stream>>>(var.cell_full, n_cells, xcd_shares, in.cell_order);
+            if ((code = hipGetLastError()) != hipSuccess) return code;
+            var.cell_order = in.cell_order;
+        }
         if (in.lds_pad_bytes > 0 &&
             (code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)in.lds_pad_bytes)) != hipSuccess) return code;
         kern<<<dim3(persistent_grid(reinterpret_cast<const void*>(kern), blocks, kBlock, in.lds_pad_bytes)), kBlock, in.lds_pad_bytes, stream>>>(
             il ? nullptr : in.cells, il ? in.cells_il : in.cells_f0, il ? nullptr : in.cell_chroma, il ? in.lib_il : in.lib,
             il ? nullptr : in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
-            item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, in.var, xcd_shares,
+            item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, var, xcd_shares,
             in.seeds, in.seeds ? in.n_seeds : 0, sort_groups, item_chunk);
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,

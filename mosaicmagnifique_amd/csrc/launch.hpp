@@ -31,6 +31,8 @@ struct Variants {
     int n_blocks;               // slots per image: ppad / 64 + 4
     const uint8_t* cell_full;   // [B] 1 = the cell's active set is its whole mask; 2 = clipped, with a per-block flag (cell statistic 7)
                                 // saying which blocks still are whole; 0 = clipped, no flags (separate gather kernels): no bound
+    const int32_t* cell_order;  // [B] filter_kernel's launch order of the cells (launch_filter fills it: within each XCD's share the
+                                // clipped cells, whose weaker bound makes their items several times as long, come first); null: 0, 1, 2 ..
     int two_stage;              // bit 0: the bound is evaluated several candidates per wave pass ahead of the pixel loops (filter_kernel
                                 // stage 1); bit 1: the whole-image bound ahead of that (stage 0; needs the image slots filled)
 };
@@ -59,6 +61,7 @@ struct FilterInputs {
     int item_chunk;             // work items a persistent workgroup takes per global atomic (0 = by launch size)
     int counters_cleared;       // 1: the counter block was zeroed by an earlier kernel of the stream (no memset here)
     int fused_seeds;            // 1: seeds, their scores and the limit in one launch (launch_prune_limits)
+    int32_t* cell_order;        // workspace [B] for Variants::cell_order (null: the cells are taken in their given order)
     const int32_t* seeds;       // [B][n_seeds] candidates launch_prune_limits scored already (their scores are in the
     int n_seeds;                // score rows): filter_kernel skips them.  null / 0: none.  n_seeds <= 256.
 };

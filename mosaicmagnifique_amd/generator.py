@@ -51,6 +51,8 @@ class HIPPhotomosaicGenerator:
         self._masks_key = None       # (_inputs_version, size step) the resident masks belong to
         self._lib_step = 0          # size step the resident library is at (it is halved per step)
         self._rows = self._cols = 0
+        self._cells_version = 0      # bumped by setCellGroup / invalidate
+        self._cell_cache = {}        # step -> (key, mm_cell records): the integer geometry of a step's valid cells
         self.lastError = ""
 
     # -- setters (PhotomosaicGeneratorBase.cpp:44-93) -------------------------
@@ -97,10 +99,12 @@ class HIPPhotomosaicGenerator:
         import copy
         self.m_cells = copy.deepcopy(cellGroup)
         self._inputs_version += 1
+        self._cells_version += 1
 
     def invalidate(self):
         """Call after editing an input array or the cell group IN PLACE: the next generate re-stages."""
         self._inputs_version += 1
+        self._cells_version += 1
 
     def getCellGroup(self):
         return self.m_cells
@@ -228,7 +232,7 @@ class HIPPhotomosaicGenerator:
                 self._masks_key = masks_key
             self.m_engine.set_cell_resize(self.m_cells.getCellSize(step), detailShape.getSize())
             state = self.m_bestFits[step]
-            cells = GridUtility.cell_records(self.m_cells, state, self._rows, self._cols, step)
+            cells = self._cells_of(step, state)
             # progress counts every grid position, weighted 4^(steps-1-step) (:54,:85-88)
             weight = int(4 ** (steps - 1 - step))
             base = self.m_progress
@@ -258,6 +262,21 @@ class HIPPhotomosaicGenerator:
         for fn in listeners:
             fn(self.getMaxProgress())
         return True
+
+    def _cells_of(self, step, state):
+        """``GridUtility.cell_records`` of a step, kept between calls: the records depend on the cell group, the image
+        size and WHICH grid positions hold a value -- not on the values -- so a second generateBestFits over the same
+        grid (another colour difference, repeat setting or library) reuses them (312 500 records of the reference
+        harness's cell size 8 are ~10 ms of numpy per call otherwise)."""
+        import hashlib
+        valid = state >= 0
+        key = (self._cells_version, self._rows, self._cols, state.shape, self.m_cells.getDetail(),
+               hashlib.blake2b(np.packbits(valid).tobytes(), digest_size=16).digest())
+        hit = self._cell_cache.get(step)
+        if hit is None or hit[0] != key:
+            hit = (key, GridUtility.cell_records(self.m_cells, state, self._rows, self._cols, step))
+            self._cell_cache[step] = hit
+        return hit[1]
 
     def buildPhotomosaic(self, backgroundColour=(0, 0, 0, 0)):
         """PhotomosaicGeneratorBase::buildPhotomosaic (PhotomosaicGeneratorBase.cpp:110-207) on the

@@ -158,42 +158,67 @@ def findCellState(cellGroup, mainImage, x, y, bounds, step):
     return 0, False
 
 
+def _meets_any_bound(bounds, qx, qy, qw, qh):
+    """findCellState's in-bounds test (GridGenerator.cpp:124-140) for arrays of cell rects at once: does the rect
+    share positive area with at least one bound?  The answer depends on the UNION of the bounds alone, and
+    ``GridBounds::mergeBounds`` never changes that union (it joins rects whose union is again a rect), so no merging is
+    needed here: the bounds are rasterised on the grid of their own edges (a difference array and two prefix sums) and
+    every query is four look-ups.  ``bounds``: int array [n, 4] of (x, y, width, height)."""
+    bounds = np.asarray(bounds, dtype=np.int64).reshape(-1, 4)
+    if len(bounds) == 0:
+        return np.zeros(np.shape(qx), dtype=bool)
+    bx0, by0 = bounds[:, 0], bounds[:, 1]
+    bx1, by1 = bx0 + bounds[:, 2], by0 + bounds[:, 3]
+    xs, ys = np.unique(np.concatenate([bx0, bx1])), np.unique(np.concatenate([by0, by1]))
+    nx, ny = len(xs) - 1, len(ys) - 1
+    diff = np.zeros((ny + 1, nx + 1), dtype=np.int64)
+    i0, i1, j0, j1 = np.searchsorted(xs, bx0), np.searchsorted(xs, bx1), np.searchsorted(ys, by0), np.searchsorted(ys, by1)
+    np.add.at(diff, (j0, i0), 1)
+    np.add.at(diff, (j0, i1), -1)
+    np.add.at(diff, (j1, i0), -1)
+    np.add.at(diff, (j1, i1), 1)
+    covered = diff.cumsum(0).cumsum(1)[:ny, :nx] > 0
+    pre = np.zeros((ny + 1, nx + 1), dtype=np.int64)
+    pre[1:, 1:] = covered.cumsum(0).cumsum(1)
+    a = np.clip(np.searchsorted(xs, qx, side="right") - 1, 0, nx)
+    b = np.clip(np.searchsorted(xs, qx + qw, side="left"), 0, nx)
+    c = np.clip(np.searchsorted(ys, qy, side="right") - 1, 0, ny)
+    d = np.clip(np.searchsorted(ys, qy + qh, side="left"), 0, ny)
+    b, d = np.maximum(a, b), np.maximum(c, d)
+    return (pre[d, b] - pre[c, b] - pre[d, a] + pre[c, a]) > 0
+
+
 def _grid_state_on_device(cellGroup, mainImage, engine):
     """getGridState's step loop with the per-cell image work (resize of the visible part, BGR2GRAY, masked
     histogram, entropy) on the device: ``engine.cell_entropy`` over all cells of a step that lie inside an active
-    bound; the integer geometry, the bounds and their merging stay here, vectorised."""
+    bound; the integer geometry and the bounds stay here, vectorised (``_meets_any_bound``)."""
     imageRows, imageCols = mainImage.shape[0], mainImage.shape[1]
     engine.set_main_image_bgr(mainImage)
     gridState = []
-    active = [Rect(0, 0, imageCols, imageRows)]
+    active = np.array([[0, 0, imageCols, imageRows]], dtype=np.int64)
     steps = cellGroup.getSizeSteps()
     for step in range(steps + 1):
-        if not active:
+        if len(active) == 0:
             break
         shape = cellGroup.getCell(step)
         gw, gh = calculateGridSize(shape, imageCols, imageRows)
         gx, gy = np.meshgrid(np.arange(gw, dtype=np.int64) - PAD_GRID, np.arange(gh, dtype=np.int64) - PAD_GRID)
         r = getRectAt(shape, gx, gy)
-        inside = np.zeros(gx.shape, dtype=bool)
-        for b in active:                                     # findCellState's in-bounds test, :124-140
-            y0, y1 = np.clip(r.y, b.y, b.y + b.height), np.clip(r.y + r.height, b.y, b.y + b.height)
-            x0, x1 = np.clip(r.x, b.x, b.x + b.width), np.clip(r.x + r.width, b.x, b.x + b.width)
-            inside |= (y0 != y1) & (x0 != x1)
+        inside = _meets_any_bound(active, r.x, r.y, r.width + 0 * r.x, r.height + 0 * r.y)
         state = np.where(inside, 0, NULLOPT).astype(np.int64)
-        nxt = []
+        active = np.zeros((0, 4), dtype=np.int64)
         if step < steps and inside.any():
             detail = cellGroup.getCell(step, True)
             engine.set_masks(detail.masks4())
             recs = cell_records(cellGroup, state, imageRows, imageCols, step)
             split = engine.cell_entropy(recs, shape.getSize()) != 0
             state[recs["grid_y"][split], recs["grid_x"][split]] = NULLOPT
-            for c in recs[split]:                            # raster order, as the reference adds them (:77-103)
-                y0, y1 = min(max(int(c["y"]), 0), imageRows), min(max(int(c["y"]) + shape.getSize(), 0), imageRows)
-                x0, x1 = min(max(int(c["x"]), 0), imageCols), min(max(int(c["x"]) + shape.getSize(), 0), imageCols)
-                if y0 != y1 and x0 != x1:
-                    nxt.append(Rect(x0, y0, x1 - x0, y1 - y0))
+            cx, cy = recs["x"][split].astype(np.int64), recs["y"][split].astype(np.int64)
+            y0, y1 = np.clip(cy, 0, imageRows), np.clip(cy + shape.getSize(), 0, imageRows)      # :77-103
+            x0, x1 = np.clip(cx, 0, imageCols), np.clip(cx + shape.getSize(), 0, imageCols)
+            keep = (y0 != y1) & (x0 != x1)
+            active = np.stack([x0, y0, x1 - x0, y1 - y0], axis=1)[keep]
         gridState.append(state)
-        active = mergeBounds(nxt) if nxt else []
     return gridState
 
 

@@ -281,6 +281,20 @@ def test_stage_one_handles_every_group_count(oracle, engine, size, two_level):
         engine.set_option("two_level", 1)
 
 
+@pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIE76])
+@pytest.mark.parametrize("size", [128, 112])
+def test_euclid_cells_too_large_for_lds_keep_the_bound(oracle, engine, t, size):
+    """128 x 128 cells at full detail -- the reference GUI's defaults (CellShape.h:36, MainWindow.cpp:150,157) -- do not fit
+    LDS (196 KB of planes): the RGB / CIE76 filter keeps its block bound, one candidate per lane, and only the survivors'
+    waves read the cell from global memory (filter_lds_kernel<.., CELL_GLOBAL>).  700 images = a ragged tile; clipped
+    cells at the right and bottom edges.  Pruned == unpruned == fp64-only == oracle, with and without repeats."""
+    rows, cols = 2 * size + size // 2, 3 * size + size // 3
+    img, lib = cases.inputs(rows, cols, size, 700, t, lattice=size)
+    tm = run_both(oracle, engine, cases.square_shape(size), img, lib, t)
+    assert tm["bound_dropped"] > 0 and tm["visited_groups"] < tm["total_groups"]
+    run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(1, 4000))
+
+
 @pytest.mark.parametrize("size", [160, 256])
 def test_cells_beyond_the_bound_s_reach(oracle, engine, size):
     """Cells of more than 64 pixel groups (over 128 x 128) are outside what the early-exit bound's prelude holds in one

@@ -36,6 +36,30 @@ def test_merge_bounds_matches_the_oracle(oracle):
     assert len(G.mergeBounds([(0, 0, 16, 16), (32, 32, 16, 16)])) == 2
 
 
+def test_in_bounds_test_on_the_union_equals_the_merged_list():
+    """The vectorised in-bounds test of the device grid-state path (`_meets_any_bound`) against findCellState's loop over
+    the merged bounds (GridGenerator.cpp:124-140): merging never changes the union, so both agree on every rect."""
+    from mosaicmagnifique_amd.grid import _meets_any_bound
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        n = int(rng.integers(1, 40))
+        unit = int(rng.choice([7, 16, 25]))
+        rects = np.stack([rng.integers(-1, 12, n) * unit, rng.integers(-1, 12, n) * unit,
+                          rng.integers(1, 4, n) * unit - rng.integers(0, 3, n), rng.integers(1, 4, n) * unit - rng.integers(0, 3, n)], axis=1)
+        merged = G.mergeBounds([tuple(int(v) for v in r) for r in rects])
+        q = int(rng.choice([5, 8, 13]))
+        qx, qy = np.meshgrid(np.arange(-3, 40) * q - int(rng.integers(0, 4)), np.arange(-3, 40) * q - int(rng.integers(0, 4)))
+        qw, qh = q + int(rng.integers(0, 3)), q + int(rng.integers(0, 3))
+        want = np.zeros(qx.shape, dtype=bool)
+        for b in merged:
+            y0, y1 = np.clip(qy, b.y, b.y + b.height), np.clip(qy + qh, b.y, b.y + b.height)
+            x0, x1 = np.clip(qx, b.x, b.x + b.width), np.clip(qx + qw, b.x, b.x + b.width)
+            want |= (y0 != y1) & (x0 != x1)
+        got = _meets_any_bound(rects, qx, qy, qw + 0 * qx, qh + 0 * qy)
+        assert np.array_equal(got, want), trial
+    assert not _meets_any_bound(np.zeros((0, 4), dtype=np.int64), np.array([0]), np.array([0]), np.array([4]), np.array([4])).any()
+
+
 @pytest.mark.parametrize("dims", [(37, 128, 18, 64), (128, 91, 64, 45), (96, 96, 32, 32), (10, 10, 5, 5), (9, 11, 4, 5)])
 def test_area_resize_matches_the_oracle(oracle, dims):
     sr, sc, dr, dc = dims

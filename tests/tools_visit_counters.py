@@ -23,3 +23,8 @@ n = len(w['cells']) * w['L']
 print(t)
 print('visited groups %d of %d = %.3f ; candidates dropped by the bound %d of %d = %.3f' % (
     t['visited_groups'], t['total_groups'], t['visited_groups'] / max(t['total_groups'], 1), t['bound_dropped'], n, t['bound_dropped'] / n))
+if os.environ.get("MOSAIC_HIP_LIB"):        # an instrumented build prints its cycle accounts from here (stderr)
+    import numpy as np
+    from mosaicmagnifique_amd import _lib
+    raw = np.zeros(3, np.uint64)
+    _lib.load().mm_debug_visit_counters(e._h, _lib.ptr(raw))
