@@ -96,6 +96,7 @@ struct mm_engine {
     int xcd_cells = 0;           // mm_set_option("xcd_cells", n): cells per sub-group of an XCD's share (0 = default)
     bool any_clipped = false;        // the cells of the call in flight: does any of them carry a bound short of the whole cell? (check_cells)
     bool long_items_first = true;    // mm_set_option("cell_order", 0 / 1): filter_kernel takes the clipped cells of each XCD's share first
+    int check_every = 0;         // mm_set_option("check_every", n): groups between two exit tests of a candidate (0 = by cell size)
     int item_chunk = 0;          // mm_set_option("item_chunk", n): work items per global atomic of the filter's persistent workgroups (0 = by launch size)
     size_t batch_per_cell = 0;   // workspace bytes per cell the batch capacity below was computed for
     int batch_capacity = 0;      // cells per device batch the last hipMemGetInfo allowed (0 = not asked yet)
@@ -706,6 +707,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     fin.xcd_aware = e->xcd_aware;
     fin.xcd_cells = e->xcd_cells;
     fin.item_chunk = e->item_chunk;
+    fin.check_every = e->check_every;
     fin.cell_order = e->long_items_first && e->any_clipped ? (int32_t*)e->cell_order.p : nullptr;     // (no clipped cell: nothing to move)
     fin.lib_stats_t = e->euclid_stage1 != 0 && diff_type != MM_CIEDE2000 ? (const float*)e->lib_stats_t.p : nullptr;
     const int4 vom = make_int4(e->var_of_mask[0], e->var_of_mask[1], e->var_of_mask[2], e->var_of_mask[3]);
@@ -2176,10 +2178,11 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }
     if (strcmp(name, "max_batch") == 0) { e->max_batch_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "two_level") == 0) { e->two_level = value != 0; return MM_OK; }
-    if (strcmp(name, "sort_groups") == 0) { e->sort_groups = std::min(16, std::max(-1, value)); return MM_OK; }
+    if (strcmp(name, "sort_groups") == 0) { e->sort_groups = std::min(64, std::max(-1, value)); return MM_OK; }
     if (strcmp(name, "interleave") == 0) { e->use_interleave = value != 0; return MM_OK; }
     if (strcmp(name, "xcd_aware") == 0) { e->xcd_aware = value != 0; return MM_OK; }
     if (strcmp(name, "cell_order") == 0) { e->long_items_first = value != 0; return MM_OK; }
+    if (strcmp(name, "check_every") == 0) { e->check_every = std::min(64, std::max(0, value)); return MM_OK; }
     if (strcmp(name, "item_chunk") == 0) { e->item_chunk = std::max(0, value); return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }

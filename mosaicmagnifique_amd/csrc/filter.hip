@@ -562,7 +562,10 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         float rest = 0.0f;                 // lane k: bound of the groups not yet visited at step k (see rest_at)
         int order = lane;                  // lane k: the group visited k-th
         const bool sorted = TYPE == CIEDE2000 && use_lb && lane_shift == 0 && sort_groups != 0;
-        const bool by_group = sorted || two_level;          // lane k of `rest`: visiting step k (else: block k)
+        // cells of 33 .. 64 groups (up to 128 x 128): a lane of the prelude holds exactly one group (four blocks), so the
+        // same descending-bound visiting order comes from ranking the 64 lanes against each other
+        const bool sorted64 = TYPE == CIEDE2000 && use_lb && lane_shift == 2 && sort_groups != 0 && !two_level;
+        const bool by_group = sorted || two_level || sorted64;      // lane k of `rest`: visiting step k (else: block k)
         if constexpr (TYPE == CIEDE2000) {
             if (use_lb) {
                 // Lane k takes blocks k*m .. k*m+m-1 (m = blocks per lane: 1 up to 64 x 64 cells, so a lane
@@ -624,8 +627,22 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     d = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dest * 4, __builtin_bit_cast(int, g)));
                     if (lane >= 16) d = 0.0f;                                   // lanes 0..15: bounds in visiting order
                 }
+                if (sorted64) {
+                    // unique keys: the bound's bits (non-negative floats order like integers) with the lane number in the low
+                    // 6 bits, lower group first among equals; lanes past the last group hold 0 and keep their places at the end
+                    const int key = (__builtin_bit_cast(int, d) & ~63) | (63 - lane);
+                    int before = 0;
+#pragma nounroll
+                    for (int j = 0; j < kWave; ++j) before += __builtin_amdgcn_readlane(key, j) > key;
+                    // as above: only the `sort_groups` largest bounds are visited out of order, the rest in plane order
+                    const unsigned long long tail_lanes = __builtin_amdgcn_ballot_w64(before >= sort_groups);
+                    const int below = __builtin_popcountll(tail_lanes & ((1ull << lane) - 1ull));
+                    const int pos = before < sort_groups ? before : sort_groups + below;
+                    order = __builtin_amdgcn_ds_permute(pos * 4, lane);
+                    d = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(pos * 4, __builtin_bit_cast(int, d)));
+                }
                 // inclusive suffix scan over lanes (lane j <- sum of lanes >= j); group bounds fill lanes 0..15 only
-                if (by_group) {
+                if (sorted || two_level) {
                     d = row_suffix_sum(d);
                 } else {
                     for (int off = 1; off < kWave; off <<= 1) {
@@ -698,7 +715,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             // latency (a group is ~430 VALU instructions), and the second register set was what kept the
             // kernel at 4 waves (155 VGPRs wanted, 128 allowed, spills).
             for (int step = 0; step < groups; ++step) {
-                const int j = sorted ? __builtin_amdgcn_readlane(order, step) : step;
+                const int j = (sorted || sorted64) ? __builtin_amdgcn_readlane(order, step) : step;
                 const LibGroup g = load_lib_group<TYPE>(b0, b1, b2, bc, IL ? lane + 4 * kWave * j : lane + kWave * j);
                 if (visit(g, j, step)) { pruned = true; break; }
             }
@@ -1731,7 +1748,9 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         if (n_known < 8) known[n_known++] = Known{kern, dyn_lds, dev, cus * per_cu * 2};
         return (unsigned)std::min<long long>(items, (long long)cus * per_cu * 2);
     };
-    const int sort_groups = in.sort_groups < 0 ? (groups >= 12 ? 16 : 0) : in.sort_groups;
+    // groups visited by descending bound (the rest in plane order): all of them from 12 groups per cell on (cells of 33 .. 64
+    // groups rank the 64 lanes of the prelude; config G: 16.2 -> 15.3 ms per launch, with the exit test at every group 14.4)
+    const int sort_groups = in.sort_groups < 0 ? (groups > 16 ? 64 : (groups >= 12 ? 16 : 0)) : in.sort_groups;
     // The LDS-resident cell tile (CIEDE2000, early exit on): ten-wave workgroups, the cell's colour planes staged once
     // per item.  Needs one block per lane in the bound's prelude (<= 16 groups = cells up to 64 x 64) and the three
     // planes beside the hue table, twice per CU.
@@ -1765,7 +1784,9 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     // one share of the cells per XCD (8 on MI355X); small launches keep one share so no XCD idles on an empty one
     const int xcd_shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
     const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : (small_cells ? 128 : 64)) : cell_group;
-    const int check_every = groups > 16 ? groups / 16 : 1;
+    // the exit test after every group wherever the bound reaches (cells up to 64 groups = 128 x 128; config G, 1024 such cells x 1000
+    // images: 15.4 ms per launch at every 4th group, 14.4 at every group); larger cells test the plain partial sum 16 times
+    const int check_every = in.check_every > 0 ? in.check_every : (groups > kWave ? groups / 16 : 1);
     // items per global atomic.  Measured (round 3, one box): taking several items at a time is SLOWER -- config C 3.53 /
     // 3.64 / 3.70 / 3.91 ms per step at 1 / 2 / 4 / 8, config E's shard 31.8 / 33.3 / 34.0 at 1 / 4 / 8, config D 46.6 / 47.7 /
     // 49.1 at 1 / 2 / 4: the atomic's round trip is hidden behind the other workgroups of the CU, while a workgroup that

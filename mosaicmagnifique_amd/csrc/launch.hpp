@@ -58,6 +58,7 @@ struct FilterInputs {
     const float* cells_il;      // [B][ppad/256][4][256] (plane 0 = cells_f0); null: the planar arrays are read
     const float* lib_stats_t;   // Euclid LDS kernel's stage 1: the library's three channel sums per block, candidate-fastest
                                 // [variant][3][ppad / 64][L] (launch_transpose_stats); null: one wave per candidate from the start
+    int check_every;            // groups between two exit tests of a candidate (0 = 1 up to 16 groups per cell, groups / 16 above)
     int item_chunk;             // work items a persistent workgroup takes per global atomic (0 = by launch size)
     int counters_cleared;       // 1: the counter block was zeroed by an earlier kernel of the stream (no memset here)
     int fused_seeds;            // 1: seeds, their scores and the limit in one launch (launch_prune_limits)

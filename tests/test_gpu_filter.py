@@ -245,6 +245,25 @@ def test_early_exit_bound_at_every_cell_size_class(oracle, engine, t, size):
     run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(1, 500))
 
 
+@pytest.mark.parametrize("size", [128, 96])
+@pytest.mark.parametrize("sort_groups,check_every", [(0, 0), (5, 1), (16, 3), (64, 1), (64, 7)])
+def test_visiting_order_of_large_cells_does_not_change_the_result(oracle, engine, size, sort_groups, check_every):
+    """Cells of 33 .. 64 pixel groups (96 px: 36 groups, a ragged last one; 128 px: all 64 lanes of the prelude) rank their
+    groups over the whole wave: plane order, the n largest bounds first, all by descending bound, the exit test after every
+    group or every few -- pruned == unpruned == fp64-only == oracle each time."""
+    t = Type.CIEDE2000
+    rows, cols = 2 * size + size // 3, 3 * size + size // 5
+    img, lib = cases.inputs(rows, cols, size, 60, t, lattice=size // 2)
+    try:
+        engine.set_option("sort_groups", sort_groups)
+        engine.set_option("check_every", check_every)
+        tm = run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(1, 400))
+        assert tm["visited_groups"] > 0 and tm["band_alarms"] == 0
+    finally:
+        engine.set_option("sort_groups", -1)
+        engine.set_option("check_every", 0)
+
+
 @pytest.mark.parametrize("size", [40, 48, 64])
 @pytest.mark.parametrize("sort_groups", [0, 1, 3, 16])
 def test_visiting_order_of_the_groups_does_not_change_the_result(oracle, engine, size, sort_groups):
