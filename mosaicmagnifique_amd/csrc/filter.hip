@@ -839,7 +839,9 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
     const int nb = ppad / 64;
     bool staged1 = false;
     if constexpr (TYPE != CIEDE2000) {
-        staged1 = lib_stats_t != nullptr && prune_above != nullptr && var.cell_full[cell] != 0 && groups <= kWave;
+        // (cells above 64 groups, CELL_GLOBAL only: stage 1 has no size limit of its own -- the survivors then walk their pixels
+        // with the plain partial-sum exit, the per-wave prelude of the rest bound holding at most 64 x 4 blocks)
+        staged1 = lib_stats_t != nullptr && prune_above != nullptr && var.cell_full[cell] != 0 && (CELL_GLOBAL || groups <= kWave);
         if (staged1) {
             const bool clip1 = var.cell_full[cell] == 2;
             const float* ct = var.cell_stats + (size_t)cell * var.n_blocks;
@@ -1800,8 +1802,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     // (Euclid: + the cell's block sums and weights, + the survivor list of a tile of up to 2048 candidates)
     const size_t lds_bytes = type == CIEDE2000 ? (size_t)kHueLutEntries * sizeof(HueEntry) + (size_t)ppad * 16
                                                : (size_t)ppad * 12 + (size_t)4 * (ppad / 64) * 4 + 2048 * 4;
-    // RGB / CIE76 cells too large for LDS (up to 64 groups: 128 x 128) with the bound available: the same kernel, the cell read from L2
-    const bool cell_global = type != CIEDE2000 && in.use_lds_form && lds_bytes > 156 * 1024 && groups <= kWave &&
+    // RGB / CIE76 cells too large for LDS (from 65 x 65 on; 128 x 128 is the reference GUI's default) with the bound available: the same
+    // kernel, the cell read from L2
+    const bool cell_global = type != CIEDE2000 && in.use_lds_form && lds_bytes > 156 * 1024 &&
+                             (size_t)4 * (ppad / 64) * 4 + 2048 * 4 <= 150 * 1024 &&      // (the block sums of a cell of ~ 750 x 750)
                              in.lib_stats_t != nullptr && prune_above != nullptr;
     if (cell_global || (in.use_lds_form && lds_bytes <= 156 * 1024)) {
         // Candidates per item: a workgroup stages the cell once per item, so the longer the item the less staging and

@@ -314,6 +314,18 @@ def test_euclid_cells_too_large_for_lds_keep_the_bound(oracle, engine, t, size):
     run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(1, 4000))
 
 
+@pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIE76])
+@pytest.mark.parametrize("size", [160, 256])
+def test_euclid_cells_beyond_64_groups_keep_stage_one(oracle, engine, t, size):
+    """Above 128 x 128 the per-wave prelude of the rest bound no longer holds a cell's blocks, but stage 1 of the RGB / CIE76
+    filter (one candidate per lane over all of the cell's block sums) has no such limit: it still drops most candidates and
+    the survivors walk their pixels with the plain partial-sum exit.  Pruned == unpruned == fp64-only == oracle."""
+    rows, cols = 2 * size + size // 3, 2 * size + size // 2
+    img, lib = cases.inputs(rows, cols, size, 150, t, lattice=size // 2)
+    tm = run_both(oracle, engine, cases.square_shape(size), img, lib, t, rep=(1, 3000))
+    assert tm["bound_dropped"] > 0
+
+
 @pytest.mark.parametrize("size", [160, 256])
 def test_cells_beyond_the_bound_s_reach(oracle, engine, size):
     """Cells of more than 64 pixel groups (over 128 x 128) are outside what the early-exit bound's prelude holds in one
