@@ -200,6 +200,9 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 //   +0,1  u64  256-pixel groups visited          +2,3  u64  groups a full visit of every candidate would take
 //   +4,5  u64  candidates dropped by the block bound alone (no pixel touched)
 //   +6    u32  unused                            +8 .. +15  u32  next item of XCD 0 .. 7 (persistent workgroups)
+#ifndef MM_STAT_BLOCKS
+#define MM_STAT_BLOCKS (4 * kWave)   // blocks of a cell whose statistics filter_kernel keeps in LDS (experiments: 64 = cells up to 64 x 64 only)
+#endif
 #ifndef MM_LONG_SPLIT
 #define MM_LONG_SPLIT 0.8f
 #endif
@@ -265,7 +268,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     __shared__ int item_share;              // the XCD share next_item belongs to (-1: none left)
     // block statistics of the cell (early-exit bound), up to 4 blocks per lane
     // (row 7: 1 where the block's mask pixels are all active in this cell, else 0 -- a clipped cell's bound counts only such blocks)
-    __shared__ __attribute__((aligned(16))) float cell_st[TYPE == CIEDE2000 ? 8 : 1][TYPE == CIEDE2000 ? (CELL_LDS ? kWave : 4 * kWave) : 1];
+    __shared__ __attribute__((aligned(16))) float cell_st[TYPE == CIEDE2000 ? 8 : 1][TYPE == CIEDE2000 ? (CELL_LDS ? kWave : MM_STAT_BLOCKS) : 1];
     extern __shared__ float4 cell_tile[];   // CELL_LDS: [3][ppad / 4] -- channel 0 (NaN = inactive), a, b
     if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
