@@ -2097,7 +2097,7 @@ mm_status mm_debug_visit_counters(mm_engine* e, unsigned long long out[3])
     {   // instrumented build: the cycle accounts of filter_kernel (words 24..31, units of 1024 cycles)
         unsigned int st[8] = {0};
         HIP_TRY(e, hipMemcpy(st, (unsigned int*)e->edge_count.p + 24, sizeof st, hipMemcpyDeviceToHost), "stamps");
-        fprintf(stderr, "stamps wait %u fetch %u stats %u stage0 %u stage1 %u stage2 %u longest lifetime %u sum of lifetimes / 16 %u\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+        fprintf(stderr, "stamps wait %u fetch %u stats %u stage0 %u stage1 %u stage2 %u longest lifetime %u sum of lifetimes / 16 %u\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
     }
 #endif
     return MM_OK;

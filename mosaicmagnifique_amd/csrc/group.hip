@@ -318,7 +318,7 @@ mm_status mm_group_generate(mm_group* g, const mm_cell* cells, int n_cells, int 
     if (progress) progress(n_cells, progress_user);
 
     std::vector<uint8_t> deep((size_t)std::max(n_cells, 1), 0);
-    for (int round = 0;; ++round) {
+    for (;;) {
         if (cancel && *cancel) return MM_CANCELLED;
         // 2. ONE all-gather of the packed lists
         if (g->rccl) {
