@@ -76,15 +76,17 @@ struct BigEndianReader {
     }
 };
 
-// 8-bit non-interlaced PNG (grey, grey+alpha, RGB or RGBA) -> its first channel; what cv::imdecode(...,
-// IMREAD_GRAYSCALE) of the masks QImage / OpenCV write gives for a grey image.  zlib does the inflating.
-std::vector<uint8_t> decodePngFirstChannel(const std::vector<uint8_t>& png, int& rows, int& cols)
+// 8-bit non-interlaced PNG (grey, grey+alpha, RGB or RGBA) -> its samples, `channels` per pixel, row-major.  zlib does the
+// inflating.  `what` names the thing being read in error texts; `max_side` bounds the header's dimensions.
+std::vector<uint8_t> decodePng(const std::vector<uint8_t>& png, int& rows, int& cols, int& channels, const char* what, int max_side)
 {
+    const std::string w(what);
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    if (png.size() < 8 || !std::equal(sig, sig + 8, png.begin())) throw std::runtime_error("mask is not a PNG");
+    if (png.size() < 8 || !std::equal(sig, sig + 8, png.begin())) throw std::runtime_error(w + " is not a PNG");
     BigEndianReader r{png, 8};
     std::vector<uint8_t> idat;
-    int channels = 0;
+    channels = 0;
+    rows = cols = 0;
     for (;;) {
         const uint32_t len = r.u32();
         const std::vector<uint8_t> type = r.bytes(4);
@@ -98,26 +100,28 @@ std::vector<uint8_t> decodePngFirstChannel(const std::vector<uint8_t>& png, int&
             h.u8(); h.u8();
             const int interlace = h.u8();
             channels = colour == 0 ? 1 : colour == 4 ? 2 : colour == 2 ? 3 : colour == 6 ? 4 : 0;
-            if (depth != 8 || channels == 0 || interlace != 0) throw std::runtime_error("unsupported PNG mask (need 8-bit, non-interlaced, no palette)");
+            if (depth != 8 || channels == 0 || interlace != 0) throw std::runtime_error("unsupported PNG " + w + " (need 8-bit, non-interlaced, no palette)");
         } else if (t == "IDAT") idat.insert(idat.end(), body.begin(), body.end());
         else if (t == "IEND") break;
     }
-    if (channels == 0 || rows <= 0 || cols <= 0) throw std::runtime_error("PNG mask without a header");
-    // a cell mask is a few hundred pixels a side (the shipped ones: 512): a header asking for more than 16384 is a
-    // damaged or crafted file, not a reason to try a multi-gigabyte allocation; deflate cannot shrink by more than ~1032
-    if (rows > 16384 || cols > 16384) throw std::runtime_error("PNG mask larger than 16384 pixels a side");
+    if (channels == 0 || rows <= 0 || cols <= 0) throw std::runtime_error("PNG " + w + " without a header");
+    // a header asking for more than max_side is a damaged or crafted file, not a reason to try a multi-gigabyte
+    // allocation; deflate cannot shrink by more than ~1032
+    if (rows > max_side || cols > max_side) throw std::runtime_error("PNG " + w + " larger than " + std::to_string(max_side) + " pixels a side");
     if (idat.empty() || ((size_t)cols * channels + 1) * (size_t)rows / 1032 > idat.size() + 64)
-        throw std::runtime_error("PNG mask data too short for its header");
+        throw std::runtime_error("PNG " + w + " data too short for its header");
     const size_t stride = (size_t)cols * channels;
     std::vector<uint8_t> raw((stride + 1) * (size_t)rows);
     uLongf got = (uLongf)raw.size();
     if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size())
-        throw std::runtime_error("PNG mask does not inflate");
-    std::vector<uint8_t> prev(stride, 0), cur(stride), out((size_t)rows * cols);
+        throw std::runtime_error("PNG " + w + " does not inflate");
+    std::vector<uint8_t> prev(stride, 0), out((size_t)rows * stride);
     for (int y = 0; y < rows; ++y) {
         const uint8_t* line = raw.data() + (size_t)y * (stride + 1);
+        uint8_t* cur = out.data() + (size_t)y * stride;
+        const uint8_t* up = y > 0 ? cur - stride : prev.data();
         for (size_t x = 0; x < stride; ++x) {
-            const int a = x >= (size_t)channels ? cur[x - channels] : 0, b = prev[x], c = x >= (size_t)channels ? prev[x - channels] : 0;
+            const int a = x >= (size_t)channels ? cur[x - channels] : 0, b = up[x], c = x >= (size_t)channels ? up[x - channels] : 0;
             int pred = 0;
             switch (line[0]) {                           // PNG filter types 0..4
             case 0: break;
@@ -130,15 +134,39 @@ std::vector<uint8_t> decodePngFirstChannel(const std::vector<uint8_t>& png, int&
             }
             cur[x] = (uint8_t)(line[1 + x] + pred);
         }
-        for (int x = 0; x < cols; ++x) out[(size_t)y * cols + x] = cur[(size_t)x * channels];
-        prev.swap(cur);
     }
     return out;
 }
 
-}  // namespace
+// ... its first channel: what cv::imdecode(..., IMREAD_GRAYSCALE) of the masks QImage / OpenCV write gives for a grey image.
+// (a cell mask is a few hundred pixels a side; the shipped ones: 512)
+std::vector<uint8_t> decodePngFirstChannel(const std::vector<uint8_t>& png, int& rows, int& cols)
+{
+    int channels = 0;
+    const std::vector<uint8_t> all = decodePng(png, rows, cols, channels, "mask", 16384);
+    if (channels == 1) return all;
+    std::vector<uint8_t> out((size_t)rows * cols);
+    for (size_t k = 0; k < out.size(); ++k) out[k] = all[k * (size_t)channels];
+    return out;
+}
 
-CellShape CellShape::loadFromFile(const std::string& path)
+// QString of a QDataStream: u32 byte length (0xFFFFFFFF = null), UTF-16BE -> UTF-8 of the BMP code points.
+std::string readQString(BigEndianReader& r)
+{
+    std::string text;
+    const uint32_t n = r.u32();
+    if (n == 0xFFFFFFFFu) return text;
+    const std::vector<uint8_t> utf16 = r.bytes(n);
+    for (size_t i = 0; i + 1 < utf16.size(); i += 2) {
+        const unsigned cp = ((unsigned)utf16[i] << 8) | utf16[i + 1];
+        if (cp < 0x80) text += (char)cp;
+        else if (cp < 0x800) { text += (char)(0xC0 | (cp >> 6)); text += (char)(0x80 | (cp & 0x3F)); }
+        else { text += (char)(0xE0 | (cp >> 12)); text += (char)(0x80 | ((cp >> 6) & 0x3F)); text += (char)(0x80 | (cp & 0x3F)); }
+    }
+    return text;
+}
+
+std::vector<uint8_t> readWholeFile(const std::string& path)
 {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open " + path);
@@ -146,22 +174,20 @@ CellShape CellShape::loadFromFile(const std::string& path)
     uint8_t buf[65536];
     for (size_t n; (n = fread(buf, 1, sizeof buf, f)) > 0;) data.insert(data.end(), buf, buf + n);
     fclose(f);
+    return data;
+}
+
+}  // namespace
+
+CellShape CellShape::loadFromFile(const std::string& path)
+{
+    const std::vector<uint8_t> data = readWholeFile(path);
     BigEndianReader r{data};
     if (r.u32() != 0x87AECFB1u) throw std::runtime_error("File is not a valid .mcs: " + path);     // CellShape.cpp:392-395
     const uint32_t version = r.u32();
     if (version > 8) throw std::runtime_error(".mcs uses a newer file version: " + path);
     if (version < 7) throw std::runtime_error(".mcs uses an outdated file version: " + path);
-    std::string name;
-    const uint32_t nameBytes = r.u32();                  // QString: byte length (0xFFFFFFFF = null), UTF-16BE
-    if (nameBytes != 0xFFFFFFFFu) {
-        const std::vector<uint8_t> utf16 = r.bytes(nameBytes);
-        for (size_t i = 0; i + 1 < utf16.size(); i += 2) {
-            const unsigned cp = ((unsigned)utf16[i] << 8) | utf16[i + 1];
-            if (cp < 0x80) name += (char)cp;             // UTF-8 of the BMP code point (shape names are short labels)
-            else if (cp < 0x800) { name += (char)(0xC0 | (cp >> 6)); name += (char)(0x80 | (cp & 0x3F)); }
-            else { name += (char)(0xE0 | (cp >> 12)); name += (char)(0x80 | ((cp >> 6) & 0x3F)); name += (char)(0x80 | (cp & 0x3F)); }
-        }
-    }
+    const std::string name = readQString(r);             // (shape names are short labels)
     int rows = 0, cols = 0;
     std::vector<uint8_t> mask;
     if (version >= 8) mask = decodePngFirstChannel(r.bytes(r.u32()), rows, cols);
@@ -189,6 +215,54 @@ CellShape CellShape::loadFromFile(const std::string& path)
     shape.alternateColFlipHorizontal = r.u8() != 0; shape.alternateColFlipVertical = r.u8() != 0;
     shape.alternateRowFlipHorizontal = r.u8() != 0; shape.alternateRowFlipVertical = r.u8() != 0;
     return shape;
+}
+
+// ImageLibrary::loadFromFile (ImageLibrary/ImageLibrary.cpp:154-231) without Qt / OpenCV.
+ImageLibraryFile ImageLibraryFile::loadFromFile(const std::string& path)
+{
+    const std::vector<uint8_t> data = readWholeFile(path);
+    BigEndianReader r{data};
+    if (r.u32() != 0xADBE2480u) throw std::runtime_error("File is not a valid .mil: " + path);       // ImageLibrary.h:13
+    const uint32_t version = r.u32();
+    if (version > 6) throw std::runtime_error(".mil uses a newer file version: " + path);
+    if (version < 4) throw std::runtime_error(".mil uses an outdated file version: " + path);
+    ImageLibraryFile lib;
+    const uint32_t size = r.u32(), count = r.u32();
+    if (size == 0 || size > 16384) throw std::runtime_error(".mil image size outside 1..16384: " + path);
+    // every image takes at least a length word and a name word: a count the file cannot hold is a damaged header
+    if ((size_t)count * 8 > data.size()) throw std::runtime_error(".mil image count exceeds the file: " + path);
+    lib.imageSize = (int)size;
+    const size_t per_image = (size_t)size * size * 3;
+    lib.names.reserve(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        int rows = 0, cols = 0, channels = 0;
+        std::vector<uint8_t> px;
+        bool rgb_order = false;
+        if (version >= 6) {                               // a PNG in a QByteArray (CustomQDataStream.h:39-45,75-81); OpenCV writes BGR mats as RGB PNGs
+            px = decodePng(r.bytes(r.u32()), rows, cols, channels, "library image", 16384);
+            rgb_order = true;
+        } else {                                          // raw cv::Mat: type, rows, cols, QByteArray (:27-37,63-72)
+            r.u32();
+            rows = (int)r.u32(); cols = (int)r.u32();
+            if (rows <= 0 || cols <= 0 || rows > 16384 || cols > 16384) throw std::runtime_error("raw .mil image larger than 16384 pixels a side");
+            px = r.bytes(r.u32());
+            if (px.size() % ((size_t)rows * cols) != 0) throw std::runtime_error("raw .mil image is not 8-bit");
+            channels = (int)(px.size() / ((size_t)rows * cols));
+        }
+        if (rows != (int)size || cols != (int)size) throw std::runtime_error(".mil image " + std::to_string(i) + " is not " + std::to_string(size) + " pixels a side");
+        if (channels != 1 && channels != 3 && channels != 4) throw std::runtime_error(".mil image " + std::to_string(i) + " has " + std::to_string(channels) + " channels");
+        const size_t at = lib.bgr.size();
+        lib.bgr.resize(at + per_image);
+        uint8_t* out = lib.bgr.data() + at;
+        for (size_t k = 0; k < (size_t)rows * cols; ++k) {
+            const uint8_t* p = px.data() + k * (size_t)channels;
+            if (channels == 1) { out[3 * k] = out[3 * k + 1] = out[3 * k + 2] = p[0]; }
+            else if (rgb_order) { out[3 * k] = p[2]; out[3 * k + 1] = p[1]; out[3 * k + 2] = p[0]; }
+            else { out[3 * k] = p[0]; out[3 * k + 1] = p[1]; out[3 * k + 2] = p[2]; }
+        }
+        lib.names.push_back(readQString(r));
+    }
+    return lib;
 }
 
 void CellGroup::setCellShape(const CellShape& shape)

@@ -67,6 +67,19 @@ std::vector<uint8_t> resizeArea(const std::vector<uint8_t>& src, int rows, int c
 double calculateEntropy(const uint8_t* bgr, int rows, int cols, const uint8_t* mask, int maskStride);
 }  // namespace ImageUtility
 
+// The `.mil` container the reference feeds to setLibrary (ImageLibrary/ImageLibrary.cpp:117-236), read without Qt / OpenCV:
+// big-endian QDataStream -- u32 magic 0xADBE2480, u32 version (4..6), u32 image size, u32 count, then per image the pixels
+// (v6: a PNG in a QByteArray; v4 / v5: raw type / rows / cols + bytes, CustomQDataStream.h:22-87) and its name as a QString.
+// Images come back in file order as u8 BGR [count][size][size][3] -- what setLibrary takes (the reference's shuffle of
+// pre-v5 files on load, :207-217, is not reproduced).
+struct ImageLibraryFile {
+    int imageSize = 0;
+    std::vector<std::string> names;
+    std::vector<uint8_t> bgr;
+    size_t count() const { return names.size(); }
+    static ImageLibraryFile loadFromFile(const std::string& path);
+};
+
 // The part of CellShape (CellShape/CellShape.h:25-113) the path reads.
 class CellShape {
 public:

@@ -1,4 +1,5 @@
-// Test driver for CellShape::loadFromFile of the C++ host mirror: prints, per .mcs file given, one JSON
+// Test driver for CellShape::loadFromFile and ImageLibraryFile::loadFromFile of the C++ host mirror.  Per .mil file given:
+// one JSON line with image size, count, the names and an FNV-1a of the BGR bytes.  Per .mcs file given, one JSON
 // line with what tests/golden/cells_mcs.json records (name, size, active pixels, FNV-1a of the
 // thresholded mask, tiling parameters, and the same after resized(64)).
 #include <cstdio>
@@ -19,6 +20,26 @@ static void params(const CellShape& s)
 int main(int argc, char** argv)
 {
     for (int i = 1; i < argc; ++i) {
+        const std::string path = argv[i];
+        if (path.size() > 4 && path.compare(path.size() - 4, 4, ".mil") == 0) {
+            try {
+                const ImageLibraryFile lib = ImageLibraryFile::loadFromFile(path);
+                unsigned long long fnv = 1469598103934665603ull;
+                for (uint8_t v : lib.bgr) fnv = (fnv ^ v) * 1099511628211ull;
+                printf("{\"imageSize\": %d, \"count\": %zu, \"bytes\": %zu, \"fnv\": \"%016llx\", \"names\": [", lib.imageSize, lib.count(), lib.bgr.size(), fnv);
+                for (size_t k = 0; k < lib.names.size(); ++k) {
+                    printf("%s\"", k ? ", " : "");
+                    for (unsigned char ch : lib.names[k]) {          // (test names hold no quotes or backslashes; control bytes escaped)
+                        if (ch < 0x20 || ch == '"' || ch == '\\') printf("\\u%04x", ch); else putchar(ch);
+                    }
+                    printf("\"");
+                }
+                printf("]}\n");
+            } catch (const std::exception& e) {
+                printf("{\"error\": \"%s\"}\n", e.what());
+            }
+            continue;
+        }
         try {
             const CellShape shape = CellShape::loadFromFile(argv[i]);
             const auto& mask = shape.getCellMask(false, false);

@@ -169,6 +169,60 @@ def test_cpp_reader_agrees_with_the_python_reader(tmp_path):
     assert "not a valid .mcs" in run_mcs_runner(runner, [bad])[0]["error"]
 
 
+def fnv_bytes(data):
+    h = 1469598103934665603
+    for v in bytes(data):
+        h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def test_cpp_mil_reader_agrees_with_the_python_reader(tmp_path):
+    """ImageLibraryFile::loadFromFile of the C++ host (ImageLibrary.cpp:154-231 without Qt / OpenCV): a v6 file written by the
+    package's writer (PNG-encoded, RGB order inside the PNG), a hand-packed v5 file (raw BGR mats), a v6 file whose PNGs are
+    grey and RGBA, and the refusals the reference makes (magic, version) plus the ones a damaged file needs."""
+    import io
+    from PIL import Image
+    runner = build_mcs_runner(str(tmp_path / "mcs_runner"))
+    images = synth.library_u8(7, 24)
+    lib = ImageLibrary(24)
+    for i, im in enumerate(images):
+        lib.addImage(im, "photo %d é ß.png" % i)
+    v6 = tmp_path / "v6.mil"
+    lib.saveToFile(v6)
+    v5 = tmp_path / "v5.mil"
+    with open(v5, "wb") as f:
+        f.write(struct.pack(">IIII", MIL_MAGIC, 5, 24, 3))
+        for im in images[:3]:
+            f.write(struct.pack(">IIII", 16, 24, 24, im.nbytes)); f.write(im.tobytes())
+            f.write(struct.pack(">I", 0xFFFFFFFF))
+    odd = tmp_path / "odd.mil"                                      # a grey PNG and an RGBA PNG inside a v6 container
+    grey = images[0][..., 1]
+    with open(odd, "wb") as f:
+        f.write(struct.pack(">IIII", MIL_MAGIC, 6, 24, 2))
+        for pil in (Image.fromarray(grey), Image.fromarray(np.dstack([images[1][..., ::-1], np.full((24, 24), 200, np.uint8)]), "RGBA")):
+            png = io.BytesIO(); pil.save(png, format="PNG"); blob = png.getvalue()
+            f.write(struct.pack(">I", len(blob))); f.write(blob)
+            name = "x".encode("utf-16-be"); f.write(struct.pack(">I", len(name))); f.write(name)
+    got = run_mcs_runner(runner, [v6, v5, odd])
+    assert got[0] == {"imageSize": 24, "count": 7, "bytes": images.nbytes, "fnv": fnv_bytes(images.tobytes()), "names": lib.getNames()}
+    assert got[1] == {"imageSize": 24, "count": 3, "bytes": images[:3].nbytes, "fnv": fnv_bytes(images[:3].tobytes()), "names": ["", "", ""]}
+    want_odd = np.stack([np.dstack([grey] * 3), images[1]])
+    assert got[2]["count"] == 2 and got[2]["fnv"] == fnv_bytes(want_odd.tobytes()) and got[2]["names"] == ["x", "x"]
+    back = ImageLibrary.loadFromFile(v6)                          # the Python reader on the same file
+    assert np.array_equal(back.getImages(), images)
+    bad = tmp_path / "bad.mil"
+    for head, text in ((struct.pack(">IIII", 0x12345678, 6, 8, 0), "not a valid .mil"), (struct.pack(">IIII", MIL_MAGIC, 7, 8, 0), "newer file version"),
+                       (struct.pack(">IIII", MIL_MAGIC, 3, 8, 0), "outdated file version"), (struct.pack(">IIII", MIL_MAGIC, 6, 0, 0), "image size"),
+                       (struct.pack(">IIII", MIL_MAGIC, 6, 8, 4000000000), "count exceeds")):
+        bad.write_bytes(head)
+        assert text in run_mcs_runner(runner, [bad])[0]["error"]
+    wrong = tmp_path / "wrong.mil"                                 # an image of another size than the header's
+    with open(wrong, "wb") as f:
+        f.write(struct.pack(">IIII", MIL_MAGIC, 5, 16, 1))
+        f.write(struct.pack(">IIII", 16, 24, 24, images[0].nbytes)); f.write(images[0].tobytes()); f.write(struct.pack(">I", 0xFFFFFFFF))
+    assert "is not 16 pixels a side" in run_mcs_runner(runner, [wrong])[0]["error"]
+
+
 def test_bench_consumes_mcs_and_mil_files(tmp_path):
     """bench.py --mcs / --mil (the purpose of N4: running the benchmark on the project's own files): the
     workload built from a written .mcs and .mil carries the file's shape, resized to the configuration's
@@ -222,9 +276,31 @@ def test_cpp_reader_survives_truncated_and_corrupted_files(tmp_path):
         p = tmp_path / ("c%d.mcs" % k)
         p.write_bytes(bytes(b))
         paths.append(p)
+    # ... and the same for a .mil (ImageLibraryFile::loadFromFile: PNG blobs of RGB images, QString names)
+    from mosaicmagnifique_amd import synth
+    from mosaicmagnifique_amd.imagelibrary import ImageLibrary
+    lib = ImageLibrary(16)
+    for i, im in enumerate(synth.library_u8(3, 16)):
+        lib.addImage(im, "n%d" % i)
+    good_mil = tmp_path / "good.mil"
+    lib.saveToFile(good_mil)
+    src_mil = good_mil.read_bytes()
+    n_mcs = len(paths)
+    for n in list(range(0, len(src_mil), 53)) + [len(src_mil) - 1]:
+        p = tmp_path / ("t%d.mil" % n)
+        p.write_bytes(src_mil[:n])
+        paths.append(p)
+    n_trunc_mil = len(paths) - n_mcs
+    for k in range(80):
+        b = bytearray(src_mil)
+        b[rnd.randrange(4, len(b))] ^= rnd.choice((0xFF, 0x01, 0x80))
+        p = tmp_path / ("c%d.mil" % k)
+        p.write_bytes(bytes(b))
+        paths.append(p)
     res = subprocess.run([runner] + [str(p) for p in paths], capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert res.returncode == 0 and "ERROR" not in res.stderr and "runtime error" not in res.stderr, res.stderr[-2000:]
     out = [json.loads(line) for line in res.stdout.splitlines()]
     assert len(out) == len(paths)
     assert sum("error" in o for o in out[:len(src) // 37 + 2]) == len(src) // 37 + 2        # every truncation is refused
+    assert all("error" in o for o in out[n_mcs:n_mcs + n_trunc_mil])                          # ... of the .mil as well
