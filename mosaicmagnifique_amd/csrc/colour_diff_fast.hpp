@@ -59,7 +59,7 @@ __device__ __forceinline__ float sqrt_ratio7_scaled(float s)
 // on the mean hue angle ALONE, so both are tabulated over the circle and interpolated
 // linearly.  The index is the "diamond angle" of the mean-hue unit vector (hc, hs):
 //   t = 2 - copysign(1 + hc / (|hc| + |hs|), hs)   in [0, 4),  monotone in the angle,
-// which needs one v_rcp_f32 and no inverse trig.  Entry i holds {T, G}, G = -2 sin(2 d_theta)
+// which needs one v_rcp_f32 and no inverse trig.  Entry i holds {0.0075 T, G} (S_H = 1 + 0.015 C T with C = csum / 2 is then one fma), G = -2 sin(2 d_theta)
 // (so that R_T = G R_C / 2 is one multiply, :136,:145), at t_i = 4 i / kHueLutSize; a lookup reads
 // entries i and i + 1 (one ds_read2_b64) and interpolates between them, so the table has
 // kHueLutSize + 2 entries: entry N repeats entry 0 and entry N + 1 entry 1.  8 bytes per entry --
@@ -101,31 +101,40 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     const float one_g = 1.5f - 0.5f * (PREP ? sqrt_ratio7_scaled(c1 + c2) : sqrt_ratio7_of_sum(c1 + c2));       // 1 + G
     const float a1 = one_g * p.c1, a2 = one_g * q.c1;
     const float b1 = p.c2, b2 = q.c2;
-    // + 1e-36: C' >= 1e-18 > 0 (rsq stays finite, a grey colour keeps a direction below)
+    // + 1e-36: C' >= 1e-18 > 0 (a grey colour keeps a direction below, and e >= P stays positive under its rsq)
     const float m1 = fmaf(a1, a1, fmaf(b1, b1, 1e-36f)), m2 = fmaf(a2, a2, fmaf(b2, b2, 1e-36f));
+#ifdef MM_CHROMA_RSQ                                      // (the form before round 3's last pass, kept for A/B builds)
     const float c1p = m1 * frsq(m1), c2p = m2 * frsq(m2);
+#else
+    const float c1p = fsqrt(m1), c2p = fsqrt(m2);            // one quarter-rate instruction each; m * rsq(m) cost a multiply more
+#endif
 
     const float dot = fmaf(a1, a2, b1 * b2);
     const float cross = fmaf(a1, b2, -(b1 * a2));
-    const float pp = c1p * c2p;
+    // (a comparison, not dot's sign bit: a grey colour -- a = b = 0 -- may give dot = -0.0 and must take the acute forms, which then
+    // yield the other colour's direction)
     const bool acute = !(dot < 0.0f);
-    *needs_exact = !acute && fabsf(cross) < 3e-5f * pp;
+    const float e = fmaf(c1p, c2p, fabsf(dot));                             // P + |dot|, P = C1' C2'
+    // within 3e-5 rad of opposite hues |cross| < 3e-5 P; there |dot| = P up to 1e-9, i.e. e = 2 P: the test reads e, and P itself
+    // is never formed
+    *needs_exact = !acute && fabsf(cross) < 1.50001e-5f * e;
 
-    const float e = pp + fabsf(dot);
     const float r = frsq(0.5f * e);                                         // = 2 rsq(2 e);  e >= P >= 1e-36
     // sign transplants as plain bit operations on one shared mask (full-rate, where v_bfi_b32 is not)
     const unsigned int sgn = __float_as_uint(cross) & 0x80000000u;
-    // (both arms are computed before the selects: three v_cndmask, no divergent branch)
-    const float dh_acute = cross * r, dh_obtuse = __uint_as_float(__float_as_uint(e * r) | sgn);   // e r > 0
-    const float d_h = acute ? dh_acute : dh_obtuse;                         // dH'  (:102): 2 cross rsq(2e) | sign 2e rsq(2e)
+    // (selects, no divergent branch; the arm is chosen BEFORE the one multiply by r: e > 0 takes cross's sign as a bit operation)
+    const float d_h = (acute ? cross : __uint_as_float(__float_as_uint(e) | sgn)) * r;     // dH'  (:102): 2 cross rsq(2e) | sign 2e rsq(2e)
 
     // mean hue direction -> table index -> T and sin(2 d_theta)
-    const float sx = a1 * c2p, sy = b1 * c2p, tx = a2 * c1p, ty = b2 * c1p;
-    const float hx_acute = sx + tx, hx_obtuse = __uint_as_float(__float_as_uint(ty - sy) ^ sgn);
-    const float hy_acute = sy + ty, hy_obtuse = __uint_as_float(__float_as_uint(sx - tx) ^ sgn);
-    const float hx = acute ? hx_acute : hx_obtuse;
-    const float hy = acute ? hy_acute : hy_obtuse;
-    const float qd = hx * frcp((fabsf(hx) + 1e-36f) + fabsf(hy));           // |qd| <= 1 + 1 ulp (v_rcp_f32: 1 ulp)
+    // with s = C2' v1, t = C1' v2: w = t + s (acute) or t - s (obtuse) -- s takes its sign through C2', t rides in the fma
+    const float c2s = acute ? c2p : -c2p;
+    // (+ 1e-30 inside the first product's fma: w vanishes only when both colours are grey -- s = 0 needs v1 = 0, t = 0 needs v2 = 0,
+    // and s = -+t with both non-zero contradicts the branch dot's sign chose -- and then the table index below must not see 0 / 0)
+    const float wx = fmaf(a2, c1p, fmaf(a1, c2s, 1e-30f)), wy = fmaf(b2, c1p, b1 * c2s);
+    // acute: w; obtuse: sign(cross) rot_{-90}(w) = sign(cross) (wy, -wx)
+    const float hx = acute ? wx : __uint_as_float(__float_as_uint(wy) ^ sgn);
+    const float hy = acute ? wy : __uint_as_float(__float_as_uint(wx) ^ sgn ^ 0x80000000u);
+    const float qd = hx * frcp(fabsf(hx) + fabsf(hy));                      // |qd| <= 1 + 1 ulp (v_rcp_f32: 1 ulp); |hx| + |hy| > 0 (above)
     // (2 - c) N/4 with the factor N/4 shortened by 2^-13: even c = +-(2 + 2 ulp) keeps x inside [0, N], where
     // truncation = floor and fract = x - floor(x) agree (2.4e-4 of a table step at most; the table's own error is
     // 2e-5 of a value).  Entry N repeats entry 0 and N + 1 entry 1: no clamp.  NaN (an inactive pixel) converts to 0.
@@ -139,11 +148,12 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     const float csum = c1p + c2p;                           // 2 * mean C'
     const float r_t = s2 * sqrt_ratio7_of_sum(csum);            // :136,:145; the table holds -2 sin(2 d_theta)
     const float lb = PREP ? p.c0 + q.c0 : 0.5f * (p.c0 + q.c0) - 50.0f;
-    const float l2 = lb * lb;
-    const float s_l = PREP ? fmaf(0.0075f * l2, frsq(20.0f + l2), 0.5f)     // S_L / 2: d_l below is half the difference
-                           : fmaf(0.015f * l2, frsq(20.0f + l2), 1.0f);
+    // with u = 20 + lb^2 (one fma): 0.0075 lb^2 = 0.0075 u - 0.15 (one fma; the cancellation near lb = 0 costs 1e-8 of an S_L of 0.5)
+    const float u_l = fmaf(lb, lb, 20.0f);
+    const float s_l = PREP ? fmaf(fmaf(0.0075f, u_l, -0.15f), frsq(u_l), 0.5f)      // S_L / 2: d_l below is half the difference
+                           : fmaf(fmaf(0.015f, u_l, -0.3f), frsq(u_l), 1.0f);
     const float s_c = fmaf(0.0225f, csum, 1.0f);
-    const float s_h = fmaf(0.0075f * csum, t, 1.0f);
+    const float s_h = fmaf(csum, t, 1.0f);                  // the table holds 0.0075 T: S_H = 1 + 0.015 (csum / 2) T
 
     // (:153-157) with ONE reciprocal for the chroma and hue terms:
     //   tC = dC/S_C = A/D, tH = dH/S_H = B/D,  D = S_C S_H, A = dC S_H, B = dH S_C
@@ -152,7 +162,7 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     const float big_d = s_c * s_h;
     const float ta = d_c * s_h;
     const float tb = d_h * s_c;
-    const float num = fmaf(ta, ta, fmaf(tb, tb, (r_t * ta) * tb));
+    const float num = fmaf(ta, fmaf(r_t, tb, ta), tb * tb);        // ta^2 + tb^2 + R_T ta tb
     const float inv_d = frcp(big_d);
     const float t_l = d_l * frcp(s_l);
     const float xx = fmaf(t_l, t_l, num * (inv_d * inv_d));

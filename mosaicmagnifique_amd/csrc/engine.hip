@@ -437,7 +437,7 @@ std::vector<float> build_hue_lut()
     }
     std::vector<float> lut((size_t)mm::kHueLutEntries * 2);       // entries 0 .. N + 1: N repeats 0, N + 1 repeats 1
     for (int i = 0; i < mm::kHueLutEntries; ++i) {
-        lut[(size_t)2 * i + 0] = (float)T[i % N];
+        lut[(size_t)2 * i + 0] = (float)(0.0075 * T[i % N]);       // S_H = 1 + 0.015 C' T = fma(C1' + C2', 0.0075 T, 1): one instruction
         lut[(size_t)2 * i + 1] = (float)G[i % N];
     }
     return lut;
