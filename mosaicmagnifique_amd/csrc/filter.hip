@@ -1589,9 +1589,13 @@ pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ seco
         const float* p = first + 3 * i;
         const float* q = second + 3 * i;
         bool edge;
-        float v = pair_fast<TYPE>(PxF{p[0], p[1], p[2]}, PxF{q[0], q[1], q[2]}, chroma_of(p[1], p[2]),
-                                  chroma_of(q[1], q[2]), lut, &edge);
-        if (edge && flag_edges) v = -1.0f;      // diagnostics: show where the fp64 form takes over
+        float v;
+        if (TYPE == CIEDE2000 && (flag_edges & 2) != 0)     // the form the dominant kernel runs: operands prepared as interleave_kernel stores them
+            v = pair_fast<TYPE, true>(PxF{fmaf(0.5f, p[0], -25.0f), p[1], p[2]}, PxF{fmaf(0.5f, q[0], -25.0f), q[1], q[2]},
+                                      __fmul_rn(kChromaPrep, chroma_of(p[1], p[2])), __fmul_rn(kChromaPrep, chroma_of(q[1], q[2])), lut, &edge);
+        else
+            v = pair_fast<TYPE>(PxF{p[0], p[1], p[2]}, PxF{q[0], q[1], q[2]}, chroma_of(p[1], p[2]), chroma_of(q[1], q[2]), lut, &edge);
+        if (edge && (flag_edges & 1)) v = -1.0f;      // diagnostics: show where the fp64 form takes over
         out[i] = v;
     }
 }

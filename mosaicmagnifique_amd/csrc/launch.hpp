@@ -121,8 +121,8 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
                                int ppad, int M, int K, float px_abs, float rel, int32_t* seeds,
                                float* seed_score, float* limit, float* scores, hipStream_t stream);
 
-// fp32 filter form of the per-pair difference (accuracy harness).  flag_edges != 0
-// writes -1 for pairs the filter hands to the fp64 form.
+// fp32 filter form of the per-pair difference (accuracy harness).  flag_edges bit 0: write -1 for pairs the filter hands
+// to the fp64 form; bit 1: the form with prepared operands (L / 2 - 25, chroma / 50), as filter_kernel runs it.
 hipError_t launch_pair_fast(int type, const float* first, const float* second, size_t n,
                             float* out, int flag_edges, const float2* hue_lut, hipStream_t stream);
 

@@ -23,6 +23,10 @@ def lab_sets(rng, n):
     a = uni(); a[:, 1:] *= 1e-3; yield "near-grey", a, uni()
     a = uni(); a[:, 1:] = 0; yield "grey-first", a, uni()
     a, b = uni(), uni(); b[:, 1:] = 0; yield "grey-second", a, b
+    a, b = uni(), uni(); a[:, 1:] = 0; b[:, 1:] = 0; yield "grey-both", a, b
+    # a grey colour whose zeros carry a minus sign: dot and cross come out as -0.0, which must not send the pair down the obtuse arm
+    a, b = uni(), uni(); a[:, 1:] = -0.0; yield "grey-first-negative-zero", a, b
+    a, b = uni(), uni(); b[:, 1] = -0.0; b[:, 2] = 0.0; yield "grey-second-mixed-zero", a, b
     th, r1, r2 = rng.uniform(0, 2 * np.pi, n), rng.uniform(1, 120, n), rng.uniform(1, 120, n)
     for spread in (1e-2, 1e-4):
         d = rng.normal(0, spread, n)
@@ -35,22 +39,30 @@ def lab_sets(rng, n):
            np.stack([rng.uniform(0, 100, n), r2 * np.cos(th2), r2 * np.sin(th2)], 1))
 
 
-def test_ciede2000_filter_error_is_inside_the_band(engine):
+@pytest.mark.parametrize("prepared", [0, 1])
+def test_ciede2000_filter_error_is_inside_the_band(engine, prepared):
+    """Both forms of the fp32 filter: operands as given, and prepared as the dominant kernel's interleaved copies hold them
+    (L / 2 - 25, chroma / 50; option probe_prepared)."""
     rng = np.random.default_rng(3)
-    for name, a, b in lab_sets(rng, 1 << 21):
-        a, b = a.astype(np.float32), b.astype(np.float32)
-        exact = engine.colour_diff_batch(2, a, b)
-        fast = engine.filter_diff_batch(2, a, b).astype(np.float64)
-        handed_over = fast < 0                     # pairs the filter gives to the fp64 form
-        err = np.abs(fast - exact)[~handed_over]
-        # the engine trusts 1e-3 + 6e-5 * value per pixel pair (engine.hip filter_band);
-        # hold the measured error to half of that
-        slack = err - (5e-4 + 3e-5 * exact[~handed_over])
-        assert slack.max() <= 0, (name, err.max())
-        if name.startswith("opposite"):
-            assert handed_over.any()
-        else:
-            assert handed_over.mean() < 1e-4, name
+    engine.set_option("probe_prepared", prepared)
+    try:
+        for name, a, b in lab_sets(rng, 1 << 21):
+            a, b = a.astype(np.float32), b.astype(np.float32)
+            exact = engine.colour_diff_batch(2, a, b)
+            fast = engine.filter_diff_batch(2, a, b).astype(np.float64)
+            handed_over = fast < 0                     # pairs the filter gives to the fp64 form
+            err = np.abs(fast - exact)[~handed_over]
+            # the engine trusts 1e-3 + 6e-5 * value per pixel pair (engine.hip filter_band);
+            # hold the measured error to half of that
+            slack = err - (5e-4 + 3e-5 * exact[~handed_over])
+            assert slack.max() <= 0, (name, err.max())
+            assert np.isfinite(fast).all(), name
+            if name.startswith("opposite"):
+                assert handed_over.any()
+            else:
+                assert handed_over.mean() < 1e-4, name
+    finally:
+        engine.set_option("probe_prepared", 0)
 
 
 def test_ciede2000_filter_band_structured_sweep(engine):

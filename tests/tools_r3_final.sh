@@ -2,6 +2,7 @@
 cd $GRAFT_REPO_ROOT
 [ "$SKIP_SUITE" = 1 ] || { python -m pytest tests -q -x -m gpu > gpurun_out/r03_gpu_suite.txt 2>&1; tail -3 gpurun_out/r03_gpu_suite.txt; }
 bash tests/tools_profile.sh r03_v34 > gpurun_out/r03_v34_profile.log 2>&1
+python3 tests/tools_filter_accuracy.py > gpurun_out/r03_filter_accuracy.txt 2>&1
 bash tests/tools_pmc_any.sh C > gpurun_out/r03_pmc_C.txt 2>&1
 bash tests/tools_pmc_any.sh B > gpurun_out/r03_pmc_B.txt 2>&1
 python3 bench.py --sweep > gpurun_out/r03_sweep.json 2> gpurun_out/r03_sweep.err

@@ -1,0 +1,14 @@
+# A/B of a -D variant of filter.hip against the default build, same box, alternating.
+# usage (on the box): bash tests/tools_r3_variant_ab.sh NAME -DMM_SOMETHING ...
+cd $GRAFT_REPO_ROOT
+name=$1; shift
+bash tests/tools_build_variant.sh $name "$@" > /dev/null 2>&1
+for round in 1 2 3; do
+for v in default $name; do
+  if [ $v = default ]; then unset MOSAIC_HIP_LIB; else export MOSAIC_HIP_LIB=$PWD/gpurun_out/$v.so; fi
+  for c in ${CONFIGS:-D E8 C}; do
+    k=6; [ $c = C ] && k=60
+    python3 bench.py --config $c --steps $k --warmup 3 --no-cpu --opt phase_timing=1 2>/dev/null | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); t=d['last_step_device_ms']; print(sys.argv[1], sys.argv[2], '%.0f cells/s %.3f ms/step filter %.3f seed %.3f' % (d['value'], d['ms_per_step'], t['score_ms'], t['seed_ms']), d.get('result_digest','')[:10])" $c $v
+  done
+done
+done
