@@ -64,6 +64,9 @@ CONFIGS = {
     # (MainWindow.cpp:60,150,157) -- on a 4096 x 4096 target with a 1000-image library, and the same shape as CIEDE2000
     "F": (4096, 4096, 128, "square", 1000, 0, 0, 0, 16),
     "G": (4096, 4096, 128, "square", 1000, 2, 0, 0, 2),
+    # config D against a library that stays in the Infinity Cache (500 images: 33 MB interleaved): what the filter kernel's
+    # instruction rate is when the fabric is out of the way
+    "D500": (4096, 4096, 64, "square", 500, 2, 4, 500, 8),
     # reduced shapes of D and E for the rank rehearsals of tests/test_gpu_bench_ranks.py (not bench lines)
     "Ds": (1024, 1024, 64, "square", 400, 2, 4, 500, 8),
     "Es": (1000, 1000, 48, "square", 500, 2, 0, 0, 4),       # 21 x 21 cells, last row / column clipped to 40 px
