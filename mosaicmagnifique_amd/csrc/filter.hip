@@ -1792,7 +1792,11 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     if (tile_used) *tile_used = cand_per_block;
     // one share of the cells per XCD (8 on MI355X); small launches keep one share so no XCD idles on an empty one
     const int xcd_shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
-    const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : (small_cells ? 128 : 64)) : cell_group;
+    // cells per XCD sub-group: the cells an XCD works on at the same time should sit in its 4 MB L2 beside the candidate tiles --
+    // 64 cells of 64 x 64 (64 KB each, interleaved), 128 of the smaller ones; cells above 16 groups by their size: 2 MB worth of them
+    // (128 x 128 = 256 KB a cell: 8; config G, 1024 such cells x 1000 images: 14.3 ms per launch at 64, 13.4 at 16, 12.7 at 8, 12.5 at 4)
+    const int big_cell_group = std::max(4, (int)((size_t)(2 << 20) / ((size_t)ppad * 16)));
+    const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : (small_cells ? 128 : (groups > 16 ? std::min(64, big_cell_group) : 64))) : cell_group;
     // the exit test after every group wherever the bound reaches (cells up to 64 groups = 128 x 128; config G, 1024 such cells x 1000
     // images: 15.4 ms per launch at every 4th group, 14.4 at every group); larger cells test the plain partial sum 16 times
     const int check_every = in.check_every > 0 ? in.check_every : (groups > kWave ? groups / 16 : 1);
