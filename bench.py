@@ -67,6 +67,7 @@ CONFIGS = {
     # config D against a library that stays in the Infinity Cache (500 images: 33 MB interleaved): what the filter kernel's
     # instruction rate is when the fabric is out of the way
     "D500": (4096, 4096, 64, "square", 500, 2, 4, 500, 8),
+    "D3800": (4096, 4096, 64, "square", 3800, 2, 4, 500, 8),     # ... and one whose interleaved copy (249 MB) just fits the 256 MB Infinity Cache
     # reduced shapes of D and E for the rank rehearsals of tests/test_gpu_bench_ranks.py (not bench lines)
     "Ds": (1024, 1024, 64, "square", 400, 2, 4, 500, 8),
     "Es": (1000, 1000, 48, "square", 500, 2, 0, 0, 4),       # 21 x 21 cells, last row / column clipped to 40 px
