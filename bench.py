@@ -66,6 +66,9 @@ CONFIGS = {
     "G": (4096, 4096, 128, "square", 1000, 2, 0, 0, 2),
     # config D against a library that stays in the Infinity Cache (500 images: 33 MB interleaved): what the filter kernel's
     # instruction rate is when the fabric is out of the way
+    # the reference harness's default line as CIEDE2000 (Benchmark_Generator.h: 5000 x 4000, cell 128 at detail 20 % = 25 px detail
+    # cells, ~200 images), at the detail size directly: 1280 cells of 25 x 25 against 214 images
+    "H": (800, 1000, 25, "square", 214, 2, 0, 0, 64),
     "D500": (4096, 4096, 64, "square", 500, 2, 4, 500, 8),
     "D3800": (4096, 4096, 64, "square", 3800, 2, 4, 500, 8),     # ... and one whose interleaved copy (249 MB) just fits the 256 MB Infinity Cache
     # reduced shapes of D and E for the rank rehearsals of tests/test_gpu_bench_ranks.py (not bench lines)
