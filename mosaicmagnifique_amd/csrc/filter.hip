@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include "colour_diff.hpp"
 #include "colour_diff_fast.hpp"
@@ -200,6 +201,12 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 //   +0,1  u64  256-pixel groups visited          +2,3  u64  groups a full visit of every candidate would take
 //   +4,5  u64  candidates dropped by the block bound alone (no pixel touched)
 //   +6    u32  unused                            +8 .. +15  u32  next item of XCD 0 .. 7 (persistent workgroups)
+#ifndef MM_GRID_MULT
+#define MM_GRID_MULT 1                // persistent workgroups launched per workgroup slot of the device (see persistent_grid)
+#endif
+#ifndef MM_LDS_GRID_CAP
+#define MM_LDS_GRID_CAP 8192          // workgroups of filter_lds_kernel at most (they stride over the items)
+#endif
 #ifndef MM_STAT_BLOCKS
 #define MM_STAT_BLOCKS (4 * kWave)   // blocks of a cell whose statistics filter_kernel keeps in LDS (experiments: 64 = cells up to 64 x 64 only)
 #endif
@@ -1738,8 +1745,17 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     const int round_of = 4 * (kWave / std::max(groups, 1));
     const int small_tile = round_of > 0 && round_of <= 64 ? 64 / round_of * round_of : 64;
     const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : (small_cells ? small_tile : 32), cell_group = 512;
-    // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited), times two
-    // so a finishing workgroup's slot refills at once
+    // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited) -- and not one more: a second workgroup
+    // per slot ("so that a finishing workgroup's slot refills at once", rounds 1 and 2) starts when the launch is nearly over, pays
+    // its start (hue table, prologue, eight counter probes) and finds nothing; measured at twice the slots against once: the
+    // reference harness's CIEDE2000 line (config H) 0.488 -> 0.310 ms per launch, config C 2.23 -> 2.02, config D 40.2 -> 39.9
+    // ... and fewer than that for a small launch: workgroups start one after the other (~0.1 us each: 0.24 ms for the 2560 of
+    // config H, whose launch took 0.49 ms), so with N items of ~20 us the launch is shortest near sqrt(N x 20 / 0.1) workgroups
+    // (config H, 5120 items: 0.312 ms at 1280 workgroups, 0.240 at 640, 0.267 at 320)
+    auto few = [](long long items, int slots) -> unsigned {
+        const long long by_start_cost = std::max<long long>(64, (long long)std::sqrt(100.0 * (double)items));
+        return (unsigned)std::min<long long>(std::min<long long>(items, slots), by_start_cost);
+    };
     auto persistent_grid = [&](const void* kern, long long items, int threads, size_t dyn_lds) -> unsigned {
         // the occupancy query costs a fraction of a millisecond: asked once per (kernel, LDS size), not per launch
         struct Known { const void* kern; size_t lds; int dev, slots; };
@@ -1749,13 +1765,13 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         (void)hipGetDevice(&dev);
         for (int i = 0; i < n_known; ++i)
             if (known[i].kern == kern && known[i].lds == dyn_lds && known[i].dev == dev)
-                return (unsigned)std::min<long long>(items, (long long)known[i].slots);
+                return few(items, known[i].slots);
         int cus = 256, per_cu = 4;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 4;
         (void)hipGetLastError();
-        if (n_known < 8) known[n_known++] = Known{kern, dyn_lds, dev, cus * per_cu * 2};
-        return (unsigned)std::min<long long>(items, (long long)cus * per_cu * 2);
+        if (n_known < 8) known[n_known++] = Known{kern, dyn_lds, dev, cus * per_cu * MM_GRID_MULT};
+        return few(items, cus * per_cu * MM_GRID_MULT);
     };
     // groups visited by descending bound (the rest in plane order): all of them from 12 groups per cell on (cells of 33 .. 64
     // groups rank the 64 lanes of the prelude; config G: 16.2 -> 15.3 ms per launch, with the exit test at every group 14.4)
@@ -1838,7 +1854,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             auto kern = filter_lds_kernel<CIEDE2000>;
             if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_bytes)) != hipSuccess) return code;
-            kern<<<dim3((unsigned)std::min<long long>(nblk, 8192)), kLdsBlock, lds_bytes, stream>>>(
+            kern<<<dim3((unsigned)std::min<long long>(nblk, MM_LDS_GRID_CAP)), kLdsBlock, lds_bytes, stream>>>(
                 in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
                 edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, nullptr);
             if ((code = hipGetLastError()) != hipSuccess) return code;
@@ -1850,7 +1866,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             if ((code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_used)) != hipSuccess) return code;
             // (at most 8192 workgroups stride over the items: 16 rounds of what the device holds at once)
-            kern<<<dim3((unsigned)std::min<long long>(nblk, 8192)), kLdsBlock, lds_used, stream>>>(
+            kern<<<dim3((unsigned)std::min<long long>(nblk, MM_LDS_GRID_CAP)), kLdsBlock, lds_used, stream>>>(
                 in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, cell_group,
                 edges, edge_count, edge_cap, prune_above, in.hue_lut, in.var, in.lib_stats_t);
         }
