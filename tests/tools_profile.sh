@@ -21,7 +21,7 @@ cp profiles/pmc_traffic.json $O/pmc_traffic.json
 [ "$ONLY" = pmc ] && exit 0
 rocprofv3 --kernel-trace --stats -d $O/kt -o d --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $O/kt.log 2>&1
 python3 bench.py --steps 10 --warmup 2 > $O/bench_D.json 2> $O/bench_D.err
-for c in A B C E8 F G; do python3 bench.py --config $c --steps 5 --warmup 2 > $O/bench_$c.json 2>/dev/null; done
+for c in A B C E8 F G H; do python3 bench.py --config $c --steps 5 --warmup 2 > $O/bench_$c.json 2>/dev/null; done
 python3 bench.py --config E --steps 2 --warmup 1 --no-cpu > $O/bench_E_1gpu.json 2>/dev/null
 MOSAIC_BENCH_FORCE_DIST=1 python3 bench.py --steps 5 --warmup 2 --no-cpu > $O/bench_D_dist1.json 2> $O/bench_D_dist1.err
 python3 bench.py --steps 5 --warmup 2 --no-cpu --opt lds_filter=1 --opt tile=128 > $O/bench_D_lds_tile.json 2>/dev/null
