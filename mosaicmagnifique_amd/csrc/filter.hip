@@ -200,7 +200,7 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 // Work counters of a launch, at edge_count + kCounterBase (u32 indices; the u64 ones are 8-byte aligned):
 //   +0,1  u64  256-pixel groups visited          +2,3  u64  groups a full visit of every candidate would take
 //   +4,5  u64  candidates dropped by the block bound alone (no pixel touched)
-//   +6    u32  unused                            +8 .. +15  u32  next item of XCD 0 .. 7 (persistent workgroups)
+//   +6    u32  unused                            words 32, 64, .. 256  u32  next item of XCD 0 .. 7 (persistent workgroups)
 #ifndef MM_GRID_MULT
 #define MM_GRID_MULT 1                // persistent workgroups launched per workgroup slot of the device (see persistent_grid)
 #endif
@@ -215,8 +215,9 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 #endif
 constexpr float kLongSplit = MM_LONG_SPLIT;   // stage 2 of filter_kernel: candidates whose block bound is below this share of the limit go first
 constexpr int kCounterBase = 2;
-constexpr int kItemCounters = 16;
-constexpr int kCounterWords = 32;        // words cleared per launch (edge count, work counters, item counters)
+// (the item counters of the eight XCD shares sit on cache lines of their own: atomics on one line are served one after the other)
+constexpr int kItemCounters = 32, kItemCounterStride = 32;
+constexpr int kCounterWords = kFilterCounterWords;        // words cleared per launch (edge count, work counters, item counters)
 
 // XCD this wave runs on (0..7): hwreg(HW_REG_XCC_ID, 0, 4).  Used for L2 affinity only.
 __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
@@ -322,7 +323,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const int sh = (my_share + k) % xcd_shares;
                 const long long lo = (long long)n_cells * sh / xcd_shares, hi = (long long)n_cells * (sh + 1) / xcd_shares;
                 const long long total = (hi - lo) * n_tiles;
-                const unsigned int it = atomicAdd(item_counter + sh, (unsigned int)item_chunk);
+                const unsigned int it = atomicAdd(item_counter + sh * kItemCounterStride, (unsigned int)item_chunk);
                 if ((long long)it < total) {
                     share = sh; item = it;
                     chunk_share = sh; chunk_next = it + 1u;

@@ -69,8 +69,8 @@ struct FilterInputs {
 
 // Words of the counter block launch_filter clears and filter_kernel fills (u32 indices into edge_count):
 // [0] discontinuity pairs logged; [2,3] [4,5] [6,7] u64: pixel groups visited, groups of a full visit,
-// candidates dropped by the block bound alone; [16..23] item counters of the persistent workgroups.
-constexpr int kFilterCounterWords = 32;
+// candidates dropped by the block bound alone; [32], [64] .. [256] item counters of the persistent workgroups (a cache line each).
+constexpr int kFilterCounterWords = 288;
 
 // Tier-1 filter scores f32 [n_cells][L] (see filter.hip).  Pairs on the discontinuity
 // are logged to `edges` (capacity edge_cap, count in *edge_count, which may exceed
