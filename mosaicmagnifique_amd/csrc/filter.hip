@@ -204,6 +204,9 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 #ifndef MM_GRID_MULT
 #define MM_GRID_MULT 1                // persistent workgroups launched per workgroup slot of the device (see persistent_grid)
 #endif
+#ifndef MM_SEED_GRID_CAP
+#define MM_SEED_GRID_CAP 8192         // workgroups of seed_score_kernel at most (grid-stride over the (cell, seed) pairs)
+#endif
 #ifndef MM_LDS_GRID_CAP
 #define MM_LDS_GRID_CAP 8192          // workgroups of filter_lds_kernel at most (they stride over the items)
 #endif
@@ -1974,7 +1977,7 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
     }
     const size_t lds = 0;
     const long long waves = (long long)n_cells * M;
-    const unsigned score_blocks = (unsigned)std::min<long long>((waves + 3) / 4, 8192);   // grid-stride: the hue table once per workgroup
+    const unsigned score_blocks = (unsigned)std::min<long long>((waves + 3) / 4, MM_SEED_GRID_CAP);   // grid-stride: the hue table once per workgroup
     if (type == CIEDE2000) {
         seed_kernel<CIEDE2000><<<n_cells, kBlock, lds, stream>>>(in.cells, in.cmask, lib_means, L, ppad, M, seeds, in.hue_lut);
         seed_score_kernel<CIEDE2000><<<score_blocks, kBlock, 0, stream>>>(
