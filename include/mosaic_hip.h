@@ -347,6 +347,7 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * image copies with prepared operands; "two_level" (1): the bound's stage 1, several candidates per wave pass;
  * "sort_groups" (-1 = by cell size): how many of a candidate's pixel groups are visited by descending bound;
  * "check_every" (0 = by cell size): pixel groups between two exit tests of a candidate;
+ * "probe_prepared" (0): mm_filter_diff_batch measures the CIEDE2000 filter form with operands prepared as the dominant kernel holds them;
  * "lds_filter" (-1 = RGB only): LDS-resident cell tile; "seeds" (-1 = 14 for CIEDE2000, 2 for RGB / CIE76): proxy-chosen seeds beyond the list length;
  * "band_guard" (64): every n-th cell carries a sentinel through the fp64 re-score (mm_timing.band_alarms);
  * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
