@@ -257,8 +257,68 @@ def cpu_parity_rows(w, img, lib, best, recs):
     return pos, picks, scores, cores, dt
 
 
+def floor_legs(engine, step, n_cells, value):
+    """What the headline owes to the content: the same step with the early exit off (`prune` 0: every candidate's every
+    pixel through the fp32 filter) and on the fp64-only path (`filter` 0: the reference's arithmetic for every pair) --
+    both produce the identical grid (tests).  Outside the timed region; up to three steps each, one if a step takes > 4 s."""
+    import torch
+    out = {}
+    for key, option in (("floor_unpruned", "prune"), ("floor_fp64_only", "filter")):
+        engine.set_option(option, 0)
+        try:
+            times = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+                if times[-1] > 4.0:
+                    break
+            dt = min(times)
+        finally:
+            engine.set_option(option, 1)
+        out[key] = {"value": n_cells / dt, "unit": "cells/s", "ms_per_step": dt * 1e3, "steps": len(times),
+                    "headline_over_floor": value / (n_cells / dt),
+                    "what": "early exit off (option prune=0): every pixel of every candidate through the fp32 filter" if option == "prune"
+                            else "fp64 only (option filter=0): the reference-form arithmetic for every pixel pair, no filter tier"}
+    return out
+
+
+def first_call_leg(w, device, opts):
+    """What generateBestFits() of a FRESH generator costs in a warm process (the reference builds one per run,
+    MainWindow.cpp:584-607; its harness times exactly that, Benchmark_Generator.h:83-104): a new engine, the u8 inputs
+    over PCIe, pre-processing, planes / statistics, the generate, the result on the host -- and the same once more with
+    another fresh engine (which adopts what the first one parked when it was destroyed).  Wall ms + the engine's stage clocks."""
+    from mosaicmagnifique_amd.engine import Engine
+    from mosaicmagnifique_amd.grid import CELL_DTYPE
+    cells = np.ascontiguousarray(w["cells"], dtype=CELL_DTYPE)
+    masks = w["shape"].masks4()
+    out = {}
+    for label in ("first", "again"):
+        t0 = time.perf_counter()
+        e = Engine(device)
+        for item in opts:
+            name, val = item.split("=")
+            e.set_option(name, int(val))
+        e.set_library_u8(w["lib_u8"], w["t"])
+        e.set_target_u8(w["img_u8"], w["t"])
+        e.set_masks(masks)
+        t1 = time.perf_counter()
+        e.generate(cells, w["grid_w"], w["grid_h"], w["t"], *w["rep"])
+        t2 = time.perf_counter()
+        clocks = e.stage_timing()
+        e.close()
+        out[label] = {"first_call_ms": (t2 - t0) * 1e3, "stage_ms": (t1 - t0) * 1e3, "generate_ms": (t2 - t1) * 1e3,
+                      "engine_clocks": {k: round(v, 3) if isinstance(v, float) else v for k, v in clocks.items()}}
+    out["first_call_ms"] = out["first"]["first_call_ms"]
+    out["what"] = ("fresh engine -> mm_set_library_u8 + mm_set_target_u8 + mm_set_masks + mm_generate -> grid on the host, wall ms in a "
+                   "warm process (HIP context and code objects loaded); `again`: a second fresh engine after the first was destroyed")
+    return out
+
+
 def pmc_record(w, opts, tile=None):
-    """rocprofv3 PMC passes of this same command (tests/tools_profile.sh), summarised per launch of the dominant
+    """rocprofv3 PMC passes of this same command (tools/profile.sh), summarised per launch of the dominant
     kernel by profiles/summarise_pmc.py and copied into profiles/ by profiles/collect.py.  Only a record measured on exactly these kernel sources, this
     configuration and these engine options is used; anything else is reported as absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -456,6 +516,34 @@ def sweep_bench(args, emit):
     }))
 
 
+def launch_ranks(n, emit, argv=None):
+    """`python3 bench.py --gpus N` without a launcher around it: run this script under `python -m torch.distributed.run`
+    with N ranks (one per GPU, rendezvous on 127.0.0.1 at a free port) as a child process, pass its single JSON line
+    on.  Nothing in this process has initialised the GPU when it gets here (device_count() does not)."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("MOSAIC_BENCH_REHEARSAL") == "1"
+    if not rehearsal:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("--gpus %d: this node shows %d GPU(s) (MOSAIC_BENCH_REHEARSAL=1 runs the N-rank path on one "
+                             "GPU over gloo, timings void)" % (n, have))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    cmd += list(sys.argv[1:] if argv is None else argv)
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)       # stderr passes through
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    if lines:
+        emit(lines[-1])
+    if p.returncode != 0 or not lines:
+        raise SystemExit(p.returncode or 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -468,7 +556,9 @@ def main():
     ap.add_argument("--bands", type=int, default=0,
                     help="weak scaling: bands of the config stacked into one mosaic (default: one per rank); with one rank it "
                          "gives the single-GPU result an N-rank weak run must reproduce")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs (and the floors / first-call legs: "
+                                                         "nothing but the timed steps reaches the device, as the PMC passes want it)")
+    ap.add_argument("--no-floors", action="store_true", help="skip the floor legs (early exit off; fp64 only) and the first-call leg")
     ap.add_argument("--mcs", default=None, help="cell shape from a MosaicMagnifique .mcs file (resized to the config's cell size)")
     ap.add_argument("--mil", default=None, help="library from a MosaicMagnifique .mil file (resized to the config's cell size)")
     ap.add_argument("--stage", choices=("build", "preprocess"), default=None,
@@ -499,9 +589,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python3 bench.py --gpus N` (how the driver runs N = 1): start the N ranks ourselves as FRESH child
+        # processes of torch.distributed.run -- before this process has touched a GPU, and never by exec -- relay
+        # rank 0's JSON line and leave with the launcher's exit code
+        return launch_ranks(args.gpus, emit)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
     scaling = args.scaling or ("strong" if args.config in ("E", "Es") else "weak")
 
@@ -564,6 +657,8 @@ def main():
     for _ in range(args.warmup):
         best, score = step()
     fence()
+    if sharded is not None:
+        sharded.reset_phases()
     t0 = time.perf_counter()
     score_ms, launches, exact, visited, groups_all, dropped = 0.0, 0, 0, 0, 0, 0
     raw = []
@@ -596,8 +691,25 @@ def main():
         launches_scale = args.steps / 3.0
     else:
         launches_scale = 1.0
+    dist_phase_ms = None
+    if sharded is not None:
+        # per-step wall time of this rank's phases; over the ranks: the maximum (what the step waits for) and, for the
+        # scoring, the minimum beside it (their gap is the load imbalance the all-gather then absorbs as waiting)
+        ph = sharded.phase_ms
+        mine = [ph[k] / max(args.steps, 1) for k in ("score", "allgather", "resolve", "deepen")]
+        hi = torch.tensor(mine, dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        lo = hi.clone()
+        if world > 1:
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist_phase_ms = dict(zip(("score", "allgather", "resolve", "deepen"), [round(float(v), 4) for v in hi.tolist()]))
+        dist_phase_ms["score_min"] = round(float(lo[0]), 4)
+        dist_phase_ms["allgather_min"] = round(float(lo[1]), 4)
+        dist_phase_ms["resolve_rounds_per_step"] = ph["rounds"] / max(args.steps, 1)
+        dist_phase_ms["note"] = ("host wall ms per step, maximum over the ranks (score_min / allgather_min: the minimum); allgather "
+                                 "includes waiting for the slowest rank's lists; resolve = the identical verifying resolve on every rank")
     if world > 1:
-        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
 
@@ -677,7 +789,7 @@ def main():
         else:
             roof["achieved"] = None
             roof["frac"] = None
-            roof["note"] = "no PMC record for this build/config: VALU rate not priced (run tests/tools_profile.sh)"
+            roof["note"] = "no PMC record for this build/config: VALU rate not priced (run tools/profile.sh)"
     else:
         # RGB-Euclid / fp64-only: memory-side view, from measured traffic only
         roof["bound"] = "hbm"
@@ -720,6 +832,11 @@ def main():
         "result_digest": result_digest(best, score),
         "last_step_device_ms": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
     }
+    if dist_phase_ms is not None:
+        out["dist_phase_ms"] = dist_phase_ms
+    if world == 1 and sharded is None and not (args.no_cpu or args.no_floors):
+        out.update(floor_legs(engine, step, n_cells, value))
+        out["first_call"] = first_call_leg(w, local_rank, args.opt)
 
     if world == 1:
         # what a plain coalesced read stream reaches on this device (4 GiB, past the Infinity Cache)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 2
+#define MM_ABI_VERSION 3
 
 /* Return codes.  The reference returns bool and reports through a modal
  * CUDAErrMessageBox that separates "expected" errors (out of memory, bad
@@ -106,6 +106,22 @@ typedef struct mm_timing {
                                * "fast_path"); 0: the step-by-step path ran (or finished the call) */
     double preprocess_ms;     /* mm_set_library_u8[_sized] / mm_set_target_u8: the resize + colour conversion kernels */
 } mm_timing;
+
+/* What a FIRST call pays besides the hot path, as host wall clocks accumulated since mm_create: the reference builds
+ * a fresh generator per run (MainWindow.cpp:584-607, Benchmark/Benchmark_Generator.h:17-104) and allocates / uploads
+ * everything inside generateBestFits (CUDAPhotomosaicGenerator.cpp:82,372-510), so for its everyday job sizes these
+ * -- not the kernels -- are the time a caller sees. */
+typedef struct mm_stage_timing {
+    double create_ms;         /* mm_create: stream, events (the HIP context is the process's) */
+    double alloc_ms;          /* device allocations (hipMalloc), all buffers of the engine */
+    double pinned_ms;         /* page-locked host buffers */
+    double h2d_ms;            /* host -> device copies of library, masks, target (mm_set_*; u8 inputs: the copy alone) */
+    double preprocess_ms;     /* u8 -> f32 / Lab conversion and resize kernels (mm_set_*_u8) */
+    double planes_ms;         /* library planes, interleaved copy, block statistics, means (once per library / mask change) */
+    int64_t allocations;      /* device allocations made */
+    int64_t allocated_bytes;
+    int64_t reused_engine;    /* 1: mm_create adopted the parked resources of a destroyed engine of this process */
+} mm_stage_timing;
 
 /* Progress: called on the calling thread between device batches with
  * monotone values up to the number of cells (the reference emits one
@@ -349,7 +365,7 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "check_every" (0 = by cell size): pixel groups between two exit tests of a candidate;
  * "probe_prepared" (0): mm_filter_diff_batch measures the CIEDE2000 filter form with operands prepared as the dominant kernel holds them;
  * "lds_filter" (-1 = RGB only): LDS-resident cell tile; "seeds" (-1 = 14 for CIEDE2000, 2 for RGB / CIE76): proxy-chosen seeds beyond the list length;
- * "band_guard" (64): every n-th cell carries a sentinel through the fp64 re-score (mm_timing.band_alarms);
+ * "band_guard" (1 = every cell; n: every n-th cell, 0: off): the best candidate the filter band EXCLUDED rides through the fp64 re-score as a sentinel; one that beats a contender is a band failure: the cell is re-done fp64-only and counted (mm_timing.band_alarms);
  * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
  * dropped in the engine's PREVIOUS CIEDE2000 launch over the same library, so the TIME of a call (never its result)
  * depends on the call history of the engine; 0 pins the size-by-cell default (mm_timing.filter_tile reports what ran).
@@ -369,6 +385,8 @@ mm_status mm_set_option(mm_engine *e, const char *name, int value);
 
 /* Timings of the last mm_generate / mm_score_cells (+ mm_resolve) on e. */
 mm_status mm_get_timing(const mm_engine *e, mm_timing *out);
+/* The stage clocks of e since mm_create (see mm_stage_timing). */
+mm_status mm_get_stage_timing(const mm_engine *e, mm_stage_timing *out);
 
 /* ---- per-pair colour difference ---------------------------------------- */
 

@@ -38,7 +38,16 @@ class MMTiming(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-ABI_VERSION = 2          # MM_ABI_VERSION of include/mosaic_hip.h
+class MMStageTiming(ctypes.Structure):
+    _fields_ = [("create_ms", ctypes.c_double), ("alloc_ms", ctypes.c_double), ("pinned_ms", ctypes.c_double),
+                ("h2d_ms", ctypes.c_double), ("preprocess_ms", ctypes.c_double), ("planes_ms", ctypes.c_double),
+                ("allocations", ctypes.c_int64), ("allocated_bytes", ctypes.c_int64), ("reused_engine", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+ABI_VERSION = 3          # MM_ABI_VERSION of include/mosaic_hip.h
 
 PROGRESS_CB = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)
 
@@ -104,6 +113,7 @@ SIGNATURES = {
     "mm_group_generate": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, _VP, _VP, _VP, _VP, _VP]),
     "mm_get_timing": (ctypes.c_int, [_VP, ctypes.POINTER(MMTiming)]),
+    "mm_get_stage_timing": (ctypes.c_int, [_VP, ctypes.POINTER(MMStageTiming)]),
     "mm_colour_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),
     "mm_filter_diff_batch": (ctypes.c_int, [_VP, ctypes.c_int, _VP, _VP, ctypes.c_size_t, _VP]),
     "mm_debug_visit_counters": (ctypes.c_int, [_VP, _VP]),

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -103,7 +104,7 @@ struct mm_engine {
     int batch_capacity = 0;      // cells per device batch the last hipMemGetInfo allowed (0 = not asked yet)
     int band_pct = 100;          // mm_set_option("band_pct", n): diagnostics -- trust only n % of the filter band (tests of the
                                  // guards; a negative value turns the band inside out: true contenders get excluded)
-    int band_guard_every = 64;   // mm_set_option("band_guard", n): every n-th cell of a batch re-scores the best candidate the
+    int band_guard_every = 1;    // mm_set_option("band_guard", n): every n-th cell of a batch (default: EVERY cell) re-scores the best candidate the
                                  // filter band excluded in fp64 (0 = off); an excluded candidate that wins is a band failure
     int euclid_stage1 = 1;       // mm_set_option("euclid_stage1", 0): the RGB / CIE76 filter gives every candidate a wave from the start
     DevBuf lib_stats_t;          // [V][3][ppad / 64][L]: the library's channel sums per block, candidate-fastest (filter_lds_kernel stage 1)
@@ -134,6 +135,7 @@ struct mm_engine {
                                       // seeds / early exit are skipped (three launches cost more than they save); -1 = default
 
     mm_timing timing{};
+    mm_stage_timing stage_clock{};    // host wall clocks of everything that is NOT the hot path (mm_get_stage_timing): what a first call pays
 };
 
 namespace {
@@ -164,9 +166,24 @@ mm_status hip_fail(mm_engine* e, hipError_t code, const char* what, const char* 
             return hip_fail((e), hip_try_code_, (what), __FILE__, __LINE__);      \
     } while (0)
 
+inline double wall_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Adds the host wall time of its scope to one field of the engine's stage clock.
+struct StageScope {
+    double* field;
+    double t0;
+    explicit StageScope(double* f) : field(f), t0(wall_ms()) {}
+    ~StageScope() { if (field) *field += wall_ms() - t0; }
+};
+
 mm_status ensure(mm_engine* e, DevBuf& b, size_t bytes, const char* what)
 {
     if (b.bytes >= bytes && b.p) return MM_OK;
+    StageScope clock(e ? &e->stage_clock.alloc_ms : nullptr);
+    if (e) { e->stage_clock.allocations += 1; e->stage_clock.allocated_bytes += (int64_t)bytes; }
     if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
     if (bytes == 0) bytes = 16;
     HIP_TRY(e, hipMalloc(&b.p, bytes), what);
@@ -290,6 +307,11 @@ mm_status by_type(int diff_type, F&& f)
 mm_status prepare_planes(mm_engine* e)
 {
     if (!e->planes_dirty) return MM_OK;
+    // (wall time of this function minus the allocations it makes, which the allocation clock has already)
+    struct PlanesClock {
+        mm_engine* e; double t0, alloc0;
+        ~PlanesClock() { e->stage_clock.planes_ms += (wall_ms() - t0) - (e->stage_clock.alloc_ms - alloc0); }
+    } planes_clock{e, wall_ms(), e->stage_clock.alloc_ms};
     const int size = e->lib_size, P = size * size, ppad = round_up(P, 256), L = e->n_lib;
     int n_var = 0;
     int first_mask_of_var[4];
@@ -458,7 +480,7 @@ mm_status ensure_hue_lut(mm_engine* e)
 // Error bounds of the fp32 filter forms (colour_diff_fast.hpp) against the fp64 forms,
 // per pixel pair:  |fp32 - fp64| <= px_abs + px_rel * value, plus the fp32 accumulation of
 // one lane's share of a cell (relative, grows with the pixels per lane).
-// Measured on 2e8 random and adversarial pairs (tests/tools_filter_accuracy.py,
+// Measured on 2e8 random and adversarial pairs (tools/filter_accuracy.py,
 // tests/test_gpu_filter.py): CIEDE2000 max |err| = 2.5e-4 + 1.8e-5 * value (the relative part
 // is the linear interpolation of the hue table); the bound trusted here is 4x the absolute
 // and 3x the relative part.  Euclid: three roundings of a value <= 442.
@@ -809,7 +831,10 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         const bool stage0 = e->stage0 != 0 && prune && diff_type == MM_CIEDE2000;
         if (stage0)
             HIP_TRY(e, mm::launch_image_stats((float*)e->cell_lsum.p, e->cell_lsum.bytes / sizeof(float) / 8, stat_slots(ppad), ppad / 64,
-                                              (e->var_active[0] + 63) / 64, (size_t)b, e->stream), "Error during cell image-statistics kernel");
+                                              (e->var_active[0] + 63) / 64, (size_t)b, e->stream, (const uint8_t*)e->cell_var.p,
+                                              make_int4((e->var_active[0] + 63) / 64, (e->var_active[1] + 63) / 64,
+                                                        (e->var_active[2] + 63) / 64, (e->var_active[3] + 63) / 64)),
+                    "Error during cell image-statistics kernel");
         fin.var.two_stage = (e->two_level ? 1 : 0) | (stage0 ? 2 : 0);
         if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
 
@@ -1099,6 +1124,7 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
 mm_status ensure_pinned(mm_engine* e, size_t bytes)
 {
     if (e->pinned && e->pinned_bytes >= bytes) return MM_OK;
+    StageScope clock(&e->stage_clock.pinned_ms);
     if (e->pinned) { (void)hipHostFree(e->pinned); e->pinned = nullptr; e->pinned_bytes = 0; }
     HIP_TRY(e, hipHostMalloc(&e->pinned, bytes, hipHostMallocDefault), "Failed to allocate page-locked result buffer");
     e->pinned_bytes = bytes;
@@ -1243,6 +1269,7 @@ mm_status mm_create(int device, mm_engine** out)
         set_err(nullptr, "Invalid device %d (%d visible)", device, count);
         return MM_INVALID_ARGUMENT;
     }
+    const double t_create = wall_ms();
     mm_engine* e = new (std::nothrow) mm_engine();
     if (!e) { set_err(nullptr, "out of host memory"); return MM_OUT_OF_MEMORY; }
     e->device = device;
@@ -1254,7 +1281,15 @@ mm_status mm_create(int device, mm_engine** out)
         mm_destroy(e);
         return st;
     }
+    e->stage_clock.create_ms = wall_ms() - t_create;
     *out = e;
+    return MM_OK;
+}
+
+mm_status mm_get_stage_timing(const mm_engine* e, mm_stage_timing* out)
+{
+    if (!e || !out) return MM_INVALID_ARGUMENT;
+    *out = e->stage_clock;
     return MM_OK;
 }
 
@@ -1292,7 +1327,10 @@ mm_status mm_set_library(mm_engine* e, const float* images, int n_images, int si
     const size_t bytes = (size_t)n_images * size * size * 3 * sizeof(float);
     mm_status st = ensure(e, e->lib_hwc, bytes, "Failed to allocate library images");
     if (st) return st;
-    HIP_TRY(e, hipMemcpy(e->lib_hwc.p, images, bytes, hipMemcpyHostToDevice), "Failed to copy library image to device");
+    {
+        StageScope clock(&e->stage_clock.h2d_ms);
+        HIP_TRY(e, hipMemcpy(e->lib_hwc.p, images, bytes, hipMemcpyHostToDevice), "Failed to copy library image to device");
+    }
     e->planes_dirty = true;        // planes are (re)built by prepare_planes() once the masks are known
     e->n_lib = n_images;
     e->lib_size = size;
@@ -1312,8 +1350,11 @@ mm_status mm_set_masks(mm_engine* e, const uint8_t* masks, int size)
     for (int m = 0; m < 4; ++m) memcpy(padded.data() + (size_t)m * ppad, masks + (size_t)m * P, (size_t)P);
     mm_status st = ensure(e, e->masks, padded.size(), "Failed to allocate cell masks");
     if (st) return st;
-    HIP_TRY(e, hipMemcpy(e->masks.p, padded.data(), padded.size(), hipMemcpyHostToDevice),
-            "Failed to copy cell mask to device");
+    {
+        StageScope clock(&e->stage_clock.h2d_ms);
+        HIP_TRY(e, hipMemcpy(e->masks.p, padded.data(), padded.size(), hipMemcpyHostToDevice),
+                "Failed to copy cell mask to device");
+    }
     e->masks_host.assign(masks, masks + (size_t)4 * P);
     e->planes_dirty = true;
     e->mask_size = size;
@@ -1331,7 +1372,10 @@ mm_status mm_set_target(mm_engine* e, const float* image, int rows, int cols)
     const size_t bytes = (size_t)rows * cols * 3 * sizeof(float);
     mm_status st = ensure(e, e->target, bytes, "Failed to allocate main image");
     if (st) return st;
-    HIP_TRY(e, hipMemcpy(e->target.p, image, bytes, hipMemcpyHostToDevice), "Failed to copy main image to device");
+    {
+        StageScope clock(&e->stage_clock.h2d_ms);
+        HIP_TRY(e, hipMemcpy(e->target.p, image, bytes, hipMemcpyHostToDevice), "Failed to copy main image to device");
+    }
     e->rows = rows;
     e->cols = cols;
     return MM_OK;
@@ -1386,6 +1430,7 @@ mm_status preprocess_u8(mm_engine* e, const uint8_t* bgr, size_t n_images, int r
     if ((st = ensure_srgb_lut(e)) || (st = ensure(e, e->stage_u8, in_bytes, "Failed to allocate u8 staging")) ||
         (st = ensure(e, dst, out_px * 3 * sizeof(float), "Failed to allocate preprocessed images")))
         return st;
+    HIP_TRY(e, hipEventRecord(e->ev[3], e->stream), "event");
     HIP_TRY(e, hipMemcpyAsync(e->stage_u8.p, bgr, in_bytes, hipMemcpyHostToDevice, e->stream), "Failed to copy u8 images to device");
     const unsigned blocks = (unsigned)std::min<size_t>((out_px + mm::kBlock - 1) / mm::kBlock, 65536);
     HIP_TRY(e, hipEventRecord(e->ev[4], e->stream), "event");
@@ -1397,6 +1442,8 @@ mm_status preprocess_u8(mm_engine* e, const uint8_t* bgr, size_t n_images, int r
     HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     e->timing = mm_timing{};
     e->timing.preprocess_ms = elapsed(e->ev[4], e->ev[5]);
+    e->stage_clock.h2d_ms += elapsed(e->ev[3], e->ev[4]);
+    e->stage_clock.preprocess_ms += e->timing.preprocess_ms;
     return MM_OK;
 }
 

@@ -4,6 +4,8 @@
 //
 // Nothing in this translation unit decides a best fit: see colour_diff_fast.hpp.
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <stdint.h>
 
 #include <algorithm>
@@ -295,7 +297,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     __shared__ int chunk_left, chunk_share;
     if (threadIdx.x == 0) chunk_left = 0;
 #ifdef MM_FILTER_STAMPS
-    // Instrumented build (tests/tools_r3_stamps.sh): where a wave's cycles go inside an item, summed over the launch
+    // Instrumented build (tools/experiments/r3_stamps.sh): where a wave's cycles go inside an item, summed over the launch
     // into words 24..31 of the counters (units of 1024 cycles): 0 waiting for the workgroup's slowest wave, 1 item fetch
     // (the global atomic), 2 statistics / seeds into LDS, 3 stage 0, 4 stage 1, 5 stage 2; 6 the longest workgroup lifetime, 7 the sum of the lifetimes / 16
     __shared__ unsigned int stamp_acc[8];
@@ -1218,11 +1220,16 @@ group_sums_kernel(const float* __restrict__ planar, const uint8_t* __restrict__ 
 // Whole-image statistics from the block statistics (see launch.hpp launch_image_stats): one WAVE per image -- lane b holds
 // block b, b + 64, ... (coalesced) --, written into the image's own slot `image_slot` of the same seven arrays.
 __global__ void __launch_bounds__(kBlock)
-image_stats_kernel(float* __restrict__ stats, size_t block_stride, int slots_per_image, int image_slot, int active_blocks, size_t n_images)
+image_stats_kernel(float* __restrict__ stats, size_t block_stride, int slots_per_image, int image_slot, int active_blocks, size_t n_images,
+                   const uint8_t* __restrict__ var_of_image, int4 blocks_of_var)
 {
     const int lane = threadIdx.x & 63;
     const size_t img = (size_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (img >= n_images) return;
+    if (var_of_image) {                 // a cell's statistics cover the blocks of ITS mask variant
+        const int v = var_of_image[img];
+        active_blocks = v == 0 ? blocks_of_var.x : v == 1 ? blocks_of_var.y : v == 2 ? blocks_of_var.z : blocks_of_var.w;
+    }
     float* st = stats + img * slots_per_image;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     float dev = 0.f, cmax = 0.f;
@@ -1761,20 +1768,28 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         return (unsigned)std::min<long long>(std::min<long long>(items, slots), by_start_cost);
     };
     auto persistent_grid = [&](const void* kern, long long items, int threads, size_t dyn_lds) -> unsigned {
-        // the occupancy query costs a fraction of a millisecond: asked once per (kernel, LDS size), not per launch
+        // the occupancy query costs a fraction of a millisecond: asked once per (kernel, LDS size, device) of the PROCESS, not
+        // per launch -- and not per thread either: the device group (group.hip) drives every engine from short-lived threads
         struct Known { const void* kern; size_t lds; int dev, slots; };
-        static thread_local Known known[8];
-        static thread_local int n_known = 0;
+        static Known known[64];
+        static int n_known = 0;
+        static std::mutex known_lock;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        for (int i = 0; i < n_known; ++i)
-            if (known[i].kern == kern && known[i].lds == dyn_lds && known[i].dev == dev)
-                return few(items, known[i].slots);
+        {
+            std::lock_guard<std::mutex> hold(known_lock);
+            for (int i = 0; i < n_known; ++i)
+                if (known[i].kern == kern && known[i].lds == dyn_lds && known[i].dev == dev)
+                    return few(items, known[i].slots);
+        }
         int cus = 256, per_cu = 4;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 4;
         (void)hipGetLastError();
-        if (n_known < 8) known[n_known++] = Known{kern, dyn_lds, dev, cus * per_cu * MM_GRID_MULT};
+        {
+            std::lock_guard<std::mutex> hold(known_lock);
+            if (n_known < 64) known[n_known++] = Known{kern, dyn_lds, dev, cus * per_cu * MM_GRID_MULT};
+        }
         return few(items, cus * per_cu * MM_GRID_MULT);
     };
     // groups visited by descending bound (the rest in plane order): all of them from 12 groups per cell on (cells of 33 .. 64
@@ -1928,11 +1943,11 @@ hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t ma
 }
 
 hipError_t launch_image_stats(float* stats, size_t block_stride, int slots_per_image, int image_slot, int active_blocks,
-                              size_t n_images, hipStream_t stream)
+                              size_t n_images, hipStream_t stream, const uint8_t* var_of_image, int4 blocks_of_var)
 {
     if (n_images == 0) return hipSuccess;
     image_stats_kernel<<<(unsigned)((n_images + kBlock / kWave - 1) / (kBlock / kWave)), kBlock, 0, stream>>>(stats, block_stride, slots_per_image, image_slot,
-                                                                                             active_blocks, n_images);
+                                                                                             active_blocks, n_images, var_of_image, blocks_of_var);
     return hipGetLastError();
 }
 

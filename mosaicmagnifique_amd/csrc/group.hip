@@ -49,6 +49,7 @@ struct Member {
     std::vector<double> score;
     std::vector<uint8_t> insufficient;
     mm_status status = MM_OK;
+    std::string own_error;       // a worker's text for a failure that is not the engine's (raw HIP call)
 };
 
 }  // namespace
@@ -109,6 +110,7 @@ bool on_all(mm_group* g, F&& fn)
     for (size_t i = 0; i < g->members.size(); ++i)
         threads.emplace_back([&, i] {
             Member& m = g->members[i];
+            m.own_error.clear();
             try { m.status = fn((int)i, m); }
             catch (...) { m.status = MM_OUT_OF_MEMORY; }      // (std::bad_alloc of a host vector: no exception leaves a worker)
         });
@@ -117,7 +119,7 @@ bool on_all(mm_group* g, F&& fn)
         const Member& m = g->members[i];
         if (m.status != MM_OK) {
             if (m.status != MM_CANCELLED && g->err.empty())
-                set_err(g, "device %d (member %zu): %s", m.device, i, mm_last_error(m.engine));
+                set_err(g, "device %d (member %zu): %s", m.device, i, m.own_error.empty() ? mm_last_error(m.engine) : m.own_error.c_str());
             return false;
         }
     }
@@ -368,7 +370,9 @@ mm_status mm_group_generate(mm_group* g, const mm_cell* cells, int n_cells, int 
         const Member& first = g->members[0];
         for (int i = 1; i < world; ++i) {
             const Member& m = g->members[(size_t)i];
+            // (the score grids bit for bit too: identical lists through identical kernels, NaN patterns of the empty cells included)
             if (memcmp(m.grid.data(), first.grid.data(), cells_total * sizeof(int64_t)) != 0 ||
+                memcmp(m.score.data(), first.score.data(), cells_total * sizeof(double)) != 0 ||
                 (speculate && memcmp(m.insufficient.data(), first.insufficient.data(), (size_t)n_cells) != 0)) {
                 set_err(g, "devices %d and %d resolved the same lists differently: inputs or engines differ", first.device, m.device);
                 return MM_DEVICE_ERROR;
@@ -398,12 +402,19 @@ mm_status mm_group_generate(mm_group* g, const mm_cell* cells, int n_cells, int 
                 const mm_status st = mm_score_cells_partial(m.engine, sub.data(), (int)sub.size(), diff_type, K, K, si.data(), ss.data(), 0,
                                                             nullptr, nullptr, cancel);
                 if (st != MM_OK) return st;
-                if (hipSetDevice(m.device) != hipSuccess) return MM_DEVICE_ERROR;
-                for (size_t r = 0; r < mine.size(); ++r) {
+                // (a raw HIP failure here is not the engine's: the worker leaves its own text, on_all reports it)
+                hipError_t code = hipSetDevice(m.device);
+                for (size_t r = 0; code == hipSuccess && r < mine.size(); ++r) {
                     const size_t row = (size_t)(mine[r] - lo);
-                    if (hipMemcpy((int32_t*)m.send + row * K, si.data() + r * K, (size_t)K * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                        hipMemcpy((double*)((char*)m.send + s_off) + row * K, ss.data() + r * K, (size_t)K * 8, hipMemcpyHostToDevice) != hipSuccess)
-                        return MM_DEVICE_ERROR;
+                    code = hipMemcpyAsync((int32_t*)m.send + row * K, si.data() + r * K, (size_t)K * 4, hipMemcpyHostToDevice, m.stream);
+                    if (code == hipSuccess)
+                        code = hipMemcpyAsync((double*)((char*)m.send + s_off) + row * K, ss.data() + r * K, (size_t)K * 8, hipMemcpyHostToDevice, m.stream);
+                }
+                if (code == hipSuccess) code = hipStreamSynchronize(m.stream);      // si / ss go out of scope
+                if (code != hipSuccess) {
+                    m.own_error = std::string("Error copying deepened lists to device: ") + hipGetErrorName(code);
+                    (void)hipGetLastError();
+                    return MM_DEVICE_ERROR;
                 }
                 return MM_OK;
             }))

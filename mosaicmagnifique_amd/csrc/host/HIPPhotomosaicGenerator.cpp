@@ -423,36 +423,54 @@ FlipState getFlipStateAt(const CellShape& s, int x, int y)         // GridUtilit
     return f;
 }
 
-void mergeBounds(std::vector<Rect>& b)
+// The active bounds of a size step as what findCellState needs of them (GridGenerator.cpp:124-140): "does this cell rect
+// share positive area with ANY bound?"  That depends on the UNION of the bounds alone, and the reference's
+// GridBounds::mergeBounds (Grid/GridBounds.cpp:36-107) only ever replaces two rects by their union when that union is
+// itself the same point set -- so the list is never merged here at all: the bounds are rasterised once on the grid their
+// own edges span (coordinate compression, coverage marks, a summed-area table) and a query is four look-ups.
+// (grid.py _meets_any_bound is the same construction; tests/test_grid_steps.py holds it to the merged list.)
+BoundsUnion::BoundsUnion(const std::vector<Rect>& bounds)
 {
-    auto unite = [](const Rect& p, const Rect& q) {
-        const int x0 = std::min(p.x, q.x), y0 = std::min(p.y, q.y);
-        const int x1 = std::max(p.x + p.width, q.x + q.width), y1 = std::max(p.y + p.height, q.y + q.height);
-        return Rect{x0, y0, x1 - x0, y1 - y0};
-    };
-    auto same = [](const Rect& p, const Rect& q) { return p.x == q.x && p.y == q.y && p.width == q.width && p.height == q.height; };
-    bool boundWasMerged = true;
-    while (boundWasMerged) {
-        boundWasMerged = false;
-        for (size_t i = 0; i + 1 < b.size();) {
-            for (size_t j = i + 1; j < b.size() && i + 1 < b.size();) {
-                bool merge = false;
-                if (b[i].x == b[j].x && b[i].width == b[j].width) {
-                    const int d = b[j].y - b[i].y;
-                    merge = d == 0 || (d > 0 && d <= b[i].height) || (d < 0 && -d <= b[j].height);
-                } else if (b[i].y == b[j].y && b[i].height == b[j].height) {
-                    const int d = b[j].x - b[i].x;
-                    merge = d == 0 || (d > 0 && d <= b[i].width) || (d < 0 && -d <= b[j].width);
-                } else {
-                    const Rect u = unite(b[i], b[j]);
-                    merge = same(u, b[i]) || same(u, b[j]);
-                }
-                if (merge) { b[i] = unite(b[i], b[j]); b.erase(b.begin() + (long)j); boundWasMerged = true; }
-                else ++j;
-            }
-            if (i + 1 < b.size()) ++i; else break;
-        }
+    for (const Rect& r : bounds) {
+        if (r.width <= 0 || r.height <= 0) continue;
+        m_xs.push_back(r.x); m_xs.push_back(r.x + r.width);
+        m_ys.push_back(r.y); m_ys.push_back(r.y + r.height);
     }
+    auto distinct = [](std::vector<int>& v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
+    distinct(m_xs);
+    distinct(m_ys);
+    if (m_xs.size() < 2 || m_ys.size() < 2) { m_xs.clear(); m_ys.clear(); return; }
+    const size_t nx = m_xs.size() - 1, ny = m_ys.size() - 1;
+    std::vector<uint8_t> covered(nx * ny, 0);
+    auto slot = [](const std::vector<int>& v, int c) { return (size_t)(std::lower_bound(v.begin(), v.end(), c) - v.begin()); };
+    for (const Rect& r : bounds) {
+        if (r.width <= 0 || r.height <= 0) continue;
+        const size_t i0 = slot(m_xs, r.x), i1 = slot(m_xs, r.x + r.width), j0 = slot(m_ys, r.y), j1 = slot(m_ys, r.y + r.height);
+        for (size_t j = j0; j < j1; ++j) std::fill(covered.begin() + (long)(j * nx + i0), covered.begin() + (long)(j * nx + i1), 1);
+    }
+    m_area.assign((nx + 1) * (ny + 1), 0);             // covered elementary boxes above and to the left of (j, i)
+    for (size_t j = 0; j < ny; ++j)
+        for (size_t i = 0; i < nx; ++i)
+            m_area[(j + 1) * (nx + 1) + i + 1] = covered[j * nx + i] + m_area[j * (nx + 1) + i + 1] +
+                                                 m_area[(j + 1) * (nx + 1) + i] - m_area[j * (nx + 1) + i];
+}
+
+bool BoundsUnion::meets(const Rect& q) const
+{
+    if (m_xs.empty() || q.width <= 0 || q.height <= 0) return false;
+    const size_t nx = m_xs.size() - 1, ny = m_ys.size() - 1;
+    // elementary boxes [first, last) that overlap the open interval (lo, hi) with positive length
+    auto span = [](const std::vector<int>& v, int lo, int hi, size_t n, size_t& first, size_t& last) {
+        const long a = (std::upper_bound(v.begin(), v.end(), lo) - v.begin()) - 1;       // last edge <= lo
+        const long b = std::lower_bound(v.begin(), v.end(), hi) - v.begin();             // first edge >= hi
+        first = (size_t)std::clamp<long>(a, 0, (long)n);
+        last = std::max(first, (size_t)std::clamp<long>(b, 0, (long)n));
+    };
+    size_t i0, i1, j0, j1;
+    span(m_xs, q.x, q.x + q.width, nx, i0, i1);
+    span(m_ys, q.y, q.y + q.height, ny, j0, j1);
+    const size_t w = nx + 1;
+    return m_area[j1 * w + i1] - m_area[j0 * w + i1] - m_area[j1 * w + i0] + m_area[j0 * w + i0] > 0;
 }
 
 // The local bound at the detail size (PhotomosaicGeneratorBase.cpp:318-326 = GridGenerator.cpp:156-170).
@@ -467,16 +485,10 @@ Rect detailBound(const Rect& local, double detail, int size)
 
 // GridGenerator::findCellState (GridGenerator.cpp:113-193)
 static std::pair<CellBestFit, bool> findCellState(const CellGroup& cells, const Image8* mainImage, int x, int y,
-                                                  const std::vector<Rect>& bounds, size_t step)
+                                                  const BoundsUnion& bounds, size_t step)
 {
     const Rect g = getRectAt(cells.getCell(step), x, y);
-    bool inBounds = false;
-    for (const Rect& it : bounds) {
-        const int yStart = std::clamp(g.y, it.y, it.y + it.height), yEnd = std::clamp(g.y + g.height, it.y, it.y + it.height);
-        const int xStart = std::clamp(g.x, it.x, it.x + it.width), xEnd = std::clamp(g.x + g.width, it.x, it.x + it.width);
-        if (yStart != yEnd && xStart != xEnd) { inBounds = true; break; }
-    }
-    if (!inBounds) return {std::nullopt, false};
+    if (!bounds.meets(g)) return {std::nullopt, false};             // GridGenerator.cpp:124-140
     if (mainImage && step < cells.getSizeSteps()) {
         const int yStart = std::clamp(g.y, 0, mainImage->rows), yEnd = std::clamp(g.y + g.height, 0, mainImage->rows);
         const int xStart = std::clamp(g.x, 0, mainImage->cols), xEnd = std::clamp(g.x + g.width, 0, mainImage->cols);
@@ -508,9 +520,10 @@ MosaicBestFit getGridState(const CellGroup& cells, const Image8* mainImage, int 
         const Point g = calculateGridSize(cells.getCell(step), gridWidth, gridHeight, PAD_GRID);
         gridState.emplace_back((size_t)g.y, std::vector<CellBestFit>((size_t)g.x));
         bounds[!active].clear();
+        const BoundsUnion inside(bounds[active]);           // (unmerged: the in-bounds test reads their union only)
         for (int y = -PAD_GRID; y < g.y - PAD_GRID; ++y)
             for (int x = -PAD_GRID; x < g.x - PAD_GRID; ++x) {
-                const auto [bestFit, entropy] = findCellState(cells, mainImage, x, y, bounds[active], step);
+                const auto [bestFit, entropy] = findCellState(cells, mainImage, x, y, inside, step);
                 gridState[step][(size_t)(y + PAD_GRID)][(size_t)(x + PAD_GRID)] = bestFit;
                 if (!entropy) continue;
                 const Rect r = getRectAt(cells.getCell(step), x, y);
@@ -520,7 +533,6 @@ MosaicBestFit getGridState(const CellGroup& cells, const Image8* mainImage, int 
                 bounds[!active].push_back(Rect{x0, y0, x1 - x0, y1 - y0});
             }
         active = !active;
-        if (!bounds[active].empty()) mergeBounds(bounds[active]);
     }
     return gridState;
 }

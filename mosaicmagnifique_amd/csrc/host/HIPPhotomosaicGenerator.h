@@ -131,8 +131,18 @@ Rect getRectAt(const CellShape& cellShape, int x, int y);
 FlipState getFlipStateAt(const CellShape& cellShape, int x, int y);
 // The local bound of a cell at the detail size (PhotomosaicGeneratorBase.cpp:318-326).
 Rect detailBound(const Rect& local, double detail, int size);
-// GridBounds::mergeBounds (Grid/GridBounds.cpp:36-107).
-void mergeBounds(std::vector<Rect>& bounds);
+// The active bounds of a size step, kept as their UNION: all findCellState asks of them is whether a cell rect shares
+// positive area with any bound (GridGenerator.cpp:124-140), and the reference's GridBounds::mergeBounds
+// (Grid/GridBounds.cpp:36-107) never changes that union -- so nothing is merged: coordinate compression + a summed-area
+// table of the covered boxes, four look-ups per query.
+class BoundsUnion {
+public:
+    explicit BoundsUnion(const std::vector<Rect>& bounds);
+    bool meets(const Rect& cellRect) const;
+private:
+    std::vector<int> m_xs, m_ys;          // distinct edge coordinates
+    std::vector<int> m_area;              // [(ys - 1) + 1][(xs - 1) + 1] summed-area table of covered elementary boxes
+};
 // GridGenerator::getGridState (Grid/GridGenerator.cpp:29-193).  mainImage (u8 BGR, may be null)
 // drives the entropy subdivision over size steps; without it every cell meeting the image is valid.
 MosaicBestFit getGridState(const CellGroup& cells, const Image8* mainImage, int imageRows, int imageCols);

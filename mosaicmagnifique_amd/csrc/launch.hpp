@@ -91,8 +91,11 @@ hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t ma
 // Whole-image statistics from the block statistics, written into each image's slot ppad / 64 of the same arrays: sums added
 // up (in fp64), maxima taken, the hue arcs of the first `active_blocks` blocks joined into one arc around the direction of
 // the image's summed (a, b) (the whole circle if a block's arc is open or reaches further than 170 deg from that direction).
+// var_of_image (may be null): the mask variant of every image (cells of a batch differ in theirs); the blocks joined are then
+// blocks_of_var[variant] instead of `active_blocks` -- four masks need not hold the same number of active pixels.
 hipError_t launch_image_stats(float* stats, size_t block_stride, int slots_per_image, int image_slot, int active_blocks,
-                              size_t n_images, hipStream_t stream);
+                              size_t n_images, hipStream_t stream, const uint8_t* var_of_image = nullptr,
+                              int4 blocks_of_var = make_int4(0, 0, 0, 0));
 
 // Candidate-fastest copy of the three channel sums (statistics 0, 2, 3) of n images: out [3][n_blocks][n_images].
 hipError_t launch_transpose_stats(const float* stats, size_t block_stride, int slots_per_image, int n_blocks, float* out,

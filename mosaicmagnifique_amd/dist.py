@@ -76,6 +76,11 @@ class ShardedBestFit:
     def __init__(self, engine, rank, world, group=None):
         self.engine, self.rank, self.world, self.group = engine, rank, world, group
         self._bufs = None
+        self.reset_phases()
+
+    def reset_phases(self):
+        """Zero the per-phase wall clocks of generate() (ms, this rank; `rounds` = resolve passes)."""
+        self.phase_ms = {"score": 0.0, "allgather": 0.0, "resolve": 0.0, "deepen": 0.0, "rounds": 0}
 
     def _buffers(self, per, k):
         import torch
@@ -120,8 +125,14 @@ class ShardedBestFit:
         all-gather, a verifying resolve on every rank (identical verdicts everywhere), then
         each rank deepens the unverified cells of its own block and the lists are gathered
         and resolved again, until no cell is left unverified."""
+        import time
+
         import torch
         n = len(cells)
+        # host wall time of this rank's phases, summed over the calls since reset_phases(): the engine calls block, and
+        # the collective is followed by a synchronize -- so these are what the step is made of on THIS rank
+        ph = self.phase_ms
+        clock = time.perf_counter
         if spec_k is None:                      # the engine's own option, as mm_generate honours it
             spec_k = getattr(self.engine, "options", {}).get("spec_k", 4)
         k = self.engine.candidates_per_cell(repeat_range, repeat_addition)
@@ -135,17 +146,24 @@ class ShardedBestFit:
             score[hi - lo:] = float("inf")
             if idx.device.type == "cuda":
                 torch.cuda.synchronize(idx.device)
+        t0 = clock()
         if hi > lo:
             self.engine.score_cells(cells[lo:hi], diff_type, k, out_index=idx.data_ptr(),
                                     out_score=score.data_ptr(), on_device=True, k_fill=ks)
+        ph["score"] += (clock() - t0) * 1e3
         deep = np.zeros(n, dtype=np.uint8) if speculate else None
         while True:
+            t0 = clock()
             idx_all, score_all = allgather_candidates(idx[:per], score[:per], n, self.world, self.group,
                                                       packed=packed if per >= 1 else None)
             if idx.device.type == "cuda":
                 torch.cuda.synchronize(idx.device)  # the engine runs on its own stream
+            t1 = clock()
+            ph["allgather"] += (t1 - t0) * 1e3      # includes the wait for the slowest rank's lists
             out = self.engine.resolve(cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, k,
                                       idx_all.data_ptr(), score_all.data_ptr(), on_device=True, deep=deep, k_fill=ks)
+            ph["resolve"] += (clock() - t1) * 1e3
+            ph["rounds"] += 1
             if not speculate:
                 return out
             best, best_score, insufficient = out
@@ -154,6 +172,7 @@ class ShardedBestFit:
             if len(todo) == 0:
                 return best, best_score
             deep[todo] = 1
+            t0 = clock()
             mine = todo[(todo >= lo) & (todo < hi)]
             if len(mine):                           # deepen this rank's own unverified cells
                 di = torch.empty((len(mine), k), dtype=torch.int32, device=idx.device)
@@ -163,6 +182,7 @@ class ShardedBestFit:
                 rows = torch.as_tensor(mine - lo, device=idx.device)
                 idx[rows] = di
                 score[rows] = ds
+            ph["deepen"] += (clock() - t0) * 1e3
 
 
 def merge_on_host(shards, n_cells):

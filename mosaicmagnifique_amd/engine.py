@@ -286,6 +286,12 @@ class Engine:
     def timing(self):
         return self.timing_raw().as_dict()
 
+    def stage_timing(self):
+        """mm_get_stage_timing: host wall clocks of everything that is not the hot path, since the engine was created."""
+        t = _lib.MMStageTiming()
+        self._check(self._lib.mm_get_stage_timing(self._h, ctypes.byref(t)))
+        return t.as_dict()
+
     def timing_raw(self):
         """mm_get_timing as the ctypes struct (cheap enough to call after every step of a timed loop)."""
         t = _lib.MMTiming()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies what tests/tools_profile.sh left under gpurun_out/<tag>/ into profiles/ as <tag>_*: the PMC record
+"""Copies what tools/profile.sh left under gpurun_out/<tag>/ into profiles/ as <tag>_*: the PMC record
 (pmc_traffic.json), the kernel-trace summary, the PMC dumps of configs D / C / B trimmed to the engine's own
 kernels, the bench lines of every configuration and the filter's resource-usage remarks.
 usage: python profiles/collect.py r02_v17"""

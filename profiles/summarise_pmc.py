@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 passes of tests/tools_profile.sh (all of the SAME command,
+"""Turns the rocprofv3 passes of tools/profile.sh (all of the SAME command,
 `python3 bench.py --config X --steps 1 --warmup 1 --no-cpu` (a warm-up step first: the item size of a CIEDE2000
 launch can follow the engine's previous launch, so the counted launches are steady-state ones), separate runs as the MI355X guide
 prescribes: --pmc FETCH_SIZE, --pmc WRITE_SIZE, --pmc SQ_*) into the per-launch record of the

@@ -36,7 +36,8 @@ def _suite_engine_options():
     """Engines of the suite run with the events between the phases on and the seeds / early exit at ANY job size
     (defaults: both only above a work threshold, because they cost a small job more than they give): most scenarios
     here are small, and the tests read phase times and work counters to see WHICH path ran.  The defaults themselves
-    are exercised by tests/test_gpu_small_jobs.py and the option matrix of tests/test_gpu_fuzz.py."""
+    are exercised by tests/test_gpu_small_jobs.py, the option matrix of tests/test_gpu_fuzz.py and the
+    "shipped_defaults" leg of the COMPARE matrix (tests/test_gpu_generator.py)."""
     try:
         from mosaicmagnifique_amd import engine as E
     except Exception:

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared_symbols():
         assert hasattr(lib, name), "missing export %s" % name
     lib.mm_abi_version.restype = ctypes.c_int
-    assert lib.mm_abi_version() == 2
+    assert lib.mm_abi_version() == 3
 
 
 def test_the_collective_is_linked_behind_the_c_abi(built):
@@ -62,6 +62,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.MMCell) == 36 == CELL_DTYPE.itemsize
     assert [n for n, _ in _lib.MMCell._fields_] == list(CELL_DTYPE.names)
     assert ctypes.sizeof(_lib.MMTiming) == 200
+    assert ctypes.sizeof(_lib.MMStageTiming) == 72          # six clocks (f64) + three counters (i64)
 
 
 def test_product_never_touches_the_oracle():

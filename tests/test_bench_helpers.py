@@ -64,3 +64,36 @@ def test_weak_bands_stack_the_single_gpu_grid():
     assert len(w3["cells"]) == 3 * len(w1["cells"]) and w3["grid_w"] == w1["grid_w"]
     assert w3["grid_h"] == 3 * (w1["grid_h"] - G.PAD_GRID) + G.PAD_GRID
     assert np.array_equal(w3["cells"]["y"][:len(w1["cells"])], w1["cells"]["y"])
+
+
+def test_gpus_n_without_a_launcher_starts_the_ranks_itself(monkeypatch):
+    """`python3 bench.py --gpus N` as the driver runs it (no WORLD_SIZE around it): the ranks are started as a CHILD
+    `python -m torch.distributed.run` (never an exec, nothing of this process has touched the GPU), rendezvous on
+    127.0.0.1, and rank 0's one JSON line is passed on; the launcher's failure is this process's failure."""
+    import subprocess
+    import sys
+    import types
+
+    import pytest
+
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["env"] = cmd, kw["env"]
+        return types.SimpleNamespace(returncode=seen.get("rc", 0), stdout="NCCL banner\n{\"metric\": \"m\", \"n_gpus\": 2}\n")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("MOSAIC_BENCH_REHEARSAL", "1")          # (no device count needed on this box)
+    out = []
+    bench.launch_ranks(2, out.append, argv=["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert out == ['{"metric": "m", "n_gpus": 2}']
+    seen["rc"] = 3
+    with pytest.raises(SystemExit) as err:
+        bench.launch_ranks(2, out.append, argv=["--gpus", "2"])
+    assert err.value.code == 3

@@ -89,3 +89,23 @@ def test_strong_shards_of_the_reduced_config_e(n):
     out = run_ranks(n, "--config", "Es")           # E-shaped configs default to strong scaling
     assert out["config"]["cells"] == single["config"]["cells"] == 441
     assert out["result_digest"] == single["result_digest"]
+
+
+@pytest.mark.gpu
+def test_plain_gpus_2_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher around it -- the form the driver uses for N = 1 -- starts the two
+    ranks itself as a child torch.distributed.run, exits 0 with rank 0's single JSON line, and (rehearsal: both ranks on
+    GPU 0 over gloo) reproduces the digest of the one-GPU run of the same two-band mosaic."""
+    single = run_single("--config", "B", "--bands", "2")
+    env = dict(os.environ, MOSAIC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "B"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = last_json(p.stdout)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["cells"] == 2 * 1024
+    assert out["result_digest"] == single["result_digest"]
+    # the phases of the sharded step, per-rank maxima: what makes the first hardware curve diagnosable
+    ph = out["dist_phase_ms"]
+    assert set(ph) >= {"score", "allgather", "resolve", "deepen"} and ph["score"] > 0 and ph["resolve"] > 0

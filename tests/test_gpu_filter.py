@@ -88,6 +88,69 @@ def test_ciede2000_filter_band_structured_sweep(engine):
     assert r["handed_over"] > 0 and r["measured"] > 5e8    # both: pairs inside the hand-over zone and just outside it
 
 
+def band_share(engine, a, b):
+    """|fp32 filter form - fp64 form| as a share of the band the engine trusts (engine.hip filter_band: 1e-3 + 6e-5 * value);
+    pairs the filter hands to the fp64 form count as 0."""
+    exact = engine.colour_diff_batch(2, a, b)
+    fast = engine.filter_diff_batch(2, a, b).astype(np.float64)
+    share = np.abs(fast - exact) / (1e-3 + 6e-5 * exact)
+    share[fast < 0] = 0.0
+    assert np.isfinite(fast).all()
+    return share, exact
+
+
+@pytest.mark.parametrize("prepared", [0, 1])
+def test_ciede2000_filter_band_adversarial_maximiser(engine, prepared):
+    """Random and structured sweeps find the TYPICAL worst error; this one climbs: 2^17 pairs of f32 Lab colours -- seeded
+    on the families where the fp32 form is weakest (near-grey with either operand, saturated blue where R_T peaks, both
+    sides of the opposite-hue seam, near-identical colours, the corners of the Lab box) -- are mutated over 80 generations
+    (both operands or one, one coordinate or all, steps from 30 units down to single ulps; the better of parent and child
+    survives, every eighth generation the weaker half is replaced by copies of the stronger half) to MAXIMISE
+    |fp32 - fp64| / band.  The worst pair it finds must stay below half of the trusted band, in both operand forms."""
+    rng = np.random.default_rng(17 + prepared)
+    n = 1 << 17
+    lo, hi = LO.astype(np.float32), HI.astype(np.float32)
+    fams = [(a.astype(np.float32), b.astype(np.float32)) for _, a, b in lab_sets(rng, n // 8)]
+    pick = rng.permutation(len(fams))[:8]
+    a = np.concatenate([fams[k][0] for k in pick])[:n]
+    b = np.concatenate([fams[k][1] for k in pick])[:n]
+    corners = rng.integers(0, 2, (n // 16, 3))
+    a[: n // 16] = np.where(corners, hi, lo)
+    a, b = np.clip(a, lo, hi), np.clip(b, lo, hi)
+    engine.set_option("probe_prepared", prepared)
+    try:
+        best, _ = band_share(engine, a, b)
+        start = best.max()
+        for gen in range(80):
+            ca, cb = a.copy(), b.copy()
+            scale = (10.0 ** rng.uniform(-6, 1.5, (n, 1))).astype(np.float32)
+            which = rng.integers(0, 3, (n, 1))                     # 0: first operand, 1: second, 2: both
+            coord = rng.uniform(size=(n, 3)) < rng.uniform(0.34, 1.0, (n, 1))
+            ulps = rng.uniform(size=n) < 0.15                      # single-ulp moves (rounding boundaries of the fp32 form)
+            da = (rng.normal(0, 1, (n, 3)).astype(np.float32) * scale) * coord * (which != 1)
+            db = (rng.normal(0, 1, (n, 3)).astype(np.float32) * scale) * coord * (which != 0)
+            ca += da; cb += db
+            step = rng.integers(-2, 3, (n, 3)).astype(np.float32)
+            ca[ulps] = np.nextafter(a[ulps], a[ulps] + step[ulps] * np.float32(1e3))       # one ulp towards sign(step)
+            cb[ulps] = b[ulps]
+            ca, cb = np.clip(ca, lo, hi), np.clip(cb, lo, hi)
+            child, _ = band_share(engine, ca, cb)
+            better = child > best
+            a[better], b[better], best[better] = ca[better], cb[better], child[better]
+            if gen % 8 == 7:                                       # selection: the stronger half breeds
+                order = np.argsort(best)
+                weak, strong = order[: n // 2], order[n // 2:]
+                a[weak], b[weak], best[weak] = a[strong], b[strong], best[strong]
+        worst = int(np.argmax(best))
+        share, exact = band_share(engine, a[worst:worst + 1], b[worst:worst + 1])
+        print("adversarial maximiser (prepared=%d): band share %.3f -> %.3f; worst pair %s vs %s, dE00 %.6f"
+              % (prepared, start, best.max(), a[worst].tolist(), b[worst].tolist(), exact[0]))
+        assert best.max() >= start                                 # it climbed (or started at its summit)
+        assert best.max() < 0.5, (a[worst].tolist(), b[worst].tolist(), float(best.max()))
+    finally:
+        engine.set_option("probe_prepared", 0)
+
+
 def test_band_guard_is_silent_on_honest_content_and_loud_on_a_broken_band(oracle, engine):
     """The run-time guard of the band: on sampled cells the best candidate the band EXCLUDED rides along
     as a sentinel and is re-scored in fp64; it must never beat a contender (mm_timing.band_alarms stays 0,
@@ -105,7 +168,7 @@ def test_band_guard_is_silent_on_honest_content_and_loud_on_a_broken_band(oracle
     state = G.getGridState(group, img.shape[0], img.shape[1])[0]
     cells = G.cell_records(group, state, img.shape[0], img.shape[1])
     try:
-        engine.set_option("band_guard", 1)               # every cell carries a sentinel
+        engine.set_option("band_guard", 1)               # every cell carries a sentinel (the default since round 4)
         tm = run_both(oracle, engine, shape, img, lib, t, rep=(2, 300))
         assert tm["band_alarms"] == 0 and tm["dense_cells"] == 0
         tm = run_both(oracle, engine, shape, img, lib2, t)
@@ -118,7 +181,7 @@ def test_band_guard_is_silent_on_honest_content_and_loud_on_a_broken_band(oracle
     finally:
         engine.set_option("band_pct", 100)
         engine.set_option("prune", 1)
-        engine.set_option("band_guard", 64)
+        engine.set_option("band_guard", 1)
 
 
 def test_euclid_filter_error_is_inside_the_band(engine):
@@ -133,11 +196,12 @@ def test_euclid_filter_error_is_inside_the_band(engine):
     assert err.max() <= 1e-4
 
 
-def run_both(oracle, engine, shape, img, lib, t, rep=(0, 0)):
+def run_both(oracle, engine, shape, img, lib, t, rep=(0, 0), masks=None):
     group = cases.group_of(shape)
     state = G.getGridState(group, img.shape[0], img.shape[1])[0]
     cells = G.cell_records(group, state, img.shape[0], img.shape[1])
-    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    masks = shape.masks4() if masks is None else masks
+    engine.set_library(lib); engine.set_masks(masks); engine.set_target(img)
     engine.set_option("filter", 1)
     engine.set_option("prune", 0)
     bestn, scoren = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
@@ -153,11 +217,35 @@ def run_both(oracle, engine, shape, img, lib, t, rep=(0, 0)):
     engine.set_option("filter", 0)
     best0, score0 = engine.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
     engine.set_option("filter", 1)
-    want, _, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), *rep)
+    want, _, _ = oracle.generate_best_fits(shape_of(shape), img, lib, masks, int(t), *rep)
     assert np.array_equal(best, best0)
     assert np.array_equal(score[state >= 0], score0[state >= 0])       # bit-identical across the two paths
     assert np.array_equal(np.where(best == len(lib), -1, best), want)
     return tm
+
+
+@pytest.mark.parametrize("first", [0, 1, 2, 3])
+def test_four_masks_of_different_areas_keep_the_whole_image_bound_sound(oracle, engine, first):
+    """The C ABI takes ANY four masks (mm_set_masks), not only the four flips of one shape: here they hold 1 / 8, 1 / 2,
+    3 / 4 and all of the cell's pixels, rotated so that each of them is variant 0 once.  Stage 0 of the filter's bound
+    compares whole-image statistics of a cell and of a library image over the blocks of the CELL'S variant -- computed
+    over variant 0's block count for every cell (round 3) a cell of a larger variant got a partial sum on one side
+    and the bound could drop the true best fit.  Pruned (stage 0 on and off) == unpruned == fp64-only == oracle."""
+    size = 64
+    shape = cases.flippy_shape(size)                      # all four flip states occur in its grid
+    yy, xx = np.mgrid[0:size, 0:size]
+    four = [np.where((xx < 16) & (yy < 32), 255, 0), np.where(xx <= yy, 255, 0),
+            np.where((xx < 48) | (yy < 16), 255, 0), np.full((size, size), 255)]
+    masks = np.stack([four[(k + first) % 4] for k in range(4)]).astype(np.uint8)
+    assert len({int((m != 0).sum()) for m in masks}) == 4
+    img, lib = cases.inputs(5 * size, 6 * size, size, 160, Type.CIEDE2000, lattice=size)
+    for stage0 in (1, 0):
+        engine.set_option("stage0", stage0)
+        try:
+            tm = run_both(oracle, engine, shape, img, lib, Type.CIEDE2000, rep=(1, 400), masks=masks)
+        finally:
+            engine.set_option("stage0", 1)
+        assert tm["seed_ms"] > 0 and tm["band_alarms"] == 0
 
 
 def opposite_hue_inputs(rng, size, n_lib, rows, cols, jitter):

@@ -65,7 +65,12 @@ def compare(oracle, shape, img, lib, t, rep=(0, 0), use_filter=1, wave_resolve="
     return gen
 
 
-@pytest.mark.parametrize("use_filter", [1, 0], ids=["two_tier", "fp64_only"])
+# the engine as it SHIPS: no events between the phases of a small job, seeds / early exit only above the work threshold
+# (tests/conftest.py turns both on for the suite's engines so that the tests can read which path ran)
+SHIPPED_DEFAULTS = (("phase_timing", -1), ("prune_min_kpairs", -1))
+
+
+@pytest.mark.parametrize("use_filter", [1, 0, "defaults"], ids=["two_tier", "fp64_only", "shipped_defaults"])
 @pytest.mark.parametrize("rep", [(0, 0), (2, 300), (20, 10000)], ids=["norepeat", "repeat2", "repeat20"])
 @pytest.mark.parametrize("shape_name", SHAPES)
 @pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIE76, Type.CIEDE2000])
@@ -73,12 +78,17 @@ def test_compare_matrix(oracle, t, shape_name, rep, use_filter):
     """COMPARE_{RGB_EUCLIDEAN,CIE76,CIEDE2000} x {square, Hexagon, flipped/offset}
     x {no repeats, repeats, the reference's (20, 10000) repeats case}.  Ragged image
     sizes so the last row / column of cells (and the x=-1 / y=-1 cells of offset
-    shapes) are clipped."""
+    shapes) are clipped.  Each on the suite's engine options (every phase forced on), on the fp64-only path and on
+    the options the engine ships with (what a small production job actually runs)."""
     shape = SHAPES[shape_name]()
     size = shape.getSize()
     rows, cols = 5 * size + size // 3, 6 * size + size // 2
     n_lib = 64 if size >= 64 else 150
     img, lib = cases.inputs(rows, cols, size, n_lib, t, lattice=2 * size)
+    if use_filter == "defaults":
+        gen = compare(oracle, shape, img, lib, t, rep, 1, options=SHIPPED_DEFAULTS)
+        assert gen.timing()["band_alarms"] == 0
+        return
     gen = compare(oracle, shape, img, lib, t, rep, use_filter)
     tm = gen.timing()
     assert (tm["rescore_ms"] > 0) == bool(use_filter and gen.m_engine.speculative_candidates(*rep) < n_lib)

@@ -3,7 +3,7 @@ filter cascade with (cur) today's block bound, (v1) + a rigorous hue term from t
 (v2) + the unattainable ideal: the true sum of dH' of the block pair."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 sys.argv = ['x']
 import oracle_ffi
 from test_filter_bound import rotation_bound, sqrt_ratio7, hue_arcs, wrap180

@@ -3,13 +3,13 @@ bench configuration: how many 256-pixel groups each candidate visits before it i
   (a) the v11 kernel: partial sums of the full fp32 dE00 + block bound of the unvisited groups;
   (b) per-pixel lower bound with the BLOCK's worst constants + the same block bound of the rest;
   (c) the same with S_C taken per pixel pair (chroma planes).
-Not a test: a design tool (python tests/tools_bound_sim.py [config] [n_cells])."""
+Not a test: a design tool (python tools/bound_sim.py [config] [n_cells])."""
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import oracle_ffi  # noqa: E402
 from test_filter_bound import rotation_bound, sqrt_ratio7  # noqa: E402

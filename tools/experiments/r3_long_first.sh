@@ -2,7 +2,7 @@
 # candidate's block bound puts it in the first class; 0 = one class, the order of round 2).  Variants built on the box.
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03_long_first.txt; : > $O
-for v in 0.0f 0.55f 0.8f 0.9f; do bash tests/tools_build_variant.sh ls_$v -DMM_LONG_SPLIT=$v > /dev/null 2>&1; done
+for v in 0.0f 0.55f 0.8f 0.9f; do bash tools/build_variant.sh ls_$v -DMM_LONG_SPLIT=$v > /dev/null 2>&1; done
 for round in 1 2; do
 for v in default 0.0f 0.55f 0.8f 0.9f; do
   if [ $v = default ]; then unset MOSAIC_HIP_LIB; else export MOSAIC_HIP_LIB=$PWD/gpurun_out/ls_$v.so; fi

@@ -1,6 +1,6 @@
 # Round 3: how many workgroups a small launch should start (filter_lds_kernel's cap; filter_kernel's rule is in launch_filter).
 cd $GRAFT_REPO_ROOT
-for m in 512 256 1024; do bash tests/tools_build_variant.sh cap$m -DMM_LDS_GRID_CAP=$m > /dev/null 2>&1; done
+for m in 512 256 1024; do bash tools/build_variant.sh cap$m -DMM_LDS_GRID_CAP=$m > /dev/null 2>&1; done
 for round in 1 2; do
 for v in default cap1024 cap512 cap256; do
   if [ $v = default ]; then unset MOSAIC_HIP_LIB; else export MOSAIC_HIP_LIB=$PWD/gpurun_out/$v.so; fi

@@ -1,6 +1,6 @@
 # Round 3: workgroups of seed_score_kernel (grid-stride; 3 waves per SIMD = 768 resident workgroups) -- cap 8192 against fewer.
 cd $GRAFT_REPO_ROOT
-for m in 768 1536 3072; do bash tests/tools_build_variant.sh sg$m -DMM_SEED_GRID_CAP=$m > /dev/null 2>&1; done
+for m in 768 1536 3072; do bash tools/build_variant.sh sg$m -DMM_SEED_GRID_CAP=$m > /dev/null 2>&1; done
 for round in 1 2; do
 for v in default sg768 sg1536 sg3072; do
   if [ $v = default ]; then unset MOSAIC_HIP_LIB; else export MOSAIC_HIP_LIB=$PWD/gpurun_out/$v.so; fi

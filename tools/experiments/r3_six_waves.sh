@@ -1,8 +1,8 @@
 # Round 3: six waves per SIMD for filter_kernel (80 VGPRs; needs the cell statistics in LDS cut to the 64 blocks of cells up to
 # 64 x 64 so that six workgroups share a CU's LDS), A/B against the default five, in one call.
 cd $GRAFT_REPO_ROOT
-bash tests/tools_build_variant.sh w6 -DMM_FILTER_WAVES=6 -DMM_STAT_BLOCKS=64 > /dev/null 2>&1
-bash tests/tools_build_variant.sh w5s -DMM_STAT_BLOCKS=64 > /dev/null 2>&1
+bash tools/build_variant.sh w6 -DMM_FILTER_WAVES=6 -DMM_STAT_BLOCKS=64 > /dev/null 2>&1
+bash tools/build_variant.sh w5s -DMM_STAT_BLOCKS=64 > /dev/null 2>&1
 for round in 1 2; do
 for v in default w6 w5s; do
   if [ $v = default ]; then unset MOSAIC_HIP_LIB; else export MOSAIC_HIP_LIB=$PWD/gpurun_out/$v.so; fi

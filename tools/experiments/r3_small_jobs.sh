@@ -1,5 +1,5 @@
 # Round 3: what the single-submission path and the fused kernels buy, per configuration (A/B pairs in one call on
-# one box).  usage (on the box): bash tests/tools_r3_small_jobs.sh TAG   -> gpurun_out/TAG/
+# one box).  usage (on the box): bash tools/experiments/r3_small_jobs.sh TAG   -> gpurun_out/TAG/
 V=${1:-r03_small}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$V

@@ -1,7 +1,7 @@
 # Round 3: C' = v_sqrt_f32(m) instead of m * v_rsq_f32(m) in the CIEDE2000 filter form (8 multiplies fewer per 4 pixel pairs),
 # A/B against a build with -DMM_CHROMA_RSQ in one call.
 cd $GRAFT_REPO_ROOT
-bash tests/tools_build_variant.sh rsq -DMM_CHROMA_RSQ > /dev/null 2>&1
+bash tools/build_variant.sh rsq -DMM_CHROMA_RSQ > /dev/null 2>&1
 for round in 1 2 3; do
 for v in default rsq; do
   if [ $v = default ]; then unset MOSAIC_HIP_LIB; else export MOSAIC_HIP_LIB=$PWD/gpurun_out/$v.so; fi

@@ -14,4 +14,4 @@ PY
 for s0 in 1 0 1 0; do run D_stage0_$s0 D 6 --opt stage0=$s0; done
 for s0 in 1 0 1 0; do run E8_stage0_$s0 E8 6 --opt stage0=$s0; done
 for s0 in 1 0 1 0; do run C_stage0_$s0 C 60 --opt stage0=$s0 --opt phase_timing=1; done
-python3 tests/tools_smooth_bench.py 2>&1 | grep -v amdgpu.ids
+python3 tools/smooth_bench.py 2>&1 | grep -v amdgpu.ids

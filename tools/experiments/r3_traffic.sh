@@ -2,7 +2,7 @@
 # traffic against idle slots are measured again on config D (item size, XCD sub-group, how many groups leave plane order, long-first split).
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03_traffic.txt; : > $O
-bash tests/tools_build_variant.sh ls0 -DMM_LONG_SPLIT=0.0f > /dev/null 2>&1
+bash tools/build_variant.sh ls0 -DMM_LONG_SPLIT=0.0f > /dev/null 2>&1
 run() { # label, lib, opts...
   label=$1; lib=$2; shift 2
   if [ $lib = default ]; then unset MOSAIC_HIP_LIB; else export MOSAIC_HIP_LIB=$PWD/gpurun_out/$lib.so; fi

@@ -1,8 +1,8 @@
 # A/B of a -D variant of filter.hip against the default build, same box, alternating.
-# usage (on the box): bash tests/tools_r3_variant_ab.sh NAME -DMM_SOMETHING ...
+# usage (on the box): bash tools/experiments/r3_variant_ab.sh NAME -DMM_SOMETHING ...
 cd $GRAFT_REPO_ROOT
 name=$1; shift
-bash tests/tools_build_variant.sh $name "$@" > /dev/null 2>&1
+bash tools/build_variant.sh $name "$@" > /dev/null 2>&1
 for round in 1 2 3; do
 for v in default $name; do
   if [ $v = default ]; then unset MOSAIC_HIP_LIB; else export MOSAIC_HIP_LIB=$PWD/gpurun_out/$v.so; fi

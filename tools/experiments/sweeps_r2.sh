@@ -1,6 +1,6 @@
 # Round-2 tuning sweeps of the filter kernel (run on the GPU box; every arm of a sweep in ONE call: the pool's
 # devices clock differently, numbers from different calls differ by a few per cent).
-#   bash tests/tools_sweeps_r2.sh tune | order | level | lds | traffic
+#   bash tools/experiments/sweeps_r2.sh tune | order | level | lds | traffic
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python3 bench.py --steps 6 --warmup 2 --no-cpu"
 g() { grep -o "\"value\": [0-9.]*\|\"score_ms\": [0-9.]*\|\"seed_ms\": [0-9.]*\|\"visited_groups\": [0-9]*\|\"bound_dropped\": [0-9]*" | tr "\n" " "; echo; }
@@ -10,7 +10,7 @@ tune)      # candidates per item x cells per XCD sub-group, seeds, waves per SIM
     echo "== $c tile=$t xcd_cells=$xc"; $B --config $c --opt tile=$t --opt xcd_cells=$xc 2>/dev/null | g; done; done; done
   for s in 10 14 22 30; do echo "== D seeds=$s"; $B --opt seeds=$s 2>/dev/null | g; done
   echo "== D xcd_aware=0"; $B --opt xcd_aware=0 2>/dev/null | g
-  for w in 4 6; do tests/tools_build_variant.sh w$w -DMM_FILTER_WAVES=$w >/dev/null 2>&1 && { echo "== waves $w"; MOSAIC_HIP_LIB=gpurun_out/w$w.so $B 2>/dev/null | g; rm -f gpurun_out/w$w.so; }; done ;;
+  for w in 4 6; do tools/build_variant.sh w$w -DMM_FILTER_WAVES=$w >/dev/null 2>&1 && { echo "== waves $w"; MOSAIC_HIP_LIB=gpurun_out/w$w.so $B 2>/dev/null | g; rm -f gpurun_out/w$w.so; }; done ;;
 order)     # how many of the largest-bound groups are visited first
   for c in D E8 C; do for m in 0 1 2 3 4 6 8 16; do echo "== $c sort_groups=$m"; $B --config $c --opt sort_groups=$m 2>/dev/null | g; done; done ;;
 level)     # the bound's stage 1 (several candidates per wave pass) against the per-candidate form, the interleaved image copies

@@ -1,5 +1,5 @@
 """Times the dominant kernel of one bench config under the engine's options
-(diagnostics; not a test).  usage: python tests/tools_filter_variants.py [CONFIG]"""
+(diagnostics; not a test).  usage: python tools/filter_variants.py [CONFIG]"""
 import os
 import sys
 

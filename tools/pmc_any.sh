@@ -1,4 +1,4 @@
-# SQ / LDS / traffic counters of one filter launch, any configuration: bash tests/tools_pmc_any.sh [CONFIG] [--opt ...]
+# SQ / LDS / traffic counters of one filter launch, any configuration: bash tools/pmc_any.sh [CONFIG] [--opt ...]
 # (a pass that asks for more counters than the hardware collects at once aborts and can hang: keep the sets small)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 C=${1:-E8}; shift

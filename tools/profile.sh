@@ -1,8 +1,8 @@
 # Round profile of the bench commands on the GPU box: the rocprofv3 PMC passes (separate runs, as the
 # MI355X guide prescribes) that bench.py's roofline is priced from -- for configs D, C, B, E8, E and A
-# (CONFIGS="E8 E" bash tests/tools_profile.sh ... for a subset; ONLY=pmc skips the bench lines) --, the
+# (CONFIGS="E8 E" bash tools/profile.sh ... for a subset; ONLY=pmc skips the bench lines) --, the
 # kernel trace of the default command, and the bench lines of every configuration.
-# usage (on the box): bash tests/tools_profile.sh r02_v13        -> gpurun_out/r02_v13/
+# usage (on the box): bash tools/profile.sh r02_v13        -> gpurun_out/r02_v13/
 set -x
 V=${1:-r03_v34}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

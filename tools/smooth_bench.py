@@ -1,10 +1,10 @@
 """One-off measurement: config D's shape (4096 x 4096 target, 64 x 64 cells, 5000 images, CIEDE2000, repeat 4 / 500)
 on NOISE-FREE content -- smooth gradients on both sides, as photographs are next to the synthetic +-32 library --
-to see what the early-exit bound does there.  python tests/tools_smooth_bench.py (on the GPU box)."""
+to see what the early-exit bound does there.  python tools/smooth_bench.py (on the GPU box)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import cases
 from mosaicmagnifique_amd import GridUtility as G
 from mosaicmagnifique_amd.engine import Engine

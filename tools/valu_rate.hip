@@ -2,7 +2,7 @@
 // instructions on gfx950, per wave-instruction per SIMD, at a given number of resident
 // waves per SIMD.  Every kernel runs 8 independent instructions of one kind (or a mix)
 // per loop iteration; time from s_memtime inside the kernel and from HIP events.
-//   hipcc --offload-arch=gfx950 -O3 -w -o build/valu_rate tests/tools_valu_rate.hip && build/valu_rate
+//   hipcc --offload-arch=gfx950 -O3 -w -o build/valu_rate tools/valu_rate.hip && build/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

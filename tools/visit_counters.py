@@ -1,5 +1,5 @@
 """Work counters of the filter kernel for one generate of a bench configuration (always on since round 2:
-mm_timing.visited_groups / total_groups / bound_dropped).   python tests/tools_visit_counters.py [D|C|E8] [NAME=VALUE ...]"""
+mm_timing.visited_groups / total_groups / bound_dropped).   python tools/visit_counters.py [D|C|E8] [NAME=VALUE ...]"""
 import os
 import sys
 
