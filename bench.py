@@ -69,6 +69,9 @@ CONFIGS = {
     # the reference harness's default line as CIEDE2000 (Benchmark_Generator.h: 5000 x 4000, cell 128 at detail 20 % = 25 px detail
     # cells, ~200 images), at the detail size directly: 1280 cells of 25 x 25 against 214 images
     "H": (800, 1000, 25, "square", 214, 2, 0, 0, 64),
+    # config D's parameters on PHOTOGRAPHIC content (tests/golden/make_photo_fixture.py: one of the reference's SampleImages as the
+    # target, 1024 tiles of 64 x 64 cut from the other four as the library): what the early-exit bound does off the synthetic patches
+    "P": (1363, 2048, 64, "square", 1024, 2, 4, 500, 16),
     "D500": (4096, 4096, 64, "square", 500, 2, 4, 500, 8),
     "D3800": (4096, 4096, 64, "square", 3800, 2, 4, 500, 8),     # ... and one whose interleaved copy (249 MB) just fits the 256 MB Infinity Cache
     # reduced shapes of D and E for the rank rehearsals of tests/test_gpu_bench_ranks.py (not bench lines)
@@ -114,6 +117,11 @@ def build_workload(name, world, scaling="weak", mcs=None, mil=None, bands=0):
         if library.getImageSize() != size:
             lib_u8 = np.stack([imageutil.resize_area_u8(im, size, size) for im in lib_u8])
         L = len(lib_u8)
+    elif name == "P":
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import make_photo_fixture
+        photo_u8, lib_u8 = make_photo_fixture.load()
+        assert photo_u8.shape == (rows, cols, 3) and lib_u8.shape == (L, size, size, 3)
     else:
         lib_u8 = synth.library_u8(L, size)
     state1 = G.getGridState(group, rows, cols)[0]
@@ -123,7 +131,7 @@ def build_workload(name, world, scaling="weak", mcs=None, mil=None, bands=0):
         n_shard = -(-len(cells1) // 8)
         cells1 = cells1[:n_shard]
         band_rows_px = min(rows, (int(cells1["y"].max()) // size + 2) * size)
-    img_u8 = synth.target_u8(band_rows_px, cols, lattice=64)
+    img_u8 = photo_u8 if name == "P" else synth.target_u8(band_rows_px, cols, lattice=64)
     big = band_rows_px * cols > 4096 * 4096   # convert on the device (mm_set_*_u8) instead of ~1 min of numpy per rank
     w = dict(name=name, shape=shape, shape_name=shape_name, t=t, rep=(rng, add), L=L, size=size,
              rows=band_rows_px, cols=cols, cpu_cells=cpu_cells, state_single=state1,
@@ -812,7 +820,9 @@ def main():
         "scaling": scaling if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f32 filter + f64 arbiter" if engine_uses_filter else "f64",
-        "data": "synthetic (REHEARSAL: all ranks on one GPU over gloo, timings void)" if rehearsal else "synthetic" if not (args.mcs or args.mil) else "synthetic target; %s" % ", ".join(
+        "data": "synthetic (REHEARSAL: all ranks on one GPU over gloo, timings void)" if rehearsal else
+                "photographs (derived fixture of the reference's SampleImages, tests/golden/photo_*.png)" if w["name"] == "P" else
+                "synthetic" if not (args.mcs or args.mil) else "synthetic target; %s" % ", ".join(
             os.path.basename(p) for p in (args.mcs, args.mil) if p),
         "config": {
             "workload": "config %s: %dx%d target%s, %dx%d %s cells, %d-image library, %s, repeat range %d (+%d)" % (

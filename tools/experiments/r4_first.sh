@@ -17,7 +17,7 @@ PY
 done > $O/guard_ab.txt 2>&1
 cat $O/guard_ab.txt
 python3 bench.py --steps 10 --warmup 2 > $O/bench_D.json 2> $O/bench_D.err
-for c in A B C H G; do python3 bench.py --config $c --steps 5 --warmup 2 > $O/bench_$c.json 2> $O/bench_$c.err; done
+for c in A B C H G P; do python3 bench.py --config $c --steps 5 --warmup 2 > $O/bench_$c.json 2> $O/bench_$c.err; done
 python3 - $O <<'PY'
 import json, sys, glob
 for p in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
