@@ -105,6 +105,9 @@ typedef struct mm_timing {
     int64_t fast_path;        /* 1: the whole generate was ONE submission read back in one result block (option
                                * "fast_path"); 0: the step-by-step path ran (or finished the call) */
     double preprocess_ms;     /* mm_set_library_u8[_sized] / mm_set_target_u8: the resize + colour conversion kernels */
+    int64_t filter_off_range; /* 1: the f32 pixels handed over (mm_set_library / mm_set_target) leave the box the fp32 filter's
+                               * error band was validated on -- Lab: channel 0 in [-0.5, 100.5], chroma <= 150; RGB / CIE76:
+                               * |channel| <= 256; or hold a non-finite value -- so the call ran fp64-only (same result) */
 } mm_timing;
 
 /* What a FIRST call pays besides the hot path, as host wall clocks accumulated since mm_create: the reference builds
@@ -136,7 +139,15 @@ int mm_abi_version(void);
 mm_status mm_device_count(int *count);
 /* CUDAPhotomosaicGenerator(const int device), CUDA/CUDAPhotomosaicGenerator.h:31. */
 mm_status mm_create(int device, mm_engine **out);
+/* Destroys the engine.  Its DEVICE RESOURCES (stream, events, device buffers, the page-locked result mirror) are
+ * parked -- one set per device -- and adopted by the next mm_create on that device, so that a fresh generator per
+ * run (MainWindow.cpp:584-607) does not pay the allocations again (mm_stage_timing).  Nothing logical survives:
+ * a new engine has no library, masks or target and the default options. */
 void mm_destroy(mm_engine *e);
+/* Releases the parked resources of destroyed engines (all devices); returns how many sets were released.
+ * MOSAIC_HIP_KEEP=0 in the environment turns the parking off altogether (mm_destroy then frees everything, as the
+ * reference does before generateBestFits returns, CUDAPhotomosaicGenerator.cpp:356). */
+int mm_trim_cache(void);
 /* Text of the last failure on this engine (e == NULL: last mm_create failure):
  * "<what>: <hipErrorName> (<code>) at <file>:<line>", the shape of
  * createCUDAErrStr (CUDA/CUDAUtility.h:27-30). */

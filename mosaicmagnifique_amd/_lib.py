@@ -32,7 +32,7 @@ class MMTiming(ctypes.Structure):
                 ("total_groups", ctypes.c_int64), ("bound_dropped", ctypes.c_int64),
                 ("band_alarms", ctypes.c_int64), ("filter_tile", ctypes.c_int64),
                 ("host_syncs", ctypes.c_int64), ("fast_path", ctypes.c_int64),
-                ("preprocess_ms", ctypes.c_double)]
+                ("preprocess_ms", ctypes.c_double), ("filter_off_range", ctypes.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -62,6 +62,7 @@ SIGNATURES = {
     "mm_device_count": (ctypes.c_int, [c_int_p]),
     "mm_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_VP)]),
     "mm_destroy": (None, [_VP]),
+    "mm_trim_cache": (ctypes.c_int, []),
     "mm_last_error": (ctypes.c_char_p, [_VP]),
     "mm_set_library": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
     "mm_set_masks": (ctypes.c_int, [_VP, _VP, ctypes.c_int]),

@@ -17,7 +17,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -134,6 +136,11 @@ struct mm_engine {
     long long prune_min_pairs = -1;   // mm_set_option("prune_min_kpairs", n): below n thousand pixel pairs per batch the
                                       // seeds / early exit are skipped (three launches cost more than they save); -1 = default
 
+    // value_range_kernel's verdict on the staged f32 inputs (bits: 1 non-finite, 2 outside the CIEDE2000 box, 4 outside the
+    // Euclidean box the filter band was validated on); u8 inputs are converted here and lie inside by construction
+    unsigned int lib_range = 0, target_range = 0;
+    DevBuf range_flags;
+
     mm_timing timing{};
     mm_stage_timing stage_clock{};    // host wall clocks of everything that is NOT the hot path (mm_get_stage_timing): what a first call pays
 };
@@ -212,7 +219,7 @@ inline bool known_type(int t) { return t == MM_RGB_EUCLIDEAN || t == MM_CIE76 ||
 
 mm_status check_ready(mm_engine* e)
 {
-    if (!e->lib_hwc.p || !e->masks.p || !e->target.p) {
+    if (e->n_lib <= 0 || e->mask_size <= 0 || e->rows <= 0) {      // (staged = the logical state; buffers may be adopted ones)
         set_err(e, "library, masks and target must be staged before generating");
         return MM_NOT_READY;
     }
@@ -299,6 +306,28 @@ mm_status by_type(int diff_type, F&& f)
 {
     if (diff_type == MM_CIEDE2000) return f(std::integral_constant<int, mm::CIEDE2000>{});
     return f(std::integral_constant<int, mm::RGB_EUCLIDEAN>{});   // CIE76 == Euclid on Lab
+}
+
+// The value range of f32 pixels handed over as they are (mm_set_library / mm_set_target): is the fp32 filter's band
+// valid for them?  One pass over the resident copy, four bytes back.
+mm_status value_range(mm_engine* e, const float* hwc_dev, size_t n_pixels, unsigned int* flags_out)
+{
+    mm_status st = ensure(e, e->range_flags, sizeof(unsigned int), "Failed to allocate range flags");
+    if (st) return st;
+    HIP_TRY(e, hipMemsetAsync(e->range_flags.p, 0, sizeof(unsigned int), e->stream), "Failed to clear range flags");
+    const unsigned blocks = (unsigned)std::min<size_t>((n_pixels + mm::kBlock - 1) / mm::kBlock, 4096);
+    mm::value_range_kernel<<<std::max(blocks, 1u), mm::kBlock, 0, e->stream>>>(hwc_dev, n_pixels, (unsigned int*)e->range_flags.p);
+    HIP_TRY(e, hipGetLastError(), "Error during value range kernel");
+    HIP_TRY(e, hipMemcpyAsync(flags_out, e->range_flags.p, sizeof(unsigned int), hipMemcpyDeviceToHost, e->stream), "range flags");
+    HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
+    return MM_OK;
+}
+
+// Whether the two-tier path may run on what is staged: the filter's band covers the validated box only.
+inline bool filter_band_covers(const mm_engine* e, int diff_type)
+{
+    const unsigned int f = e->lib_range | e->target_range;
+    return (f & (diff_type == MM_CIEDE2000 ? 3u : 5u)) == 0u;
 }
 
 // De-duplicates the 4 mask variants, builds each distinct variant's pixel permutation
@@ -624,8 +653,11 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         row_map_dev = (const int*)e->row_map.p;
     }
     // detail cells of up to 64 pixels: one wave per cell from the image to the list (tiny_cells_kernel), fp64 throughout
-    const bool tiny = e->tiny_path != 0 && P <= mm::kTinyPositions && e->lib_tiny.p != nullptr;
-    const bool two_tier = !tiny && e->use_filter != 0 && K < L;
+    const bool tiny = e->tiny_path != 0 && P <= mm::kTinyPositions && e->lib_tiny.p != nullptr;     // (prepare_planes above built it for this P)
+    // (values outside the box the filter band was validated on -- possible only through the f32 setters -- go fp64-only)
+    const bool in_range = filter_band_covers(e, diff_type);
+    if (!in_range) e->timing.filter_off_range = 1;
+    const bool two_tier = !tiny && e->use_filter != 0 && K < L && in_range;
     const int Kc = two_tier ? std::min(L, round_up(K + 32, 4)) : 0;
     // Early exit needs seeds: K <= M <= 256 of them.
     // (extra seeds tighten the CIEDE2000 limit -- 10..30 measured flat within 1 % of the filter time -- but buy the RGB /
@@ -1226,6 +1258,88 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
     return MM_OK;
 }
 
+// ---- resources kept across engines -----------------------------------------------------------------------------
+// The reference builds a fresh generator per run (MainWindow.cpp:584-607) and its device path allocates and frees
+// everything inside generateBestFits (CUDAPhotomosaicGenerator.cpp:82,356).  For its everyday job sizes that is most
+// of what a call costs here too (mm_stage_timing: stream and event creation, ~40 hipMallocs, a page-locked buffer --
+// milliseconds against a 0.1 ms generate).  So mm_destroy PARKS the engine's device resources -- stream, events,
+// every device buffer, the page-locked result mirror -- instead of releasing them (one set per device), and the next
+// mm_create on that device adopts them: buffers that are large enough are reused as they are (`ensure`), the two
+// constant tables (hue table, sRGB decode table) stay valid, everything logical (what is staged, options, timings)
+// starts from the defaults.  mm_trim_cache() releases what is parked; MOSAIC_HIP_KEEP=0 in the environment turns
+// the parking off.
+DevBuf mm_engine::* const kDeviceBuffers[] = {
+    &mm_engine::lib, &mm_engine::masks, &mm_engine::target, &mm_engine::recs, &mm_engine::cells, &mm_engine::cmask, &mm_engine::scores,
+    &mm_engine::cand_i, &mm_engine::cand_s, &mm_engine::grid, &mm_engine::best, &mm_engine::counter, &mm_engine::scratch,
+    &mm_engine::cont_i, &mm_engine::cont_f, &mm_engine::cont_s, &mm_engine::flags, &mm_engine::edges, &mm_engine::edge_count,
+    &mm_engine::dense_recs, &mm_engine::dense_i, &mm_engine::lib_means, &mm_engine::seeds, &mm_engine::seed_score, &mm_engine::limits,
+    &mm_engine::row_slot, &mm_engine::dense_rows_buf, &mm_engine::row_index, &mm_engine::lib_chroma, &mm_engine::cell_chroma,
+    &mm_engine::hue_lut, &mm_engine::row_map, &mm_engine::spec_recs, &mm_engine::deep, &mm_engine::insufficient, &mm_engine::lib_bgr,
+    &mm_engine::owner, &mm_engine::mosaic, &mm_engine::lib_hwc, &mm_engine::perm, &mm_engine::inv_perm, &mm_engine::cell_var,
+    &mm_engine::cell_full, &mm_engine::cell_order, &mm_engine::pos_mask, &mm_engine::lib_lsum, &mm_engine::cell_lsum,
+    &mm_engine::stage_u8, &mm_engine::srgb_lut, &mm_engine::shrink_tmp, &mm_engine::covered, &mm_engine::cells_f0, &mm_engine::area_tab,
+    &mm_engine::sweep_counts, &mm_engine::sentinel, &mm_engine::lib_il, &mm_engine::cells_il, &mm_engine::result, &mm_engine::main_bgr,
+    &mm_engine::entropy_out, &mm_engine::exceeded_out, &mm_engine::lib_tiny, &mm_engine::lib_stats_t, &mm_engine::range_flags };
+
+std::mutex g_park_lock;
+std::vector<mm_engine*> g_parked;           // at most one per device: engines that only hold resources
+
+bool parking_enabled()
+{
+    const char* v = std::getenv("MOSAIC_HIP_KEEP");
+    return !(v && v[0] == '0');
+}
+
+void free_resources(mm_engine* e)
+{
+    for (DevBuf mm_engine::* m : kDeviceBuffers) release(e->*m);
+    if (e->pinned) (void)hipHostFree(e->pinned);
+    e->pinned = nullptr; e->pinned_bytes = 0;
+    for (auto& ev : e->ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    if (e->stream) { (void)hipStreamDestroy(e->stream); e->stream = nullptr; }
+}
+
+// Moves the resources of `from` into `to` (which holds none).
+void move_resources(mm_engine* to, mm_engine* from)
+{
+    for (DevBuf mm_engine::* m : kDeviceBuffers) { to->*m = from->*m; from->*m = DevBuf{}; }
+    to->pinned = from->pinned; to->pinned_bytes = from->pinned_bytes;
+    from->pinned = nullptr; from->pinned_bytes = 0;
+    to->stream = from->stream; from->stream = nullptr;
+    for (int i = 0; i < 12; ++i) { to->ev[i] = from->ev[i]; from->ev[i] = nullptr; }
+}
+
+// mm_destroy: true if the engine's resources were parked (the caller deletes the shell).
+bool park_resources(mm_engine* e)
+{
+    if (!parking_enabled() || !e->stream) return false;
+    for (const auto& ev : e->ev) if (!ev) return false;       // (an engine whose creation failed half way)
+    mm_engine* keep = new (std::nothrow) mm_engine();
+    if (!keep) return false;
+    std::lock_guard<std::mutex> hold(g_park_lock);
+    for (const mm_engine* p : g_parked)
+        if (p->device == e->device) { delete keep; return false; }       // one set per device: this one is released
+    keep->device = e->device;
+    move_resources(keep, e);
+    g_parked.push_back(keep);
+    return true;
+}
+
+// mm_create: the parked resources of this device, if any.
+bool adopt_resources(mm_engine* e)
+{
+    mm_engine* from = nullptr;
+    {
+        std::lock_guard<std::mutex> hold(g_park_lock);
+        for (size_t i = 0; i < g_parked.size(); ++i)
+            if (g_parked[i]->device == e->device) { from = g_parked[i]; g_parked.erase(g_parked.begin() + (long)i); break; }
+    }
+    if (!from) return false;
+    move_resources(e, from);
+    delete from;
+    return true;
+}
+
 int64_t count_pair_evals(const mm_engine* e, const mm_cell* cells, int n)
 {
     // Upper bound used for reporting: bound area per cell x candidates (the mask
@@ -1274,8 +1388,12 @@ mm_status mm_create(int device, mm_engine** out)
     if (!e) { set_err(nullptr, "out of host memory"); return MM_OUT_OF_MEMORY; }
     e->device = device;
     code = hipSetDevice(device);
-    if (code == hipSuccess) code = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    for (int i = 0; code == hipSuccess && i < 12; ++i) code = hipEventCreate(&e->ev[i]);
+    if (code == hipSuccess && adopt_resources(e)) {
+        e->stage_clock.reused_engine = 1;
+    } else {
+        if (code == hipSuccess) code = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        for (int i = 0; code == hipSuccess && i < 12; ++i) code = hipEventCreate(&e->ev[i]);
+    }
     if (code != hipSuccess) {
         mm_status st = hip_fail(nullptr, code, "Failed to initialise device", __FILE__, __LINE__);
         mm_destroy(e);
@@ -1298,20 +1416,24 @@ void mm_destroy(mm_engine* e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)sync_stream(e);
-    for (DevBuf* b : { &e->lib, &e->masks, &e->target, &e->recs, &e->cells, &e->cmask, &e->scores,
-                       &e->cand_i, &e->cand_s, &e->grid, &e->best, &e->counter, &e->scratch,
-                       &e->cont_i, &e->cont_f, &e->cont_s, &e->flags, &e->edges, &e->edge_count,
-                       &e->dense_recs, &e->dense_i, &e->lib_means, &e->seeds,
-                       &e->seed_score, &e->limits, &e->row_slot, &e->dense_rows_buf, &e->row_index, &e->lib_chroma, &e->cell_chroma,
-                       &e->hue_lut, &e->row_map, &e->spec_recs, &e->deep, &e->insufficient, &e->lib_bgr, &e->owner, &e->mosaic, &e->lib_hwc, &e->perm, &e->inv_perm,
-                       &e->cell_var, &e->cell_full, &e->cell_order, &e->pos_mask, &e->lib_lsum, &e->cell_lsum,
-                       &e->stage_u8, &e->srgb_lut, &e->shrink_tmp, &e->covered, &e->cells_f0, &e->area_tab,
-                       &e->sweep_counts, &e->sentinel, &e->lib_il, &e->cells_il, &e->result, &e->main_bgr, &e->entropy_out, &e->exceeded_out, &e->lib_tiny, &e->lib_stats_t })
-        release(*b);
-    if (e->pinned) (void)hipHostFree(e->pinned);
-    for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (park_resources(e)) { delete e; return; }       // kept for the next mm_create on this device (mm_trim_cache frees them)
+    free_resources(e);
     delete e;
+}
+
+int mm_trim_cache(void)
+{
+    std::vector<mm_engine*> parked;
+    {
+        std::lock_guard<std::mutex> hold(g_park_lock);
+        parked.swap(g_parked);
+    }
+    for (mm_engine* p : parked) {
+        (void)hipSetDevice(p->device);
+        free_resources(p);
+        delete p;
+    }
+    return (int)parked.size();
 }
 
 const char* mm_last_error(const mm_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
@@ -1334,7 +1456,7 @@ mm_status mm_set_library(mm_engine* e, const float* images, int n_images, int si
     e->planes_dirty = true;        // planes are (re)built by prepare_planes() once the masks are known
     e->n_lib = n_images;
     e->lib_size = size;
-    return MM_OK;
+    return value_range(e, (const float*)e->lib_hwc.p, (size_t)n_images * size * size, &e->lib_range);
 }
 
 mm_status mm_set_masks(mm_engine* e, const uint8_t* masks, int size)
@@ -1378,7 +1500,7 @@ mm_status mm_set_target(mm_engine* e, const float* image, int rows, int cols)
     }
     e->rows = rows;
     e->cols = cols;
-    return MM_OK;
+    return value_range(e, (const float*)e->target.p, (size_t)rows * cols, &e->target_range);
 }
 
 namespace {
@@ -1463,6 +1585,7 @@ mm_status mm_set_library_u8(mm_engine* e, const uint8_t* bgr, int n_images, int 
     e->planes_dirty = true;
     e->n_lib = n_images;
     e->lib_size = size / shrink;
+    e->lib_range = 0;              // converted here: inside the box by construction
     return MM_OK;
 }
 
@@ -1520,6 +1643,7 @@ mm_status mm_set_library_u8_sized(mm_engine* e, const uint8_t* bgr, int n_images
     e->planes_dirty = true;
     e->n_lib = n_images;
     e->lib_size = detail_size;
+    e->lib_range = 0;
     return MM_OK;
 }
 
@@ -1535,6 +1659,7 @@ mm_status mm_set_target_u8(mm_engine* e, const uint8_t* bgr, int rows, int cols,
     if (st) return st;
     e->rows = rows;
     e->cols = cols;
+    e->target_range = 0;
     return MM_OK;
 }
 
@@ -2009,7 +2134,7 @@ mm_status mm_build_photomosaic_step(mm_engine* e, const mm_cell* cells, int n_ce
         set_err(e, "mm_build_photomosaic_step: step %d without a step 0 of the same %dx%d mosaic", step_index, cols, rows);
         return MM_NOT_READY;
     }
-    if (!e->lib_bgr.p || !e->masks.p) {
+    if (!e->lib_bgr.p || e->n_lib_bgr <= 0 || !e->masks.p || e->mask_size <= 0) {
         set_err(e, "u8 library (mm_set_library_bgr) and masks must be staged before building the photomosaic");
         return MM_NOT_READY;
     }
@@ -2093,7 +2218,7 @@ mm_status mm_cell_entropy(mm_engine* e, const mm_cell* cells, int n_cells, int n
 {
     if (!e) return MM_INVALID_ARGUMENT;
     if (n_cells < 0 || (n_cells > 0 && (!cells || !exceeded_out)) || normal_size <= 0) { set_err(e, "mm_cell_entropy: bad arguments"); return MM_INVALID_ARGUMENT; }
-    if (!e->main_bgr.p || !e->masks.p) { set_err(e, "the u8 main image (mm_set_main_image_bgr) and the step's detail masks must be staged first"); return MM_NOT_READY; }
+    if (!e->main_bgr.p || e->main_rows <= 0 || !e->masks.p || e->mask_size <= 0) { set_err(e, "the u8 main image (mm_set_main_image_bgr) and the step's detail masks must be staged first"); return MM_NOT_READY; }
     const int ds = e->mask_size;
     if (ds > normal_size) { set_err(e, "mm_cell_entropy: detail masks of %d px against a normal cell of %d px", ds, normal_size); return MM_INVALID_ARGUMENT; }
     for (int i = 0; i < n_cells; ++i) {

@@ -2158,6 +2158,25 @@ stream_read_kernel(const float4* __restrict__ src, size_t n_vec, float* __restri
     sink[(size_t)blockIdx.x * kBlock + threadIdx.x] = (acc.x + acc.y) + (acc.z + acc.w);
 }
 
+// The box the fp32 filter's error band was validated on (engine.hip filter_band): f32 HWC pixels
+// whose channel 0 lies in [-0.5, 100.5] and whose chroma sqrt(c1^2 + c2^2) is at most 150 (CIEDE2000 on Lab: the domain
+// of the structured sweep and of the adversarial maximiser), or whose three channels lie within [-256, 256] (the
+// Euclidean forms: three roundings of a value <= 442).  Bits OR-ed into *flags: 1 a non-finite value, 2 outside the
+// CIEDE2000 box, 4 outside the Euclidean box.  The engine runs such inputs fp64-only (mm_timing.filter_off_range).
+__global__ void __launch_bounds__(kBlock)
+value_range_kernel(const float* __restrict__ hwc, size_t n_pixels, unsigned int* __restrict__ flags)
+{
+    unsigned int f = 0u;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_pixels; i += (size_t)gridDim.x * kBlock) {
+        const float c0 = hwc[3 * i], c1 = hwc[3 * i + 1], c2 = hwc[3 * i + 2];
+        if (!(fabsf(c0) <= 3.0e38f && fabsf(c1) <= 3.0e38f && fabsf(c2) <= 3.0e38f)) f |= 1u;       // NaN or infinite
+        if (!(c0 >= -0.5f && c0 <= 100.5f && c1 * c1 + c2 * c2 <= 150.0f * 150.0f)) f |= 2u;
+        if (!(fabsf(c0) <= 256.0f && fabsf(c1) <= 256.0f && fabsf(c2) <= 256.0f)) f |= 4u;
+    }
+    for (int off = 32; off > 0; off >>= 1) f |= (unsigned int)__shfl_xor((int)f, off, kWave);
+    if ((threadIdx.x & 63) == 0 && f != 0u) atomicOr(flags, f);
+}
+
 // ---------------------------------------------------------------------------
 // per-pair batch (KATs, differential tests)
 // ---------------------------------------------------------------------------

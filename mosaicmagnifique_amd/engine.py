@@ -31,6 +31,11 @@ def device_count():
     return n.value
 
 
+def trim_cache():
+    """mm_trim_cache: release the device resources destroyed engines left parked; returns the number of sets released."""
+    return _lib.load().mm_trim_cache()
+
+
 class Engine:
     def __init__(self, device=0):
         self._lib = _lib.load()

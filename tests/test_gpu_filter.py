@@ -463,3 +463,35 @@ def test_library_larger_than_any_table_in_lds(oracle, engine, t):
     picks, scores = oracle.picks_given_grid(shape_of(shape), img, lib, shape.masks4(), int(t), 2, 50, grid, pos, threads=16)
     got = best[pos[:, 0], pos[:, 1]]
     assert np.array_equal(np.where(got == n_lib, -1, got), picks)
+
+
+@pytest.mark.parametrize("t,where,value", [(Type.CIEDE2000, "library", (50.0, 160.0, 20.0)), (Type.CIEDE2000, "target", (104.0, 5.0, 5.0)),
+                                           (Type.RGB_EUCLIDEAN, "library", (300.0, 10.0, 10.0)), (Type.CIEDE2000, "target", (50.0, float("inf"), 0.0))])
+def test_values_outside_the_validated_box_run_fp64_only(oracle, engine, t, where, value):
+    """The fp32 filter's band (engine.hip filter_band) is validated on a box -- Lab: L in [0, 100], chroma <= 150; RGB / CIE76:
+    |channel| <= 256 (the structured sweep, the adversarial maximiser).  The f32 setters take ANY floats: a single pixel
+    outside the box (or non-finite) sends the call down the fp64-only path -- mm_timing.filter_off_range says so -- and the
+    grid is the oracle's all the same; back inside the box the two-tier path runs again."""
+    shape = cases.square_shape(32)
+    img, lib = cases.inputs(128, 160, 32, 120, t)
+    img, lib = img.copy(), lib.copy()
+    finite = np.isfinite(value).all()
+    if where == "library":
+        lib[7, 3, 5] = value
+    else:
+        img[40, 50] = value
+    group = cases.group_of(shape)
+    state = G.getGridState(group, img.shape[0], img.shape[1])[0]
+    cells = G.cell_records(group, state, img.shape[0], img.shape[1])
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t))
+    tm = engine.timing()
+    assert tm["filter_off_range"] == 1 and tm["rescore_ms"] == 0 and tm["seed_ms"] == 0
+    if finite:
+        want, _, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t))
+        assert np.array_equal(np.where(best == len(lib), -1, best), want)
+    img2, lib2 = cases.inputs(128, 160, 32, 120, t)
+    engine.set_library(lib2); engine.set_target(img2)
+    engine.generate(cells, state.shape[1], state.shape[0], int(t))
+    tm = engine.timing()
+    assert tm["filter_off_range"] == 0 and tm["rescore_ms"] > 0
