@@ -215,6 +215,9 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 #ifndef MM_STAT_BLOCKS
 #define MM_STAT_BLOCKS (4 * kWave)   // blocks of a cell whose statistics filter_kernel keeps in LDS (experiments: 64 = cells up to 64 x 64 only)
 #endif
+#ifndef MM_BIG_CELL_STAGE0
+#define MM_BIG_CELL_STAGE0 1         // cells above 16 groups: stage 0 of the bound ahead of the candidate loop, bound-ordered visits from 17 groups on (0: round 3's form, for A/B builds)
+#endif
 #ifndef MM_LONG_SPLIT
 #define MM_LONG_SPLIT 0.8f
 #endif
@@ -445,7 +448,10 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // Unclipped cells only (the image statistics are over the whole mask).
     bool stage0 = false;
     if constexpr (TYPE == CIEDE2000) {
-        stage0 = two_level && (var.two_stage & 2) != 0 && var.cell_full[cell] == 1;
+        // (cells above 16 groups have no stage 1 -- a lane of the prelude holds two or four blocks there -- but stage 0 is the same
+        // one pass of wave 0 whatever the cell size: the survivors' compacted list then feeds the candidate loop directly)
+        stage0 = use_lb && groups > 0 && cand_per_block <= 64 && (var.two_stage & 2) != 0 && var.cell_full[cell] == 1 &&
+                 (two_level || (MM_BIG_CELL_STAGE0 != 0 && lane_shift > 0));
         // (the image-level statistics sit in slot ppad / 64 of each image's block statistics: no arguments of their own)
         if (stage0 && threadIdx.x < 7)
             cell_ist[threadIdx.x] = var.cell_stats[(size_t)threadIdx.x * var.cell_stats_stride + (size_t)cell * var.n_blocks + ppad / 64];
@@ -542,7 +548,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     MM_STAMP(4);
     // (the masks are read from LDS again per candidate: four more SGPRs held across the pixel loop cost more in spills)
     const int n_long = two_level ? __builtin_popcount(alive_mask[0]) + __builtin_popcount(alive_mask[1]) : 0;
-    const int n_todo = two_level ? n_long + __builtin_popcount(alive_mask[2]) + __builtin_popcount(alive_mask[3]) : n_here;
+    const int n_todo = two_level ? n_long + __builtin_popcount(alive_mask[2]) + __builtin_popcount(alive_mask[3]) : (stage0 ? n_surv : n_here);
     for (int turn = two_level ? 0 : wave; ;) {
         if (two_level) {                                    // the next survivor not yet taken by any wave
             int nxt = 0;
@@ -557,13 +563,15 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             const int nth = turn < n_long ? turn : turn - n_long;
             const bool mine = ((survivors >> lane) & 1ull) != 0 && __builtin_popcountll(survivors & ((1ull << lane) - 1ull)) == nth;
             idx = __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine));
+        } else if (stage0) {
+            idx = __builtin_amdgcn_readfirstlane((int)surv_idx[turn]);     // stage 0's compacted list (seeds are not on it)
         }
         const int l = l_base + idx;
         if (!two_level) {   // the next candidate of this tile not yet taken by any wave
             int nxt = 0;
             if (lane == 0) nxt = atomicAdd(&next_candidate, 1);
             turn = __builtin_amdgcn_readfirstlane(nxt);      // scalar: library addresses stay in SGPRs
-            if (n_seeds > 0) {
+            if (n_seeds > 0 && !stage0) {
                 // scored already as a seed (seed_score_kernel left its score in the row): nothing to do
                 bool hit = false;
                 for (int t = lane; t < n_seeds; t += kWave) hit = hit || seed_ids[t] == l;
@@ -580,7 +588,9 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         const bool sorted = TYPE == CIEDE2000 && use_lb && lane_shift == 0 && sort_groups != 0;
         // cells of 33 .. 64 groups (up to 128 x 128): a lane of the prelude holds exactly one group (four blocks), so the
         // same descending-bound visiting order comes from ranking the 64 lanes against each other
-        const bool sorted64 = TYPE == CIEDE2000 && use_lb && lane_shift == 2 && sort_groups != 0 && !two_level;
+        // ... and cells of 17 .. 32 groups (72 .. 90 px), whose lanes hold HALF a group each: the halves are added up into lanes
+        // 0 .. 31 first (two ds_bpermute), then ranked the same way
+        const bool sorted64 = TYPE == CIEDE2000 && use_lb && lane_shift >= (MM_BIG_CELL_STAGE0 != 0 ? 1 : 2) && sort_groups != 0 && !two_level;
         const bool by_group = sorted || two_level || sorted64;      // lane k of `rest`: visiting step k (else: block k)
         if constexpr (TYPE == CIEDE2000) {
             if (use_lb) {
@@ -644,6 +654,11 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     if (lane >= 16) d = 0.0f;                                   // lanes 0..15: bounds in visiting order
                 }
                 if (sorted64) {
+                    if (lane_shift == 1) {      // lane j < 32 <- group j = the blocks of lanes 2 j and 2 j + 1
+                        const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((2 * lane) * 4, __builtin_bit_cast(int, d)));
+                        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((2 * lane + 1) * 4, __builtin_bit_cast(int, d)));
+                        d = lane < kWave / 2 ? lo + hi : 0.0f;
+                    }
                     // unique keys: the bound's bits (non-negative floats order like integers) with the lane number in the low
                     // 6 bits, lower group first among equals; lanes past the last group hold 0 and keep their places at the end
                     const int key = (__builtin_bit_cast(int, d) & ~63) | (63 - lane);
@@ -738,7 +753,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         if (lane == 0) {                        // the counters are per lane (stage 1 counts on the candidates' first lanes)
             n_visited += (unsigned int)visited;
-            if (!two_level) n_groups_all += (unsigned int)groups;
+            if (!two_level && !stage0) n_groups_all += (unsigned int)groups;      // (stage 0 counted its candidates itself)
             n_bound_dropped += (pruned && visited == 0) ? 1u : 0u;
         }
         acc = wave_sum_all(acc + acc_edge);
