@@ -69,6 +69,8 @@ CONFIGS = {
     # the reference harness's default line as CIEDE2000 (Benchmark_Generator.h: 5000 x 4000, cell 128 at detail 20 % = 25 px detail
     # cells, ~200 images), at the detail size directly: 1280 cells of 25 x 25 against 214 images
     "H": (800, 1000, 25, "square", 214, 2, 0, 0, 64),
+    # 80 x 80 cells (25 groups of 256 pixels: the class between 64 x 64 and the GUI's 128 x 128), CIEDE2000
+    "I": (4000, 4000, 80, "square", 1000, 2, 0, 0, 4),
     # config D's parameters on PHOTOGRAPHIC content (tests/golden/make_photo_fixture.py: one of the reference's SampleImages as the
     # target, 1024 tiles of 64 x 64 cut from the other four as the library): what the early-exit bound does off the synthetic patches
     "P": (1363, 2048, 64, "square", 1024, 2, 4, 500, 16),

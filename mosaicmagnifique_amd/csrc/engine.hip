@@ -769,7 +769,12 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     // the fused ranking kernel keeps a cell's contenders in LDS (16 bytes each)
     // (config D, 4096 cells of CIEDE2000: the separate re-score balances the contenders better -- 2.21 + 0.15 ms against
     // 2.53 fused; up to ~2000 cells the two launches saved weigh more)
-    const bool fused_rank = e->fused != 0 && (size_t)Kc * 16 <= 48 * 1024 && (diff_type != MM_CIEDE2000 || n <= 2048);
+    // ... and only for SHORT lists: a workgroup re-scores its cell's contenders four at a time, so a deepened cell (K = 42 at
+    // repeat range 4: >= 42 contenders of 4096 pixels each) keeps one workgroup busy for eleven rounds of fp64 CIEDE2000 while the
+    // device idles -- photographic content, where neighbours collide and a fifth of the cells are deepened (bench.py --config P):
+    // 5.96 ms of an 11.2 ms step in this kernel; the separate re-score gives every (cell, contender) a wave of its own
+    const bool fused_rank = e->fused != 0 && (size_t)Kc * 16 <= 48 * 1024 && (diff_type != MM_CIEDE2000 || n <= 2048) &&
+                            (K <= 8 || diff_type != MM_CIEDE2000);
 
     std::vector<uint8_t> flags_host;
     for (int done = 0; done < n; done += batch) {
