@@ -2040,15 +2040,46 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     }
     for (int round = 0;; ++round) {
         if (!(round == 0 && have_verdicts)) {
-            if (speculate) {
-                HIP_TRY(e, hipMemcpyAsync(e->deep.p, deep.data(), (size_t)n_cells, hipMemcpyHostToDevice, e->stream), "Failed to copy list flags");
-                HIP_TRY(e, hipMemsetAsync(e->insufficient.p, 0, (size_t)n_cells, e->stream), "Failed to clear list flags");
+            // The resolve of a later round as ONE submission too (result block initialised, eight sweeps, one copy, one wait)
+            // where the first round took that path: the step-by-step resolve asks the host about ten times per round -- on
+            // photographic content, where neighbours collide and the lists are deepened over several rounds (bench.py
+            // --config P: 4 rounds, 42 host waits, 2.3 of 7.3 ms), that was the largest phase of the step.  Anything the
+            // block cannot vouch for (an overflow mark, sweeps that did not settle) falls through to the step-by-step form.
+            bool resolved = false;
+            if (want_fast) {
+                if ((st = begin_single_submission(e, n_cells, grid_w, grid_h, speculate))) return st;
+                if (speculate)      // (after the block's initialisation, which clears the flag arrays, in stream order)
+                    HIP_TRY(e, hipMemcpyAsync(e->deep.p, deep.data(), (size_t)n_cells, hipMemcpyHostToDevice, e->stream), "Failed to copy list flags");
+                st = resolve_single_submission(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition,
+                                               K, Ks, speculate, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr,
+                                               nullptr, false);
+                if (st) return st;
+                const mm::ResultHeader& h = *(const mm::ResultHeader*)e->pinned;
+                int settled = -1;
+                for (unsigned int i = 0; i < h.sweeps && settled < 0; ++i)
+                    if (h.sweep_changes[i] == 0) settled = (int)i;
+                if (h.n_marked == 0 && (!sequential || settled >= 0)) {
+                    if (e->phase_events) e->timing.resolve_ms += elapsed(e->ev[10], e->ev[11]);
+                    e->timing.resolve_sweeps += sequential ? settled + 1 : 0;
+                    e->timing.exact_rescored += (int64_t)(sequential ? h.sweep_exact[settled] : h.exact_plain);
+                    e->timing.dense_rows += (int64_t)h.dense_count;
+                    const char* body = (const char*)e->pinned + sizeof(mm::ResultHeader);
+                    memcpy(best_fit_out, body, cells_total * sizeof(int64_t));
+                    if (best_score_out) memcpy(best_score_out, body + cells_total * sizeof(int64_t), cells_total * sizeof(double));
+                    resolved = true;
+                }
             }
-            st = resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
-                                repeat_addition, K, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p,
-                                best_fit_out, best_score_out,
-                                speculate ? (const uint8_t*)e->deep.p : nullptr, speculate ? (uint8_t*)e->insufficient.p : nullptr, Ks);
-            if (st) return st;
+            if (!resolved) {
+                if (speculate) {
+                    HIP_TRY(e, hipMemcpyAsync(e->deep.p, deep.data(), (size_t)n_cells, hipMemcpyHostToDevice, e->stream), "Failed to copy list flags");
+                    HIP_TRY(e, hipMemsetAsync(e->insufficient.p, 0, (size_t)n_cells, e->stream), "Failed to clear list flags");
+                }
+                st = resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
+                                    repeat_addition, K, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p,
+                                    best_fit_out, best_score_out,
+                                    speculate ? (const uint8_t*)e->deep.p : nullptr, speculate ? (uint8_t*)e->insufficient.p : nullptr, Ks);
+                if (st) return st;
+            }
         }
         e->timing.spec_rounds = round + 1;
         if (!speculate) break;

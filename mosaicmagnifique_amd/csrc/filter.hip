@@ -255,7 +255,10 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // copy (interleave_kernel) an image is [group][plane][256 positions]: the four planes of a group are 1 KB
 // apart, inside the 13-bit immediate offset of global_load, so ONE base per image and one VGPR offset
 // address everything, and the groups a candidate visits before its early exit are one contiguous prefix.
-template <int TYPE, int THREADS, bool CELL_LDS, bool IL>
+// BIG: the instantiation for cells above 16 groups (80 x 80 .. 128 x 128): stage 0 of the bound ahead of the candidate loop and
+// bound-ordered visits from 17 groups on.  A template parameter and not a run-time branch: the extra scalars it keeps alive
+// cost the 64 x 64 instantiation three more spilled SGPRs and config D 0.3 % (measured, tools/experiments/r4_second.sh).
+template <int TYPE, int THREADS, bool CELL_LDS, bool IL, bool BIG = false>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(MM_FILTER_WAVES, MM_FILTER_WAVES)))
 filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
               const float* __restrict__ cell_chroma, const float* __restrict__ lib,
@@ -451,7 +454,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         // (cells above 16 groups have no stage 1 -- a lane of the prelude holds two or four blocks there -- but stage 0 is the same
         // one pass of wave 0 whatever the cell size: the survivors' compacted list then feeds the candidate loop directly)
         stage0 = use_lb && groups > 0 && cand_per_block <= 64 && (var.two_stage & 2) != 0 && var.cell_full[cell] == 1 &&
-                 (two_level || (MM_BIG_CELL_STAGE0 != 0 && lane_shift > 0));
+                 (two_level || (BIG && MM_BIG_CELL_STAGE0 != 0 && lane_shift > 0));
         // (the image-level statistics sit in slot ppad / 64 of each image's block statistics: no arguments of their own)
         if (stage0 && threadIdx.x < 7)
             cell_ist[threadIdx.x] = var.cell_stats[(size_t)threadIdx.x * var.cell_stats_stride + (size_t)cell * var.n_blocks + ppad / 64];
@@ -548,7 +551,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     MM_STAMP(4);
     // (the masks are read from LDS again per candidate: four more SGPRs held across the pixel loop cost more in spills)
     const int n_long = two_level ? __builtin_popcount(alive_mask[0]) + __builtin_popcount(alive_mask[1]) : 0;
-    const int n_todo = two_level ? n_long + __builtin_popcount(alive_mask[2]) + __builtin_popcount(alive_mask[3]) : (stage0 ? n_surv : n_here);
+    const int n_todo = two_level ? n_long + __builtin_popcount(alive_mask[2]) + __builtin_popcount(alive_mask[3]) : (BIG && stage0 ? n_surv : n_here);
     for (int turn = two_level ? 0 : wave; ;) {
         if (two_level) {                                    // the next survivor not yet taken by any wave
             int nxt = 0;
@@ -563,7 +566,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             const int nth = turn < n_long ? turn : turn - n_long;
             const bool mine = ((survivors >> lane) & 1ull) != 0 && __builtin_popcountll(survivors & ((1ull << lane) - 1ull)) == nth;
             idx = __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine));
-        } else if (stage0) {
+        } else if (BIG && stage0) {
             idx = __builtin_amdgcn_readfirstlane((int)surv_idx[turn]);     // stage 0's compacted list (seeds are not on it)
         }
         const int l = l_base + idx;
@@ -571,7 +574,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             int nxt = 0;
             if (lane == 0) nxt = atomicAdd(&next_candidate, 1);
             turn = __builtin_amdgcn_readfirstlane(nxt);      // scalar: library addresses stay in SGPRs
-            if (n_seeds > 0 && !stage0) {
+            if (n_seeds > 0 && !(BIG && stage0)) {
                 // scored already as a seed (seed_score_kernel left its score in the row): nothing to do
                 bool hit = false;
                 for (int t = lane; t < n_seeds; t += kWave) hit = hit || seed_ids[t] == l;
@@ -590,7 +593,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         // same descending-bound visiting order comes from ranking the 64 lanes against each other
         // ... and cells of 17 .. 32 groups (72 .. 90 px), whose lanes hold HALF a group each: the halves are added up into lanes
         // 0 .. 31 first (two ds_bpermute), then ranked the same way
-        const bool sorted64 = TYPE == CIEDE2000 && use_lb && lane_shift >= (MM_BIG_CELL_STAGE0 != 0 ? 1 : 2) && sort_groups != 0 && !two_level;
+        const bool sorted64 = TYPE == CIEDE2000 && use_lb && lane_shift >= (BIG && MM_BIG_CELL_STAGE0 != 0 ? 1 : 2) && sort_groups != 0 && !two_level;
         const bool by_group = sorted || two_level || sorted64;      // lane k of `rest`: visiting step k (else: block k)
         if constexpr (TYPE == CIEDE2000) {
             if (use_lb) {
@@ -753,7 +756,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         if (lane == 0) {                        // the counters are per lane (stage 1 counts on the candidates' first lanes)
             n_visited += (unsigned int)visited;
-            if (!two_level && !stage0) n_groups_all += (unsigned int)groups;      // (stage 0 counted its candidates itself)
+            if (!two_level && !(BIG && stage0)) n_groups_all += (unsigned int)groups;      // (stage 0 counted its candidates itself)
             n_bound_dropped += (pruned && visited == 0) ? 1u : 0u;
         }
         acc = wave_sum_all(acc + acc_edge);
@@ -1908,7 +1911,9 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     }
     const bool il = in.lib_il && in.cells_il;
     if (type == CIEDE2000) {
-        auto kern = il ? filter_kernel<CIEDE2000, kBlock, false, true> : filter_kernel<CIEDE2000, kBlock, false, false>;
+        const bool big = groups > 16 && il;
+        auto kern = big ? filter_kernel<CIEDE2000, kBlock, false, true, true>
+                        : (il ? filter_kernel<CIEDE2000, kBlock, false, true> : filter_kernel<CIEDE2000, kBlock, false, false>);
         Variants var = in.var;
         var.cell_order = nullptr;
         if (in.cell_order != nullptr && xcd_shares > 1 && prune_above != nullptr && var.cell_full != nullptr) {
