@@ -376,6 +376,9 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "check_every" (0 = by cell size): pixel groups between two exit tests of a candidate;
  * "probe_prepared" (0): mm_filter_diff_batch measures the CIEDE2000 filter form with operands prepared as the dominant kernel holds them;
  * "lds_filter" (-1 = RGB only): LDS-resident cell tile; "seeds" (-1 = 14 for CIEDE2000, 2 for RGB / CIE76): proxy-chosen seeds beyond the list length;
+ * "spec_auto" (1): the length of the speculative short lists ("spec_k", 4) doubles (up to 16) when the engine's PREVIOUS
+ * generate over the same library had to deepen more than 2 % of its cells -- content on which neighbouring cells want the same few
+ * images; as with "item_auto" only the TIME of a call depends on the engine's history, never its result; 0 pins "spec_k";
  * "band_guard" (1 = every cell; n: every n-th cell, 0: off): the best candidate the filter band EXCLUDED rides through the fp64 re-score as a sentinel; one that beats a contender is a band failure: the cell is re-done fp64-only and counted (mm_timing.band_alarms);
  * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
  * dropped in the engine's PREVIOUS CIEDE2000 launch over the same library, so the TIME of a call (never its result)

@@ -68,6 +68,9 @@ struct mm_engine {
     DevBuf area_tab;             // [detail + 1] first | [entries] src | [entries] alpha (kernels.hpp CellResize)
     int area_entries = 0;
     int spec_k = 4;              // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
+    int spec_auto = 1;           // mm_set_option("spec_auto", 0): the list length no longer follows the share of cells the engine's
+                                 // previous generate over the same library had to deepen (below)
+    int spec_k_learned = 0, spec_lib = 0, spec_size = 0;     // ... what it learned, and for which library (count, cell size)
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
     // per distinct mask in that mask's active-pixels-first order whenever either changes
@@ -663,7 +666,11 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     // (extra seeds tighten the CIEDE2000 limit -- 10..30 measured flat within 1 % of the filter time -- but buy the RGB /
     // CIE76 filter nothing: config B's kernel runs 0.315 ms at 0, 2, 6, 10 or 14 extra seeds while the seed phase grows from
     // 0.042 to 0.129 ms, so the Euclidean forms take two)
-    const int extra_seeds = e->extra_seeds >= 0 ? e->extra_seeds : (diff_type == MM_CIEDE2000 ? 14 : 2);
+    // (and a SMALL CIEDE2000 call -- the reference harness's line, config H: 1280 cells of 25 x 25 against 214 images -- is made of
+    // its fixed costs: 2 extra seeds instead of 14 take the seed phase from 0.109 to 0.041 ms and the step from 0.576 to 0.520 ms,
+    // while config C, 27 times the work, runs the same within 1 % from 6 to 14; tools/experiments/r4_third.sh)
+    const bool small_call = (double)std::min(n, 32768) * L * P < 1e9;
+    const int extra_seeds = e->extra_seeds >= 0 ? e->extra_seeds : (diff_type == MM_CIEDE2000 ? (small_call ? 2 : 14) : 2);
     const int M = std::min(L, std::min(256, round_up(K + extra_seeds, 4)));
     // Seeds and the early exit pay three launches (one when fused) and ~M full scores per cell for the pixel pairs they
     // save: below ~1e8 pairs of an RGB launch (~2e7 of CIEDE2000's, eight times the work per pair) the unpruned filter
@@ -1204,11 +1211,14 @@ mm_status begin_single_submission(mm_engine* e, int n, int grid_w, int grid_h, b
 mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n, int grid_w, int grid_h,
                                     int diff_type, int range, int addition, int K, int k_fill, bool speculate,
                                     const int32_t* cand_i_dev, const double* cand_s_dev, bool want_scores,
-                                    const uint8_t* flags_dev, bool counted)
+                                    const uint8_t* flags_dev, bool counted, bool continuing = false)
 {
+    // continuing: the block holds the state after sweeps that had not settled yet (nothing else wrong with it): the header is
+    // cleared and another set of sweeps runs from that state -- a fix-point iteration may be resumed anywhere
     const size_t cells_total = (size_t)grid_w * grid_h;
-    mm::ResultHeader* hdr = e->fast_hdr;
+    mm::ResultHeader* hdr = continuing ? (mm::ResultHeader*)e->result.p : e->fast_hdr;
     e->fast_hdr = nullptr;
+    if (continuing) HIP_TRY(e, hipMemsetAsync(hdr, 0, sizeof(mm::ResultHeader), e->stream), "Failed to clear the result header");
     long long* grid_dev = (long long*)((char*)e->result.p + sizeof(mm::ResultHeader));
     double* best_dev = (double*)(grid_dev + cells_total);
     mm_status st;
@@ -1219,7 +1229,7 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
     a.dense_count = &hdr->dense_count;
     a.row_slot = nullptr;                       // a mark voids the block; the step-by-step path then builds the rows
     a.insufficient_count = speculate ? &hdr->n_insufficient : nullptr;
-    if (!counted) {
+    if (!counted && !continuing) {
         if ((st = ensure(e, e->row_slot, (size_t)n * sizeof(int) + sizeof(int), "Failed to allocate row slots"))) return st;
         mm::mark_scan_kernel<<<std::min((n + mm::kBlock - 1) / mm::kBlock, 256), mm::kBlock, 0, e->stream>>>(
             cand_i_dev, n, K, a.deep, (int*)e->row_slot.p, (int*)&hdr->n_marked);
@@ -1260,6 +1270,30 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
     if (sequential && sweeps > 0) h->n_insufficient = h->sweep_insufficient[sweeps - 1];     // the final state's verdicts
     h->edge_pairs = h->filter_counters[0];
     memcpy(h->work, h->filter_counters + 2, sizeof h->work);
+    return MM_OK;
+}
+
+// The block's sweeps have not settled (content on which neighbours want the same few images -- photographs -- needs more than
+// the eight enqueued at first): further sets of sweeps from the state the block holds, one copy and one wait each, until a
+// sweep changes nothing or `max_sweeps` are spent.  Returns the index of the settling sweep within the LAST set (-1: none),
+// and the sweeps run before that set in *before.
+mm_status settle_sweeps(mm_engine* e, const mm_cell* recs_dev, int n, int grid_w, int grid_h, int diff_type, int range, int addition,
+                        int K, int k_fill, bool speculate, const int32_t* cand_i_dev, const double* cand_s_dev, bool want_scores,
+                        int* settled, int* before)
+{
+    const mm::ResultHeader& h = *(const mm::ResultHeader*)e->pinned;
+    *before = 0;
+    int done = (int)h.sweeps;
+    while (*settled < 0 && done < e->max_sweeps) {
+        if (e->phase_events) e->timing.resolve_ms += elapsed(e->ev[10], e->ev[11]);      // (the set that did not settle)
+        mm_status st = resolve_single_submission(e, recs_dev, n, grid_w, grid_h, diff_type, range, addition, K, k_fill, speculate,
+                                                 cand_i_dev, cand_s_dev, want_scores, nullptr, false, true);
+        if (st) return st;
+        *before = done;
+        for (unsigned int i = 0; i < h.sweeps && *settled < 0; ++i)
+            if (h.sweep_changes[i] == 0) *settled = (int)i;
+        done += (int)h.sweeps;
+    }
     return MM_OK;
 }
 
@@ -1957,8 +1991,20 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     e->syncs = 0;
 
     const int K = std::max(1, mm_candidates_per_cell(e->n_lib, repeat_range, repeat_addition));
-    const int Ks = std::max(1, mm_speculative_candidates(e->n_lib, repeat_range, repeat_addition, e->spec_k));
+    // Short lists of 4 verify every pick of the synthetic benchmark in one round; on content where neighbouring cells want the
+    // same few images (photographs: bench.py --config P deepens a fifth of its cells over four rounds at 4 entries, 7.5 ms per
+    // step; at 12 entries five cells in two rounds, 5.3 ms) longer lists are cheaper than the rounds.  So the length follows
+    // what the engine's PREVIOUS generate over the same library saw: more than 2 % of the cells deepened doubles it (up to 16).
+    // As with the filter's item size, only the TIME of a call depends on the history, never its result ("spec_auto" 0 pins it).
+    int spec_k = e->spec_k;
+    if (e->spec_auto != 0 && spec_k > 0 && e->spec_lib == e->n_lib && e->spec_size == e->lib_size) spec_k = std::max(spec_k, e->spec_k_learned);
+    const int Ks = std::max(1, mm_speculative_candidates(e->n_lib, repeat_range, repeat_addition, spec_k));
     const bool speculate = Ks < K && n_cells > 0;
+    auto learn_list_length = [&]() {
+        if (!speculate || e->spec_auto == 0) return;
+        if (e->spec_lib != e->n_lib || e->spec_size != e->lib_size) { e->spec_lib = e->n_lib; e->spec_size = e->lib_size; e->spec_k_learned = 0; }
+        if ((double)e->timing.deepened_cells > 0.02 * n_cells) e->spec_k_learned = std::min(16, 2 * Ks);
+    };
     const size_t cells_total = (size_t)grid_w * grid_h;
     HIP_TRY(e, hipEventRecord(e->ev[6], e->stream), "event");
     if ((st = ensure(e, e->recs, (size_t)std::max(n_cells, 1) * sizeof(mm_cell), "Failed to allocate cell records")) ||
@@ -2001,6 +2047,11 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
         int settled = -1;                  // first sweep that changed nothing
         for (unsigned int i = 0; i < h.sweeps && settled < 0; ++i)
             if (h.sweep_changes[i] == 0) settled = (int)i;
+        int sweeps_before = 0;
+        if (lists_ok && h.n_marked == 0 && sequential && settled < 0 &&
+            (st = settle_sweeps(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, K, Ks, speculate,
+                                (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr, &settled, &sweeps_before)))
+            return st;
         const bool resolved_ok = lists_ok && h.n_marked == 0 && (!sequential || settled >= 0);
         if (!lists_ok) {
             std::vector<uint8_t> flags_host((size_t)n_cells);
@@ -2011,7 +2062,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
         }
         if (resolved_ok) {
             if (e->phase_events) e->timing.resolve_ms += elapsed(e->ev[10], e->ev[11]);
-            e->timing.resolve_sweeps += sequential ? settled + 1 : 0;
+            e->timing.resolve_sweeps += sequential ? sweeps_before + settled + 1 : 0;
             e->timing.exact_rescored += (int64_t)(sequential ? h.sweep_exact[settled] : h.exact_plain);
             e->timing.dense_rows += (int64_t)h.dense_count;
             const char* body = (const char*)e->pinned + sizeof(mm::ResultHeader);
@@ -2055,12 +2106,16 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
                                                nullptr, false);
                 if (st) return st;
                 const mm::ResultHeader& h = *(const mm::ResultHeader*)e->pinned;
-                int settled = -1;
+                int settled = -1, sweeps_before = 0;
                 for (unsigned int i = 0; i < h.sweeps && settled < 0; ++i)
                     if (h.sweep_changes[i] == 0) settled = (int)i;
+                if (h.n_marked == 0 && sequential && settled < 0 &&
+                    (st = settle_sweeps(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, K, Ks, speculate,
+                                        (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr, &settled, &sweeps_before)))
+                    return st;
                 if (h.n_marked == 0 && (!sequential || settled >= 0)) {
                     if (e->phase_events) e->timing.resolve_ms += elapsed(e->ev[10], e->ev[11]);
-                    e->timing.resolve_sweeps += sequential ? settled + 1 : 0;
+                    e->timing.resolve_sweeps += sequential ? sweeps_before + settled + 1 : 0;
                     e->timing.exact_rescored += (int64_t)(sequential ? h.sweep_exact[settled] : h.exact_plain);
                     e->timing.dense_rows += (int64_t)h.dense_count;
                     const char* body = (const char*)e->pinned + sizeof(mm::ResultHeader);
@@ -2104,6 +2159,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
     e->timing.pair_evals = count_pair_evals(e, cells, n_cells);
     e->timing.host_syncs = e->syncs;
+    learn_list_length();
     return MM_OK;
 }
 
@@ -2381,7 +2437,8 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "sweep_resolve") == 0) { e->use_sweep_resolve = value != 0; return MM_OK; }
     if (strcmp(name, "max_sweeps") == 0) { if (value < 1 || value > 4096) return MM_INVALID_ARGUMENT; e->max_sweeps = value; return MM_OK; }
     if (strcmp(name, "lds_filter") == 0) { e->use_lds_filter = value < 0 ? -1 : (value != 0); return MM_OK; }
-    if (strcmp(name, "spec_k") == 0) { e->spec_k = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "spec_k") == 0) { e->spec_k = std::max(0, value); e->spec_k_learned = 0; return MM_OK; }
+    if (strcmp(name, "spec_auto") == 0) { e->spec_auto = value != 0; e->spec_k_learned = 0; return MM_OK; }
     if (strcmp(name, "seeds") == 0) { e->extra_seeds = std::max(-1, value); return MM_OK; }
     if (strcmp(name, "lds_pad_kb") == 0) { e->lds_pad_kb = std::min(120, std::max(0, value)); return MM_OK; }
     if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }

@@ -644,6 +644,16 @@ mm_timing HIPPhotomosaicGenerator::timing() const
     return t;
 }
 
+std::vector<std::pair<std::string, double>> HIPPhotomosaicGenerator::timingLog() const
+{
+    const mm_timing t = timing();
+    mm_stage_timing st{};
+    mm_get_stage_timing(m_engine, &st);
+    return {{"generateBestFits", t.total_ms}, {"Preprocess", st.preprocess_ms}, {"cudaMalloc", st.alloc_ms + st.pinned_ms},
+            {"cudaMemcpy", t.stage_ms}, {"DiffReduce", t.seed_ms + t.score_ms + t.rescore_ms}, {"Flatten", t.select_ms},
+            {"Repeats+FindLowest", t.resolve_ms}};
+}
+
 // One record per cell of a size step, raster order (CPUPhotomosaicGenerator.cpp:63-77).
 // painting = false: cells with a value, bound at the detail size (getCellAt,
 // PhotomosaicGeneratorBase.cpp:299-326); painting = true: the same cells with the bound of the

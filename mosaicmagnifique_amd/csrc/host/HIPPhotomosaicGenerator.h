@@ -21,6 +21,7 @@
 #include <functional>
 #include <optional>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/mosaic_hip.h"
@@ -199,6 +200,10 @@ public:
     std::function<void(int)> progress;                            // the progress(int) signal
     const std::string& lastError() const { return m_lastError; }
     mm_timing timing() const;
+    // The last generateBestFits' times (ms) under the ids the reference's TimingLogger records for its device path
+    // (CUDAPhotomosaicGenerator.cpp:45-358,376-506): generateBestFits, Preprocess, cudaMalloc, cudaMemcpy, DiffReduce,
+    // Flatten, Repeats+FindLowest -- the coarse view of mm_timing / mm_stage_timing a maintainer comparing logs wants.
+    std::vector<std::pair<std::string, double>> timingLog() const;
 
 private:
     mm_engine* m_engine = nullptr;          // m_engines[0]: the one that resolves and paints

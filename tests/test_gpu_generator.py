@@ -580,3 +580,15 @@ def test_smooth_content(oracle, size):
         tm = gen.timing()
         assert tm["band_alarms"] == 0
     assert tm["bound_dropped"] > 0
+
+
+def test_timing_log_uses_the_reference_s_phase_ids(oracle):
+    """timingLog(): the last run's times under the ids the reference's TimingLogger records on its device path
+    (CUDAPhotomosaicGenerator.cpp:45-358,376-506) -- every id present, every time non-negative, the parts within the whole."""
+    shape = cases.square_shape(32)
+    img, lib = cases.inputs(160, 192, 32, 90, Type.CIEDE2000)
+    gen = compare(oracle, shape, img, lib, Type.CIEDE2000, (2, 300))
+    log = gen.timingLog()
+    assert set(log) == {"generateBestFits", "Preprocess", "cudaMalloc", "cudaMemcpy", "DiffReduce", "Flatten", "Repeats+FindLowest"}
+    assert all(v >= 0 for v in log.values()) and log["generateBestFits"] > 0 and log["DiffReduce"] > 0
+    assert log["cudaMemcpy"] + log["DiffReduce"] + log["Flatten"] + log["Repeats+FindLowest"] <= log["generateBestFits"] * 1.05
