@@ -383,6 +383,8 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
  * dropped in the engine's PREVIOUS CIEDE2000 launch over the same library, so the TIME of a call (never its result)
  * depends on the call history of the engine; 0 pins the size-by-cell default (mm_timing.filter_tile reports what ran).
+ * "pretier" (1): CIEDE2000 candidates first walk their pixel groups in a packed-fp16 form (two pixel pairs per lane-instruction) that only
+ * takes early-exit decisions, against the limit widened by its own measured band; survivors are scored by the fp32 form as before;
  * "stage0" (1): one whole-image bound per candidate ahead of the block bound; "euclid_stage1" (1): the RGB / CIE76 filter
  * judges the block bound one candidate per lane before any wave is spent on a candidate; "item_chunk" (0 = 1): work items a persistent
  * filter workgroup takes per global atomic; "cell_order" (1): the CIEDE2000 filter takes each XCD share's clipped cells (long items) first; "tiny" (1): detail cells of <= 64 pixels take the one-wave-per-cell path;
@@ -425,7 +427,10 @@ mm_status mm_filter_diff_batch(mm_engine *e, int diff_type,
  * grid on both sides of the opposite-hue discontinuity (hue difference 180 deg +- 1e-7 .. 3e-2 rad).
  * out: max |fp32 - fp64|, max (|err| - 6e-5 v), max |err| / (band px_abs + 6e-5 v) -- the share of
  * the trusted band the worst pair uses, must stay below 1 --, the largest fp64 value met, pairs
- * handed to the fp64 form, pairs measured. */
+ * handed to the fp64 form, pairs measured.  Modes 2 and 3: the same two sweeps for the filter's packed-fp16 pre-tier
+ * (operands rounded to halfs as the engine stores them) against ITS band; the share is then the signed OVER-estimate
+ * (fp16 - fp64) / band -- an under-estimate only delays an early exit --, "handed over" counts the pairs the form counts as 0
+ * near the opposite-hue seam, and a non-finite value off the seam reports a share of 1e9. */
 mm_status mm_debug_filter_band_sweep(mm_engine *e, int mode, uint64_t seed, uint64_t n_pairs, double out[6]);
 
 /* Diagnostics: {pixel groups visited by the filter kernel, groups a full visit takes,

@@ -56,6 +56,8 @@ struct mm_engine {
     DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, sentinel;
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut, lib_il, cells_il;
+    DevBuf lib_h, cells_h;       // the interleaved copies as halfs (the filter's packed-fp16 pre-tier)
+    int pretier = 1;             // mm_set_option("pretier", 0): no packed-fp16 pre-tier ahead of the fp32 filter form
     DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
     DevBuf stage_u8, srgb_lut, shrink_tmp, covered, cells_f0;
     DevBuf main_bgr;   int main_rows = 0, main_cols = 0;      // mm_set_main_image_bgr: the u8 main image (entropy test)
@@ -425,6 +427,10 @@ mm_status prepare_planes(mm_engine* e)
     if ((st = ensure(e, e->lib_il, (size_t)n_var * L * 4 * ppad * sizeof(float), "Failed to allocate interleaved library"))) return st;
     HIP_TRY(e, mm::launch_interleave((const float*)e->lib.p, (const float*)e->lib_chroma.p, nullptr, (float*)e->lib_il.p,
                                      (size_t)n_var * L, ppad, e->stream), "Error during library interleave kernel");
+    // ... and once more as halfs, for the filter's packed-fp16 pre-tier
+    if ((st = ensure(e, e->lib_h, (size_t)n_var * L * 4 * ppad * sizeof(uint16_t), "Failed to allocate the half-precision library"))) return st;
+    HIP_TRY(e, mm::launch_interleave_h((const float*)e->lib_il.p, e->lib_h.p, (size_t)n_var * L, ppad, e->stream),
+            "Error during half-precision library kernel");
     // whole-image statistics for stage 0 of the filter's bound (the blocks holding active pixels, joined), into slot ppad / 64
     for (int v = 0; v < n_var; ++v)
         HIP_TRY(e, mm::launch_image_stats((float*)e->lib_lsum.p + (size_t)v * L * stat_slots(ppad), (size_t)n_var * L * stat_slots(ppad),
@@ -682,7 +688,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     // Batch so that every per-cell workspace stays within a budget: score row, the planar / NaN-marked / chroma /
     // interleaved copies of the cell and its mask, block statistics, contenders, seeds, flags.
     const size_t per_cell = tiny ? (size_t)L * sizeof(double) + 16
-                                 : (size_t)L * sizeof(double) + (size_t)ppad * (12 + 1 + (two_tier ? 4 + 4 + 16 : 0)) +
+                                 : (size_t)L * sizeof(double) + (size_t)ppad * (12 + 1 + (two_tier ? 4 + 4 + 16 + 8 : 0)) +
                                    (size_t)8 * stat_slots(ppad) * sizeof(float) + (size_t)Kc * 16 + (prune ? (size_t)M * 8 + 4 : 0) + 20;
     // hipMemGetInfo is a driver round trip: asked again only when this call needs more cells per batch than the
     // last budget allowed (the workspaces below are kept between calls)
@@ -732,7 +738,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                 (st = ensure_hue_lut(e)) ||
                 (st = ensure(e, e->cell_chroma, (size_t)bt * ppad * sizeof(float), "Failed to allocate cell chroma planes")) ||
                 (st = ensure(e, e->cells_f0, (size_t)bt * ppad * sizeof(float), "Failed to allocate cell planes")) ||
-                (st = ensure(e, e->cells_il, (size_t)bt * 4 * ppad * sizeof(float), "Failed to allocate interleaved cells")))
+                (st = ensure(e, e->cells_il, (size_t)bt * 4 * ppad * sizeof(float), "Failed to allocate interleaved cells")) ||
+                (st = ensure(e, e->cells_h, (size_t)bt * 4 * ppad * sizeof(uint16_t), "Failed to allocate half-precision cells")))
                 return st;
         }
         if (prune) {
@@ -880,6 +887,13 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                                                         (e->var_active[2] + 63) / 64, (e->var_active[3] + 63) / 64)),
                     "Error during cell image-statistics kernel");
         fin.var.two_stage = (e->two_level ? 1 : 0) | (stage0 ? 2 : 0);
+        // the packed-fp16 pre-tier reads half copies of the cells and the library (CIEDE2000 with the early exit, interleaved form)
+        const bool pretier = e->pretier != 0 && prune && diff_type == MM_CIEDE2000 && e->use_interleave != 0 && fin.use_lds_form == 0;
+        fin.lib_h = pretier ? e->lib_h.p : nullptr;
+        fin.cells_h = pretier ? e->cells_h.p : nullptr;
+        if (pretier)
+            HIP_TRY(e, mm::launch_interleave_h((const float*)e->cells_il.p, e->cells_h.p, (size_t)b, ppad, e->stream),
+                    "Error during half-precision cell kernel");
         if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[1], e->stream), "event");
 
         // tier 1: fp32 filter score of every (cell, candidate), with early exit against a
@@ -1318,7 +1332,7 @@ DevBuf mm_engine::* const kDeviceBuffers[] = {
     &mm_engine::cell_full, &mm_engine::cell_order, &mm_engine::pos_mask, &mm_engine::lib_lsum, &mm_engine::cell_lsum,
     &mm_engine::stage_u8, &mm_engine::srgb_lut, &mm_engine::shrink_tmp, &mm_engine::covered, &mm_engine::cells_f0, &mm_engine::area_tab,
     &mm_engine::sweep_counts, &mm_engine::sentinel, &mm_engine::lib_il, &mm_engine::cells_il, &mm_engine::result, &mm_engine::main_bgr,
-    &mm_engine::entropy_out, &mm_engine::exceeded_out, &mm_engine::lib_tiny, &mm_engine::lib_stats_t, &mm_engine::range_flags };
+    &mm_engine::entropy_out, &mm_engine::exceeded_out, &mm_engine::lib_tiny, &mm_engine::lib_stats_t, &mm_engine::range_flags, &mm_engine::lib_h, &mm_engine::cells_h };
 
 std::mutex g_park_lock;
 std::vector<mm_engine*> g_parked;           // at most one per device: engines that only hold resources
@@ -2406,7 +2420,7 @@ mm_status mm_debug_stream_read(mm_engine* e, size_t bytes, int repeats, double* 
 // out[4], out[5] = pairs handed to the fp64 form / pairs measured.
 mm_status mm_debug_filter_band_sweep(mm_engine* e, int mode, uint64_t seed, uint64_t n_pairs, double out[6])
 {
-    if (!e || !out || (mode != 0 && mode != 1) || n_pairs == 0) return MM_INVALID_ARGUMENT;
+    if (!e || !out || mode < 0 || mode > 3 || n_pairs == 0) return MM_INVALID_ARGUMENT;       // (modes 2, 3: the packed-fp16 pre-tier's form against its own band)
     HIP_TRY(e, select_device(e), "Failed to select device");
     mm_status st = ensure_hue_lut(e);
     if (st) return st;
@@ -2455,6 +2469,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }
     if (strcmp(name, "euclid_stage1") == 0) { e->euclid_stage1 = value != 0; return MM_OK; }
     if (strcmp(name, "stage0") == 0) { e->stage0 = value != 0; return MM_OK; }
+    if (strcmp(name, "pretier") == 0) { e->pretier = value != 0; return MM_OK; }
     if (strcmp(name, "tiny") == 0) { e->tiny_path = value != 0; return MM_OK; }
     if (strcmp(name, "item_auto") == 0) { e->item_auto = value != 0; return MM_OK; }
     if (strcmp(name, "fused") == 0) { e->fused = value != 0; return MM_OK; }

@@ -218,6 +218,16 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 #ifndef MM_BIG_CELL_STAGE0
 #define MM_BIG_CELL_STAGE0 1         // cells above 16 groups: stage 0 of the bound ahead of the candidate loop, bound-ordered visits from 17 groups on (0: round 3's form, for A/B builds)
 #endif
+// Error band of the packed-fp16 pre-tier per pixel pair: |fp16 form - fp64 form| <= kPreAbs + kPreRel * value for operands
+// inside the validated box, with the operands rounded to halfs as interleave_h_kernel stores them (measured by
+// band_sweep_kernel modes 2 / 3 and held below half of this by tests/test_gpu_filter.py); the pre-tier's accumulation is fp32.
+#ifndef MM_PRE_ABS
+#define MM_PRE_ABS 0.35f
+#endif
+#ifndef MM_PRE_REL
+#define MM_PRE_REL 8e-3f
+#endif
+constexpr float kPreAbs = MM_PRE_ABS, kPreRel = MM_PRE_REL;
 #ifndef MM_LONG_SPLIT
 #define MM_LONG_SPLIT 0.8f
 #endif
@@ -258,7 +268,14 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // BIG: the instantiation for cells above 16 groups (80 x 80 .. 128 x 128): stage 0 of the bound ahead of the candidate loop and
 // bound-ordered visits from 17 groups on.  A template parameter and not a run-time branch: the extra scalars it keeps alive
 // cost the 64 x 64 instantiation three more spilled SGPRs and config D 0.3 % (measured, tools/experiments/r4_second.sh).
-template <int TYPE, int THREADS, bool CELL_LDS, bool IL, bool BIG = false>
+// PRE: the packed-fp16 pre-tier (colour_diff_fast.hpp ciede2000_h2).  A candidate first walks its groups in the fp16 form,
+// two pixel pairs per lane-instruction, from half copies of the cell and the library (`cells` and `lib_chroma`, which the
+// interleaved fp32 form leaves unused, carry their addresses), with the exit test against the limit widened by the fp16
+// form's own band; only a candidate that survives ALL its groups there is walked again by the fp32 form, whose score is the
+// one the contender selection reads.  Dropped candidates get +inf as before.  Sound because every term is >= 0 and the fp16
+// sum under-estimates by at most its band: "fp16 sum of the visited groups + bound of the others > limit + band" implies the
+// same for the true sum against the limit.
+template <int TYPE, int THREADS, bool CELL_LDS, bool IL, bool BIG = false, bool PRE = false>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(MM_FILTER_WAVES, MM_FILTER_WAVES)))
 filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
               const float* __restrict__ cell_chroma, const float* __restrict__ lib,
@@ -688,9 +705,40 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 pruned = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), 0)) > limit;
             }
         }
+        int visited = 0;
+        if constexpr (PRE) {
+            if (!pruned && groups > 0 && prune_above != nullptr) {
+                // half copies: [image][group][plane][256] halfs -- a group is 2 KB, a plane 512 B, a lane's four positions 8 B
+                const char* const ch = reinterpret_cast<const char*>(cells) + (size_t)cell * 8 * ppad;
+                const char* const lh = reinterpret_cast<const char*>(lib_chroma_base) + ((size_t)v * L + l) * 8 * (size_t)ppad;
+                // (the band over ALL of the cell's positions: an upper bound of the active ones)
+                const float limit16 = fmaf(limit, 1.0f + kPreRel, kPreAbs * (float)(groups * 4 * kWave));
+                float acc16 = 0.0f;
+                bool out16 = false;
+                for (int step = 0; step < groups; ++step) {
+                    const int j = (sorted || sorted64) ? __builtin_amdgcn_readlane(order, step) : step;
+                    if (step != 0 && step % check_every == 0) {
+                        const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), by_group ? step : (4 * step) >> lane_shift)) : 0.0f;
+                        if (wave_sum_exceeds(acc16, rest_j, limit16)) { out16 = true; break; }
+                    }
+                    const unsigned int off = (unsigned int)j * 2048u + (unsigned int)lane * 8u;
+                    const uint2 p0 = *reinterpret_cast<const uint2*>(ch + off), p1 = *reinterpret_cast<const uint2*>(ch + off + 512u),
+                                p2 = *reinterpret_cast<const uint2*>(ch + off + 1024u), pc = *reinterpret_cast<const uint2*>(ch + off + 1536u);
+                    const uint2 q0 = *reinterpret_cast<const uint2*>(lh + off), q1 = *reinterpret_cast<const uint2*>(lh + off + 512u),
+                                q2 = *reinterpret_cast<const uint2*>(lh + off + 1024u), qc = *reinterpret_cast<const uint2*>(lh + off + 1536u);
+                    const half2_t va = ciede2000_h2(h2_from(p0.x), h2_from(p1.x), h2_from(p2.x), h2_from(pc.x),
+                                                    h2_from(q0.x), h2_from(q1.x), h2_from(q2.x), h2_from(qc.x), lut);
+                    const half2_t vb = ciede2000_h2(h2_from(p0.y), h2_from(p1.y), h2_from(p2.y), h2_from(pc.y),
+                                                    h2_from(q0.y), h2_from(q1.y), h2_from(q2.y), h2_from(qc.y), lut);
+                    acc16 += ((float)va.x + (float)va.y) + ((float)vb.x + (float)vb.y);
+                    visited += 1;
+                }
+                if (!out16 && wave_sum_exceeds(acc16, 0.0f, limit16)) out16 = true;
+                if (out16) pruned = true;       // (a survivor goes on to the fp32 form below)
+            }
+        }
         float acc = 0.0f;          // terms with a proven error bound
         float acc_edge = 0.0f;     // terms awaiting the fp64 patch
-        int visited = 0;
         if (!pruned && groups > 0) {
             // One 256-pixel group of the candidate against the cell; true = candidate dropped.
             auto visit = [&](const LibGroup& cur, int j, int step) -> bool {
@@ -1159,6 +1207,20 @@ interleave_kernel(const float* __restrict__ planar, const float* __restrict__ ch
         dst[2 * kWave] = src[2 * per + q];
         float4 ch = chroma ? reinterpret_cast<const float4*>(chroma + img * (size_t)ppad)[q] : float4{0.f, 0.f, 0.f, 0.f};
         dst[3 * kWave] = float4{__fmul_rn(kChromaPrep, ch.x), __fmul_rn(kChromaPrep, ch.y), __fmul_rn(kChromaPrep, ch.z), __fmul_rn(kChromaPrep, ch.w)};
+    }
+}
+
+// The interleaved copy once more as halfs, for the packed-fp16 pre-tier (colour_diff_fast.hpp ciede2000_h2): the same
+// [image][group][plane][256] order, planes L / 2 - 25, a / 4, b / 4, C / 50, round-to-nearest; a NaN stays a NaN.
+__global__ void __launch_bounds__(kBlock)
+interleave_h_kernel(const float4* __restrict__ il, uint2* __restrict__ out, size_t n_vec)
+{
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n_vec; t += (size_t)gridDim.x * kBlock) {
+        const int plane = (int)((t >> 6) & 3);                    // 64 float4 per plane, four planes per group
+        const float sc = (plane == 1 || plane == 2) ? kHalfOperandScale : 1.0f;
+        const float4 v = il[t];
+        const half2_t lo{(half1_t)(sc * v.x), (half1_t)(sc * v.y)}, hi{(half1_t)(sc * v.z), (half1_t)(sc * v.w)};
+        out[t] = uint2{h2_bits(lo), h2_bits(hi)};
     }
 }
 
@@ -1674,7 +1736,7 @@ band_sweep_kernel(int mode, unsigned long long seed, unsigned long long n_pairs,
         const float j0 = (float)(u & 1023u) * (1.0f / 1024.0f), j1 = (float)((u >> 10) & 1023u) * (1.0f / 1024.0f),
                     j2 = (float)((u >> 20) & 1023u) * (1.0f / 1024.0f);
         double h1, h2;
-        if (mode == 0) {
+        if ((mode & 1) == 0) {
             const int h2i = (int)(r % 512); r /= 512;
             const int h1i = (int)(r % 512);
             h1 = 6.283185307179586 * ((double)h1i + j0) / 512.0;
@@ -1691,13 +1753,31 @@ band_sweep_kernel(int mode, unsigned long long seed, unsigned long long n_pairs,
         const float l2 = fminf(fmaxf(l1 + dl_levels[li % 5] + 2.0f * (j2 - 0.5f), 0.0f), 100.0f);
         const PxF p{l1, (float)(ch1 * cos(h1)), (float)(ch1 * sin(h1))}, q{l2, (float)(ch2 * cos(h2)), (float)(ch2 * sin(h2))};
         bool edge;
-        const float fast = ciede2000_fast(p, q, chroma_of(p.c1, p.c2), chroma_of(q.c1, q.c2), lut, &edge);
+        float fast;
+        if (mode & 2) {
+            // the packed-fp16 pre-tier's form on operands rounded to halfs as interleave_h_kernel stores them; pairs it counts as 0
+            // (near the seam) are "handed over".  What must hold is the OVER-estimate: fp16 - fp64 <= band (an under-estimate only
+            // delays an exit), so the share reported is the signed one; max_err stays the absolute error
+            auto prep = [](const PxF& c, half2_t& l, half2_t& a, half2_t& b, half2_t& ch) {
+                l = h2_splat(fmaf(0.5f, c.c0, -25.0f)); a = h2_splat(kHalfOperandScale * c.c1); b = h2_splat(kHalfOperandScale * c.c2);
+                ch = h2_splat(__fmul_rn(kChromaPrep, chroma_of(c.c1, c.c2)));
+            };
+            half2_t pl, pa, pb, pch, ql, qa, qb, qch;
+            prep(p, pl, pa, pb, pch); prep(q, ql, qa, qb, qch);
+            unsigned int seam = 0u;
+            const half2_t v16 = ciede2000_h2(pl, pa, pb, pch, ql, qa, qb, qch, lut, &seam);
+            fast = (float)v16.x;
+            edge = (seam & 0xffffu) != 0u;
+            if (!edge && !(fast == fast && fabsf(fast) < 1e30f)) m_ratio = 1e9;       // NaN / inf outside the seam: must not happen in the box
+        } else {
+            fast = ciede2000_fast(p, q, chroma_of(p.c1, p.c2), chroma_of(q.c1, q.c2), lut, &edge);
+        }
         if (edge) { handed += 1; continue; }
         const double exact = ciede2000(Px{p.c0, p.c1, p.c2}, Px{q.c0, q.c1, q.c2});
         const double err = fabs((double)fast - exact);
         m_err = fmax(m_err, err);
         m_abs = fmax(m_abs, err - (double)rel * exact);
-        m_ratio = fmax(m_ratio, err / ((double)px_abs + (double)rel * exact));
+        m_ratio = fmax(m_ratio, ((mode & 2) ? (double)fast - exact : err) / ((double)px_abs + (double)rel * exact));
         m_val = fmax(m_val, exact);
         measured += 1;
     }
@@ -1724,6 +1804,8 @@ hipError_t launch_band_sweep(int mode, unsigned long long seed, unsigned long lo
 {
     hipError_t code = hipMemsetAsync(out6, 0, 6 * sizeof(unsigned long long), stream);
     if (code != hipSuccess) return code;
+    // modes 2 / 3: the same two sweeps for the packed-fp16 pre-tier's form, against ITS band
+    if (mode & 2) { px_abs = kPreAbs; rel = kPreRel; }
     band_sweep_kernel<<<256 * 16, kBlock, 0, stream>>>(mode, seed, n_pairs, px_abs, rel, hue_lut, out6);
     return hipGetLastError();
 }
@@ -1912,8 +1994,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     const bool il = in.lib_il && in.cells_il;
     if (type == CIEDE2000) {
         const bool big = groups > 16 && il;
-        auto kern = big ? filter_kernel<CIEDE2000, kBlock, false, true, true>
-                        : (il ? filter_kernel<CIEDE2000, kBlock, false, true> : filter_kernel<CIEDE2000, kBlock, false, false>);
+        const bool pre = il && in.lib_h != nullptr && in.cells_h != nullptr && prune_above != nullptr;
+        auto kern = pre ? (big ? filter_kernel<CIEDE2000, kBlock, false, true, true, true> : filter_kernel<CIEDE2000, kBlock, false, true, false, true>)
+                        : big ? filter_kernel<CIEDE2000, kBlock, false, true, true>
+                              : (il ? filter_kernel<CIEDE2000, kBlock, false, true> : filter_kernel<CIEDE2000, kBlock, false, false>);
         Variants var = in.var;
         var.cell_order = nullptr;
         if (in.cell_order != nullptr && xcd_shares > 1 && prune_above != nullptr && var.cell_full != nullptr) {
@@ -1925,8 +2009,8 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             (code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)in.lds_pad_bytes)) != hipSuccess) return code;
         kern<<<dim3(persistent_grid(reinterpret_cast<const void*>(kern), blocks, kBlock, in.lds_pad_bytes)), kBlock, in.lds_pad_bytes, stream>>>(
-            il ? nullptr : in.cells, il ? in.cells_il : in.cells_f0, il ? nullptr : in.cell_chroma, il ? in.lib_il : in.lib,
-            il ? nullptr : in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
+            pre ? reinterpret_cast<const float*>(in.cells_h) : (il ? nullptr : in.cells), il ? in.cells_il : in.cells_f0, il ? nullptr : in.cell_chroma,
+            il ? in.lib_il : in.lib, pre ? reinterpret_cast<const float*>(in.lib_h) : (il ? nullptr : in.lib_chroma), scores, n_cells, L, ppad, cand_per_block,
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, var, xcd_shares,
             in.seeds, in.seeds ? in.n_seeds : 0, sort_groups, item_chunk);
         if ((code = hipGetLastError()) != hipSuccess) return code;
@@ -1948,6 +2032,15 @@ hipError_t launch_interleave(const float* planar, const float* chroma, const flo
     const unsigned blocks = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 65536);
     if (blocks == 0) return hipSuccess;
     interleave_kernel<<<blocks, kBlock, 0, stream>>>(planar, chroma, plane0, out, n_images, ppad);
+    return hipGetLastError();
+}
+
+hipError_t launch_interleave_h(const float* il, void* out_halfs, size_t n_images, int ppad, hipStream_t stream)
+{
+    const size_t n_vec = n_images * (size_t)ppad;                  // 4 planes x ppad floats = ppad float4
+    const unsigned blocks = (unsigned)std::min<size_t>((n_vec + kBlock - 1) / kBlock, 65536);
+    if (blocks == 0) return hipSuccess;
+    interleave_h_kernel<<<blocks, kBlock, 0, stream>>>(reinterpret_cast<const float4*>(il), reinterpret_cast<uint2*>(out_halfs), n_vec);
     return hipGetLastError();
 }
 

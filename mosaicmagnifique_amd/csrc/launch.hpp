@@ -56,6 +56,8 @@ struct FilterInputs {
                                 // plane order (cells up to 64 x 64); 0: plane order
     const float* lib_il;        // interleaved copies for filter_kernel<IL> (launch_interleave): [V][L][ppad/256][4][256] and
     const float* cells_il;      // [B][ppad/256][4][256] (plane 0 = cells_f0); null: the planar arrays are read
+    const void* lib_h;          // the interleaved copies as halfs (launch_interleave_h), for the packed-fp16 pre-tier of
+    const void* cells_h;        // filter_kernel<.., PRE>; null: no pre-tier
     const float* lib_stats_t;   // Euclid LDS kernel's stage 1: the library's three channel sums per block, candidate-fastest
                                 // [variant][3][ppad / 64][L] (launch_transpose_stats); null: one wave per candidate from the start
     int check_every;            // groups between two exit tests of a candidate (0 = 1 up to 16 groups per cell, groups / 16 above)
@@ -101,6 +103,8 @@ hipError_t launch_image_stats(float* stats, size_t block_stride, int slots_per_i
 hipError_t launch_transpose_stats(const float* stats, size_t block_stride, int slots_per_image, int n_blocks, float* out,
                                   size_t n_images, hipStream_t stream);
 
+// The interleaved copy of n images as halfs ([image][group][plane][256], a and b / 4): what the packed-fp16 pre-tier reads.
+hipError_t launch_interleave_h(const float* il, void* out_halfs, size_t n_images, int ppad, hipStream_t stream);
 // Interleaved copy of n planar images (+ chroma, + optional replacement of channel 0): [n][ppad/256][4][256].
 hipError_t launch_interleave(const float* planar, const float* chroma, const float* plane0, float* out,
                              size_t n_images, int ppad, hipStream_t stream);

@@ -88,6 +88,25 @@ def test_ciede2000_filter_band_structured_sweep(engine):
     assert r["handed_over"] > 0 and r["measured"] > 5e8    # both: pairs inside the hand-over zone and just outside it
 
 
+def test_packed_fp16_pretier_band_structured_sweep(engine):
+    """The filter's packed-fp16 pre-tier (colour_diff_fast.hpp ciede2000_h2) takes early-exit decisions only, against the
+    limit widened by ITS band (filter.hip kPreAbs + kPreRel * value per pixel pair).  What must hold is the over-estimate:
+    fp16 form - fp64 form <= band on operands rounded to halfs as the engine stores them (an under-estimate only delays an
+    exit; pairs near the opposite-hue seam count 0).  The same two structured sweeps that back the fp32 band -- hue x hue x
+    chroma x chroma x lightness, and both sides of the seam -- : the worst over-estimate stays below half of the band, and
+    nothing comes out non-finite inside the box (reported as a share of 1e9)."""
+    grid = 512 * 512 * 24 * 24 * 25
+    for seed in range(2):
+        r = engine.filter_band_sweep(2, grid, seed=seed)
+        print("fp16 pre-tier sweep mode 2 seed %d: %s" % (seed, r))
+        assert r["band_share"] <= 0.5, r
+        assert r["measured"] > 3e9 and r["max_value"] > 100
+    r = engine.filter_band_sweep(3, 512 * 128 * 24 * 24 * 25, seed=7)
+    print("fp16 pre-tier sweep mode 3: %s" % r)
+    assert r["band_share"] <= 0.5, r
+    assert r["handed_over"] > 0 and r["measured"] > 1e8
+
+
 def band_share(engine, a, b):
     """|fp32 filter form - fp64 form| as a share of the band the engine trusts (engine.hip filter_band: 1e-3 + 6e-5 * value);
     pairs the filter hands to the fp64 form count as 0."""
