@@ -57,7 +57,12 @@ struct mm_engine {
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut, lib_il, cells_il;
     DevBuf lib_h, cells_h;       // the interleaved copies as halfs (the filter's packed-fp16 pre-tier)
-    int pretier = 1;             // mm_set_option("pretier", 0): no packed-fp16 pre-tier ahead of the fp32 filter form
+    bool lib_h_ready = false;    // lib_h holds the current library (prepare_planes builds it only where the pre-tier may run)
+    int pretier = -1;            // mm_set_option("pretier", 0 / 1): the packed-fp16 pre-tier ahead of the fp32 filter form never / always;
+                                 // -1 = by cell size: for cells above 32 pixel groups (up to 128 x 128, the reference GUI's default), whose
+                                 // launches are bound by the fabric and gain from operands half the size (config G 16.1 -> 14.9 ms per
+                                 // step); smaller cells are bound by VALU issue, where the pre-tier's later exits and the second walk of
+                                 // its survivors cost more than its cheaper arithmetic saves (config D 44.5 -> 46.1 ms: HISTORY.md)
     DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
     DevBuf stage_u8, srgb_lut, shrink_tmp, covered, cells_f0;
     DevBuf main_bgr;   int main_rows = 0, main_cols = 0;      // mm_set_main_image_bgr: the u8 main image (entropy test)
@@ -427,10 +432,7 @@ mm_status prepare_planes(mm_engine* e)
     if ((st = ensure(e, e->lib_il, (size_t)n_var * L * 4 * ppad * sizeof(float), "Failed to allocate interleaved library"))) return st;
     HIP_TRY(e, mm::launch_interleave((const float*)e->lib.p, (const float*)e->lib_chroma.p, nullptr, (float*)e->lib_il.p,
                                      (size_t)n_var * L, ppad, e->stream), "Error during library interleave kernel");
-    // ... and once more as halfs, for the filter's packed-fp16 pre-tier
-    if ((st = ensure(e, e->lib_h, (size_t)n_var * L * 4 * ppad * sizeof(uint16_t), "Failed to allocate the half-precision library"))) return st;
-    HIP_TRY(e, mm::launch_interleave_h((const float*)e->lib_il.p, e->lib_h.p, (size_t)n_var * L, ppad, e->stream),
-            "Error during half-precision library kernel");
+    e->lib_h_ready = false;        // (the half copy for the packed-fp16 pre-tier is made by the first call that wants it)
     // whole-image statistics for stage 0 of the filter's bound (the blocks holding active pixels, joined), into slot ppad / 64
     for (int v = 0; v < n_var; ++v)
         HIP_TRY(e, mm::launch_image_stats((float*)e->lib_lsum.p + (size_t)v * L * stat_slots(ppad), (size_t)n_var * L * stat_slots(ppad),
@@ -888,7 +890,14 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                     "Error during cell image-statistics kernel");
         fin.var.two_stage = (e->two_level ? 1 : 0) | (stage0 ? 2 : 0);
         // the packed-fp16 pre-tier reads half copies of the cells and the library (CIEDE2000 with the early exit, interleaved form)
-        const bool pretier = e->pretier != 0 && prune && diff_type == MM_CIEDE2000 && e->use_interleave != 0 && fin.use_lds_form == 0;
+        const bool pretier = (e->pretier > 0 || (e->pretier < 0 && ppad / 256 > 32)) && prune && diff_type == MM_CIEDE2000 &&
+                             e->use_interleave != 0 && fin.use_lds_form == 0;
+        if (pretier && !e->lib_h_ready) {       // the library's half copy, once per library / mask change
+            if ((st = ensure(e, e->lib_h, (size_t)e->n_var * L * 4 * ppad * sizeof(uint16_t), "Failed to allocate the half-precision library"))) return st;
+            HIP_TRY(e, mm::launch_interleave_h((const float*)e->lib_il.p, e->lib_h.p, (size_t)e->n_var * L, ppad, e->stream),
+                    "Error during half-precision library kernel");
+            e->lib_h_ready = true;
+        }
         fin.lib_h = pretier ? e->lib_h.p : nullptr;
         fin.cells_h = pretier ? e->cells_h.p : nullptr;
         if (pretier)
@@ -2469,7 +2478,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }
     if (strcmp(name, "euclid_stage1") == 0) { e->euclid_stage1 = value != 0; return MM_OK; }
     if (strcmp(name, "stage0") == 0) { e->stage0 = value != 0; return MM_OK; }
-    if (strcmp(name, "pretier") == 0) { e->pretier = value != 0; return MM_OK; }
+    if (strcmp(name, "pretier") == 0) { e->pretier = value < 0 ? -1 : (value != 0); return MM_OK; }
     if (strcmp(name, "tiny") == 0) { e->tiny_path = value != 0; return MM_OK; }
     if (strcmp(name, "item_auto") == 0) { e->item_auto = value != 0; return MM_OK; }
     if (strcmp(name, "fused") == 0) { e->fused = value != 0; return MM_OK; }

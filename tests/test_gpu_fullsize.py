@@ -91,7 +91,11 @@ def assert_same_on_every_path(engine, cells, gw, gh, t, rep, valid, L):
     nb, ns = with_options(engine, {"prune": 0}, run)
     assert np.array_equal(nb, best), int((nb != best).sum())
     assert np.array_equal(ns[valid], score[valid])
-    pb, ps = with_options(engine, {"pretier": 0}, run)         # without the packed-fp16 pre-tier
+    try:                                                       # with the packed-fp16 pre-tier forced on (default: big cells only)
+        engine.set_option("pretier", 1)
+        pb, ps = run()
+    finally:
+        engine.set_option("pretier", -1)
     assert np.array_equal(pb, best), int((pb != best).sum())
     assert np.array_equal(ps[valid], score[valid])
     fb, fs = with_options(engine, {"filter": 0}, run)
