@@ -97,3 +97,17 @@ def test_gpus_n_without_a_launcher_starts_the_ranks_itself(monkeypatch):
     with pytest.raises(SystemExit) as err:
         bench.launch_ranks(2, out.append, argv=["--gpus", "2"])
     assert err.value.code == 3
+
+
+def test_parity_sample_moves_to_interior_rows_once_the_golden_vouches_for_the_grid():
+    """With the whole grid equal to the committed CPU golden the induction over the raster order has its base anywhere: the
+    sample is two full grid rows at a seeded interior offset, with the whole rows-above window of calculateRepeats in play."""
+    shape = cases.square_shape(64)
+    cells = cells_of(shape, 1024, 1024)                                          # 16 x 16 cells
+    w = dict(rep=(4, 500), size=64, shape=shape, L=5000, golden_ok=True)
+    sample, text = bench.parity_sample(w, cells)
+    rows = np.unique(sample["grid_y"])
+    assert len(sample) == 32 and len(rows) == 2 and rows[1] == rows[0] + 1
+    assert rows[0] - cells["grid_y"].min() >= 5 and "interior" in text          # at least range + 1 rows above
+    again, _ = bench.parity_sample(w, cells)
+    assert np.array_equal(sample, again)
