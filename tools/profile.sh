@@ -1,14 +1,14 @@
 # Round profile of the bench commands on the GPU box: the rocprofv3 PMC passes (separate runs, as the
-# MI355X guide prescribes) that bench.py's roofline is priced from -- for configs D, C, B, E8, E and A
+# MI355X guide prescribes) that bench.py's roofline is priced from -- for configs D, C, B, E8, E, A, F, G, H, I and P
 # (CONFIGS="E8 E" bash tools/profile.sh ... for a subset; ONLY=pmc skips the bench lines) --, the
 # kernel trace of the default command, and the bench lines of every configuration.
 # usage (on the box): bash tools/profile.sh r02_v13        -> gpurun_out/r02_v13/
 set -x
-V=${1:-r03_v34}
+V=${1:-r04_v40}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$V
 mkdir -p $O
-for c in ${CONFIGS:-D C B E8 E A}; do
+for c in ${CONFIGS:-D C B E8 E A F G H I P}; do
   P=$O/pmc_$c
   mkdir -p $P
   CMD="python3 bench.py --config $c --steps 1 --warmup 1 --no-cpu"
@@ -21,7 +21,7 @@ cp profiles/pmc_traffic.json $O/pmc_traffic.json
 [ "$ONLY" = pmc ] && exit 0
 rocprofv3 --kernel-trace --stats -d $O/kt -o d --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $O/kt.log 2>&1
 python3 bench.py --steps 10 --warmup 2 > $O/bench_D.json 2> $O/bench_D.err
-for c in A B C E8 F G H; do python3 bench.py --config $c --steps 5 --warmup 2 > $O/bench_$c.json 2>/dev/null; done
+for c in A B C E8 F G H I P; do python3 bench.py --config $c --steps 5 --warmup 2 > $O/bench_$c.json 2>/dev/null; done
 python3 bench.py --config E --steps 2 --warmup 1 --no-cpu > $O/bench_E_1gpu.json 2>/dev/null
 MOSAIC_BENCH_FORCE_DIST=1 python3 bench.py --steps 5 --warmup 2 --no-cpu > $O/bench_D_dist1.json 2> $O/bench_D_dist1.err
 python3 bench.py --steps 5 --warmup 2 --no-cpu --opt lds_filter=1 --opt tile=128 > $O/bench_D_lds_tile.json 2>/dev/null
