@@ -4,6 +4,7 @@
 // thresholded mask, tiling parameters, and the same after resized(64)).
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../mosaicmagnifique_amd/csrc/host/HIPPhotomosaicGenerator.h"
 
@@ -17,8 +18,28 @@ static void params(const CellShape& s)
            s.alternateRowFlipHorizontal ? "true" : "false", s.alternateRowFlipVertical ? "true" : "false");
 }
 
+// --bounds FILE: "nb nq" then nb bound rects and nq query rects ("x y w h" each) -> one line of 0 / 1 per query:
+// GridUtility::BoundsUnion::meets (the in-bounds test of findCellState, GridGenerator.cpp:124-140, on the union of the bounds)
+static int bounds_mode(const char* path)
+{
+    using GridUtility::Rect;
+    FILE* f = fopen(path, "r");
+    if (!f) return 2;
+    int nb = 0, nq = 0;
+    if (fscanf(f, "%d %d", &nb, &nq) != 2) { fclose(f); return 2; }
+    std::vector<Rect> bounds((size_t)nb), queries((size_t)nq);
+    for (Rect& r : bounds) if (fscanf(f, "%d %d %d %d", &r.x, &r.y, &r.width, &r.height) != 4) { fclose(f); return 2; }
+    for (Rect& r : queries) if (fscanf(f, "%d %d %d %d", &r.x, &r.y, &r.width, &r.height) != 4) { fclose(f); return 2; }
+    fclose(f);
+    const GridUtility::BoundsUnion u(bounds);
+    for (const Rect& q : queries) putchar(u.meets(q) ? '1' : '0');
+    putchar('\n');
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 3 && std::string(argv[1]) == "--bounds") return bounds_mode(argv[2]);
     for (int i = 1; i < argc; ++i) {
         const std::string path = argv[i];
         if (path.size() > 4 && path.compare(path.size() - 4, 4, ".mil") == 0) {

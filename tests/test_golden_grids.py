@@ -149,3 +149,25 @@ def test_config_e_whole_grid_equals_the_cpu_golden(engine):
     10 000 images, CIEDE2000 -- all 29 241 cells."""
     tm, rel, same = whole_grid_against_golden(engine, "E")
     print(json.dumps(dict(config="E", max_rel_score_err=rel, inputs_identical=same)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,members", [("D", 8), ("C", 3)])
+def test_sharded_group_whole_grid_equals_the_cpu_golden(name, members):
+    """The multi-GPU split at the benchmarked size against the CPU golden itself (not only against one engine): `members`
+    engines (all on device 0 here, so the lists travel through host memory; on an 8-GPU node through ONE ncclAllGather) each
+    score a contiguous block of the raster-ordered cells with short lists, the lists are gathered, every member runs the
+    identical verifying resolve -- config D: eight blocks of 512 cells with the repeat window reaching across every seam --
+    and the grid that comes back equals the oracle's over every cell."""
+    from mosaicmagnifique_amd.engine import EngineGroup
+    best_want, score_want, meta = golden(name)
+    s = make_grids.scenario(name)
+    state, L, t = s["state"], s["L"], s["t"]
+    with EngineGroup([0] * members) as g:
+        g.set_library(s["lib"]); g.set_masks(s["shape"].masks4()); g.set_target(s["img"])
+        best, score = g.generate(s["cells"], state.shape[1], state.shape[0], t, *s["rep"])
+    got = np.where(best < L, best, -1)
+    assert np.array_equal(got, best_want), int((got != best_want).sum())
+    valid = state >= 0
+    rel = np.abs(score[valid] - score_want[valid]) / np.maximum(np.abs(score_want[valid]), 1e-300)
+    assert rel[score_want[valid] != 0].max() <= REL_TOL[t]

@@ -144,3 +144,36 @@ def test_cell_group_steps_and_detail():
     s0 = group.getCell(0)
     assert s1.rowSpacing == max(s0.rowSpacing // 2, 1) and s1.alternateRowOffset == s0.alternateRowOffset // 2
     assert set(np.unique(group.getCell(2, True).getCellMask())) <= {0, 255}
+
+
+def test_cpp_bounds_union_equals_the_brute_force_and_the_python_mirror(tmp_path):
+    """The C++ host keeps a step's active bounds as their UNION (GridUtility::BoundsUnion: coordinate compression + a
+    summed-area table; the reference's mergeBounds never changes the union, so nothing is merged): for random sets of
+    overlapping, touching, nested and degenerate rects every query equals "shares positive area with at least one
+    bound" by brute force, the Python mirror's answer, and the answer on the list mergeBounds leaves."""
+    import subprocess
+    from test_image_library import build_mcs_runner
+    runner = build_mcs_runner(str(tmp_path / "runner"))
+    rng = np.random.default_rng(99)
+    for trial in range(40):
+        nb = int(rng.integers(0, 14))
+        b = np.stack([rng.integers(-20, 60, nb), rng.integers(-20, 60, nb), rng.integers(0, 30, nb), rng.integers(0, 30, nb)], axis=1) if nb else np.zeros((0, 4), int)
+        if nb >= 3:                                   # touching and nested ones
+            b[1] = (b[0][0] + b[0][2], b[0][1], 7, b[0][3])
+            b[2] = (b[0][0] + 1, b[0][1] + 1, max(b[0][2] - 2, 0), max(b[0][3] - 2, 0))
+        nq = 60
+        q = np.stack([rng.integers(-30, 80, nq), rng.integers(-30, 80, nq), rng.integers(0, 25, nq), rng.integers(0, 25, nq)], axis=1)
+        path = tmp_path / ("bounds_%d.txt" % trial)
+        path.write_text("%d %d\n" % (nb, nq) + "".join("%d %d %d %d\n" % tuple(r) for r in list(b) + list(q)))
+        out = subprocess.run([runner, "--bounds", str(path)], check=True, capture_output=True, text=True).stdout.strip()
+        got = np.array([ch == "1" for ch in out])
+        brute = np.array([any(min(x + w, bx + bw) > max(x, bx) and min(y + h, by + bh) > max(y, by) and w > 0 and h > 0 and bw > 0 and bh > 0
+                              for bx, by, bw, bh in b) for x, y, w, h in q])
+        assert np.array_equal(got, brute), trial
+        positive = b[(b[:, 2] > 0) & (b[:, 3] > 0)] if nb else b
+        mirror = G._meets_any_bound(positive, q[:, 0], q[:, 1], q[:, 2], q[:, 3]) & (q[:, 2] > 0) & (q[:, 3] > 0)
+        assert np.array_equal(mirror, brute), trial
+        merged = G.mergeBounds([tuple(int(v) for v in r) for r in positive])
+        on_merged = np.array([any(min(x + w, bx + bw) > max(x, bx) and min(y + h, by + bh) > max(y, by) and w > 0 and h > 0
+                                  for bx, by, bw, bh in merged) for x, y, w, h in q])
+        assert np.array_equal(on_merged, brute), trial
