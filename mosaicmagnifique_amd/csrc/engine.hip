@@ -2172,14 +2172,10 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
         if ((st = ensure(e, e->spec_recs, (size_t)ns * sizeof(mm_cell), "Failed to allocate cell records"))) return st;
         HIP_TRY(e, hipMemcpyAsync(e->spec_recs.p, sub_cells.data(), (size_t)ns * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
                 "Failed to copy cell records to device");
-        // A HANDFUL of cells to deepen is over sooner on the fp64-only path (gather, score, select: ~0.15 ms) than on the two-tier
-        // one, whose seeds, filter, contenders, re-score and re-rank are six launches of latencies whatever the batch (config P: one
-        // cell of 704 deepened at lists of 16 -- and that one cell's round was 1.5 ms of a 5.5 ms step).  Same lists either way.
-        const int filter_option = e->use_filter;
-        if ((double)ns * e->n_lib * e->lib_size * e->lib_size <= 4e7) e->use_filter = 0;
+        // (a handful of cells is latency either way: sending them down the fp64-only path instead -- three launches for six -- was
+        // measured no faster, config P 5.5 -> 5.6 ms: one cell's 1024 fp64 rows are 64 workgroups of a kernel laid out for thousands)
         st = score_cells_device(e, sub_cells.data(), (const mm_cell*)e->spec_recs.p, ns, diff_type, K, K,
                                 (int32_t*)e->cand_i.p, (double*)e->cand_s.p, sub_rows.data(), nullptr, nullptr, cancel);
-        e->use_filter = filter_option;
         if (st) return st;
         e->timing.deepened_cells += ns;
     }
