@@ -66,5 +66,21 @@ def main():
         print("stream:", d["roofline"].get("hbm_stream_read_measured_gbs"))
 
 
+def sweep(path):
+    """The harness-shape table of DESIGN section 5 from a `bench.py --sweep` line."""
+    doc = json.loads([ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1])
+    print("| block | colour difference | detail | size steps | cell (detail cell) | cells per step | grid ms | first ms | warm ms (device) | build ms | cpu ms | cpu ÷ first / ÷ warm |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for ln in doc["sweep"]:
+        print("| %s | %s | %d %% | %d | %d (%d px) | %s | %.1f | %.1f | %.2f (%.2f) | %.1f | %s%.0f | %.0f× / %.0f× |" % (
+            ln["block"], ln["diff_type"], ln["detail_percent"], ln["size_steps"], ln["cell_size"], ln["detail_cell"],
+            " + ".join(str(c) for c in ln["cells_per_step"]), ln["grid_ms"], ln["first_ms"], ln["warm_ms"], ln["last_step_device_ms"],
+            ln["build_ms"], "~" if ln["cpu_estimated_from_prefix"] else "", ln["cpu_ms"], ln["speedup_first"], ln["speedup_warm"]))
+    print("all indices equal on the CPU's cells:", all(ln["indices_equal_on_cpu_cells"] for ln in doc["sweep"]))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "--sweep":
+        sweep(sys.argv[2])
+    else:
+        main()
