@@ -40,6 +40,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 TESTS = os.path.dirname(HERE)
 sys.path.insert(0, TESTS)
 sys.path.insert(0, os.path.dirname(TESTS))
+sys.path.insert(0, HERE)
 
 # name: rows, cols, cell size, shape, library size, difference type, repeat range, repeat addition
 CONFIGS = {
@@ -47,6 +48,15 @@ CONFIGS = {
     "C": (2048, 2048, 64, "hexagon", 1000, 2, 0, 0),
     "D": (4096, 4096, 64, "square", 5000, 2, 4, 500),
     "E": (8192, 8192, 48, "square", 10000, 2, 0, 0),
+    # bench.py's further configurations: the reference's CPU-runnable case (A), the GUI's default cell size as RGB and as
+    # CIEDE2000 (F, G: 128 px -- where the packed-fp16 pre-tier is on), its harness's CIEDE2000 line (H), 80-px cells (I),
+    # photographs with config D's parameters (P: tests/golden/photo_*.png)
+    "A": (512, 512, 32, "square", 100, 0, 0, 0),
+    "F": (4096, 4096, 128, "square", 1000, 0, 0, 0),
+    "G": (4096, 4096, 128, "square", 1000, 2, 0, 0),
+    "H": (800, 1000, 25, "square", 214, 2, 0, 0),
+    "I": (4000, 4000, 80, "square", 1000, 2, 0, 0),
+    "P": (1363, 2048, 64, "square", 1024, 2, 4, 500),
     # reduced shapes (seconds): used by the CPU suite to hold this script's two modes to each other
     "d": (512, 512, 32, "square", 60, 2, 4, 500),
 }
@@ -61,7 +71,13 @@ def scenario(name):
     from mosaicmagnifique_amd import GridUtility as G
     rows, cols, size, shape_name, L, t, rng, add = CONFIGS[name]
     shape = cases.hexagon_shape() if shape_name == "hexagon" else cases.square_shape(size)
-    img, lib = cases._inputs(rows, cols, size, L, t, lattice=64)
+    if name == "P":
+        import make_photo_fixture
+        from mosaicmagnifique_amd import synth
+        img_u8, lib_u8 = make_photo_fixture.load()
+        img, lib = synth.preprocess(img_u8, t), synth.preprocess(lib_u8, t)
+    else:
+        img, lib = cases._inputs(rows, cols, size, L, t, lattice=64)
     group = cases.group_of(shape)
     state = G.getGridState(group, rows, cols)[0]
     cells = G.cell_records(group, state, rows, cols)
