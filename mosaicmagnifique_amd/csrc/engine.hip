@@ -58,6 +58,7 @@ struct mm_engine {
     DevBuf lib_chroma, cell_chroma, hue_lut, lib_il, cells_il;
     DevBuf lib_h, cells_h;       // the interleaved copies as halfs (the filter's packed-fp16 pre-tier)
     bool lib_h_ready = false;    // lib_h holds the current library (prepare_planes builds it only where the pre-tier may run)
+    float dbg_pre_abs = 0.0f, dbg_pre_rel = 0.0f;      // diagnostics: the band mm_debug_filter_band_sweep modes 2 / 3 measure against (0: the pre-tier's own)
     int pretier = -1;            // mm_set_option("pretier", 0 / 1): the packed-fp16 pre-tier ahead of the fp32 filter form never / always;
                                  // -1 = by cell size: for cells above 32 pixel groups (up to 128 x 128, the reference GUI's default), whose
                                  // launches are bound by the fabric and gain from operands half the size (config G 16.1 -> 14.9 ms per
@@ -2439,8 +2440,10 @@ mm_status mm_debug_filter_band_sweep(mm_engine* e, int mode, uint64_t seed, uint
     if ((st = ensure(e, buf, 6 * sizeof(unsigned long long), "Failed to allocate sweep result"))) return st;
     const mm::FilterBand band = filter_band(MM_CIEDE2000, 0);
     // the per-pair part of the band: px_abs absolute, 6e-5 relative (the rest of band.rel is the accumulation's)
-    hipError_t code = mm::launch_band_sweep(mode, seed, n_pairs, band.px_abs, 6e-5f, (const float2*)e->hue_lut.p,
-                                            (unsigned long long*)buf.p, e->stream);
+    // (modes 2 / 3 measure against the pre-tier's own band; "dbg_pre_abs_1e4" / "dbg_pre_rel_1e6" try another one: how the band was sized)
+    const bool own = (mode & 2) != 0 && (e->dbg_pre_abs > 0.0f || e->dbg_pre_rel > 0.0f);
+    hipError_t code = mm::launch_band_sweep(own ? mode | 4 : mode, seed, n_pairs, own ? e->dbg_pre_abs : band.px_abs, own ? e->dbg_pre_rel : 6e-5f,
+                                            (const float2*)e->hue_lut.p, (unsigned long long*)buf.p, e->stream);
     unsigned long long raw[6] = {0};
     if (code == hipSuccess) code = hipMemcpyAsync(raw, buf.p, sizeof raw, hipMemcpyDeviceToHost, e->stream);
     if (code == hipSuccess) code = sync_stream(e);
@@ -2480,6 +2483,8 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "band_guard") == 0) { e->band_guard_every = std::max(0, value); return MM_OK; }
     if (strcmp(name, "euclid_stage1") == 0) { e->euclid_stage1 = value != 0; return MM_OK; }
     if (strcmp(name, "stage0") == 0) { e->stage0 = value != 0; return MM_OK; }
+    if (strcmp(name, "dbg_pre_abs_1e4") == 0) { e->dbg_pre_abs = 1e-4f * (float)std::max(0, value); return MM_OK; }
+    if (strcmp(name, "dbg_pre_rel_1e6") == 0) { e->dbg_pre_rel = 1e-6f * (float)std::max(0, value); return MM_OK; }
     if (strcmp(name, "pretier") == 0) { e->pretier = value < 0 ? -1 : (value != 0); return MM_OK; }
     if (strcmp(name, "tiny") == 0) { e->tiny_path = value != 0; return MM_OK; }
     if (strcmp(name, "item_auto") == 0) { e->item_auto = value != 0; return MM_OK; }

@@ -1805,7 +1805,7 @@ hipError_t launch_band_sweep(int mode, unsigned long long seed, unsigned long lo
     hipError_t code = hipMemsetAsync(out6, 0, 6 * sizeof(unsigned long long), stream);
     if (code != hipSuccess) return code;
     // modes 2 / 3: the same two sweeps for the packed-fp16 pre-tier's form, against ITS band
-    if (mode & 2) { px_abs = kPreAbs; rel = kPreRel; }
+    if ((mode & 2) && !(mode & 4)) { px_abs = kPreAbs; rel = kPreRel; }       // (bit 2: the caller's own band, diagnostics)
     band_sweep_kernel<<<256 * 16, kBlock, 0, stream>>>(mode, seed, n_pairs, px_abs, rel, hue_lut, out6);
     return hipGetLastError();
 }
