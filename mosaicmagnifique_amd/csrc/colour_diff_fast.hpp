@@ -196,9 +196,22 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ half2_t h2_splat(float v) { return half2_t{(half1_t)v, (half1_t)v}; }
 __device__ __forceinline__ unsigned int h2_bits(half2_t v) { return __builtin_bit_cast(unsigned int, v); }
 __device__ __forceinline__ half2_t h2_from(unsigned int v) { return __builtin_bit_cast(half2_t, v); }
-__device__ __forceinline__ half2_t h2_rsq(half2_t v) { return half2_t{(half1_t)__builtin_amdgcn_rsqh(v.x), (half1_t)__builtin_amdgcn_rsqh(v.y)}; }
-__device__ __forceinline__ half2_t h2_rcp(half2_t v) { return half2_t{(half1_t)__builtin_amdgcn_rcph(v.x), (half1_t)__builtin_amdgcn_rcph(v.y)}; }
-__device__ __forceinline__ half2_t h2_sqrt(half2_t v) { return half2_t{(half1_t)__builtin_amdgcn_sqrth(v.x), (half1_t)__builtin_amdgcn_sqrth(v.y)}; }
+// A transcendental handles ONE half per instruction.  Written through the builtins the compiler computes the high half into
+// the low word of a second register (SDWA source select) and spends a v_pack_b32_f16 to join the two -- 22 of them per four
+// pixels.  The SDWA destination select does the join itself: the second instruction writes the HIGH word of the register the
+// first one filled and preserves the low one.
+#define MM_H2_UNARY(NAME, OP)                                                                                              \
+    __device__ __forceinline__ half2_t NAME(half2_t v)                                                                     \
+    {                                                                                                                      \
+        unsigned int in = h2_bits(v), out;                                                                                 \
+        asm(OP "_e32 %0, %1\n\t" OP "_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"               \
+            : "=&v"(out) : "v"(in));                                                                                       \
+        return h2_from(out);                                                                                               \
+    }
+MM_H2_UNARY(h2_rsq, "v_rsq_f16")
+MM_H2_UNARY(h2_rcp, "v_rcp_f16")
+MM_H2_UNARY(h2_sqrt, "v_sqrt_f16")
+#undef MM_H2_UNARY
 // per-half select by a mask that holds 0xffff or 0 in each half
 __device__ __forceinline__ half2_t h2_sel(unsigned int mask, half2_t a, half2_t b) { return h2_from((h2_bits(a) & mask) | (h2_bits(b) & ~mask)); }
 // 0xffff in every half whose sign bit is set in `signs` (a value masked with 0x80008000)
@@ -257,10 +270,13 @@ __device__ __forceinline__ half2_t ciede2000_h2(half2_t pl, half2_t pa, half2_t 
     const half2_t s_l = (h2_splat(0.0075f) * u_l - h2_splat(0.15f)) * h2_rsq(u_l) + h2_splat(0.5f);      // S_L / 2
     const half2_t s_c = h2_splat(0.09f) * csum + h2_splat(1.0f);     // 1 + 0.045 mean C'
     const half2_t s_h = csum * t4 + h2_splat(1.0f);                 // 1 + 0.015 mean C' T
-    const half2_t inv_d = h2_rcp(s_c * s_h) * h2_splat(4.0f);       // (the differences below are carried / 4)
+    // one reciprocal for all three terms: per-half transcendentals cost two instructions a pair, packed multiplies one
+    const half2_t big_d = s_c * s_h;                                // <= 72
+    const half2_t inv_all = h2_rcp(big_d * s_l);                     // S_L / 2 in [0.5, 0.88]: the product stays within [0.5, 64]
+    const half2_t inv_d = (inv_all * s_l) * h2_splat(4.0f);          // (the differences below are carried / 4)
     const half2_t t_c = ((c2p - c1p) * s_h) * inv_d;
     const half2_t t_h = (d_h * s_c) * inv_d;
-    const half2_t t_l = (ql - pl) * h2_rcp(s_l);
+    const half2_t t_l = (ql - pl) * (inv_all * big_d);
     const half2_t xx = t_l * t_l + (t_c * (r_t * t_h + t_c) + t_h * t_h);
     // max(NaN, 0) = 0: an inactive pixel (NaN in the cell's operands), or anything else that went wrong, adds nothing
     const half2_t v = h2_sqrt(__builtin_elementwise_max(xx, h2_splat(0.0f)));

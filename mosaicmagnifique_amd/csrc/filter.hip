@@ -221,11 +221,17 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 // Error band of the packed-fp16 pre-tier per pixel pair: |fp16 form - fp64 form| <= kPreAbs + kPreRel * value for operands
 // inside the validated box, with the operands rounded to halfs as interleave_h_kernel stores them (measured by
 // band_sweep_kernel modes 2 / 3 and held below half of this by tests/test_gpu_filter.py); the pre-tier's accumulation is fp32.
+// (sized on the frontier of the sweeps -- tools/experiments/r4_pre_band_explore.py, profiles/r04_pretier_band_explore.txt: the error is
+// mostly RELATIVE, 0.11 + 6e-3 v holds the worst over-estimate of 7.3e9 pairs below half of itself where 0.35 + 8e-3 v did the same
+// at 2.8 times the width for the benchmark's typical pair)
+#ifndef MM_PRE_PREFETCH
+#define MM_PRE_PREFETCH 1            // the pre-tier fetches the next group's operands while it computes this one (0: A/B builds)
+#endif
 #ifndef MM_PRE_ABS
-#define MM_PRE_ABS 0.35f
+#define MM_PRE_ABS 0.11f
 #endif
 #ifndef MM_PRE_REL
-#define MM_PRE_REL 8e-3f
+#define MM_PRE_REL 6e-3f
 #endif
 constexpr float kPreAbs = MM_PRE_ABS, kPreRel = MM_PRE_REL;
 #ifndef MM_LONG_SPLIT
@@ -711,29 +717,47 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 // half copies: [image][group][plane][256] halfs -- a group is 2 KB, a plane 512 B, a lane's four positions 8 B
                 const char* const ch = reinterpret_cast<const char*>(cells) + (size_t)cell * 8 * ppad;
                 const char* const lh = reinterpret_cast<const char*>(lib_chroma_base) + ((size_t)v * L + l) * 8 * (size_t)ppad;
-                // (the band over ALL of the cell's positions: an upper bound of the active ones)
-                const float limit16 = fmaf(limit, 1.0f + kPreRel, kPreAbs * (float)(groups * 4 * kWave));
+                // true sum of the visited pairs >= (acc16 - abs x pairs visited) / (1 + rel): the exit test compares acc16 + rest with
+                // limit (1 + rel) + abs x (positions visited so far) -- the absolute part grows with the walk instead of being charged
+                // for the whole cell up front
+                const float limit_rel = limit * (1.0f + kPreRel);
                 float acc16 = 0.0f;
                 bool out16 = false;
+                // the operands of the NEXT group are fetched while this one is computed: a group of the fp16 form is ~280 instructions
+                // (the fp32 one ~430) and its sixteen registers of operands leave room for a second set inside the kernel's 96
+                struct HalfGroup { uint2 p0, p1, p2, pc, q0, q1, q2, qc; };
+                auto fetch = [&](int j) {
+                    const unsigned int off = (unsigned int)j * 2048u + (unsigned int)lane * 8u;
+                    HalfGroup g;
+                    g.p0 = *reinterpret_cast<const uint2*>(ch + off); g.p1 = *reinterpret_cast<const uint2*>(ch + off + 512u);
+                    g.p2 = *reinterpret_cast<const uint2*>(ch + off + 1024u); g.pc = *reinterpret_cast<const uint2*>(ch + off + 1536u);
+                    g.q0 = *reinterpret_cast<const uint2*>(lh + off); g.q1 = *reinterpret_cast<const uint2*>(lh + off + 512u);
+                    g.q2 = *reinterpret_cast<const uint2*>(lh + off + 1024u); g.qc = *reinterpret_cast<const uint2*>(lh + off + 1536u);
+                    return g;
+                };
+                HalfGroup cur = fetch((sorted || sorted64) ? __builtin_amdgcn_readlane(order, 0) : 0);
                 for (int step = 0; step < groups; ++step) {
-                    const int j = (sorted || sorted64) ? __builtin_amdgcn_readlane(order, step) : step;
                     if (step != 0 && step % check_every == 0) {
                         const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), by_group ? step : (4 * step) >> lane_shift)) : 0.0f;
-                        if (wave_sum_exceeds(acc16, rest_j, limit16)) { out16 = true; break; }
+                        if (wave_sum_exceeds(acc16, rest_j, fmaf(kPreAbs * (float)(4 * kWave), (float)step, limit_rel))) { out16 = true; break; }
                     }
-                    const unsigned int off = (unsigned int)j * 2048u + (unsigned int)lane * 8u;
-                    const uint2 p0 = *reinterpret_cast<const uint2*>(ch + off), p1 = *reinterpret_cast<const uint2*>(ch + off + 512u),
-                                p2 = *reinterpret_cast<const uint2*>(ch + off + 1024u), pc = *reinterpret_cast<const uint2*>(ch + off + 1536u);
-                    const uint2 q0 = *reinterpret_cast<const uint2*>(lh + off), q1 = *reinterpret_cast<const uint2*>(lh + off + 512u),
-                                q2 = *reinterpret_cast<const uint2*>(lh + off + 1024u), qc = *reinterpret_cast<const uint2*>(lh + off + 1536u);
-                    const half2_t va = ciede2000_h2(h2_from(p0.x), h2_from(p1.x), h2_from(p2.x), h2_from(pc.x),
-                                                    h2_from(q0.x), h2_from(q1.x), h2_from(q2.x), h2_from(qc.x), lut);
-                    const half2_t vb = ciede2000_h2(h2_from(p0.y), h2_from(p1.y), h2_from(p2.y), h2_from(pc.y),
-                                                    h2_from(q0.y), h2_from(q1.y), h2_from(q2.y), h2_from(qc.y), lut);
+#if MM_PRE_PREFETCH
+                    const int nxt = step + 1 < groups ? step + 1 : step;         // (the last step fetches its own group again: no branch)
+                    const HalfGroup ahead = fetch((sorted || sorted64) ? __builtin_amdgcn_readlane(order, nxt) : nxt);
+#else
+                    if (step != 0) cur = fetch((sorted || sorted64) ? __builtin_amdgcn_readlane(order, step) : step);
+#endif
+                    const half2_t va = ciede2000_h2(h2_from(cur.p0.x), h2_from(cur.p1.x), h2_from(cur.p2.x), h2_from(cur.pc.x),
+                                                    h2_from(cur.q0.x), h2_from(cur.q1.x), h2_from(cur.q2.x), h2_from(cur.qc.x), lut);
+                    const half2_t vb = ciede2000_h2(h2_from(cur.p0.y), h2_from(cur.p1.y), h2_from(cur.p2.y), h2_from(cur.pc.y),
+                                                    h2_from(cur.q0.y), h2_from(cur.q1.y), h2_from(cur.q2.y), h2_from(cur.qc.y), lut);
                     acc16 += ((float)va.x + (float)va.y) + ((float)vb.x + (float)vb.y);
                     visited += 1;
+#if MM_PRE_PREFETCH
+                    cur = ahead;
+#endif
                 }
-                if (!out16 && wave_sum_exceeds(acc16, 0.0f, limit16)) out16 = true;
+                if (!out16 && wave_sum_exceeds(acc16, 0.0f, fmaf(kPreAbs * (float)(4 * kWave), (float)groups, limit_rel))) out16 = true;
                 if (out16) pruned = true;       // (a survivor goes on to the fp32 form below)
             }
         }
