@@ -199,12 +199,14 @@ __device__ __forceinline__ half2_t h2_from(unsigned int v) { return __builtin_bi
 // A transcendental handles ONE half per instruction.  Written through the builtins the compiler computes the high half into
 // the low word of a second register (SDWA source select) and spends a v_pack_b32_f16 to join the two -- 22 of them per four
 // pixels.  The SDWA destination select does the join itself: the second instruction writes the HIGH word of the register the
-// first one filled and preserves the low one.
+// first one filled and preserves the low one.  (gfx940 / gfx950: a VALU write through dst_sel needs ONE wait state before a VALU reads
+// that register -- the compiler inserts it for its own code, inline asm is not hazard-checked: the s_nop 0.  Found the hard way: without
+// it the structured sweep returned inf and config G's golden failed.)
 #define MM_H2_UNARY(NAME, OP)                                                                                              \
     __device__ __forceinline__ half2_t NAME(half2_t v)                                                                     \
     {                                                                                                                      \
         unsigned int in = h2_bits(v), out;                                                                                 \
-        asm(OP "_e32 %0, %1\n\t" OP "_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"               \
+        asm(OP "_e32 %0, %1\n\t" OP "_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0"     \
             : "=&v"(out) : "v"(in));                                                                                       \
         return h2_from(out);                                                                                               \
     }
