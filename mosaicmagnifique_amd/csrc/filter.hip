@@ -712,6 +712,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             }
         }
         int visited = 0;
+        float pre_sum = -1.0f;         // PRE: lane-partial fp16-form sum of a candidate that survived the pre-tier (else < 0)
         if constexpr (PRE) {
             if (!pruned && groups > 0 && prune_above != nullptr) {
                 // half copies: [image][group][plane][256] halfs -- a group is 2 KB, a plane 512 B, a lane's four positions 8 B
@@ -759,6 +760,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 }
                 if (!out16 && wave_sum_exceeds(acc16, 0.0f, fmaf(kPreAbs * (float)(4 * kWave), (float)groups, limit_rel))) out16 = true;
                 if (out16) pruned = true;       // (a survivor goes on to the fp32 form below)
+                else pre_sum = acc16;
             }
         }
         float acc = 0.0f;          // terms with a proven error bound
@@ -832,6 +834,16 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             n_bound_dropped += (pruned && visited == 0) ? 1u : 0u;
         }
         acc = wave_sum_all(acc + acc_edge);
+        if constexpr (PRE) {
+            // Canary of the pre-tier: a candidate that walked ALL its groups in both forms has two sums of the same terms (the fp16 one
+            // without its seam pairs, which can only make it smaller).  An fp16 sum ABOVE the fp32 one by more than the band's worth says
+            // the fp16 form over-estimates here -- what its early exits must never do -- and voids the launch: the discontinuity log is
+            // pushed past its capacity, which sends the whole batch down the fp64-only path (and shows in mm_timing.edge_pairs).
+            if (pre_sum >= 0.0f && !pruned) {
+                const float sum16 = wave_sum_all(pre_sum);
+                if (lane == 0 && sum16 > fmaf(acc, 1.0f + kPreRel, kPreAbs * (float)(groups * 4 * kWave))) atomicAdd(edge_count, edge_cap + 1u);
+            }
+        }
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }
     MM_STAMP(5);
