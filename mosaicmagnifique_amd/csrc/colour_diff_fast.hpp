@@ -201,12 +201,17 @@ __device__ __forceinline__ half2_t h2_from(unsigned int v) { return __builtin_bi
 // pixels.  The SDWA destination select does the join itself: the second instruction writes the HIGH word of the register the
 // first one filled and preserves the low one.  (gfx940 / gfx950: a VALU write through dst_sel needs ONE wait state before a VALU reads
 // that register -- the compiler inserts it for its own code, inline asm is not hazard-checked: the s_nop 0.  Found the hard way: without
-// it the structured sweep returned inf and config G's golden failed.)
+// it the structured sweep returned inf and config G's golden failed.  And the SDWA instruction's PRESERVE is itself a read of the register
+// the e32 instruction has just written: issued back to back it kept a stale low half in a third of the cases
+// (tools/experiments/r4_sdwa_test.hip) -- a wait state between the two as well.)
+#ifndef MM_SDWA_GAP
+#define MM_SDWA_GAP "s_nop 0\n\t"     // wait states between the low half's write and the SDWA instruction that PRESERVES it (see above)
+#endif
 #define MM_H2_UNARY(NAME, OP)                                                                                              \
     __device__ __forceinline__ half2_t NAME(half2_t v)                                                                     \
     {                                                                                                                      \
         unsigned int in = h2_bits(v), out;                                                                                 \
-        asm(OP "_e32 %0, %1\n\t" OP "_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0"     \
+        asm(OP "_e32 %0, %1\n\t" MM_SDWA_GAP OP "_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0" \
             : "=&v"(out) : "v"(in));                                                                                       \
         return h2_from(out);                                                                                               \
     }
