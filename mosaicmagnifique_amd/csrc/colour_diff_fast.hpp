@@ -204,6 +204,9 @@ __device__ __forceinline__ half2_t h2_from(unsigned int v) { return __builtin_bi
 // it the structured sweep returned inf and config G's golden failed.  And the SDWA instruction's PRESERVE is itself a read of the register
 // the e32 instruction has just written: issued back to back it kept a stale low half in a third of the cases
 // (tools/experiments/r4_sdwa_test.hip) -- a wait state between the two as well.)
+#ifndef MM_PRE_ONE_RCP
+#define MM_PRE_ONE_RCP 1             // ciede2000_h2: one reciprocal for t_L, t_C and t_H (0: two, as the fp32 form has them)
+#endif
 #ifndef MM_SDWA_GAP
 #define MM_SDWA_GAP "s_nop 0\n\t"     // wait states between the low half's write and the SDWA instruction that PRESERVES it (see above)
 #endif
@@ -277,13 +280,18 @@ __device__ __forceinline__ half2_t ciede2000_h2(half2_t pl, half2_t pa, half2_t 
     const half2_t s_l = (h2_splat(0.0075f) * u_l - h2_splat(0.15f)) * h2_rsq(u_l) + h2_splat(0.5f);      // S_L / 2
     const half2_t s_c = h2_splat(0.09f) * csum + h2_splat(1.0f);     // 1 + 0.045 mean C'
     const half2_t s_h = csum * t4 + h2_splat(1.0f);                 // 1 + 0.015 mean C' T
+#if MM_PRE_ONE_RCP
     // one reciprocal for all three terms: per-half transcendentals cost two instructions a pair, packed multiplies one
     const half2_t big_d = s_c * s_h;                                // <= 72
     const half2_t inv_all = h2_rcp(big_d * s_l);                     // S_L / 2 in [0.5, 0.88]: the product stays within [0.5, 64]
     const half2_t inv_d = (inv_all * s_l) * h2_splat(4.0f);          // (the differences below are carried / 4)
+    const half2_t t_l = (ql - pl) * (inv_all * big_d);
+#else
+    const half2_t inv_d = h2_rcp(s_c * s_h) * h2_splat(4.0f);       // (the differences below are carried / 4)
+    const half2_t t_l = (ql - pl) * h2_rcp(s_l);
+#endif
     const half2_t t_c = ((c2p - c1p) * s_h) * inv_d;
     const half2_t t_h = (d_h * s_c) * inv_d;
-    const half2_t t_l = (ql - pl) * (inv_all * big_d);
     const half2_t xx = t_l * t_l + (t_c * (r_t * t_h + t_c) + t_h * t_h);
     // max(NaN, 0) = 0: an inactive pixel (NaN in the cell's operands), or anything else that went wrong, adds nothing
     const half2_t v = h2_sqrt(__builtin_elementwise_max(xx, h2_splat(0.0f)));
