@@ -383,7 +383,7 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
  * dropped in the engine's PREVIOUS CIEDE2000 launch over the same library, so the TIME of a call (never its result)
  * depends on the call history of the engine; 0 pins the size-by-cell default (mm_timing.filter_tile reports what ran).
- * "pretier" (-1 = for cells above 32 pixel groups, i.e. 96 .. 128 px; 0 never, 1 always): CIEDE2000 candidates first walk their pixel groups in
+ * "pretier" (-1 = for cells above 32 pixel groups, i.e. 96 .. 128 px, and for calls of >= 1e10 pixel pairs; 0 never, 1 always): CIEDE2000 candidates first walk their pixel groups in
  * a packed-fp16 form (two pixel pairs per lane-instruction, operands half the size) that only takes early-exit decisions, against the limit
  * widened by its own measured band; survivors are scored by the fp32 form as before;
  * "stage0" (1): one whole-image bound per candidate ahead of the block bound; "euclid_stage1" (1): the RGB / CIE76 filter

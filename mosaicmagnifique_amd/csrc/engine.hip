@@ -60,10 +60,11 @@ struct mm_engine {
     bool lib_h_ready = false;    // lib_h holds the current library (prepare_planes builds it only where the pre-tier may run)
     float dbg_pre_abs = 0.0f, dbg_pre_rel = 0.0f;      // diagnostics: the band mm_debug_filter_band_sweep modes 2 / 3 measure against (0: the pre-tier's own)
     int pretier = -1;            // mm_set_option("pretier", 0 / 1): the packed-fp16 pre-tier ahead of the fp32 filter form never / always;
-                                 // -1 = by cell size: for cells above 32 pixel groups (up to 128 x 128, the reference GUI's default), whose
-                                 // launches are bound by the fabric and gain from operands half the size (config G 16.1 -> 14.9 ms per
-                                 // step); smaller cells are bound by VALU issue, where the pre-tier's later exits and the second walk of
-                                 // its survivors cost more than its cheaper arithmetic saves (config D 44.5 -> 46.1 ms: HISTORY.md)
+                                 // -1 = by the size of the job: for cells above 32 pixel groups (up to 128 x 128, the reference GUI's
+                                 // default: config G 16.3 -> 14.4 ms per step) and for calls of >= 1e10 pixel pairs (config D 45.7 ->
+                                 // 42.8, E's shard 30.1 -> 29.4, 80-px cells 11.7 -> 11.0); smaller jobs lose to it (config C 3.21 ->
+                                 // 3.36: their candidates sit closer to the limit, so the wider limit exits later and more of them walk
+                                 // twice).  Results are identical either way
     DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
     DevBuf stage_u8, srgb_lut, shrink_tmp, covered, cells_f0;
     DevBuf main_bgr;   int main_rows = 0, main_cols = 0;      // mm_set_main_image_bgr: the u8 main image (entropy test)
@@ -891,7 +892,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                     "Error during cell image-statistics kernel");
         fin.var.two_stage = (e->two_level ? 1 : 0) | (stage0 ? 2 : 0);
         // the packed-fp16 pre-tier reads half copies of the cells and the library (CIEDE2000 with the early exit, interleaved form)
-        const bool pretier = (e->pretier > 0 || (e->pretier < 0 && ppad / 256 > 32)) && prune && diff_type == MM_CIEDE2000 &&
+        const bool pretier = (e->pretier > 0 || (e->pretier < 0 && (ppad / 256 > 32 || call_pairs >= 1e10))) && prune && diff_type == MM_CIEDE2000 &&
                              e->use_interleave != 0 && fin.use_lds_form == 0;
         if (pretier && !e->lib_h_ready) {       // the library's half copy, once per library / mask change
             if ((st = ensure(e, e->lib_h, (size_t)e->n_var * L * 4 * ppad * sizeof(uint16_t), "Failed to allocate the half-precision library"))) return st;

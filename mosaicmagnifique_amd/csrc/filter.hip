@@ -221,17 +221,18 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 // Error band of the packed-fp16 pre-tier per pixel pair: |fp16 form - fp64 form| <= kPreAbs + kPreRel * value for operands
 // inside the validated box, with the operands rounded to halfs as interleave_h_kernel stores them (measured by
 // band_sweep_kernel modes 2 / 3 and held below half of this by tests/test_gpu_filter.py); the pre-tier's accumulation is fp32.
-// (sized on the frontier of the sweeps -- tools/experiments/r4_pre_band_explore.py, profiles/r04_pretier_band_explore.txt: the error is
-// mostly RELATIVE, 0.11 + 6e-3 v holds the worst over-estimate of 7.3e9 pairs below half of itself where 0.35 + 8e-3 v did the same
-// at 2.8 times the width for the benchmark's typical pair)
+// (twice the worst over-estimate of 1.1e10 swept pairs, as a quarter-grid exploration of the (abs, rel) frontier could not be trusted to
+// find it: tools/experiments/r4_pre3.sh, profiles/r04_pretier_band_frontier.txt -- 0.11 + 6e-3 v holds the worst pair at 0.99 of
+// itself, 0.16 + 8e-3 v at 0.72, this one at 0.47.  The narrower ones buy little once the absolute part is charged as the walk
+// proceeds: config D 41.9 / 42.2 / 42.8 ms per step against 45.7 without the pre-tier, profiles/r04_pretier_band_width_ab.txt)
 #ifndef MM_PRE_PREFETCH
 #define MM_PRE_PREFETCH 1            // the pre-tier fetches the next group's operands while it computes this one (0: A/B builds)
 #endif
 #ifndef MM_PRE_ABS
-#define MM_PRE_ABS 0.11f
+#define MM_PRE_ABS 0.38f
 #endif
 #ifndef MM_PRE_REL
-#define MM_PRE_REL 6e-3f
+#define MM_PRE_REL 8e-3f
 #endif
 constexpr float kPreAbs = MM_PRE_ABS, kPreRel = MM_PRE_REL;
 #ifndef MM_LONG_SPLIT

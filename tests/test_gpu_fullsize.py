@@ -91,13 +91,14 @@ def assert_same_on_every_path(engine, cells, gw, gh, t, rep, valid, L):
     nb, ns = with_options(engine, {"prune": 0}, run)
     assert np.array_equal(nb, best), int((nb != best).sum())
     assert np.array_equal(ns[valid], score[valid])
-    try:                                                       # with the packed-fp16 pre-tier forced on (default: big cells only)
-        engine.set_option("pretier", 1)
-        pb, ps = run()
-    finally:
-        engine.set_option("pretier", -1)
-    assert np.array_equal(pb, best), int((pb != best).sum())
-    assert np.array_equal(ps[valid], score[valid])
+    for forced in (1, 0):                                      # the packed-fp16 pre-tier forced on and off (default: by the size of the job)
+        try:
+            engine.set_option("pretier", forced)
+            pb, ps = run()
+        finally:
+            engine.set_option("pretier", -1)
+        assert np.array_equal(pb, best), (forced, int((pb != best).sum()))
+        assert np.array_equal(ps[valid], score[valid]), forced
     fb, fs = with_options(engine, {"filter": 0}, run)
     assert engine.timing()["rescore_ms"] == 0
     assert np.array_equal(fb, best), int((fb != best).sum())

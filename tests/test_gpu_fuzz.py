@@ -156,7 +156,8 @@ OPTION_SETS = [
     {"fused_seeds": 0},                             # seeds, their scores and the limit as three launches
     {"prune_min_kpairs": -1, "phase_timing": -1},   # the engine's own defaults: no seeds / early exit and no phase events below a work threshold
     {"prune_min_kpairs": 2000000000},               # never pruned
-    {"pretier": 1},                                 # the packed-fp16 pre-tier ahead of the fp32 filter form (default: cells above 32 groups only)
+    {"pretier": 1},                                 # the packed-fp16 pre-tier ahead of the fp32 filter form (default: large jobs and cells above 32 groups)
+    {"pretier": 0},
     {"pretier": 1, "tile": 64},
     {"spec_auto": 0, "spec_k": 3},                  # the short-list length pinned
     {"cell_order": 0},                              # the cells of an XCD's share in their given order (default: clipped cells first)
