@@ -780,6 +780,10 @@ def main():
     visited_per_launch = visited / max(launches * launches_scale, 1)
     pairs_alg = total_pa * w["L"] / launches_per_step
     ciede = t == 2 and engine_uses_filter
+    forced = [int(o.split("=")[1]) for o in args.opt if o.startswith("pretier=")]
+    ppad_groups = -(-w["size"] * w["size"] // 256)
+    pretier_on = ciede and (forced[-1] > 0 if forced and forced[-1] >= 0 else
+                            (ppad_groups > 32 or float(min(len(my_cells), 32768)) * w["L"] * w["size"] * w["size"] >= 1e10))
 
     pmc, pmc_src = pmc_record(w, args.opt, tm.get("filter_tile")) if world == 1 else (None, "PMC records are single-GPU")
     roof = {
@@ -856,7 +860,9 @@ def main():
         "higher_is_better": True,
         "scaling": scaling if world > 1 else "weak",
         "vs_baseline": None,
-        "dtype": "f32 filter + f64 arbiter" if engine_uses_filter else "f64",
+        # (every reported score and every index decision is the f64 tier's; the f32 filter only selects its contenders, and on
+        # large CIEDE2000 jobs a packed-f16 pre-tier takes the filter's early-exit decisions: engine option "pretier")
+        "dtype": ("f16 pre-tier + f32 filter + f64 arbiter" if pretier_on else "f32 filter + f64 arbiter") if engine_uses_filter else "f64",
         "data": "synthetic (REHEARSAL: all ranks on one GPU over gloo, timings void)" if rehearsal else
                 "photographs (derived fixture of the reference's SampleImages, tests/golden/photo_*.png)" if w["name"] == "P" else
                 "synthetic" if not (args.mcs or args.mil) else "synthetic target; %s" % ", ".join(
