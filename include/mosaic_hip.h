@@ -396,7 +396,8 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "fast_path" (1): mm_generate enqueues a whole generate and reads ONE result block back (one host wait) whenever the
  * cells fit one batch, falling back to the step-by-step path when the block says a host decision was needed; "fused" (1):
  * cell gather + chroma + interleave + block statistics in one launch and contenders + fp64 re-score + re-rank in one.
- * diagnostics only: "band_pct" (100, a deliberately wrong band), "lds_pad_kb".  Results are identical whatever the
+ * diagnostics only: "band_pct" (100, a deliberately wrong band), "lds_pad_kb", "dbg_pre_abs_1e4" / "dbg_pre_rel_1e6" (the band
+ * mm_debug_filter_band_sweep modes 2 / 3 measure the pre-tier's form against, in units of 1e-4 / 1e-6; 0: the pre-tier's own).  Results are identical whatever the
  * options (tests/test_gpu_fuzz.py::test_tuning_options_do_not_change_the_result). */
 mm_status mm_set_option(mm_engine *e, const char *name, int value);
 
