@@ -780,10 +780,7 @@ def main():
     visited_per_launch = visited / max(launches * launches_scale, 1)
     pairs_alg = total_pa * w["L"] / launches_per_step
     ciede = t == 2 and engine_uses_filter
-    forced = [int(o.split("=")[1]) for o in args.opt if o.startswith("pretier=")]
-    ppad_groups = -(-w["size"] * w["size"] // 256)
-    pretier_on = ciede and (forced[-1] > 0 if forced and forced[-1] >= 0 else
-                            (ppad_groups > 32 or float(min(len(my_cells), 32768)) * w["L"] * w["size"] * w["size"] >= 1e10))
+    pretier_on = ciede and bool(tm.get("pretier"))       # (the engine measures on its first two launches whether the pre-tier pays on this content)
 
     pmc, pmc_src = pmc_record(w, args.opt, tm.get("filter_tile")) if world == 1 else (None, "PMC records are single-GPU")
     roof = {

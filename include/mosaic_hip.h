@@ -108,6 +108,7 @@ typedef struct mm_timing {
     int64_t filter_off_range; /* 1: the f32 pixels handed over (mm_set_library / mm_set_target) leave the box the fp32 filter's
                                * error band was validated on -- Lab: channel 0 in [-0.5, 100.5], chroma <= 150; RGB / CIE76:
                                * |channel| <= 256; or hold a non-finite value -- so the call ran fp64-only (same result) */
+    int64_t pretier;          /* 1: the last CIEDE2000 filter launch ran with the packed-fp16 pre-tier (option "pretier") */
 } mm_timing;
 
 /* What a FIRST call pays besides the hot path, as host wall clocks accumulated since mm_create: the reference builds
@@ -383,7 +384,10 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
  * dropped in the engine's PREVIOUS CIEDE2000 launch over the same library, so the TIME of a call (never its result)
  * depends on the call history of the engine; 0 pins the size-by-cell default (mm_timing.filter_tile reports what ran).
- * "pretier" (-1 = for cells above 32 pixel groups, i.e. 96 .. 128 px, and for calls of >= 1e10 pixel pairs; 0 never, 1 always): CIEDE2000 candidates first walk their pixel groups in
+ * "pretier" (-1 = measured: jobs large enough to gain -- cells above 32 pixel groups, i.e. 96 .. 128 px, or calls of >= 1e10 pixel pairs -- run
+ * their first filter launch over a (library, cell size, batch, target) without it, the second with it, and keep the faster form from the third on:
+ * whether it pays depends on the content (synthetic patches: yes; photographs: no); 0 never, 1 always; as with "item_auto" only the TIME of a call
+ * depends on the engine's history): CIEDE2000 candidates first walk their pixel groups in
  * a packed-fp16 form (two pixel pairs per lane-instruction, operands half the size) that only takes early-exit decisions, against the limit
  * widened by its own measured band; survivors are scored by the fp32 form as before;
  * "stage0" (1): one whole-image bound per candidate ahead of the block bound; "euclid_stage1" (1): the RGB / CIE76 filter

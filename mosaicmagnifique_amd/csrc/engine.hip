@@ -42,7 +42,7 @@ struct DevBuf {
 struct mm_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[12] = {};
+    hipEvent_t ev[14] = {};      // [12], [13]: around the filter launch of a pre-tier trial (below)
     std::string err;
 
     // staged inputs
@@ -56,15 +56,22 @@ struct mm_engine {
     DevBuf cont_i, cont_f, cont_s, flags, edges, edge_count, dense_recs, dense_i, sentinel;
     DevBuf lib_means, seeds, seed_score, limits, row_slot, dense_rows_buf, row_index;
     DevBuf lib_chroma, cell_chroma, hue_lut, lib_il, cells_il;
+    // pretier = -1: WHETHER the pre-tier pays is a property of the content -- on the synthetic benchmark candidates leave the pixel loop
+    // far above the limit and the pre-tier's cheaper arithmetic wins (config D -6.3 %); on photographs the block bound is tight, many
+    // candidates sit within the fp16 band of the limit, walk all their groups in fp16 and then again in fp32 (the photo fixture enlarged to
+    // 2752 / 6144 cells: +6 % / +4 %, tools/experiments/r4_photo_scale.py).  So a job large enough to be eligible MEASURES it: the first
+    // filter launch over a (library, cell size, batch size, target) runs without the pre-tier, the second with it, both between two
+    // events, and the faster form is kept from the third on.  As with the item size and the list length only the TIME of a call
+    // depends on the engine's history, never its result.
+    struct PreAuto { int lib = 0, size = 0, cells = 0, have = 0, pending = -1, choice = -1; float ms[2] = {0.f, 0.f}; } pre_auto;
     DevBuf lib_h, cells_h;       // the interleaved copies as halfs (the filter's packed-fp16 pre-tier)
     bool lib_h_ready = false;    // lib_h holds the current library (prepare_planes builds it only where the pre-tier may run)
     float dbg_pre_abs = 0.0f, dbg_pre_rel = 0.0f;      // diagnostics: the band mm_debug_filter_band_sweep modes 2 / 3 measure against (0: the pre-tier's own)
     int pretier = -1;            // mm_set_option("pretier", 0 / 1): the packed-fp16 pre-tier ahead of the fp32 filter form never / always;
-                                 // -1 = by the size of the job: for cells above 32 pixel groups (up to 128 x 128, the reference GUI's
-                                 // default: config G 16.3 -> 14.4 ms per step) and for calls of >= 1e10 pixel pairs (config D 45.7 ->
-                                 // 42.8, E's shard 30.1 -> 29.4, 80-px cells 11.7 -> 11.0); smaller jobs lose to it (config C 3.21 ->
-                                 // 3.36: their candidates sit closer to the limit, so the wider limit exits later and more of them walk
-                                 // twice).  Results are identical either way
+                                 // -1 = measured (PreAuto below) for jobs large enough to gain -- cells above 32 pixel groups (up to
+                                 // 128 x 128, the reference GUI's default: config G 16.3 -> 14.4 ms per step) and calls of >= 1e10 pixel
+                                 // pairs (config D 45.7 -> 42.8, E's shard 30.1 -> 29.4, 80-px cells 11.7 -> 11.0) --, off for smaller
+                                 // ones (config C 3.21 -> 3.36).  Results are identical either way
     DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
     DevBuf stage_u8, srgb_lut, shrink_tmp, covered, cells_f0;
     DevBuf main_bgr;   int main_rows = 0, main_cols = 0;      // mm_set_main_image_bgr: the u8 main image (entropy test)
@@ -435,6 +442,7 @@ mm_status prepare_planes(mm_engine* e)
     HIP_TRY(e, mm::launch_interleave((const float*)e->lib.p, (const float*)e->lib_chroma.p, nullptr, (float*)e->lib_il.p,
                                      (size_t)n_var * L, ppad, e->stream), "Error during library interleave kernel");
     e->lib_h_ready = false;        // (the half copy for the packed-fp16 pre-tier is made by the first call that wants it)
+    e->pre_auto = mm_engine::PreAuto{};
     // whole-image statistics for stage 0 of the filter's bound (the blocks holding active pixels, joined), into slot ppad / 64
     for (int v = 0; v < n_var; ++v)
         HIP_TRY(e, mm::launch_image_stats((float*)e->lib_lsum.p + (size_t)v * L * stat_slots(ppad), (size_t)n_var * L * stat_slots(ppad),
@@ -627,6 +635,13 @@ void account_score_batch(mm_engine* e, bool two_tier, bool prune, int diff_type,
     e->timing.visited_groups += (int64_t)work[0];
     e->timing.total_groups += (int64_t)work[1];
     e->timing.bound_dropped += (int64_t)work[2];
+    if (e->pre_auto.pending >= 0) {             // a pre-tier trial: this launch's time, and the verdict once both forms have one
+        mm_engine::PreAuto& a = e->pre_auto;
+        a.ms[a.pending] = elapsed(e->ev[12], e->ev[13]);
+        a.have |= 1 << a.pending;
+        a.pending = -1;
+        if (a.have == 3) a.choice = a.ms[1] < 0.98f * a.ms[0] ? 1 : 0;
+    }
     if (prune && diff_type == MM_CIEDE2000 && b > 0) {
         e->drop_rate = (double)work[2] / ((double)b * (double)e->n_lib);
         e->drop_rate_lib = e->n_lib; e->drop_rate_size = e->lib_size;
@@ -892,8 +907,18 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                     "Error during cell image-statistics kernel");
         fin.var.two_stage = (e->two_level ? 1 : 0) | (stage0 ? 2 : 0);
         // the packed-fp16 pre-tier reads half copies of the cells and the library (CIEDE2000 with the early exit, interleaved form)
-        const bool pretier = (e->pretier > 0 || (e->pretier < 0 && (ppad / 256 > 32 || call_pairs >= 1e10))) && prune && diff_type == MM_CIEDE2000 &&
-                             e->use_interleave != 0 && fin.use_lds_form == 0;
+        const bool pre_possible = prune && diff_type == MM_CIEDE2000 && e->use_interleave != 0 && fin.use_lds_form == 0;
+        bool pretier = pre_possible && e->pretier > 0;
+        bool pre_trial = false;
+        // (eligible by size -- small jobs lose to it, config C +5 % -- and not a deepening sub-batch: decided by measurement)
+        if (pre_possible && e->pretier < 0 && row_map_host == nullptr && (ppad / 256 > 32 || call_pairs >= 1e10)) {
+            mm_engine::PreAuto& a = e->pre_auto;
+            if (a.lib != L || a.size != size || a.cells != b) { a = mm_engine::PreAuto{}; a.lib = L; a.size = size; a.cells = b; }
+            if (a.choice >= 0) pretier = a.choice != 0;
+            else if (done == 0) { pretier = (a.have & 1) != 0; a.pending = pretier ? 1 : 0; pre_trial = true; }    // off first, then on
+            else pretier = false;
+        }
+        if (row_map_host == nullptr) e->timing.pretier = pretier ? 1 : 0;
         if (pretier && !e->lib_h_ready) {       // the library's half copy, once per library / mask change
             if ((st = ensure(e, e->lib_h, (size_t)e->n_var * L * 4 * ppad * sizeof(uint16_t), "Failed to allocate the half-precision library"))) return st;
             HIP_TRY(e, mm::launch_interleave_h((const float*)e->lib_il.p, e->lib_h.p, (size_t)e->n_var * L, ppad, e->stream),
@@ -928,11 +953,13 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             e->drop_rate_lib == L && e->drop_rate_size == size)
             fin.tile_candidates = 64;
         int tile_used = 0;
+        if (pre_trial) HIP_TRY(e, hipEventRecord(e->ev[12], e->stream), "event");
         HIP_TRY(e, mm::launch_filter(ftype, fin, (float*)e->scores.p, b, L, ppad,
                                      (mm::EdgeEntry*)e->edges.p, counters_dev, edge_cap,
                                      prune ? (const float*)e->limits.p : nullptr, e->stream, &tile_used),
                 "Error during filter colour difference kernel");
         e->timing.filter_tile = tile_used;
+        if (pre_trial) HIP_TRY(e, hipEventRecord(e->ev[13], e->stream), "event");
         if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
 
         if (fused_rank) {
@@ -1370,7 +1397,7 @@ void move_resources(mm_engine* to, mm_engine* from)
     to->pinned = from->pinned; to->pinned_bytes = from->pinned_bytes;
     from->pinned = nullptr; from->pinned_bytes = 0;
     to->stream = from->stream; from->stream = nullptr;
-    for (int i = 0; i < 12; ++i) { to->ev[i] = from->ev[i]; from->ev[i] = nullptr; }
+    for (int i = 0; i < 14; ++i) { to->ev[i] = from->ev[i]; from->ev[i] = nullptr; }
 }
 
 // mm_destroy: true if the engine's resources were parked (the caller deletes the shell).
@@ -1456,7 +1483,7 @@ mm_status mm_create(int device, mm_engine** out)
         e->stage_clock.reused_engine = 1;
     } else {
         if (code == hipSuccess) code = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-        for (int i = 0; code == hipSuccess && i < 12; ++i) code = hipEventCreate(&e->ev[i]);
+        for (int i = 0; code == hipSuccess && i < 14; ++i) code = hipEventCreate(&e->ev[i]);
     }
     if (code != hipSuccess) {
         mm_status st = hip_fail(nullptr, code, "Failed to initialise device", __FILE__, __LINE__);
@@ -1564,6 +1591,7 @@ mm_status mm_set_target(mm_engine* e, const float* image, int rows, int cols)
     }
     e->rows = rows;
     e->cols = cols;
+    e->pre_auto = mm_engine::PreAuto{};          // other content: the pre-tier is measured again
     return value_range(e, (const float*)e->target.p, (size_t)rows * cols, &e->target_range);
 }
 
@@ -1724,6 +1752,7 @@ mm_status mm_set_target_u8(mm_engine* e, const uint8_t* bgr, int rows, int cols,
     e->rows = rows;
     e->cols = cols;
     e->target_range = 0;
+    e->pre_auto = mm_engine::PreAuto{};
     return MM_OK;
 }
 
@@ -2486,7 +2515,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "stage0") == 0) { e->stage0 = value != 0; return MM_OK; }
     if (strcmp(name, "dbg_pre_abs_1e4") == 0) { e->dbg_pre_abs = 1e-4f * (float)std::max(0, value); return MM_OK; }
     if (strcmp(name, "dbg_pre_rel_1e6") == 0) { e->dbg_pre_rel = 1e-6f * (float)std::max(0, value); return MM_OK; }
-    if (strcmp(name, "pretier") == 0) { e->pretier = value < 0 ? -1 : (value != 0); return MM_OK; }
+    if (strcmp(name, "pretier") == 0) { e->pretier = value < 0 ? -1 : (value != 0); e->pre_auto = mm_engine::PreAuto{}; return MM_OK; }
     if (strcmp(name, "tiny") == 0) { e->tiny_path = value != 0; return MM_OK; }
     if (strcmp(name, "item_auto") == 0) { e->item_auto = value != 0; return MM_OK; }
     if (strcmp(name, "fused") == 0) { e->fused = value != 0; return MM_OK; }

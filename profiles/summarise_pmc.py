@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 passes of tools/profile.sh (all of the SAME command,
-`python3 bench.py --config X --steps 1 --warmup 1 --no-cpu` (a warm-up step first: the item size of a CIEDE2000
+`python3 bench.py --config X --steps 1 --warmup 2 --no-cpu` (warm-up steps first: the item size of a CIEDE2000
 launch can follow the engine's previous launch, so the counted launches are steady-state ones), separate runs as the MI355X guide
 prescribes: --pmc FETCH_SIZE, --pmc WRITE_SIZE, --pmc SQ_*) into the per-launch record of the
 dominant kernel that bench.py prices its roofline with (profiles/pmc_traffic.json).
@@ -27,14 +27,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+FILTER = r"\bfilter_kernel<|filter_lds_kernel<|mm::score_kernel<"
+
+
 def per_kernel(dirname):
-    """{kernel name: {counter: (launches, sum)}} from a rocprofv3 counter_collection.csv under dirname."""
-    out = {}
+    """{kernel name: {counter: (launches, sum)}} from a rocprofv3 counter_collection.csv under dirname -- of the dominant
+    (filter) kernel only the LAST dispatch: a large job measures the fp16 pre-tier over its first two launches (two
+    instantiations of filter_kernel), the counted step is the one after them."""
+    rows = []
     for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(path)):
-            k = out.setdefault(r["Kernel_Name"], {})
-            n, v = k.get(r["Counter_Name"], (0, 0.0))
-            k[r["Counter_Name"]] = (n + 1, v + float(r["Counter_Value"]))
+        rows += list(csv.DictReader(open(path)))
+    filters = [r for r in rows if re.search(FILTER, r["Kernel_Name"])]
+    last = max((int(r["Dispatch_Id"]) for r in filters), default=None)
+    out = {}
+    for r in rows:
+        if re.search(FILTER, r["Kernel_Name"]) and int(r["Dispatch_Id"]) != last:
+            continue
+        k = out.setdefault(r["Kernel_Name"], {})
+        n, v = k.get(r["Counter_Name"], (0, 0.0))
+        k[r["Counter_Name"]] = (n + 1, v + float(r["Counter_Value"]))
     return out
 
 
@@ -61,7 +72,7 @@ def main():
         "WRITE_SIZE_KiB_per_launch": wv / wn,
         "fetch_correction": 2.0,
         "traffic_bytes_per_launch": (2.0 * fv / fn + wv / wn) * 1024.0,
-        "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> -- python3 bench.py --config %s --steps 1 --warmup 1 --no-cpu %s" % (
+        "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> -- python3 bench.py --config %s --steps 1 --warmup 2 --no-cpu %s" % (
             config, " ".join("--opt " + o for o in opts)),
     }
     if name in sq:

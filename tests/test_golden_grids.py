@@ -96,6 +96,11 @@ def whole_grid_against_golden(engine, name, options=None):
     try:
         best, score = engine.generate(cells, state.shape[1], state.shape[0], t, *s["rep"])
         tm = engine.timing()
+        # large jobs measure the fp16 pre-tier over their first two launches (off, then on) and keep the faster form: all three
+        # launches must give this grid
+        for _ in range(2 if name in ("D", "E", "G", "I") and not options else 0):
+            again, again_score = engine.generate(cells, state.shape[1], state.shape[0], t, *s["rep"])
+            assert np.array_equal(again, best) and np.array_equal(again_score, score, equal_nan=True)
     finally:
         for k in (options or {}):
             engine.set_option(k, 1)

@@ -29,6 +29,14 @@ for f in (1, 2, 3):
             t0 = time.perf_counter(); b, s = e.generate(cells, state.shape[1], state.shape[0], 2, 4, 500); ts.append((time.perf_counter() - t0) * 1e3)
         tm = e.timing()
         res.setdefault(pre, []).append((min(ts[1:]), tm["visited_groups"] / max(tm["total_groups"], 1), tm["spec_rounds"], b))
+    # the measured rule (option -1): launches 1 and 2 are the trial (off, on), from the third on the kept form
+    e.set_option("pretier", -1)
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter(); b, s = e.generate(cells, state.shape[1], state.shape[0], 2, 4, 500); ts.append((time.perf_counter() - t0) * 1e3)
+    res[-1] = [(min(ts[3:]), 0.0, 0, b)]
+    kept = e.timing()["pretier"]
     same = all(np.array_equal(res[0][0][3], r[3]) for p in res for r in res[p])
     print("x%d: %d cells, %.3g pixel pairs | pretier 0: %s ms  pretier 1: %s ms | visited %.4f / %.4f | same grid %s" % (
-        f, len(cells), len(cells) * 1024.0 * 4096, ["%.2f" % r[0] for r in res[0]], ["%.2f" % r[0] for r in res[1]], res[0][0][1], res[1][0][1], same), flush=True)
+        f, len(cells), len(cells) * 1024.0 * 4096, ["%.2f" % r[0] for r in res[0]], ["%.2f" % r[0] for r in res[1]], res[0][0][1], res[1][0][1], same),
+        "| measured rule: %.2f ms, kept pretier=%d (launch times %s)" % (res[-1][0][0], kept, ["%.1f" % t for t in ts]), flush=True)
