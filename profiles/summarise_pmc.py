@@ -38,7 +38,9 @@ def per_kernel(dirname):
     for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         rows += list(csv.DictReader(open(path)))
     filters = [r for r in rows if re.search(FILTER, r["Kernel_Name"])]
-    last = max((int(r["Dispatch_Id"]) for r in filters), default=None)
+    # (the MAIN launch of the last step: deepening rounds launch the filter again over a handful of cells -- far smaller grids)
+    biggest = max((int(r["Grid_Size"]) for r in filters), default=0)
+    last = max((int(r["Dispatch_Id"]) for r in filters if 2 * int(r["Grid_Size"]) >= biggest), default=None)
     out = {}
     for r in rows:
         if re.search(FILTER, r["Kernel_Name"]) and int(r["Dispatch_Id"]) != last:
