@@ -33,6 +33,8 @@ def main():
         r = d["roofline"]
         hbm = r.get("hbm") or {}
         frac = r.get("frac")
+        if r.get("launches_per_step", 1) > 1.5:       # a step of several launches of very different sizes (deepening rounds): the average launch is not a kernel
+            frac, hbm = None, {}
         print("| %s | %s | **%.3g** | `%s` %.3g | %s | %s | %s |" % (
             NAMES[name], ("%.2f M" % (d["value"] / 1e6)) if d["value"] >= 1e6 else ("%.1f k" % (d["value"] / 1e3)), d["ms_per_step"],
             r["kernel"], r["avg_launch_ms"], ("%.1f %%" % (100 * r["visited_fraction_of_groups"])) if r.get("visited_fraction_of_groups") else "—",
