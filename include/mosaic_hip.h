@@ -375,7 +375,8 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * image copies with prepared operands; "two_level" (1): the bound's stage 1, several candidates per wave pass;
  * "sort_groups" (-1 = by cell size): how many of a candidate's pixel groups are visited by descending bound;
  * "check_every" (0 = by cell size): pixel groups between two exit tests of a candidate;
- * "probe_prepared" (0): mm_filter_diff_batch measures the CIEDE2000 filter form with operands prepared as the dominant kernel holds them;
+ * "probe_prepared" (0): mm_filter_diff_batch measures the CIEDE2000 filter form with operands prepared as the dominant kernel holds them
+ * (1), or the packed-fp16 pre-tier's form on operands rounded to halfs (2; pairs it counts as 0 near the opposite-hue seam read -1);
  * "lds_filter" (-1 = RGB only): LDS-resident cell tile; "seeds" (-1 = 14 for CIEDE2000, 2 for RGB / CIE76): proxy-chosen seeds beyond the list length;
  * "spec_auto" (1): the length of the speculative short lists ("spec_k", 4) doubles (up to 16) when the engine's PREVIOUS
  * generate over the same library had to deepen more than 2 % of its cells -- content on which neighbouring cells want the same few

@@ -118,7 +118,7 @@ struct mm_engine {
     int xcd_cells = 0;           // mm_set_option("xcd_cells", n): cells per sub-group of an XCD's share (0 = default)
     bool any_clipped = false;        // the cells of the call in flight: does any of them carry a bound short of the whole cell? (check_cells)
     bool long_items_first = true;    // mm_set_option("cell_order", 0 / 1): filter_kernel takes the clipped cells of each XCD's share first
-    bool probe_prepared = false; // mm_set_option("probe_prepared", 0 / 1): mm_filter_diff_batch measures the prepared-operand form of the CIEDE2000 filter
+    int probe_prepared = 0;      // mm_set_option("probe_prepared", 0 / 1 / 2): mm_filter_diff_batch measures the prepared-operand form of the CIEDE2000 filter (1) or the packed-fp16 pre-tier's form (2)
     int check_every = 0;         // mm_set_option("check_every", n): groups between two exit tests of a candidate (0 = by cell size)
     int item_chunk = 0;          // mm_set_option("item_chunk", n): work items per global atomic of the filter's persistent workgroups (0 = by launch size)
     size_t batch_per_cell = 0;   // workspace bytes per cell the batch capacity below was computed for
@@ -2506,7 +2506,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "interleave") == 0) { e->use_interleave = value != 0; return MM_OK; }
     if (strcmp(name, "xcd_aware") == 0) { e->xcd_aware = value != 0; return MM_OK; }
     if (strcmp(name, "cell_order") == 0) { e->long_items_first = value != 0; return MM_OK; }
-    if (strcmp(name, "probe_prepared") == 0) { e->probe_prepared = value != 0; return MM_OK; }
+    if (strcmp(name, "probe_prepared") == 0) { e->probe_prepared = value == 2 ? 2 : value != 0; return MM_OK; }
     if (strcmp(name, "check_every") == 0) { e->check_every = std::min(64, std::max(0, value)); return MM_OK; }
     if (strcmp(name, "item_chunk") == 0) { e->item_chunk = std::max(0, value); return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
@@ -2590,7 +2590,7 @@ mm_status mm_filter_diff_batch(mm_engine* e, int diff_type, const float* first, 
     if (code == hipSuccess) code = hipMemcpyAsync(b.p, second, n * 3 * sizeof(float), hipMemcpyHostToDevice, e->stream);
     if (code == hipSuccess)
         code = mm::launch_pair_fast(diff_type == MM_CIEDE2000 ? mm::CIEDE2000 : mm::RGB_EUCLIDEAN,
-                                    (const float*)a.p, (const float*)b.p, n, (float*)o.p, 1 | (e->probe_prepared ? 2 : 0),
+                                    (const float*)a.p, (const float*)b.p, n, (float*)o.p, 1 | (e->probe_prepared == 2 ? 4 : e->probe_prepared ? 2 : 0),
                                     (const float2*)e->hue_lut.p, e->stream);
     if (code == hipSuccess) code = hipMemcpyAsync(out, o.p, n * sizeof(float), hipMemcpyDeviceToHost, e->stream);
     if (code == hipSuccess) code = sync_stream(e);

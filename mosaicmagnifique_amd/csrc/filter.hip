@@ -1725,7 +1725,17 @@ pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ seco
         const float* q = second + 3 * i;
         bool edge;
         float v;
-        if (TYPE == CIEDE2000 && (flag_edges & 2) != 0)     // the form the dominant kernel runs: operands prepared as interleave_kernel stores them
+        if (TYPE == CIEDE2000 && (flag_edges & 4) != 0) {   // the packed-fp16 pre-tier's form on operands rounded to halfs as interleave_h_kernel stores them
+            auto half_operands = [](const float* c, half2_t& l, half2_t& a, half2_t& b, half2_t& ch) {
+                l = h2_splat(fmaf(0.5f, c[0], -25.0f)); a = h2_splat(kHalfOperandScale * c[1]); b = h2_splat(kHalfOperandScale * c[2]);
+                ch = h2_splat(__fmul_rn(kChromaPrep, chroma_of(c[1], c[2])));
+            };
+            half2_t pl, pa, pb, pch, ql, qa, qb, qch;
+            half_operands(p, pl, pa, pb, pch); half_operands(q, ql, qa, qb, qch);
+            unsigned int seam = 0u;
+            v = (float)ciede2000_h2(pl, pa, pb, pch, ql, qa, qb, qch, lut, &seam).x;
+            edge = (seam & 0xffffu) != 0u;                  // counted as 0 by the pre-tier
+        } else if (TYPE == CIEDE2000 && (flag_edges & 2) != 0)     // the form the dominant kernel runs: operands prepared as interleave_kernel stores them
             v = pair_fast<TYPE, true>(PxF{fmaf(0.5f, p[0], -25.0f), p[1], p[2]}, PxF{fmaf(0.5f, q[0], -25.0f), q[1], q[2]},
                                       __fmul_rn(kChromaPrep, chroma_of(p[1], p[2])), __fmul_rn(kChromaPrep, chroma_of(q[1], q[2])), lut, &edge);
         else

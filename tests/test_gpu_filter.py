@@ -107,25 +107,28 @@ def test_packed_fp16_pretier_band_structured_sweep(engine):
     assert r["handed_over"] > 0 and r["measured"] > 1e8
 
 
-def band_share(engine, a, b):
+def band_share(engine, a, b, fp16=False):
     """|fp32 filter form - fp64 form| as a share of the band the engine trusts (engine.hip filter_band: 1e-3 + 6e-5 * value);
-    pairs the filter hands to the fp64 form count as 0."""
+    pairs the filter hands to the fp64 form count as 0.  fp16: the packed-fp16 pre-tier's form against ITS band (filter.hip
+    kPreAbs + kPreRel * value) -- the signed over-estimate, which is what an early exit relies on; seam pairs count as 0."""
     exact = engine.colour_diff_batch(2, a, b)
     fast = engine.filter_diff_batch(2, a, b).astype(np.float64)
-    share = np.abs(fast - exact) / (1e-3 + 6e-5 * exact)
+    share = (fast - exact) / (0.38 + 8e-3 * exact) if fp16 else np.abs(fast - exact) / (1e-3 + 6e-5 * exact)
     share[fast < 0] = 0.0
     assert np.isfinite(fast).all()
     return share, exact
 
 
-@pytest.mark.parametrize("prepared", [0, 1])
+@pytest.mark.parametrize("prepared", [0, 1, 2])
 def test_ciede2000_filter_band_adversarial_maximiser(engine, prepared):
     """Random and structured sweeps find the TYPICAL worst error; this one climbs: 2^17 pairs of f32 Lab colours -- seeded
     on the families where the fp32 form is weakest (near-grey with either operand, saturated blue where R_T peaks, both
     sides of the opposite-hue seam, near-identical colours, the corners of the Lab box) -- are mutated over 80 generations
     (both operands or one, one coordinate or all, steps from 30 units down to single ulps; the better of parent and child
     survives, every eighth generation the weaker half is replaced by copies of the stronger half) to MAXIMISE
-    |fp32 - fp64| / band.  The worst pair it finds must stay below half of the trusted band, in both operand forms."""
+    |fp32 - fp64| / band.  The worst pair it finds must stay below half of the trusted band, in both operand forms.
+    prepared = 2: the same climb on the packed-fp16 pre-tier's form (operands rounded to halfs) against the pre-tier's own
+    band, maximising the OVER-estimate fp16 - fp64 (what an early exit relies on), with moves of half-precision size."""
     rng = np.random.default_rng(17 + prepared)
     n = 1 << 17
     lo, hi = LO.astype(np.float32), HI.astype(np.float32)
@@ -138,11 +141,12 @@ def test_ciede2000_filter_band_adversarial_maximiser(engine, prepared):
     a, b = np.clip(a, lo, hi), np.clip(b, lo, hi)
     engine.set_option("probe_prepared", prepared)
     try:
-        best, _ = band_share(engine, a, b)
+        fp16 = prepared == 2
+        best, _ = band_share(engine, a, b, fp16)
         start = best.max()
         for gen in range(80):
             ca, cb = a.copy(), b.copy()
-            scale = (10.0 ** rng.uniform(-6, 1.5, (n, 1))).astype(np.float32)
+            scale = (10.0 ** rng.uniform(-3 if fp16 else -6, 1.5, (n, 1))).astype(np.float32)
             which = rng.integers(0, 3, (n, 1))                     # 0: first operand, 1: second, 2: both
             coord = rng.uniform(size=(n, 3)) < rng.uniform(0.34, 1.0, (n, 1))
             ulps = rng.uniform(size=n) < 0.15                      # single-ulp moves (rounding boundaries of the fp32 form)
@@ -153,7 +157,7 @@ def test_ciede2000_filter_band_adversarial_maximiser(engine, prepared):
             ca[ulps] = np.nextafter(a[ulps], a[ulps] + step[ulps] * np.float32(1e3))       # one ulp towards sign(step)
             cb[ulps] = b[ulps]
             ca, cb = np.clip(ca, lo, hi), np.clip(cb, lo, hi)
-            child, _ = band_share(engine, ca, cb)
+            child, _ = band_share(engine, ca, cb, fp16)
             better = child > best
             a[better], b[better], best[better] = ca[better], cb[better], child[better]
             if gen % 8 == 7:                                       # selection: the stronger half breeds
@@ -161,7 +165,7 @@ def test_ciede2000_filter_band_adversarial_maximiser(engine, prepared):
                 weak, strong = order[: n // 2], order[n // 2:]
                 a[weak], b[weak], best[weak] = a[strong], b[strong], best[strong]
         worst = int(np.argmax(best))
-        share, exact = band_share(engine, a[worst:worst + 1], b[worst:worst + 1])
+        share, exact = band_share(engine, a[worst:worst + 1], b[worst:worst + 1], fp16)
         print("adversarial maximiser (prepared=%d): band share %.3f -> %.3f; worst pair %s vs %s, dE00 %.6f"
               % (prepared, start, best.max(), a[worst].tolist(), b[worst].tolist(), exact[0]))
         assert best.max() >= start                                 # it climbed (or started at its summit)
