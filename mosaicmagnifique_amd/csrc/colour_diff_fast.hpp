@@ -184,7 +184,7 @@ __device__ __forceinline__ float chroma_of(float a, float b) { return fsqrt(fmaf
 // what happens to everything awkward: pairs near the opposite-hue seam (|cross| < 2^-7 e: the fp16 branch choice may differ
 // from the fp64 one) and anything that came out NaN contribute 0.  What may NOT happen is an over-estimate beyond the band,
 // so no intermediate may overflow for inputs inside the validated box (L in [0, 100], chroma <= 150):
-//   operands are prepared (interleave_h_kernel): L / 2 - 25, a / 4, b / 4, C / 50 -- a' <= 57, products <= 4600, e <= 9200;
+//   operands are prepared (interleave_h_kernel): L / 2 - 25, a / 4, b / 4, C / 4 -- a' <= 57, products <= 4600, e <= 9200;
 //   the 7th power of the mean chroma over 25 is clamped at 4.8^7 (the ratio is 1 - 9e-6 there) and enters as
 //   rsq(1 + rcp(z)) -- z -> 0 gives rcp = inf, rsq(inf) = 0, the right limit -- instead of z rsq(z^2 + z), whose square
 //   leaves fp16's range on either side; e carries + 2^-13 under its rsq (a chroma of 0.04: no hue to speak of);
@@ -222,28 +222,61 @@ MM_H2_UNARY(h2_rsq, "v_rsq_f16")
 MM_H2_UNARY(h2_rcp, "v_rcp_f16")
 MM_H2_UNARY(h2_sqrt, "v_sqrt_f16")
 #undef MM_H2_UNARY
+// the larger of two NON-NEGATIVE halfs, per half (unsigned order of the bit patterns; a NaN wins)
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half2_t h2_umax(half2_t a, half2_t b)
+{
+    return __builtin_bit_cast(half2_t, __builtin_elementwise_max(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
+}
 // per-half select by a mask that holds 0xffff or 0 in each half
 __device__ __forceinline__ half2_t h2_sel(unsigned int mask, half2_t a, half2_t b) { return h2_from((h2_bits(a) & mask) | (h2_bits(b) & ~mask)); }
 // 0xffff in every half whose sign bit is set in `signs` (a value masked with 0x80008000)
 __device__ __forceinline__ unsigned int h2_sign_mask(unsigned int signs) { const unsigned int t = signs >> 15; return (t << 16) - t; }
 
 // sqrt(z / (z + 1)), z = s^7, for s = mean chroma / 25
+#ifndef MM_PRE_CHROMA_FLOOR
+#define MM_PRE_CHROMA_FLOOR 1        // ciede2000_h2: C' floored by the stored chroma (0: A/B builds only -- unsound for chroma 1e-5 .. 1e-3 beside saturated colours)
+#endif
+#ifndef MM_PRE_RATIO_ONE_RSQ
+#define MM_PRE_RATIO_ONE_RSQ 1       // one transcendental per ratio instead of two (0: rsq(1 + rcp(z)))
+#endif
 __device__ __forceinline__ half2_t h2_ratio7(half2_t s)
 {
+#if MM_PRE_RATIO_ONE_RSQ
+    // z / (z + 1) = y^2 / (y^2 + y / 16) for y = z / 16, so the ratio is y rsq(y (y + 1/16)): per-half transcendentals cost two
+    // instructions a pair and wait states around them, packed multiplies one.  s is clamped at 3.26 (y <= 245, y^2 inside the
+    // halfs' range; the ratio is within 1.3e-4 of 1 from there on), and 2^-24 -- the smallest subnormal half -- keeps the root's operand
+    // above zero where y underflows (s < 0.1, where the ratio is below 3e-4: it comes out as 0)
+    s = __builtin_elementwise_min(s, h2_splat(3.26f));
+    const half2_t s2 = s * s;
+    const half2_t y = ((s2 * s2) * s2) * (s * h2_splat(1.0f / 16.0f));
+    return y * h2_rsq(y * (y + h2_splat(1.0f / 16.0f)) + h2_splat(0x1p-24f));
+#else
     s = __builtin_elementwise_min(s, h2_splat(4.8f));
     const half2_t s2 = s * s;
     const half2_t z = ((s2 * s2) * s2) * s;                         // <= 58 700
     return h2_rsq(h2_splat(1.0f) + h2_rcp(z));
+#endif
 }
 
 constexpr float kHalfOperandScale = 0.25f;     // a and b are stored / 4
+constexpr float kHalfChromaScale = 12.5f;      // ... and the chroma plane, held as C / 50 in the fp32 copies, as C / 4 as well
 
 __device__ __forceinline__ half2_t ciede2000_h2(half2_t pl, half2_t pa, half2_t pb, half2_t pc, half2_t ql, half2_t qa, half2_t qb, half2_t qc,
                                                 const HueEntry* __restrict__ lut, unsigned int* seam_out = nullptr)
 {
-    const half2_t one_g = h2_splat(1.5f) - h2_splat(0.5f) * h2_ratio7(pc + qc);
+    const half2_t one_g = h2_splat(1.5f) - h2_splat(0.5f) * h2_ratio7((pc + qc) * h2_splat(0.08f));     // mean C / 25 = (C1 / 4 + C2 / 4) x 4 / 2 / 25
     const half2_t a1 = one_g * pa, a2 = one_g * qa;
+    // C' >= C (G >= 1): the stored chroma is a floor for C'.  It is what C' comes out as when the squares underflow -- a pixel with a chroma
+    // of 1e-5 .. 1e-3 (greys as a float conversion leaves them) -- : with C1' = 0 beside a saturated C2' the cross product below is still
+    // right but `e` is not, and dH' came out six times too large (+1.3 on a pair of 33.7: what tests/test_gpu_filter.py's maximiser
+    // found first when it was pointed at this form)
+#if MM_PRE_CHROMA_FLOOR
+    // (non-negative halfs order like their bit patterns: one v_pk_max_u16 each -- the floating-point maximum quiets both operands first, three instructions)
+    const half2_t c1p = h2_umax(h2_sqrt(a1 * a1 + pb * pb), pc), c2p = h2_umax(h2_sqrt(a2 * a2 + qb * qb), qc);
+#else
     const half2_t c1p = h2_sqrt(a1 * a1 + pb * pb), c2p = h2_sqrt(a2 * a2 + qb * qb);
+#endif
     const half2_t dot = a1 * a2 + pb * qb;
     const half2_t cross = a1 * qb - pb * a2;
     const unsigned int obtuse = h2_sign_mask(h2_bits(dot) & 0x80008000u);

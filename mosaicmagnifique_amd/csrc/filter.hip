@@ -218,21 +218,24 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 #ifndef MM_BIG_CELL_STAGE0
 #define MM_BIG_CELL_STAGE0 1         // cells above 16 groups: stage 0 of the bound ahead of the candidate loop, bound-ordered visits from 17 groups on (0: round 3's form, for A/B builds)
 #endif
-// Error band of the packed-fp16 pre-tier per pixel pair: |fp16 form - fp64 form| <= kPreAbs + kPreRel * value for operands
+// Error band of the packed-fp16 pre-tier per pixel pair: fp16 form - fp64 form <= kPreAbs + kPreRel * value for operands
 // inside the validated box, with the operands rounded to halfs as interleave_h_kernel stores them (measured by
-// band_sweep_kernel modes 2 / 3 and held below half of this by tests/test_gpu_filter.py); the pre-tier's accumulation is fp32.
-// (twice the worst over-estimate of 1.1e10 swept pairs, as a quarter-grid exploration of the (abs, rel) frontier could not be trusted to
-// find it: tools/experiments/r4_pre3.sh, profiles/r04_pretier_band_frontier.txt -- 0.11 + 6e-3 v holds the worst pair at 0.99 of
-// itself, 0.16 + 8e-3 v at 0.72, this one at 0.47.  The narrower ones buy little once the absolute part is charged as the walk
-// proceeds: config D 41.9 / 42.2 / 42.8 ms per step against 45.7 without the pre-tier, profiles/r04_pretier_band_width_ab.txt)
+// band_sweep_kernel modes 2 / 3 and climbed against by the adversarial maximiser, both held below half of this by
+// tests/test_gpu_filter.py); the pre-tier's accumulation is fp32.
+// History of the number: 0.38 + 8e-3 v was twice the worst over-estimate of 1.1e10 swept pairs (a quarter-grid exploration of the
+// (abs, rel) frontier had under-estimated it: tools/experiments/r4_pre3.sh, profiles/r04_pretier_band_frontier.txt).  The maximiser, once
+// pointed at this form, found what the sweeps' chroma levels step over -- a chroma of 1e-5 .. 1e-3 beside a saturated colour, +1.3 on a pair
+// of 33.7, 1.9 of that band; fixed in ciede2000_h2 by flooring C' with the stored chroma -- and the fix also removed the sweeps' worst pair:
+// share 0.32 of the old band, 0.42 of this one for sweeps and maximiser alike (profiles/r04_pretier_maximiser.txt).  Narrower bands buy
+// little once the absolute part is charged as the walk proceeds (config D: 0.26 + 5.5e-3 v is 1.6 % faster than 0.38 + 8e-3 v).
 #ifndef MM_PRE_PREFETCH
 #define MM_PRE_PREFETCH 1            // the pre-tier fetches the next group's operands while it computes this one (0: A/B builds)
 #endif
 #ifndef MM_PRE_ABS
-#define MM_PRE_ABS 0.38f
+#define MM_PRE_ABS 0.29f
 #endif
 #ifndef MM_PRE_REL
-#define MM_PRE_REL 8e-3f
+#define MM_PRE_REL 6e-3f
 #endif
 constexpr float kPreAbs = MM_PRE_ABS, kPreRel = MM_PRE_REL;
 #ifndef MM_LONG_SPLIT
@@ -1248,13 +1251,13 @@ interleave_kernel(const float* __restrict__ planar, const float* __restrict__ ch
 }
 
 // The interleaved copy once more as halfs, for the packed-fp16 pre-tier (colour_diff_fast.hpp ciede2000_h2): the same
-// [image][group][plane][256] order, planes L / 2 - 25, a / 4, b / 4, C / 50, round-to-nearest; a NaN stays a NaN.
+// [image][group][plane][256] order, planes L / 2 - 25, a / 4, b / 4, C / 4, round-to-nearest; a NaN stays a NaN.
 __global__ void __launch_bounds__(kBlock)
 interleave_h_kernel(const float4* __restrict__ il, uint2* __restrict__ out, size_t n_vec)
 {
     for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < n_vec; t += (size_t)gridDim.x * kBlock) {
         const int plane = (int)((t >> 6) & 3);                    // 64 float4 per plane, four planes per group
-        const float sc = (plane == 1 || plane == 2) ? kHalfOperandScale : 1.0f;
+        const float sc = (plane == 1 || plane == 2) ? kHalfOperandScale : plane == 3 ? kHalfChromaScale : 1.0f;
         const float4 v = il[t];
         const half2_t lo{(half1_t)(sc * v.x), (half1_t)(sc * v.y)}, hi{(half1_t)(sc * v.z), (half1_t)(sc * v.w)};
         out[t] = uint2{h2_bits(lo), h2_bits(hi)};
@@ -1728,7 +1731,7 @@ pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ seco
         if (TYPE == CIEDE2000 && (flag_edges & 4) != 0) {   // the packed-fp16 pre-tier's form on operands rounded to halfs as interleave_h_kernel stores them
             auto half_operands = [](const float* c, half2_t& l, half2_t& a, half2_t& b, half2_t& ch) {
                 l = h2_splat(fmaf(0.5f, c[0], -25.0f)); a = h2_splat(kHalfOperandScale * c[1]); b = h2_splat(kHalfOperandScale * c[2]);
-                ch = h2_splat(__fmul_rn(kChromaPrep, chroma_of(c[1], c[2])));
+                ch = h2_splat(kHalfChromaScale * __fmul_rn(kChromaPrep, chroma_of(c[1], c[2])));
             };
             half2_t pl, pa, pb, pch, ql, qa, qb, qch;
             half_operands(p, pl, pa, pb, pch); half_operands(q, ql, qa, qb, qch);
@@ -1807,7 +1810,7 @@ band_sweep_kernel(int mode, unsigned long long seed, unsigned long long n_pairs,
             // delays an exit), so the share reported is the signed one; max_err stays the absolute error
             auto prep = [](const PxF& c, half2_t& l, half2_t& a, half2_t& b, half2_t& ch) {
                 l = h2_splat(fmaf(0.5f, c.c0, -25.0f)); a = h2_splat(kHalfOperandScale * c.c1); b = h2_splat(kHalfOperandScale * c.c2);
-                ch = h2_splat(__fmul_rn(kChromaPrep, chroma_of(c.c1, c.c2)));
+                ch = h2_splat(kHalfChromaScale * __fmul_rn(kChromaPrep, chroma_of(c.c1, c.c2)));
             };
             half2_t pl, pa, pb, pch, ql, qa, qb, qch;
             prep(p, pl, pa, pb, pch); prep(q, ql, qa, qb, qch);
