@@ -226,8 +226,11 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 // (abs, rel) frontier had under-estimated it: tools/experiments/r4_pre3.sh, profiles/r04_pretier_band_frontier.txt).  The maximiser, once
 // pointed at this form, found what the sweeps' chroma levels step over -- a chroma of 1e-5 .. 1e-3 beside a saturated colour, +1.3 on a pair
 // of 33.7, 1.9 of that band; fixed in ciede2000_h2 by flooring C' with the stored chroma -- and the fix also removed the sweeps' worst pair:
-// share 0.32 of the old band, 0.42 of this one for sweeps and maximiser alike (profiles/r04_pretier_maximiser.txt).  Narrower bands buy
-// little once the absolute part is charged as the walk proceeds (config D: 0.26 + 5.5e-3 v is 1.6 % faster than 0.38 + 8e-3 v).
+// share 0.32 of the old band.  This one, 0.29 + 8e-3 v, is twice the worst over-estimate of every search so far: the sweeps' worst pair
+// sits at 0.42 of it (absolute part: small differences), twelve seeds of the maximiser over 400 generations at 0.48 (relative part: saturated
+// colours at opposite corners of the box, dE00 ~ 135, where eleven bits of mantissa show; with 6e-3 v they reached 0.60) --
+// profiles/r04_pretier_maximiser.txt.  Narrower bands buy little once the absolute part is charged as the walk proceeds (config D:
+// 0.26 + 5.5e-3 v is 1.6 % faster than 0.38 + 8e-3 v).
 #ifndef MM_PRE_PREFETCH
 #define MM_PRE_PREFETCH 1            // the pre-tier fetches the next group's operands while it computes this one (0: A/B builds)
 #endif
@@ -235,7 +238,7 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 #define MM_PRE_ABS 0.29f
 #endif
 #ifndef MM_PRE_REL
-#define MM_PRE_REL 6e-3f
+#define MM_PRE_REL 8e-3f
 #endif
 constexpr float kPreAbs = MM_PRE_ABS, kPreRel = MM_PRE_REL;
 #ifndef MM_LONG_SPLIT
