@@ -720,6 +720,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         int visited = 0;
         float pre_sum = -1.0f;         // PRE: lane-partial fp16-form sum of a candidate that survived the pre-tier (else < 0)
+        bool audited = false;          // PRE: dropped by the pre-tier, walked by the fp32 form as a check of that decision
         if constexpr (PRE) {
             if (!pruned && groups > 0 && prune_above != nullptr) {
                 // half copies: [image][group][plane][256] halfs -- a group is 2 KB, a plane 512 B, a lane's four positions 8 B
@@ -728,7 +729,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 // true sum of the visited pairs >= (acc16 - abs x pairs visited) / (1 + rel): the exit test compares acc16 + rest with
                 // limit (1 + rel) + abs x (positions visited so far) -- the absolute part grows with the walk instead of being charged
                 // for the whole cell up front
-                const float limit_rel = limit * (1.0f + kPreRel);
+                const float pre_abs = kPreAbs * var.pre_band_scale;
+                const float limit_rel = limit * fmaf(kPreRel, var.pre_band_scale, 1.0f);
                 float acc16 = 0.0f;
                 bool out16 = false;
                 // the operands of the NEXT group are fetched while this one is computed: a group of the fp16 form is ~280 instructions
@@ -747,7 +749,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 for (int step = 0; step < groups; ++step) {
                     if (step != 0 && step % check_every == 0) {
                         const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), by_group ? step : (4 * step) >> lane_shift)) : 0.0f;
-                        if (wave_sum_exceeds(acc16, rest_j, fmaf(kPreAbs * (float)(4 * kWave), (float)step, limit_rel))) { out16 = true; break; }
+                        if (wave_sum_exceeds(acc16, rest_j, fmaf(pre_abs * (float)(4 * kWave), (float)step, limit_rel))) { out16 = true; break; }
                     }
 #if MM_PRE_PREFETCH
                     const int nxt = step + 1 < groups ? step + 1 : step;         // (the last step fetches its own group again: no branch)
@@ -765,9 +767,16 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     cur = ahead;
 #endif
                 }
-                if (!out16 && wave_sum_exceeds(acc16, 0.0f, fmaf(kPreAbs * (float)(4 * kWave), (float)groups, limit_rel))) out16 = true;
-                if (out16) pruned = true;       // (a survivor goes on to the fp32 form below)
-                else pre_sum = acc16;
+                if (!out16 && wave_sum_exceeds(acc16, 0.0f, fmaf(pre_abs * (float)(4 * kWave), (float)groups, limit_rel))) out16 = true;
+                // The audit: a candidate that leaves here is seen by neither the canary below (survivors only) nor the engine's band guard
+                // (fully scored candidates only), so one in `pre_audit` of them -- by a hash of (cell, candidate): the same ones every run --
+                // is walked by the fp32 form all the same; if THAT finds it below the limit the exit was wrong and the launch is voided
+                if (out16) {
+                    audited = var.pre_audit != 0u && ((((unsigned int)cell * 0x9E3779B1u) ^ ((unsigned int)l * 0x85EBCA77u)) >> 7 & (var.pre_audit - 1u)) == 0u;
+                    pruned = !audited;
+                } else {
+                    pre_sum = acc16;            // (a survivor goes on to the fp32 form below)
+                }
             }
         }
         float acc = 0.0f;          // terms with a proven error bound
@@ -850,6 +859,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const float sum16 = wave_sum_all(pre_sum);
                 if (lane == 0 && sum16 > fmaf(acc, 1.0f + kPreRel, kPreAbs * (float)(groups * 4 * kWave))) atomicAdd(edge_count, edge_cap + 1u);
             }
+            // (an audited candidate that walked all its groups and ended at or below the limit: the pre-tier dropped a possible contender)
+            if (audited && !pruned && lane == 0 && acc <= limit) atomicAdd(edge_count, edge_cap + 1u);
         }
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }

@@ -339,6 +339,49 @@ def test_discontinuity_log_overflow_falls_back_to_fp64(oracle, engine):
     assert tm["edge_pairs"] > 1_000_000 and tm["dense_cells"] == 9
 
 
+def test_pretier_audit_voids_a_launch_whose_fp16_exits_were_wrong(engine):
+    """A candidate the packed-fp16 pre-tier drops is seen by neither its canary (survivors only) nor the band guard (fully
+    scored candidates only), so one in `pre_audit` of them (512) is walked by the fp32 form all the same, and a launch in which
+    such a candidate ends at or below the limit is redone without the filter tiers.  Silent on an honest band -- with EVERY
+    dropped candidate audited (`pre_audit` = 1) -- and loud on a deliberately broken one (`dbg_pre_band_pct` = -3000: the limit
+    the fp16 walk tests against drops below the truth, contenders leave early): audited at 1 in 4 and 1 in 32 -- this job has
+    17 000 walked candidates of which 4 % are contenders, a benchmark-size launch 10^7 -- the launch is voided and the grid is the
+    reference one; with the audit off the same band returns wrong cells (the test has teeth)."""
+    t = Type.CIEDE2000
+    shape = cases.square_shape(64)
+    img, lib = cases.inputs(8 * 64, 8 * 64, 64, 600, t)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, img.shape[0], img.shape[1])[0]
+    cells = G.cell_records(group, state, img.shape[0], img.shape[1])
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    run = lambda: engine.generate(cells, state.shape[1], state.shape[0], int(t), 2, 300)
+    try:
+        engine.set_option("pretier", 0)
+        want, want_score = run()
+        engine.set_option("pretier", 1)
+        for every in (512, 1):
+            engine.set_option("pre_audit", every)
+            best, score = run()
+            tm = engine.timing()
+            assert tm["pretier"] == 1 and tm["dense_cells"] == 0 and tm["band_alarms"] == 0, tm
+            assert np.array_equal(best, want) and np.array_equal(score, want_score, equal_nan=True)
+        engine.set_option("dbg_pre_band_pct", -3000)
+        for every in (4, 32):
+            engine.set_option("pre_audit", every)
+            best, score = run()
+            tm = engine.timing()
+            print("broken fp16 band, audit 1 in %d: dense_cells %d edge_pairs %d" % (every, tm["dense_cells"], tm["edge_pairs"]))
+            assert tm["dense_cells"] == len(cells), tm                 # the launch was voided: every cell re-done fp64-only
+            assert np.array_equal(best, want) and np.array_equal(score, want_score, equal_nan=True)
+        engine.set_option("pre_audit", 0)
+        best, score = run()
+        wrong = int((best != want).sum())
+        print("broken fp16 band, audit off: %d of %d cells wrong" % (wrong, len(cells)))
+        assert wrong > 0
+    finally:
+        engine.set_option("pretier", -1); engine.set_option("pre_audit", 512); engine.set_option("dbg_pre_band_pct", 100)
+
+
 @pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIEDE2000])
 def test_too_many_contenders_fall_back_to_fp64(oracle, engine, t):
     """60 library images that differ from each other by less than the filter can resolve:
