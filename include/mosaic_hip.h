@@ -390,9 +390,10 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * whether it pays depends on the content (synthetic patches: yes; photographs: no); 0 never, 1 always; as with "item_auto" only the TIME of a call
  * depends on the engine's history): CIEDE2000 candidates first walk their pixel groups in
  * a packed-fp16 form (two pixel pairs per lane-instruction, operands half the size) that only takes early-exit decisions, against the limit
- * widened by its own measured band; survivors are scored by the fp32 form as before; "pre_audit" (512; a power of two, 0 = off): one in N
- * of the candidates the pre-tier drops is walked by the fp32 form all the same, and a launch in which such a candidate turns out to lie
- * at or below the limit is redone without the filter tiers (as when the pre-tier's canary trips);
+ * widened by its own measured band; survivors are scored by the fp32 form as before; "audit" (1024; a power of two, 0 = off): one in N
+ * of the CIEDE2000 candidates that leave the filter without a full score -- dropped by the bound, by the pre-tier's walk or by the fp32 walk's
+ * exit test -- is walked once more by the fp32 form WITHOUT the bound, and a launch in which such a candidate turns out to lie clearly below
+ * the limit is redone without the filter tiers (as when the pre-tier's canary trips);
  * "stage0" (1): one whole-image bound per candidate ahead of the block bound; "euclid_stage1" (1): the RGB / CIE76 filter
  * judges the block bound one candidate per lane before any wave is spent on a candidate; "item_chunk" (0 = 1): work items a persistent
  * filter workgroup takes per global atomic; "cell_order" (1): the CIEDE2000 filter takes each XCD share's clipped cells (long items) first; "tiny" (1): detail cells of <= 64 pixels take the one-wave-per-cell path;
@@ -403,7 +404,7 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "fast_path" (1): mm_generate enqueues a whole generate and reads ONE result block back (one host wait) whenever the
  * cells fit one batch, falling back to the step-by-step path when the block says a host decision was needed; "fused" (1):
  * cell gather + chroma + interleave + block statistics in one launch and contenders + fp64 re-score + re-rank in one.
- * diagnostics only: "band_pct" (100, a deliberately wrong band), "lds_pad_kb", "dbg_pre_band_pct" (100; the pre-tier's band in per cent, negative = drops contenders: what the audit is for), "dbg_pre_abs_1e4" / "dbg_pre_rel_1e6" (the band
+ * diagnostics only: "band_pct" (100, a deliberately wrong band), "lds_pad_kb", "dbg_pre_band_pct" (100; the pre-tier's band in per cent, negative = drops contenders) and "dbg_bound_pct" (100; the early exit's lower bound in per cent, above 100 = drops contenders): what the audit is for, "dbg_pre_abs_1e4" / "dbg_pre_rel_1e6" (the band
  * mm_debug_filter_band_sweep modes 2 / 3 measure the pre-tier's form against, in units of 1e-4 / 1e-6; 0: the pre-tier's own).  Results are identical whatever the
  * options (tests/test_gpu_fuzz.py::test_tuning_options_do_not_change_the_result). */
 mm_status mm_set_option(mm_engine *e, const char *name, int value);

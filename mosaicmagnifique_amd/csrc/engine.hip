@@ -67,8 +67,10 @@ struct mm_engine {
     DevBuf lib_h, cells_h;       // the interleaved copies as halfs (the filter's packed-fp16 pre-tier)
     bool lib_h_ready = false;    // lib_h holds the current library (prepare_planes builds it only where the pre-tier may run)
     float dbg_pre_abs = 0.0f, dbg_pre_rel = 0.0f;      // diagnostics: the band mm_debug_filter_band_sweep modes 2 / 3 measure against (0: the pre-tier's own)
-    int pre_audit = 512;         // mm_set_option("pre_audit", N): one in N (a power of two) of the candidates the pre-tier drops is checked by the fp32 form; 0: none
+    int audit = 1024;            // mm_set_option("audit", N): one in N (a power of two) of the CIEDE2000 candidates that leave the filter without a full score
+                                 // (bound, fp16 walk, fp32 walk) is walked again by the fp32 form without the bound; a wrong drop voids the launch; 0: none
     int pre_band_pct = 100;      // diagnostics ("dbg_pre_band_pct"): the pre-tier's band in per cent of the validated one (negative: drops contenders)
+    int bound_pct = 100;         // diagnostics ("dbg_bound_pct"): the early exit's lower bound in per cent (above 100: drops contenders)
     int pretier = -1;            // mm_set_option("pretier", 0 / 1): the packed-fp16 pre-tier ahead of the fp32 filter form never / always;
                                  // -1 = measured (PreAuto below) for jobs large enough to gain -- cells above 32 pixel groups (up to
                                  // 128 x 128, the reference GUI's default: config G 16.3 -> 14.4 ms per step) and calls of >= 1e10 pixel
@@ -484,8 +486,9 @@ mm::Variants variants_of(const mm_engine* e)
     v.n_blocks = stat_slots(ppad);
     v.cell_full = (const uint8_t*)e->cell_full.p;
     v.two_stage = e->two_level ? 1 : 0;     // (bit 1, stage 0, is set per batch once the cells' image statistics exist)
-    v.pre_audit = (unsigned int)e->pre_audit;
+    v.audit = (unsigned int)e->audit;
     v.pre_band_scale = 0.01f * (float)e->pre_band_pct;
+    v.bound_scale = 0.01f * (float)e->bound_pct;
     return v;
 }
 
@@ -2519,13 +2522,14 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "stage0") == 0) { e->stage0 = value != 0; return MM_OK; }
     if (strcmp(name, "dbg_pre_abs_1e4") == 0) { e->dbg_pre_abs = 1e-4f * (float)std::max(0, value); return MM_OK; }
     if (strcmp(name, "dbg_pre_rel_1e6") == 0) { e->dbg_pre_rel = 1e-6f * (float)std::max(0, value); return MM_OK; }
-    if (strcmp(name, "pre_audit") == 0) {
+    if (strcmp(name, "audit") == 0) {
         int n = std::max(0, std::min(value, 1 << 20));
         while (n & (n - 1)) n &= n - 1;             // the largest power of two not above it
-        e->pre_audit = n;
+        e->audit = n;
         return MM_OK;
     }
     if (strcmp(name, "dbg_pre_band_pct") == 0) { e->pre_band_pct = value; return MM_OK; }
+    if (strcmp(name, "dbg_bound_pct") == 0) { e->bound_pct = std::max(0, value); return MM_OK; }
     if (strcmp(name, "pretier") == 0) { e->pretier = value < 0 ? -1 : (value != 0); e->pre_auto = mm_engine::PreAuto{}; return MM_OK; }
     if (strcmp(name, "tiny") == 0) { e->tiny_path = value != 0; return MM_OK; }
     if (strcmp(name, "item_auto") == 0) { e->item_auto = value != 0; return MM_OK; }

@@ -250,6 +250,12 @@ constexpr int kCounterBase = 2;
 constexpr int kItemCounters = 32, kItemCounterStride = 32;
 constexpr int kCounterWords = kFilterCounterWords;        // words cleared per launch (edge count, work counters, item counters)
 
+// Whether candidate l of cell `cell` is one of the one-in-`every` (a power of two; 0: none) the filter audits (filter_kernel)
+__device__ __forceinline__ bool audit_pick(unsigned int every, int cell, int l)
+{
+    return every != 0u && (((((unsigned int)cell * 0x9E3779B1u) ^ ((unsigned int)l * 0x85EBCA77u)) >> 7) & (every - 1u)) == 0u;
+}
+
 // XCD this wave runs on (0..7): hwreg(HW_REG_XCC_ID, 0, 4).  Used for L2 affinity only.
 __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
 
@@ -458,7 +464,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             for (int t = threadIdx.x; t < 4 * groups; t += THREADS) {
                 for (int k = 0; k < 7; ++k)
                     cell_st[k][t] = var.cell_stats[(size_t)k * var.cell_stats_stride + (size_t)cell * var.n_blocks + t];
-                cell_st[7][t] = clipped ? var.cell_stats[(size_t)7 * var.cell_stats_stride + (size_t)cell * var.n_blocks + t] : 1.0f;
+                // (statistic 7, the factor of every block's bound, carries the diagnostics' scale of the bound: 1)
+                cell_st[7][t] = var.bound_scale * (clipped ? var.cell_stats[(size_t)7 * var.cell_stats_stride + (size_t)cell * var.n_blocks + t] : 1.0f);
             }
         }
     }
@@ -507,7 +514,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const float b0 = stats_bound(cell_ist[0], cell_ist[1], cell_ist[2], cell_ist[3], cell_ist[4], cell_ist[5], cell_ist[6],
                                              is[0], is[ss], is[2 * ss], is[3 * ss], is[4 * ss], is[5 * ss], is[6 * ss], 1.0f);
                 n_groups_all += (unsigned int)groups;
-                if (b0 > limit) {
+                if (b0 * var.bound_scale > limit && !audit_pick(var.audit, cell, l)) {      // (an audited candidate goes on to stage 2, which walks it without the bound)
                     scores[(size_t)cell * L + l] = __builtin_huge_valf();
                     n_bound_dropped += 1;
                     keep = false;
@@ -566,7 +573,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 }
             }
             if (g == 0 && valid && !seed) {
-                if (b > limit) {
+                if (b > limit && !audit_pick(var.audit, cell, l)) {
                     scores[(size_t)cell * L + l] = __builtin_huge_valf();
                     n_bound_dropped += 1;       // (per lane; summed over the wave's lanes at the end)
                 } else {
@@ -720,7 +727,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         int visited = 0;
         float pre_sum = -1.0f;         // PRE: lane-partial fp16-form sum of a candidate that survived the pre-tier (else < 0)
-        bool audited = false;          // PRE: dropped by the pre-tier, walked by the fp32 form as a check of that decision
+        bool out16 = false;            // PRE: dropped by the pre-tier
         if constexpr (PRE) {
             if (!pruned && groups > 0 && prune_above != nullptr) {
                 // half copies: [image][group][plane][256] halfs -- a group is 2 KB, a plane 512 B, a lane's four positions 8 B
@@ -732,7 +739,6 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const float pre_abs = kPreAbs * var.pre_band_scale;
                 const float limit_rel = limit * fmaf(kPreRel, var.pre_band_scale, 1.0f);
                 float acc16 = 0.0f;
-                bool out16 = false;
                 // the operands of the NEXT group are fetched while this one is computed: a group of the fp16 form is ~280 instructions
                 // (the fp32 one ~430) and its sixteen registers of operands leave room for a second set inside the kernel's 96
                 struct HalfGroup { uint2 p0, p1, p2, pc, q0, q1, q2, qc; };
@@ -768,26 +774,26 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
 #endif
                 }
                 if (!out16 && wave_sum_exceeds(acc16, 0.0f, fmaf(pre_abs * (float)(4 * kWave), (float)groups, limit_rel))) out16 = true;
-                // The audit: a candidate that leaves here is seen by neither the canary below (survivors only) nor the engine's band guard
-                // (fully scored candidates only), so one in `pre_audit` of them -- by a hash of (cell, candidate): the same ones every run --
-                // is walked by the fp32 form all the same; if THAT finds it below the limit the exit was wrong and the launch is voided
-                if (out16) {
-                    audited = var.pre_audit != 0u && ((((unsigned int)cell * 0x9E3779B1u) ^ ((unsigned int)l * 0x85EBCA77u)) >> 7 & (var.pre_audit - 1u)) == 0u;
-                    pruned = !audited;
-                } else {
-                    pre_sum = acc16;            // (a survivor goes on to the fp32 form below)
-                }
+                if (out16) pruned = true;       // (a survivor goes on to the fp32 form below)
+                else pre_sum = acc16;
             }
         }
         float acc = 0.0f;          // terms with a proven error bound
         float acc_edge = 0.0f;     // terms awaiting the fp64 patch
+        // The audit.  A candidate that leaves without a full score -- dropped by the bound (stages 0 and 1 let an audited one through to
+        // here), by the pre-tier's walk or by the walk below -- is seen by neither the pre-tier's canary (survivors only) nor the engine's
+        // band guard (fully scored candidates only).  So one in `var.audit` of the candidates (a hash of cell and candidate: the same ones
+        // every run) that were dropped is walked once more by the fp32 form WITHOUT the bound, where only its own partial sums can end
+        // the walk; if it completes clearly below the limit the drop was wrong, and the launch is voided like a tripped canary.
+        bool auditing = false;
+        for (;;) {
         if (!pruned && groups > 0) {
             // One 256-pixel group of the candidate against the cell; true = candidate dropped.
             auto visit = [&](const LibGroup& cur, int j, int step) -> bool {
                 if (step != 0 && step % check_every == 0) {
                     // bound of what is still unvisited: sorted, lane `step` of the scan over the visiting order; else group
                     // `step` starts at block 4 step = the first block of lane (4 step) >> lane_shift
-                    const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), by_group ? step : (4 * step) >> lane_shift)) : 0.0f;
+                    const float rest_j = use_lb && !auditing ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), by_group ? step : (4 * step) >> lane_shift)) : 0.0f;
                     if (wave_sum_exceeds(acc, rest_j, limit)) return true;
                 }
                 const int q = lane + kWave * j;
@@ -844,6 +850,9 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 if (visit(g, j, step)) { pruned = true; break; }
             }
         }
+        if (auditing || !pruned || groups <= 0 || !(use_lb || out16) || !audit_pick(var.audit, cell, l)) break;
+        auditing = true; pruned = false; acc = 0.0f; acc_edge = 0.0f;
+        }
         if (lane == 0) {                        // the counters are per lane (stage 1 counts on the candidates' first lanes)
             n_visited += (unsigned int)visited;
             if (!two_level && !(BIG && stage0)) n_groups_all += (unsigned int)groups;      // (stage 0 counted its candidates itself)
@@ -859,8 +868,12 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const float sum16 = wave_sum_all(pre_sum);
                 if (lane == 0 && sum16 > fmaf(acc, 1.0f + kPreRel, kPreAbs * (float)(groups * 4 * kWave))) atomicAdd(edge_count, edge_cap + 1u);
             }
-            // (an audited candidate that walked all its groups and ended at or below the limit: the pre-tier dropped a possible contender)
-            if (audited && !pruned && lane == 0 && acc <= limit) atomicAdd(edge_count, edge_cap + 1u);
+        }
+        if (auditing) {
+            // (clearly: ten times the fp32 form's own error on a cell's sum away from the limit -- a bound that sits within rounding of the
+            // limit must not void launches)
+            if (!pruned && lane == 0 && acc <= limit * (1.0f - 1e-3f)) atomicAdd(edge_count, edge_cap + 1u);
+            pruned = true;                      // the candidate stays dropped whatever the audit found
         }
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }

@@ -35,9 +35,11 @@ struct Variants {
                                 // clipped cells, whose weaker bound makes their items several times as long, come first); null: 0, 1, 2 ..
     int two_stage;              // bit 0: the bound is evaluated several candidates per wave pass ahead of the pixel loops (filter_kernel
                                 // stage 1); bit 1: the whole-image bound ahead of that (stage 0; needs the image slots filled)
-    unsigned int pre_audit;     // filter_kernel<.., PRE>: N = 2^k > 0 -- one in N of the candidates the packed-fp16 pre-tier drops is walked by the
-                                // fp32 form all the same, and a launch in which such a candidate turns out to be below the limit is voided; 0: none
+    unsigned int audit;         // filter_kernel (CIEDE2000): N = 2^k > 0 -- one in N of the candidates that leave without a full score (dropped by the
+                                // bound, by the packed-fp16 pre-tier's walk or by the fp32 walk) is walked once more by the fp32 form without the
+                                // bound, and a launch in which such a candidate turns out to lie clearly below the limit is voided; 0: none
     float pre_band_scale;       // 1; diagnostics: the pre-tier's band times this (negative: a band that drops true contenders -- what the audit is for)
+    float bound_scale;          // 1; diagnostics: the early exit's lower bound times this (above 1: a bound that drops true contenders)
 };
 
 // Device inputs of the fp32 filter kernels.

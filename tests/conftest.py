@@ -49,7 +49,7 @@ def _suite_engine_options():
         orig(self, device)
         self.set_option("phase_timing", 1)
         self.set_option("prune_min_kpairs", 0)
-        # soak runs: MOSAIC_TEST_OPTS="pretier=1,pre_audit=1" puts every engine of the session on a non-default path
+        # soak runs: MOSAIC_TEST_OPTS="pretier=1,audit=1" puts every engine of the session on a non-default path
         for kv in filter(None, os.environ.get("MOSAIC_TEST_OPTS", "").split(",")):
             name, value = kv.split("=")
             self.set_option(name.strip(), int(value))

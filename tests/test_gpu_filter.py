@@ -339,14 +339,19 @@ def test_discontinuity_log_overflow_falls_back_to_fp64(oracle, engine):
     assert tm["edge_pairs"] > 1_000_000 and tm["dense_cells"] == 9
 
 
-def test_pretier_audit_voids_a_launch_whose_fp16_exits_were_wrong(engine):
-    """A candidate the packed-fp16 pre-tier drops is seen by neither its canary (survivors only) nor the band guard (fully
-    scored candidates only), so one in `pre_audit` of them (512) is walked by the fp32 form all the same, and a launch in which
-    such a candidate ends at or below the limit is redone without the filter tiers.  Silent on an honest band -- with EVERY
-    dropped candidate audited (`pre_audit` = 1) -- and loud on a deliberately broken one (`dbg_pre_band_pct` = -3000: the limit
-    the fp16 walk tests against drops below the truth, contenders leave early): audited at 1 in 4 and 1 in 32 -- this job has
-    17 000 walked candidates of which 4 % are contenders, a benchmark-size launch 10^7 -- the launch is voided and the grid is the
-    reference one; with the audit off the same band returns wrong cells (the test has teeth)."""
+@pytest.mark.parametrize("broken", ["fp16 band", "bound"])
+def test_audit_voids_a_launch_that_dropped_a_contender(engine, broken):
+    """A candidate that leaves the CIEDE2000 filter without a full score -- dropped by the bound's stages 0 / 1, by the
+    packed-fp16 pre-tier's walk or by the fp32 walk's exit test -- is seen by neither the pre-tier's canary (survivors only) nor
+    the band guard (fully scored candidates only).  So one in `audit` of them (1024; a hash of cell and candidate) is walked once
+    more by the fp32 form WITHOUT the bound, and a launch in which such a candidate ends clearly below the limit is redone
+    without the filter tiers.  Silent on the honest kernel with EVERY dropped candidate audited (`audit` = 1); loud on a
+    deliberately broken pre-tier band (`dbg_pre_band_pct` = -3000: the limit the fp16 walk tests against drops below the
+    truth) and on a deliberately broken bound (`dbg_bound_pct` = 300: the lower bound is no lower bound any more): audited at 1
+    in 2 and 1 in 8 -- this job has 38 000 candidates of which some 50 lie below the limit without being seeds (at 1 in 32 one
+    or none of them is drawn); a benchmark-size launch has 2 x 10^7 candidates -- the
+    launch is voided and the grid is the reference one; with the audit off the same kernel returns wrong cells (the test has
+    teeth)."""
     t = Type.CIEDE2000
     shape = cases.square_shape(64)
     img, lib = cases.inputs(8 * 64, 8 * 64, 64, 600, t)
@@ -355,31 +360,32 @@ def test_pretier_audit_voids_a_launch_whose_fp16_exits_were_wrong(engine):
     cells = G.cell_records(group, state, img.shape[0], img.shape[1])
     engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
     run = lambda: engine.generate(cells, state.shape[1], state.shape[0], int(t), 2, 300)
+    knob, value = ("dbg_pre_band_pct", -3000) if broken == "fp16 band" else ("dbg_bound_pct", 300)
     try:
-        engine.set_option("pretier", 0)
+        engine.set_option("pretier", 0); engine.set_option("prune", 0)
         want, want_score = run()
-        engine.set_option("pretier", 1)
-        for every in (512, 1):
-            engine.set_option("pre_audit", every)
+        engine.set_option("prune", 1); engine.set_option("pretier", 1 if broken == "fp16 band" else 0)
+        for every in (1024, 1):
+            engine.set_option("audit", every)
             best, score = run()
             tm = engine.timing()
-            assert tm["pretier"] == 1 and tm["dense_cells"] == 0 and tm["band_alarms"] == 0, tm
+            assert tm["dense_cells"] == 0 and tm["band_alarms"] == 0 and tm["visited_groups"] > 0, tm
             assert np.array_equal(best, want) and np.array_equal(score, want_score, equal_nan=True)
-        engine.set_option("dbg_pre_band_pct", -3000)
-        for every in (4, 32):
-            engine.set_option("pre_audit", every)
+        engine.set_option(knob, value)
+        for every in (2, 8):
+            engine.set_option("audit", every)
             best, score = run()
             tm = engine.timing()
-            print("broken fp16 band, audit 1 in %d: dense_cells %d edge_pairs %d" % (every, tm["dense_cells"], tm["edge_pairs"]))
+            print("broken %s, audit 1 in %d: dense_cells %d edge_pairs %d" % (broken, every, tm["dense_cells"], tm["edge_pairs"]))
             assert tm["dense_cells"] == len(cells), tm                 # the launch was voided: every cell re-done fp64-only
             assert np.array_equal(best, want) and np.array_equal(score, want_score, equal_nan=True)
-        engine.set_option("pre_audit", 0)
+        engine.set_option("audit", 0)
         best, score = run()
         wrong = int((best != want).sum())
-        print("broken fp16 band, audit off: %d of %d cells wrong" % (wrong, len(cells)))
+        print("broken %s, audit off: %d of %d cells wrong" % (broken, wrong, len(cells)))
         assert wrong > 0
     finally:
-        engine.set_option("pretier", -1); engine.set_option("pre_audit", 512); engine.set_option("dbg_pre_band_pct", 100)
+        engine.set_option("pretier", -1); engine.set_option("audit", 1024); engine.set_option(knob, 100); engine.set_option("prune", 1)
 
 
 @pytest.mark.parametrize("t", [Type.RGB_EUCLIDEAN, Type.CIEDE2000])

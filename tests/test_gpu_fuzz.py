@@ -159,8 +159,9 @@ OPTION_SETS = [
     {"pretier": 1},                                 # the packed-fp16 pre-tier ahead of the fp32 filter form (default: large jobs and cells above 32 groups)
     {"pretier": 0},
     {"pretier": 1, "tile": 64},
-    {"pretier": 1, "pre_audit": 1},                 # ... with every candidate it drops checked by the fp32 form (default: one in 512)
-    {"pretier": 1, "pre_audit": 0},
+    {"pretier": 1, "audit": 1},                     # ... with EVERY candidate that leaves without a full score walked again without the bound (default: one in 1024)
+    {"audit": 1},
+    {"pretier": 1, "audit": 0},
     {"spec_auto": 0, "spec_k": 3},                  # the short-list length pinned
     {"cell_order": 0},                              # the cells of an XCD's share in their given order (default: clipped cells first)
     {"cell_order": 0, "xcd_cells": 16, "tile": 16}, # ... with small sub-groups
@@ -190,7 +191,7 @@ def test_tuning_options_do_not_change_the_result(oracle, engine, opts):
     defaults = {"interleave": 1, "xcd_aware": 1, "tile": 0, "xcd_cells": 0, "two_level": 1, "sort_groups": -1,
                 "lds_filter": -1, "seeds": -1, "spec_k": 4, "fused": 1, "fast_path": 1, "item_auto": 1,
                 "fused_seeds": 2048, "prune_min_kpairs": 0, "phase_timing": 1, "stage0": 1, "euclid_stage1": 1, "cell_order": 1,
-                "pretier": -1, "spec_auto": 1, "pre_audit": 512}
+                "pretier": -1, "spec_auto": 1, "audit": 1024}
     try:
         for name, value in opts.items():
             engine.set_option(name, value)
