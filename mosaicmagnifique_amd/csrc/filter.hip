@@ -250,7 +250,7 @@ constexpr int kCounterBase = 2;
 constexpr int kItemCounters = 32, kItemCounterStride = 32;
 constexpr int kCounterWords = kFilterCounterWords;        // words cleared per launch (edge count, work counters, item counters)
 
-// Whether candidate l of cell `cell` is one of the one-in-`every` (a power of two; 0: none) the filter audits (filter_kernel)
+// Whether candidate l of cell `cell` is one of the one-in-`every` (a power of two; 0: none) that audit_kernel checks
 __device__ __forceinline__ bool audit_pick(unsigned int every, int cell, int l)
 {
     return every != 0u && (((((unsigned int)cell * 0x9E3779B1u) ^ ((unsigned int)l * 0x85EBCA77u)) >> 7) & (every - 1u)) == 0u;
@@ -514,7 +514,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const float b0 = stats_bound(cell_ist[0], cell_ist[1], cell_ist[2], cell_ist[3], cell_ist[4], cell_ist[5], cell_ist[6],
                                              is[0], is[ss], is[2 * ss], is[3 * ss], is[4 * ss], is[5 * ss], is[6 * ss], 1.0f);
                 n_groups_all += (unsigned int)groups;
-                if (b0 * var.bound_scale > limit && !audit_pick(var.audit, cell, l)) {      // (an audited candidate goes on to stage 2, which walks it without the bound)
+                if (b0 * var.bound_scale > limit) {
                     scores[(size_t)cell * L + l] = __builtin_huge_valf();
                     n_bound_dropped += 1;
                     keep = false;
@@ -573,7 +573,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 }
             }
             if (g == 0 && valid && !seed) {
-                if (b > limit && !audit_pick(var.audit, cell, l)) {
+                if (b > limit) {
                     scores[(size_t)cell * L + l] = __builtin_huge_valf();
                     n_bound_dropped += 1;       // (per lane; summed over the wave's lanes at the end)
                 } else {
@@ -727,7 +727,6 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         int visited = 0;
         float pre_sum = -1.0f;         // PRE: lane-partial fp16-form sum of a candidate that survived the pre-tier (else < 0)
-        bool out16 = false;            // PRE: dropped by the pre-tier
         if constexpr (PRE) {
             if (!pruned && groups > 0 && prune_above != nullptr) {
                 // half copies: [image][group][plane][256] halfs -- a group is 2 KB, a plane 512 B, a lane's four positions 8 B
@@ -739,6 +738,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const float pre_abs = kPreAbs * var.pre_band_scale;
                 const float limit_rel = limit * fmaf(kPreRel, var.pre_band_scale, 1.0f);
                 float acc16 = 0.0f;
+                bool out16 = false;
                 // the operands of the NEXT group are fetched while this one is computed: a group of the fp16 form is ~280 instructions
                 // (the fp32 one ~430) and its sixteen registers of operands leave room for a second set inside the kernel's 96
                 struct HalfGroup { uint2 p0, p1, p2, pc, q0, q1, q2, qc; };
@@ -780,20 +780,13 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         float acc = 0.0f;          // terms with a proven error bound
         float acc_edge = 0.0f;     // terms awaiting the fp64 patch
-        // The audit.  A candidate that leaves without a full score -- dropped by the bound (stages 0 and 1 let an audited one through to
-        // here), by the pre-tier's walk or by the walk below -- is seen by neither the pre-tier's canary (survivors only) nor the engine's
-        // band guard (fully scored candidates only).  So one in `var.audit` of the candidates (a hash of cell and candidate: the same ones
-        // every run) that were dropped is walked once more by the fp32 form WITHOUT the bound, where only its own partial sums can end
-        // the walk; if it completes clearly below the limit the drop was wrong, and the launch is voided like a tripped canary.
-        bool auditing = false;
-        for (;;) {
         if (!pruned && groups > 0) {
             // One 256-pixel group of the candidate against the cell; true = candidate dropped.
             auto visit = [&](const LibGroup& cur, int j, int step) -> bool {
                 if (step != 0 && step % check_every == 0) {
                     // bound of what is still unvisited: sorted, lane `step` of the scan over the visiting order; else group
                     // `step` starts at block 4 step = the first block of lane (4 step) >> lane_shift
-                    const float rest_j = use_lb && !auditing ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), by_group ? step : (4 * step) >> lane_shift)) : 0.0f;
+                    const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), by_group ? step : (4 * step) >> lane_shift)) : 0.0f;
                     if (wave_sum_exceeds(acc, rest_j, limit)) return true;
                 }
                 const int q = lane + kWave * j;
@@ -850,9 +843,6 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 if (visit(g, j, step)) { pruned = true; break; }
             }
         }
-        if (auditing || !pruned || groups <= 0 || !(use_lb || out16) || !audit_pick(var.audit, cell, l)) break;
-        auditing = true; pruned = false; acc = 0.0f; acc_edge = 0.0f;
-        }
         if (lane == 0) {                        // the counters are per lane (stage 1 counts on the candidates' first lanes)
             n_visited += (unsigned int)visited;
             if (!two_level && !(BIG && stage0)) n_groups_all += (unsigned int)groups;      // (stage 0 counted its candidates itself)
@@ -868,12 +858,6 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 const float sum16 = wave_sum_all(pre_sum);
                 if (lane == 0 && sum16 > fmaf(acc, 1.0f + kPreRel, kPreAbs * (float)(groups * 4 * kWave))) atomicAdd(edge_count, edge_cap + 1u);
             }
-        }
-        if (auditing) {
-            // (clearly: ten times the fp32 form's own error on a cell's sum away from the limit -- a bound that sits within rounding of the
-            // limit must not void launches)
-            if (!pruned && lane == 0 && acc <= limit * (1.0f - 1e-3f)) atomicAdd(edge_count, edge_cap + 1u);
-            pruned = true;                      // the candidate stays dropped whatever the audit found
         }
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }
@@ -1742,6 +1726,72 @@ edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ cell_
     }
 }
 
+// The audit.  A candidate that leaves filter_kernel without a full score -- dropped by the bound's stage 0 or 1, by the packed-fp16
+// pre-tier's walk or by the fp32 walk's exit test: +inf in its score row -- is seen by neither the pre-tier's canary (survivors only)
+// nor the engine's band guard (fully scored candidates only).  So one in `var.audit` of all (cell, candidate) slots -- a hash: the
+// same ones every run -- that hold +inf is walked once more here, by the fp32 form on the interleaved copies WITHOUT any bound:
+// only its own partial sums, every term >= 0, can end the walk.  Pairs on the opposite-hue discontinuity take the fp64 form on the
+// spot (the candidates the bound drops first are the ones of opposite hue).  A walk that completes CLEARLY below the limit -- by
+// 1e-3 of it: ten times the fp32 form's own error on a cell's sum; a bound within rounding of the limit must not void launches --
+// means the drop was wrong, and the launch is voided like a tripped canary (the discontinuity log pushed past its capacity: the
+// engine redoes the batch without the filter tiers).  A kernel of its own, after the filter: inside filter_kernel the same check
+// cost every candidate (spills: config D +0.75 % with the audit switched off), here only the audited ones.
+// One wave per run of 64 slots: a hash test and a score read per lane, then the wave walks the run's audited slots one by one.
+__global__ void __launch_bounds__(kBlock)
+audit_kernel(const float* __restrict__ cells_il, const float* __restrict__ lib_il, const float* __restrict__ scores,
+             int n_cells, int L, int ppad, const float* __restrict__ prune_above, const HueEntry* __restrict__ hue_lut,
+             Variants var, unsigned int* __restrict__ edge_count, unsigned int edge_cap)
+{
+    __shared__ HueEntry lut[kHueLutEntries];
+    load_hue_lut(lut, hue_lut);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long total = (long long)n_cells * L;
+    const long long n_runs = (total + kWave - 1) / kWave;
+    for (long long run = (long long)blockIdx.x * (kBlock / kWave) + wave; run < n_runs; run += (long long)gridDim.x * (kBlock / kWave)) {
+        const long long slot = run * kWave + lane;
+        int cell = 0, l = 0;
+        bool todo = false;
+        if (slot < total) {
+            cell = (int)(slot / L);
+            l = (int)(slot - (long long)cell * L);
+            todo = audit_pick(var.audit, cell, l) && scores[slot] == __builtin_huge_valf();
+        }
+        unsigned long long todo_lanes = __builtin_amdgcn_ballot_w64(todo);
+        while (todo_lanes != 0ull) {
+            const int src = __builtin_ctzll(todo_lanes);
+            todo_lanes &= todo_lanes - 1ull;
+            const int c = __builtin_amdgcn_readlane(cell, src), cand = __builtin_amdgcn_readlane(l, src);
+            const float limit = prune_above[c];
+            const int v = var.cell_var[c];
+            const int groups = var.groups[v];
+            const float4* cb = reinterpret_cast<const float4*>(cells_il + (size_t)c * 4 * ppad);
+            const float4* lb = reinterpret_cast<const float4*>(lib_il + (size_t)v * var.chroma_stride * 4 + (size_t)cand * 4 * ppad);
+            float acc = 0.0f;
+            bool over = false;
+            for (int j = 0; j < groups; ++j) {
+                if (j != 0 && wave_sum_exceeds(acc, 0.0f, limit)) { over = true; break; }
+                const int at = 4 * kWave * j + lane;
+                const float4 p0 = cb[at], p1 = cb[at + kWave], p2 = cb[at + 2 * kWave], pc = cb[at + 3 * kWave];
+                const float4 q0 = lb[at], q1 = lb[at + kWave], q2 = lb[at + 2 * kWave], qc = lb[at + 3 * kWave];
+                auto term = [&](float a0, float a1, float a2, float ac, float b0, float b1, float b2, float bc) {
+                    bool edge;
+                    float t = pair_fast<CIEDE2000, true>(PxF{a0, a1, a2}, PxF{b0, b1, b2}, ac, bc, lut, &edge);
+                    // (operands are prepared: channel 0 is L / 2 - 25; an inactive pixel is a NaN there and comes out as 0, never as an edge)
+                    if (edge && a0 == a0)
+                        t = (float)ciede2000(Px{2.0f * (a0 + 25.0f), a1, a2}, Px{2.0f * (b0 + 25.0f), b1, b2});
+                    return t;
+                };
+                acc += (term(p0.x, p1.x, p2.x, pc.x, q0.x, q1.x, q2.x, qc.x) + term(p0.y, p1.y, p2.y, pc.y, q0.y, q1.y, q2.y, qc.y))
+                     + (term(p0.z, p1.z, p2.z, pc.z, q0.z, q1.z, q2.z, qc.z) + term(p0.w, p1.w, p2.w, pc.w, q0.w, q1.w, q2.w, qc.w));
+            }
+            if (!over) {
+                const float sum = wave_sum_all(acc);
+                if (lane == 0 && sum <= limit * (1.0f - 1e-3f)) atomicAdd(edge_count, edge_cap + 1u);
+            }
+        }
+    }
+}
+
 template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
 pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ second,
@@ -1918,6 +1968,17 @@ cell_order_kernel(const uint8_t* __restrict__ cell_full, int n_cells, int shares
     }
 }
 
+// audit_kernel after a CIEDE2000 filter launch over interleaved copies (the launch's own Variants: its `audit` says how many)
+static hipError_t launch_audit(const FilterInputs& in, const Variants& var, const float* scores, int n_cells, int L, int ppad,
+                               const float* prune_above, unsigned int* edge_count, unsigned int edge_cap, hipStream_t stream)
+{
+    if (in.lib_il == nullptr || in.cells_il == nullptr || prune_above == nullptr || var.audit == 0u) return hipSuccess;
+    const long long runs = ((long long)n_cells * L + kWave - 1) / kWave;
+    audit_kernel<<<dim3((unsigned)std::min<long long>((runs + 3) / 4, 2048)), kBlock, 0, stream>>>(
+        in.cells_il, in.lib_il, scores, n_cells, L, ppad, prune_above, in.hue_lut, var, edge_count, edge_cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream, int* tile_used)
@@ -1994,6 +2055,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             in.cells, il ? in.cells_il : in.cells_f0, in.cell_chroma, il ? in.lib_il : in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, sub,
             edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares, in.seeds, in.seeds ? in.n_seeds : 0, sort_groups, 1);
         if ((code = hipGetLastError()) != hipSuccess) return code;
+        if (il && (code = launch_audit(in, in.var, scores, n_cells, L, ppad, prune_above, edge_count, edge_cap, stream)) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var, il ? 1 : 0);
         return hipGetLastError();
@@ -2091,6 +2153,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, var, xcd_shares,
             in.seeds, in.seeds ? in.n_seeds : 0, sort_groups, item_chunk);
         if ((code = hipGetLastError()) != hipSuccess) return code;
+        if (il && (code = launch_audit(in, var, scores, n_cells, L, ppad, prune_above, edge_count, edge_cap, stream)) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var, il ? 1 : 0);
     } else {
