@@ -732,7 +732,7 @@ def main():
             launches += r.score_launches
         tm_phase = engine.timing()
         engine.set_option("phase_timing", -1)
-        tm.update({k: tm_phase[k] for k in ("stage_ms", "seed_ms", "score_ms", "rescore_ms", "select_ms", "resolve_ms")})
+        tm.update({k: tm_phase[k] for k in ("stage_ms", "seed_ms", "score_ms", "audit_ms", "rescore_ms", "select_ms", "resolve_ms")})
         launches_scale = args.steps / 3.0
     else:
         launches_scale = 1.0

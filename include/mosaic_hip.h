@@ -109,6 +109,7 @@ typedef struct mm_timing {
                                * error band was validated on -- Lab: channel 0 in [-0.5, 100.5], chroma <= 150; RGB / CIE76:
                                * |channel| <= 256; or hold a non-finite value -- so the call ran fp64-only (same result) */
     int64_t pretier;          /* 1: the last CIEDE2000 filter launch ran with the packed-fp16 pre-tier (option "pretier") */
+    double audit_ms;          /* the audit of the candidates the CIEDE2000 filter dropped (option "audit"), between the filter and the selection */
 } mm_timing;
 
 /* What a FIRST call pays besides the hot path, as host wall clocks accumulated since mm_create: the reference builds

@@ -32,7 +32,7 @@ class MMTiming(ctypes.Structure):
                 ("total_groups", ctypes.c_int64), ("bound_dropped", ctypes.c_int64),
                 ("band_alarms", ctypes.c_int64), ("filter_tile", ctypes.c_int64),
                 ("host_syncs", ctypes.c_int64), ("fast_path", ctypes.c_int64),
-                ("preprocess_ms", ctypes.c_double), ("filter_off_range", ctypes.c_int64), ("pretier", ctypes.c_int64)]
+                ("preprocess_ms", ctypes.c_double), ("filter_off_range", ctypes.c_int64), ("pretier", ctypes.c_int64), ("audit_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

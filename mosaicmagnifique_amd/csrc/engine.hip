@@ -42,7 +42,7 @@ struct DevBuf {
 struct mm_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[14] = {};      // [12], [13]: around the filter launch of a pre-tier trial (below)
+    hipEvent_t ev[15] = {};      // [12], [13]: around the filter launch of a pre-tier trial (below); [14]: after the filter's audit
     std::string err;
 
     // staged inputs
@@ -657,7 +657,8 @@ void account_score_batch(mm_engine* e, bool two_tier, bool prune, int diff_type,
         e->timing.stage_ms += elapsed(e->ev[0], e->ev[1]);
         e->timing.seed_ms += elapsed(e->ev[1], e->ev[4]);
         e->timing.score_ms += elapsed(e->ev[4], e->ev[2]);
-        e->timing.select_ms += elapsed(e->ev[2], e->ev[3]) + elapsed(e->ev[8], e->ev[9]);
+        e->timing.audit_ms += elapsed(e->ev[2], e->ev[14]);
+        e->timing.select_ms += elapsed(e->ev[14], e->ev[3]) + elapsed(e->ev[8], e->ev[9]);
         e->timing.rescore_ms += elapsed(e->ev[3], e->ev[8]);
     }
     e->timing.score_launches += 1;
@@ -968,6 +969,11 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         e->timing.filter_tile = tile_used;
         if (pre_trial) HIP_TRY(e, hipEventRecord(e->ev[13], e->stream), "event");
         if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
+        // the audit of what the filter dropped: reads the score rows, may void the launch through the edge counter
+        HIP_TRY(e, mm::launch_filter_audit(ftype, fin, (const float*)e->scores.p, b, L, ppad, prune ? (const float*)e->limits.p : nullptr,
+                                           counters_dev, edge_cap, e->stream),
+                "Error during filter audit kernel");
+        if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[14], e->stream), "event");
 
         if (fused_rank) {
             // contenders, their fp64 reference-form scores and the K lowest of them in one launch
@@ -1404,7 +1410,7 @@ void move_resources(mm_engine* to, mm_engine* from)
     to->pinned = from->pinned; to->pinned_bytes = from->pinned_bytes;
     from->pinned = nullptr; from->pinned_bytes = 0;
     to->stream = from->stream; from->stream = nullptr;
-    for (int i = 0; i < 14; ++i) { to->ev[i] = from->ev[i]; from->ev[i] = nullptr; }
+    for (int i = 0; i < 15; ++i) { to->ev[i] = from->ev[i]; from->ev[i] = nullptr; }
 }
 
 // mm_destroy: true if the engine's resources were parked (the caller deletes the shell).
@@ -1490,7 +1496,7 @@ mm_status mm_create(int device, mm_engine** out)
         e->stage_clock.reused_engine = 1;
     } else {
         if (code == hipSuccess) code = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-        for (int i = 0; code == hipSuccess && i < 14; ++i) code = hipEventCreate(&e->ev[i]);
+        for (int i = 0; code == hipSuccess && i < 15; ++i) code = hipEventCreate(&e->ev[i]);
     }
     if (code != hipSuccess) {
         mm_status st = hip_fail(nullptr, code, "Failed to initialise device", __FILE__, __LINE__);

@@ -1968,14 +1968,15 @@ cell_order_kernel(const uint8_t* __restrict__ cell_full, int n_cells, int shares
     }
 }
 
-// audit_kernel after a CIEDE2000 filter launch over interleaved copies (the launch's own Variants: its `audit` says how many)
-static hipError_t launch_audit(const FilterInputs& in, const Variants& var, const float* scores, int n_cells, int L, int ppad,
+// audit_kernel after a CIEDE2000 filter launch over interleaved copies (in.var.audit says how many; a launch of its own so
+// that the engine can clock it apart from the filter)
+hipError_t launch_filter_audit(int type, const FilterInputs& in, const float* scores, int n_cells, int L, int ppad,
                                const float* prune_above, unsigned int* edge_count, unsigned int edge_cap, hipStream_t stream)
 {
-    if (in.lib_il == nullptr || in.cells_il == nullptr || prune_above == nullptr || var.audit == 0u) return hipSuccess;
+    if (type != CIEDE2000 || in.lib_il == nullptr || in.cells_il == nullptr || prune_above == nullptr || in.var.audit == 0u) return hipSuccess;
     const long long runs = ((long long)n_cells * L + kWave - 1) / kWave;
     audit_kernel<<<dim3((unsigned)std::min<long long>((runs + 3) / 4, 2048)), kBlock, 0, stream>>>(
-        in.cells_il, in.lib_il, scores, n_cells, L, ppad, prune_above, in.hue_lut, var, edge_count, edge_cap);
+        in.cells_il, in.lib_il, scores, n_cells, L, ppad, prune_above, in.hue_lut, in.var, edge_count, edge_cap);
     return hipGetLastError();
 }
 
@@ -2055,7 +2056,6 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             in.cells, il ? in.cells_il : in.cells_f0, in.cell_chroma, il ? in.lib_il : in.lib, in.lib_chroma, scores, n_cells, L, ppad, cpb, sub,
             edges, edge_count, edge_cap, prune_above, 1, in.hue_lut, in.var, shares, in.seeds, in.seeds ? in.n_seeds : 0, sort_groups, 1);
         if ((code = hipGetLastError()) != hipSuccess) return code;
-        if (il && (code = launch_audit(in, in.var, scores, n_cells, L, ppad, prune_above, edge_count, edge_cap, stream)) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var, il ? 1 : 0);
         return hipGetLastError();
@@ -2153,7 +2153,6 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, var, xcd_shares,
             in.seeds, in.seeds ? in.n_seeds : 0, sort_groups, item_chunk);
         if ((code = hipGetLastError()) != hipSuccess) return code;
-        if (il && (code = launch_audit(in, var, scores, n_cells, L, ppad, prune_above, edge_count, edge_cap, stream)) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var, il ? 1 : 0);
     } else {

@@ -650,7 +650,7 @@ std::vector<std::pair<std::string, double>> HIPPhotomosaicGenerator::timingLog()
     mm_stage_timing st{};
     mm_get_stage_timing(m_engine, &st);
     return {{"generateBestFits", t.total_ms}, {"Preprocess", st.preprocess_ms}, {"cudaMalloc", st.alloc_ms + st.pinned_ms},
-            {"cudaMemcpy", t.stage_ms}, {"DiffReduce", t.seed_ms + t.score_ms + t.rescore_ms}, {"Flatten", t.select_ms},
+            {"cudaMemcpy", t.stage_ms}, {"DiffReduce", t.seed_ms + t.score_ms + t.audit_ms + t.rescore_ms}, {"Flatten", t.select_ms},
             {"Repeats+FindLowest", t.resolve_ms}};
 }
 

@@ -321,9 +321,9 @@ class HIPPhotomosaicGenerator:
         are finer and differently cut (mm_timing); this is the coarse view a maintainer comparing logs wants:
         cudaMalloc = device allocations since the engine was made, Preprocess = the u8 -> f32 / Lab kernels,
         cudaMemcpy = cell records to the device + the cell gather (the reference uploads every cell, :176-229),
-        DiffReduce = seeds + filter + fp64 re-score (the reference's difference and reduction kernels, :231-259),
+        DiffReduce = seeds + filter + its audit + fp64 re-score (the reference's difference and reduction kernels, :231-259),
         Flatten = candidate selection (:262-268), Repeats + FindLowest = the resolve (:271-292)."""
         t, st = self.m_engine.timing(), self.m_engine.stage_timing()
         return {"generateBestFits": t["total_ms"], "Preprocess": st["preprocess_ms"], "cudaMalloc": st["alloc_ms"] + st["pinned_ms"],
-                "cudaMemcpy": t["stage_ms"], "DiffReduce": t["seed_ms"] + t["score_ms"] + t["rescore_ms"],
+                "cudaMemcpy": t["stage_ms"], "DiffReduce": t["seed_ms"] + t["score_ms"] + t["audit_ms"] + t["rescore_ms"],
                 "Flatten": t["select_ms"], "Repeats+FindLowest": t["resolve_ms"]}

@@ -61,7 +61,7 @@ def test_struct_layouts_match_the_header():
     from mosaicmagnifique_amd.grid import CELL_DTYPE
     assert ctypes.sizeof(_lib.MMCell) == 36 == CELL_DTYPE.itemsize
     assert [n for n, _ in _lib.MMCell._fields_] == list(CELL_DTYPE.names)
-    assert ctypes.sizeof(_lib.MMTiming) == 216
+    assert ctypes.sizeof(_lib.MMTiming) == 224
     assert ctypes.sizeof(_lib.MMStageTiming) == 72          # six clocks (f64) + three counters (i64)
 
 

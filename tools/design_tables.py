@@ -63,7 +63,7 @@ def main():
     d = load(tag, "D")
     if d:
         t = d["last_step_device_ms"]
-        print("config D step:", {k: t[k] for k in ("stage_ms", "seed_ms", "score_ms", "rescore_ms", "select_ms", "resolve_ms", "total_ms", "resolve_sweeps", "host_syncs")})
+        print("config D step:", {k: t[k] for k in ("stage_ms", "seed_ms", "score_ms", "audit_ms", "rescore_ms", "select_ms", "resolve_ms", "total_ms", "resolve_sweeps", "host_syncs")})
         print("cpu:", d["cpu_baseline"], d["speedup_vs_cpu"], d["cpu_baseline_all_cores"], d["speedup_vs_cpu_all_cores"])
         print("stream:", d["roofline"].get("hbm_stream_read_measured_gbs"))
 
