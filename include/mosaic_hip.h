@@ -394,7 +394,8 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * widened by its own measured band; survivors are scored by the fp32 form as before; "audit" (1024; a power of two, 0 = off): one in N
  * of the CIEDE2000 candidates that leave the filter without a full score -- dropped by the bound, by the pre-tier's walk or by the fp32 walk's
  * exit test -- is walked once more by the fp32 form WITHOUT the bound, and a launch in which such a candidate turns out to lie clearly below
- * the limit is redone without the filter tiers (as when the pre-tier's canary trips);
+ * the limit is redone without the filter tiers (as when the pre-tier's canary trips); the RGB / CIE76 filter is audited the same way at an
+ * eighth of the rate (its bound has two rounding constants, and an audited walk costs it relatively more);
  * "stage0" (1): one whole-image bound per candidate ahead of the block bound; "euclid_stage1" (1): the RGB / CIE76 filter
  * judges the block bound one candidate per lane before any wave is spent on a candidate; "item_chunk" (0 = 1): work items a persistent
  * filter workgroup takes per global atomic; "cell_order" (1): the CIEDE2000 filter takes each XCD share's clipped cells (long items) first; "tiny" (1): detail cells of <= 64 pixels take the one-wave-per-cell path;

@@ -1015,7 +1015,7 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
                     b += cst[3 * nb + blk] * 0.9999f * fsqrt(fmaf(d0, d0, fmaf(d1, d1, d2 * d2)));
                 }
             }
-            if (b > limit) {
+            if (b * var.bound_scale > limit) {        // (bound_scale: 1; diagnostics)
                 scores[(size_t)cell * L + l] = __builtin_huge_valf();
                 n_bound_dropped += 1;
                 n_groups_all += (unsigned int)groups;
@@ -1065,7 +1065,7 @@ filter_lds_kernel(const float* __restrict__ cells, const float* __restrict__ cel
                 const float up = __shfl_down(d, off, kWave);
                 if (lane + off < kWave) d += up;
             }
-            rest = d;
+            rest = d * var.bound_scale;
             pruned = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), 0)) > limit;
         }
         float acc = 0.0f, acc_edge = 0.0f;
@@ -1726,68 +1726,94 @@ edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ cell_
     }
 }
 
-// The audit.  A candidate that leaves filter_kernel without a full score -- dropped by the bound's stage 0 or 1, by the packed-fp16
+// The audit.  A candidate that leaves the filter without a full score -- dropped by the bound's stage 0 or 1, by the packed-fp16
 // pre-tier's walk or by the fp32 walk's exit test: +inf in its score row -- is seen by neither the pre-tier's canary (survivors only)
 // nor the engine's band guard (fully scored candidates only).  So one in `var.audit` of all (cell, candidate) slots -- a hash: the
-// same ones every run -- that hold +inf is walked once more here, by the fp32 form on the interleaved copies WITHOUT any bound:
-// only its own partial sums, every term >= 0, can end the walk.  Pairs on the opposite-hue discontinuity take the fp64 form on the
-// spot (the candidates the bound drops first are the ones of opposite hue).  A walk that completes CLEARLY below the limit -- by
-// 1e-3 of it: ten times the fp32 form's own error on a cell's sum; a bound within rounding of the limit must not void launches --
-// means the drop was wrong, and the launch is voided like a tripped canary (the discontinuity log pushed past its capacity: the
-// engine redoes the batch without the filter tiers).  A kernel of its own, after the filter: inside filter_kernel the same check
-// cost every candidate (spills: config D +0.75 % with the audit switched off), here only the audited ones.
-// One wave per run of 64 slots: a hash test and a score read per lane, then the wave walks the run's audited slots one by one.
+// same ones every run -- that hold +inf is walked once more here, by the fp32 form WITHOUT any bound: only its own partial sums,
+// every term >= 0, can end the walk.  CIEDE2000 pairs on the opposite-hue discontinuity take the fp64 form on the spot (the
+// candidates the bound drops first are the ones of opposite hue).  A walk that completes CLEARLY below the limit -- by 1e-3 of it:
+// ten times the fp32 form's own error on a cell's sum; a bound within rounding of the limit must not void launches -- means the
+// drop was wrong, and the launch is voided like a tripped canary (the discontinuity log pushed past its capacity: the engine
+// redoes the batch without the filter tiers).  A kernel of its own, after the filter: inside filter_kernel the same check cost
+// every candidate (spills: config D +0.75 % with the audit switched off), here only the audited ones.
+// TYPE = CIEDE2000: the interleaved copies (`cells` = [B][ppad/256][4][256], `lib` likewise per variant; `cells_f0` unused);
+// otherwise (RGB, CIE76: filter_lds_kernel, whose bound carries two constants of its own -- 2e-2 of rounding slack per block sum and
+// the factor 0.9999): the planar cell with channel 0 from the NaN-marked plane `cells_f0`, the planar library.
+// A workgroup takes 256 slots at a time -- a hash test and a score read per thread -- and then walks the audited ones TOGETHER, wave w
+// the groups w, w + 4, ..: a small job's audit is as long as its longest walk (a 128-px cell: 64 groups), which four waves with a
+// shared running sum cut to a quarter (config F: 35 -> 12 us, 3.4 % -> 1.1 % of its step).
+template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
-audit_kernel(const float* __restrict__ cells_il, const float* __restrict__ lib_il, const float* __restrict__ scores,
-             int n_cells, int L, int ppad, const float* __restrict__ prune_above, const HueEntry* __restrict__ hue_lut,
-             Variants var, unsigned int* __restrict__ edge_count, unsigned int edge_cap)
+audit_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0, const float* __restrict__ lib,
+             const float* __restrict__ scores, int n_cells, int L, int ppad, const float* __restrict__ prune_above,
+             const HueEntry* __restrict__ hue_lut, Variants var, unsigned int* __restrict__ edge_count, unsigned int edge_cap)
 {
-    __shared__ HueEntry lut[kHueLutEntries];
-    load_hue_lut(lut, hue_lut);
+    __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
+    __shared__ int todo_list[kBlock];
+    __shared__ int n_todo;
+    __shared__ float part[2][kBlock / kWave];
+    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long total = (long long)n_cells * L;
-    const long long n_runs = (total + kWave - 1) / kWave;
-    for (long long run = (long long)blockIdx.x * (kBlock / kWave) + wave; run < n_runs; run += (long long)gridDim.x * (kBlock / kWave)) {
-        const long long slot = run * kWave + lane;
-        int cell = 0, l = 0;
-        bool todo = false;
+    const long long n_chunks = (total + kBlock - 1) / kBlock;
+    const int pq = ppad / 4;
+    for (long long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {       // (workgroup-uniform)
+        if (threadIdx.x == 0) n_todo = 0;
+        __syncthreads();
+        const long long slot = chunk * kBlock + threadIdx.x;
         if (slot < total) {
-            cell = (int)(slot / L);
-            l = (int)(slot - (long long)cell * L);
-            todo = audit_pick(var.audit, cell, l) && scores[slot] == __builtin_huge_valf();
+            const int cell = (int)(slot / L), l = (int)(slot - (long long)cell * L);
+            if (audit_pick(var.audit, cell, l) && scores[slot] == __builtin_huge_valf()) todo_list[atomicAdd(&n_todo, 1)] = (int)threadIdx.x;
         }
-        unsigned long long todo_lanes = __builtin_amdgcn_ballot_w64(todo);
-        while (todo_lanes != 0ull) {
-            const int src = __builtin_ctzll(todo_lanes);
-            todo_lanes &= todo_lanes - 1ull;
-            const int c = __builtin_amdgcn_readlane(cell, src), cand = __builtin_amdgcn_readlane(l, src);
+        __syncthreads();
+        const int n_here = n_todo;
+        for (int t = 0; t < n_here; ++t) {
+            const long long s = chunk * kBlock + todo_list[t];
+            const int c = (int)(s / L), cand = (int)(s - (long long)c * L);
             const float limit = prune_above[c];
             const int v = var.cell_var[c];
             const int groups = var.groups[v];
-            const float4* cb = reinterpret_cast<const float4*>(cells_il + (size_t)c * 4 * ppad);
-            const float4* lb = reinterpret_cast<const float4*>(lib_il + (size_t)v * var.chroma_stride * 4 + (size_t)cand * 4 * ppad);
+            const float4* cb = reinterpret_cast<const float4*>(cells + (size_t)c * (TYPE == CIEDE2000 ? 4 : 3) * ppad);
+            const float4* c0 = TYPE == CIEDE2000 ? cb : reinterpret_cast<const float4*>(cells_f0 + (size_t)c * ppad);
+            const float4* lb = reinterpret_cast<const float4*>(lib + (size_t)v * (TYPE == CIEDE2000 ? var.chroma_stride * 4 : var.lib_stride) +
+                                                               (size_t)cand * (TYPE == CIEDE2000 ? 4 : 3) * ppad);
             float acc = 0.0f;
             bool over = false;
-            for (int j = 0; j < groups; ++j) {
-                if (j != 0 && wave_sum_exceeds(acc, 0.0f, limit)) { over = true; break; }
-                const int at = 4 * kWave * j + lane;
-                const float4 p0 = cb[at], p1 = cb[at + kWave], p2 = cb[at + 2 * kWave], pc = cb[at + 3 * kWave];
-                const float4 q0 = lb[at], q1 = lb[at + kWave], q2 = lb[at + 2 * kWave], qc = lb[at + 3 * kWave];
-                auto term = [&](float a0, float a1, float a2, float ac, float b0, float b1, float b2, float bc) {
-                    bool edge;
-                    float t = pair_fast<CIEDE2000, true>(PxF{a0, a1, a2}, PxF{b0, b1, b2}, ac, bc, lut, &edge);
-                    // (operands are prepared: channel 0 is L / 2 - 25; an inactive pixel is a NaN there and comes out as 0, never as an edge)
-                    if (edge && a0 == a0)
-                        t = (float)ciede2000(Px{2.0f * (a0 + 25.0f), a1, a2}, Px{2.0f * (b0 + 25.0f), b1, b2});
-                    return t;
-                };
-                acc += (term(p0.x, p1.x, p2.x, pc.x, q0.x, q1.x, q2.x, qc.x) + term(p0.y, p1.y, p2.y, pc.y, q0.y, q1.y, q2.y, qc.y))
-                     + (term(p0.z, p1.z, p2.z, pc.z, q0.z, q1.z, q2.z, qc.z) + term(p0.w, p1.w, p2.w, pc.w, q0.w, q1.w, q2.w, qc.w));
+            for (int base = 0, round = 0; base < groups; base += kBlock / kWave, ++round) {
+                const int j = base + wave;
+                if (j < groups) {
+                    if constexpr (TYPE == CIEDE2000) {
+                        const int at = 4 * kWave * j + lane;
+                        const float4 p0 = cb[at], p1 = cb[at + kWave], p2 = cb[at + 2 * kWave], pc = cb[at + 3 * kWave];
+                        const float4 q0 = lb[at], q1 = lb[at + kWave], q2 = lb[at + 2 * kWave], qc = lb[at + 3 * kWave];
+                        auto term = [&](float a0, float a1, float a2, float ac, float b0, float b1, float b2, float bc) {
+                            bool edge;
+                            float d = pair_fast<CIEDE2000, true>(PxF{a0, a1, a2}, PxF{b0, b1, b2}, ac, bc, lut, &edge);
+                            // (operands are prepared: channel 0 is L / 2 - 25; an inactive pixel is a NaN there and comes out as 0, never as an edge)
+                            if (edge && a0 == a0)
+                                d = (float)ciede2000(Px{2.0f * (a0 + 25.0f), a1, a2}, Px{2.0f * (b0 + 25.0f), b1, b2});
+                            return d;
+                        };
+                        acc += (term(p0.x, p1.x, p2.x, pc.x, q0.x, q1.x, q2.x, qc.x) + term(p0.y, p1.y, p2.y, pc.y, q0.y, q1.y, q2.y, qc.y))
+                             + (term(p0.z, p1.z, p2.z, pc.z, q0.z, q1.z, q2.z, qc.z) + term(p0.w, p1.w, p2.w, pc.w, q0.w, q1.w, q2.w, qc.w));
+                    } else {
+                        const int q = kWave * j + lane;
+                        const float4 p0 = c0[q], p1 = cb[pq + q], p2 = cb[2 * pq + q];
+                        const float4 q0 = lb[q], q1 = lb[pq + q], q2 = lb[2 * pq + q];
+                        acc += (euclidean_fast(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}) + euclidean_fast(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}))
+                             + (euclidean_fast(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}) + euclidean_fast(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}));
+                    }
+                }
+                // the four waves' running sums, after every round of four groups (two buffers: one barrier per round)
+                const float mine = wave_sum_all(acc);
+                if (lane == 0) part[round & 1][wave] = mine;
+                __syncthreads();
+                const float so_far = (part[round & 1][0] + part[round & 1][1]) + (part[round & 1][2] + part[round & 1][3]);
+                if (so_far > limit) { over = true; break; }                          // (workgroup-uniform: every thread reads the same four)
+                if (base + kBlock / kWave >= groups && threadIdx.x == 0 && so_far <= limit * (1.0f - 1e-3f)) atomicAdd(edge_count, edge_cap + 1u);
             }
-            if (!over) {
-                const float sum = wave_sum_all(acc);
-                if (lane == 0 && sum <= limit * (1.0f - 1e-3f)) atomicAdd(edge_count, edge_cap + 1u);
-            }
+            (void)over;
+            __syncthreads();        // (the sums' buffers are free again before the next walk writes them)
         }
     }
 }
@@ -1968,15 +1994,25 @@ cell_order_kernel(const uint8_t* __restrict__ cell_full, int n_cells, int shares
     }
 }
 
-// audit_kernel after a CIEDE2000 filter launch over interleaved copies (in.var.audit says how many; a launch of its own so
-// that the engine can clock it apart from the filter)
+// audit_kernel / audit_euclid_kernel after a filter launch (in.var.audit says how many; a launch of its own so that the engine
+// can clock it apart from the filter).  CIEDE2000: over the interleaved copies only (the default layout)
 hipError_t launch_filter_audit(int type, const FilterInputs& in, const float* scores, int n_cells, int L, int ppad,
                                const float* prune_above, unsigned int* edge_count, unsigned int edge_cap, hipStream_t stream)
 {
-    if (type != CIEDE2000 || in.lib_il == nullptr || in.cells_il == nullptr || prune_above == nullptr || in.var.audit == 0u) return hipSuccess;
-    const long long runs = ((long long)n_cells * L + kWave - 1) / kWave;
-    audit_kernel<<<dim3((unsigned)std::min<long long>((runs + 3) / 4, 2048)), kBlock, 0, stream>>>(
-        in.cells_il, in.lib_il, scores, n_cells, L, ppad, prune_above, in.hue_lut, in.var, edge_count, edge_cap);
+    if (prune_above == nullptr || in.var.audit == 0u) return hipSuccess;
+    const long long chunks = ((long long)n_cells * L + kBlock - 1) / kBlock;
+    const dim3 grid((unsigned)std::min<long long>(chunks, 4096));
+    if (type == CIEDE2000) {
+        if (in.lib_il == nullptr || in.cells_il == nullptr) return hipSuccess;
+        audit_kernel<CIEDE2000><<<grid, kBlock, 0, stream>>>(in.cells_il, nullptr, in.lib_il, scores, n_cells, L, ppad, prune_above, in.hue_lut, in.var, edge_count, edge_cap);
+    } else {
+        // an eighth of the rate (one in 8192 at the default; `audit` = 1 still means every drop): the Euclidean filter drops 99 % of its
+        // candidates on the bound alone, so an audited walk costs it relatively more, and its bound is the triangle inequality with two
+        // rounding constants, not a derivation with a page of them
+        Variants var = in.var;
+        if (var.audit > 1u) var.audit = std::min(var.audit * 8u, 1u << 20);
+        audit_kernel<RGB_EUCLIDEAN><<<grid, kBlock, 0, stream>>>(in.cells, in.cells_f0, in.lib, scores, n_cells, L, ppad, prune_above, in.hue_lut, var, edge_count, edge_cap);
+    }
     return hipGetLastError();
 }
 

@@ -88,10 +88,10 @@ constexpr int kFilterCounterWords = 288;
 hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_cells, int L, int ppad,
                          EdgeEntry* edges, unsigned int* edge_count, unsigned int edge_cap,
                          const float* prune_above, hipStream_t stream, int* tile_used = nullptr);
-// The audit of a CIEDE2000 launch_filter over interleaved copies (filter.hip audit_kernel): one in in.var.audit of the
-// (cell, candidate) slots that the launch left at +inf is walked again by the fp32 form without the bound; a walk that completes
-// clearly below the cell's limit pushes *edge_count past edge_cap (the caller must then not trust the scores).  A no-op for
-// the other types, without interleaved copies, without limits or with audit = 0.
+// The audit of a launch_filter (filter.hip audit_kernel, audit_euclid_kernel): one in in.var.audit of the (cell, candidate) slots
+// that the launch left at +inf is walked again by the fp32 form without the bound; a walk that completes clearly below the
+// cell's limit pushes *edge_count past edge_cap (the caller must then not trust the scores).  A no-op without limits, with
+// audit = 0, and for CIEDE2000 without interleaved copies.
 hipError_t launch_filter_audit(int type, const FilterInputs& in, const float* scores, int n_cells, int L, int ppad,
                                const float* prune_above, unsigned int* edge_count, unsigned int edge_cap, hipStream_t stream);
 
