@@ -67,6 +67,7 @@ struct mm_engine {
     DevBuf lib_h, cells_h;       // the interleaved copies as halfs (the filter's packed-fp16 pre-tier)
     bool lib_h_ready = false;    // lib_h holds the current library (prepare_planes builds it only where the pre-tier may run)
     float dbg_pre_abs = 0.0f, dbg_pre_rel = 0.0f;      // diagnostics: the band mm_debug_filter_band_sweep modes 2 / 3 measure against (0: the pre-tier's own)
+    int spin_wait_us = 1000;     // mm_set_option("spin_wait_us", n): the host polls the stream for up to n microseconds before it blocks on it (0: blocks at once)
     int audit = 1024;            // mm_set_option("audit", N): one in N (a power of two) of the CIEDE2000 candidates that leave the filter without a full score
                                  // (bound, fp16 walk, fp32 walk) is walked again by the fp32 form without the bound; a wrong drop voids the launch; 0: none
     int pre_band_pct = 100;      // diagnostics ("dbg_pre_band_pct"): the pre-tier's band in per cent of the validated one (negative: drops contenders)
@@ -311,9 +312,24 @@ hipError_t select_device(mm_engine* e)
     return code;
 }
 
+// The host's wait for the stream.  A blocking hipStreamSynchronize wakes the thread through an interrupt, tens of microseconds after the
+// last kernel has ended -- a tenth of a sub-millisecond generate (profiles/r04_small_job_gaps.txt) --, so the first `spin_wait_us`
+// microseconds are spent polling instead (one core, bounded: a 43 ms step polls for its first millisecond and then blocks as before).
 hipError_t sync_stream(mm_engine* e)
 {
     e->syncs += 1;
+    if (e->spin_wait_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto budget = std::chrono::microseconds(e->spin_wait_us);
+        do {
+            const hipError_t q = hipStreamQuery(e->stream);
+            if (q != hipErrorNotReady) {
+                if (q == hipSuccess) (void)hipGetLastError();       // (a hipErrorNotReady of an earlier poll must not look like an error of a later launch)
+                return q;
+            }
+        } while (std::chrono::steady_clock::now() - t0 < budget);
+        (void)hipGetLastError();
+    }
     return hipStreamSynchronize(e->stream);
 }
 
@@ -2528,6 +2544,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "stage0") == 0) { e->stage0 = value != 0; return MM_OK; }
     if (strcmp(name, "dbg_pre_abs_1e4") == 0) { e->dbg_pre_abs = 1e-4f * (float)std::max(0, value); return MM_OK; }
     if (strcmp(name, "dbg_pre_rel_1e6") == 0) { e->dbg_pre_rel = 1e-6f * (float)std::max(0, value); return MM_OK; }
+    if (strcmp(name, "spin_wait_us") == 0) { e->spin_wait_us = std::max(0, std::min(value, 1000000)); return MM_OK; }
     if (strcmp(name, "audit") == 0) {
         int n = std::max(0, std::min(value, 1 << 20));
         while (n & (n - 1)) n &= n - 1;             // the largest power of two not above it
