@@ -4,7 +4,7 @@
 # kernel trace of the default command, and the bench lines of every configuration.
 # usage (on the box): bash tools/profile.sh r02_v13        -> gpurun_out/r02_v13/
 set -x
-V=${1:-r04_v47}
+V=${1:-r04_v48}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$V
 mkdir -p $O
