@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 3
+#define MM_ABI_VERSION 4
 
 /* Return codes.  The reference returns bool and reports through a modal
  * CUDAErrMessageBox that separates "expected" errors (out of memory, bad
@@ -110,6 +110,8 @@ typedef struct mm_timing {
                                * |channel| <= 256; or hold a non-finite value -- so the call ran fp64-only (same result) */
     int64_t pretier;          /* 1: the last CIEDE2000 filter launch ran with the packed-fp16 pre-tier (option "pretier") */
     double audit_ms;          /* the audit of the candidates the CIEDE2000 filter dropped (option "audit"), between the filter and the selection */
+    int64_t voided_launches;  /* filter launches whose scores were thrown away -- the pre-tier's canary tripped, or the audit found a dropped
+                               * candidate below the limit -- and whose cells were re-done fp64-only (must stay 0; same result either way) */
 } mm_timing;
 
 /* What a FIRST call pays besides the hot path, as host wall clocks accumulated since mm_create: the reference builds
@@ -144,7 +146,10 @@ mm_status mm_create(int device, mm_engine **out);
 /* Destroys the engine.  Its DEVICE RESOURCES (stream, events, device buffers, the page-locked result mirror) are
  * parked -- one set per device -- and adopted by the next mm_create on that device, so that a fresh generator per
  * run (MainWindow.cpp:584-607) does not pay the allocations again (mm_stage_timing).  Nothing logical survives:
- * a new engine has no library, masks or target and the default options. */
+ * a new engine has no library, masks or target and the default options.  A parked set holds at most
+ * MOSAIC_HIP_KEEP_MB (environment; default 256) megabytes of device memory: its largest buffers are released
+ * first -- the fixed costs are what parking saves, the large workspaces allocate again in a fraction of a
+ * millisecond and would otherwise be kept from everyone else on the device. */
 void mm_destroy(mm_engine *e);
 /* Releases the parked resources of destroyed engines (all devices); returns how many sets were released.
  * MOSAIC_HIP_KEEP=0 in the environment turns the parking off altogether (mm_destroy then frees everything, as the

@@ -32,7 +32,8 @@ class MMTiming(ctypes.Structure):
                 ("total_groups", ctypes.c_int64), ("bound_dropped", ctypes.c_int64),
                 ("band_alarms", ctypes.c_int64), ("filter_tile", ctypes.c_int64),
                 ("host_syncs", ctypes.c_int64), ("fast_path", ctypes.c_int64),
-                ("preprocess_ms", ctypes.c_double), ("filter_off_range", ctypes.c_int64), ("pretier", ctypes.c_int64), ("audit_ms", ctypes.c_double)]
+                ("preprocess_ms", ctypes.c_double), ("filter_off_range", ctypes.c_int64), ("pretier", ctypes.c_int64), ("audit_ms", ctypes.c_double),
+                ("voided_launches", ctypes.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -47,7 +48,7 @@ class MMStageTiming(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-ABI_VERSION = 3          # MM_ABI_VERSION of include/mosaic_hip.h
+ABI_VERSION = 4          # MM_ABI_VERSION of include/mosaic_hip.h
 
 PROGRESS_CB = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)
 

@@ -210,17 +210,30 @@ __device__ __forceinline__ half2_t h2_from(unsigned int v) { return __builtin_bi
 #ifndef MM_SDWA_GAP
 #define MM_SDWA_GAP "s_nop 0\n\t"     // wait states between the low half's write and the SDWA instruction that PRESERVES it (see above)
 #endif
-#define MM_H2_UNARY(NAME, OP)                                                                                              \
+// The same forwarding hazard exists on the way IN: should the compiler ever produce the operand with a dst_sel / op_sel-high write of
+// its own in the instruction just before the block (today it is always a full-register v_pk_* result), the e32 instruction would read
+// it one wait state early, and the hazard recognizer does not look into inline asm -- so the block opens with a wait state as well
+// (MM_SDWA_LEAD; measured cost in HISTORY.md).  The encodings and wait states are gfx950's: any other target takes the builtins and
+// lets the compiler join the halves (the v_pack_b32_f16 per pair this block exists to avoid).
+#ifndef MM_SDWA_LEAD
+#define MM_SDWA_LEAD "s_nop 0\n\t"
+#endif
+#if defined(__gfx950__) || !defined(__HIP_DEVICE_COMPILE__)
+#define MM_H2_UNARY(NAME, OP, BUILTIN)                                                                                     \
     __device__ __forceinline__ half2_t NAME(half2_t v)                                                                     \
     {                                                                                                                      \
         unsigned int in = h2_bits(v), out;                                                                                 \
-        asm(OP "_e32 %0, %1\n\t" MM_SDWA_GAP OP "_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0" \
+        asm(MM_SDWA_LEAD OP "_e32 %0, %1\n\t" MM_SDWA_GAP OP "_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0" \
             : "=&v"(out) : "v"(in));                                                                                       \
         return h2_from(out);                                                                                               \
     }
-MM_H2_UNARY(h2_rsq, "v_rsq_f16")
-MM_H2_UNARY(h2_rcp, "v_rcp_f16")
-MM_H2_UNARY(h2_sqrt, "v_sqrt_f16")
+#else
+#define MM_H2_UNARY(NAME, OP, BUILTIN)                                                                                     \
+    __device__ __forceinline__ half2_t NAME(half2_t v) { return half2_t{(half1_t)BUILTIN((__fp16)v.x), (half1_t)BUILTIN((__fp16)v.y)}; }
+#endif
+MM_H2_UNARY(h2_rsq, "v_rsq_f16", __builtin_amdgcn_rsqh)
+MM_H2_UNARY(h2_rcp, "v_rcp_f16", __builtin_amdgcn_rcph)
+MM_H2_UNARY(h2_sqrt, "v_sqrt_f16", __builtin_amdgcn_sqrth)
 #undef MM_H2_UNARY
 // the larger of two NON-NEGATIVE halfs, per half (unsigned order of the bit patterns; a NaN wins)
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));

@@ -545,8 +545,9 @@ mm_status ensure_hue_lut(mm_engine* e)
     const std::vector<float> lut = build_hue_lut();
     mm_status st = ensure(e, e->hue_lut, lut.size() * sizeof(float), "Failed to allocate hue table");
     if (st) return st;
-    HIP_TRY(e, hipMemcpy(e->hue_lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice),
-            "Failed to copy hue table to device");
+    // (a non-null table means a FILLED table -- also to the engine that adopts this one's buffers: a failed upload leaves none)
+    const hipError_t code = hipMemcpy(e->hue_lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (code != hipSuccess) { release(e->hue_lut); return hip_fail(e, code, "Failed to copy hue table to device", __FILE__, __LINE__); }
     return MM_OK;
 }
 
@@ -644,7 +645,7 @@ mm_status redo_flagged_cells(mm_engine* e, const mm_cell* cells_host, int first,
 
 // Phase times and work counters of a score batch whose events have completed.
 void account_score_batch(mm_engine* e, bool two_tier, bool prune, int diff_type, int b, unsigned int edge_n,
-                         const unsigned long long work[3])
+                         const unsigned long long work[3], bool voided = false)
 {
     if (!two_tier) {
         if (e->phase_events) {
@@ -679,6 +680,7 @@ void account_score_batch(mm_engine* e, bool two_tier, bool prune, int diff_type,
     }
     e->timing.score_launches += 1;
     e->timing.edge_pairs += edge_n;
+    e->timing.voided_launches += voided ? 1 : 0;
 }
 
 // Scores `n` cells in batches and leaves the K lowest candidates per cell in rows of
@@ -936,10 +938,16 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         bool pre_trial = false;
         // (eligible by size -- small jobs lose to it, config C +5 % -- and not a deepening sub-batch: decided by measurement)
         if (pre_possible && e->pretier < 0 && row_map_host == nullptr && (ppad / 256 > 32 || call_pairs >= 1e10)) {
+            // The state is keyed on the FULL batch of the job (library, cell size, cells per full batch) and only full batches touch it:
+            // a job cut into several batches ends on a shorter one, which must neither reset what the full ones measured nor be timed
+            // against them -- it runs the form chosen so far (none yet: without the pre-tier).  The two trials are the first two full
+            // batches, of one call or of two.
             mm_engine::PreAuto& a = e->pre_auto;
-            if (a.lib != L || a.size != size || a.cells != b) { a = mm_engine::PreAuto{}; a.lib = L; a.size = size; a.cells = b; }
-            if (a.choice >= 0) pretier = a.choice != 0;
-            else if (done == 0) { pretier = (a.have & 1) != 0; a.pending = pretier ? 1 : 0; pre_trial = true; }    // off first, then on
+            const bool full = b == batch;
+            if (full && (a.lib != L || a.size != size || a.cells != batch)) { a = mm_engine::PreAuto{}; a.lib = L; a.size = size; a.cells = batch; }
+            const bool mine = a.lib == L && a.size == size && a.cells == batch;
+            if (mine && a.choice >= 0) pretier = a.choice != 0;
+            else if (mine && full && a.pending < 0) { pretier = (a.have & 1) != 0; a.pending = pretier ? 1 : 0; pre_trial = true; }    // off first, then on
             else pretier = false;
         }
         if (row_map_host == nullptr) e->timing.pretier = pretier ? 1 : 0;
@@ -977,17 +985,19 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             e->drop_rate_lib == L && e->drop_rate_size == size)
             fin.tile_candidates = 64;
         int tile_used = 0;
-        if (pre_trial) HIP_TRY(e, hipEventRecord(e->ev[12], e->stream), "event");
+        // (a trial's two events are recorded by launch_filter itself, directly around the kernel: after the one-time occupancy query
+        // and attribute calls of a kernel's first launch, which are host time the device would otherwise be seen waiting for)
+        fin.clock_begin = pre_trial ? e->ev[12] : nullptr;
+        fin.clock_end = pre_trial ? e->ev[13] : nullptr;
         HIP_TRY(e, mm::launch_filter(ftype, fin, (float*)e->scores.p, b, L, ppad,
                                      (mm::EdgeEntry*)e->edges.p, counters_dev, edge_cap,
                                      prune ? (const float*)e->limits.p : nullptr, e->stream, &tile_used),
                 "Error during filter colour difference kernel");
         e->timing.filter_tile = tile_used;
-        if (pre_trial) HIP_TRY(e, hipEventRecord(e->ev[13], e->stream), "event");
         if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
-        // the audit of what the filter dropped: reads the score rows, may void the launch through the edge counter
+        // the audit of what the filter dropped: reads the score rows, may void the launch through the counter block's void word
         HIP_TRY(e, mm::launch_filter_audit(ftype, fin, (const float*)e->scores.p, b, L, ppad, prune ? (const float*)e->limits.p : nullptr,
-                                           counters_dev, edge_cap, e->stream),
+                                           counters_dev, e->stream),
                 "Error during filter audit kernel");
         if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[14], e->stream), "event");
 
@@ -1035,16 +1045,17 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         }
 
         flags_host.resize((size_t)b);
-        unsigned int counters[8] = {0};          // [0] logged discontinuity pairs, [2..7] three u64 work counters
+        unsigned int counters[8] = {0};          // [0] logged discontinuity pairs, [1] the void word, [2..7] three u64 work counters
         HIP_TRY(e, hipMemcpyAsync(flags_host.data(), e->flags.p, (size_t)b, hipMemcpyDeviceToHost, e->stream), "flags");
         HIP_TRY(e, hipMemcpyAsync(counters, e->edge_count.p, sizeof counters, hipMemcpyDeviceToHost, e->stream), "edge count");
         HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
         const unsigned int edge_n = counters[0];
+        const bool voided = counters[mm::kFilterVoidWord] != 0u;      // the pre-tier's canary or the audit: no score of the launch is trusted
         unsigned long long work[3];
         memcpy(work, counters + 2, sizeof work);
-        account_score_batch(e, true, prune, diff_type, b, edge_n, work);
+        account_score_batch(e, true, prune, diff_type, b, edge_n, work, voided);
         // cells the filter could not vouch for go through the fp64-only path
-        if ((st = redo_flagged_cells(e, cells_host, done, b, flags_host.data(), edge_n > edge_cap /* log overflowed */,
+        if ((st = redo_flagged_cells(e, cells_host, done, b, flags_host.data(), voided || edge_n > edge_cap /* log overflowed */,
                                      diff_type, K, KW, cand_i_dev, cand_s_dev, row_map_host)))
             return st;
         if (progress) progress(done + b, user);
@@ -1350,6 +1361,7 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
     h->sweeps = (unsigned int)sweeps;
     if (sequential && sweeps > 0) h->n_insufficient = h->sweep_insufficient[sweeps - 1];     // the final state's verdicts
     h->edge_pairs = h->filter_counters[0];
+    h->launch_void = h->filter_counters[mm::kFilterVoidWord];
     memcpy(h->work, h->filter_counters + 2, sizeof h->work);
     return MM_OK;
 }
@@ -1410,6 +1422,17 @@ bool parking_enabled()
     return !(v && v[0] == '0');
 }
 
+// Device bytes a parked set may hold (MOSAIC_HIP_KEEP_MB, default 256).  What parking buys is the fixed cost of a fresh
+// generator -- stream, events, the page-locked mirror, forty small allocations: config A 6 ms -> 0.3 -- not the large
+// workspaces: config D's 2.6 GB take 0.3 ms to allocate again, and left parked they are memory a co-tenant of the device (a
+// second engine budgeting on hipMemGetInfo, PyTorch / RCCL in dist.py) does not get back until mm_trim_cache.
+size_t parked_bytes_cap()
+{
+    const char* v = std::getenv("MOSAIC_HIP_KEEP_MB");
+    const long long mb = v && v[0] ? std::atoll(v) : 256;
+    return (size_t)std::max<long long>(mb, 0) << 20;
+}
+
 void free_resources(mm_engine* e)
 {
     for (DevBuf mm_engine::* m : kDeviceBuffers) release(e->*m);
@@ -1441,6 +1464,18 @@ bool park_resources(mm_engine* e)
         if (p->device == e->device) { delete keep; return false; }       // one set per device: this one is released
     keep->device = e->device;
     move_resources(keep, e);
+    // the largest buffers are released until the set fits its cap (the two constant tables are a few KB: they stay)
+    const size_t cap = parked_bytes_cap();
+    size_t held = 0;
+    for (DevBuf mm_engine::* m : kDeviceBuffers) held += (keep->*m).bytes;
+    while (held > cap) {
+        DevBuf* largest = nullptr;
+        for (DevBuf mm_engine::* m : kDeviceBuffers)
+            if ((keep->*m).p && (!largest || (keep->*m).bytes > largest->bytes)) largest = &(keep->*m);
+        if (!largest) break;
+        held -= largest->bytes;
+        release(*largest);
+    }
     g_parked.push_back(keep);
     return true;
 }
@@ -1638,7 +1673,8 @@ mm_status ensure_srgb_lut(mm_engine* e)
     }
     mm_status st = ensure(e, e->srgb_lut, sizeof lut, "Failed to allocate sRGB table");
     if (st) return st;
-    HIP_TRY(e, hipMemcpy(e->srgb_lut.p, lut, sizeof lut, hipMemcpyHostToDevice), "Failed to copy sRGB table to device");
+    const hipError_t code = hipMemcpy(e->srgb_lut.p, lut, sizeof lut, hipMemcpyHostToDevice);     // (non-null = filled, as the hue table)
+    if (code != hipSuccess) { release(e->srgb_lut); return hip_fail(e, code, "Failed to copy sRGB table to device", __FILE__, __LINE__); }
     return MM_OK;
 }
 
@@ -2124,9 +2160,10 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
                                        pd.two_tier ? (const uint8_t*)e->flags.p : nullptr, pd.counted);
         if (st) return st;
         const mm::ResultHeader& h = *(const mm::ResultHeader*)e->pinned;
-        account_score_batch(e, pd.two_tier, pd.prune, pd.diff_type, pd.b, h.edge_pairs, h.work);
+        const bool untrusted = pd.two_tier && (h.launch_void != 0u || h.edge_pairs > pd.edge_cap);     // voided, or the log overflowed
+        account_score_batch(e, pd.two_tier, pd.prune, pd.diff_type, pd.b, h.edge_pairs, h.work, pd.two_tier && h.launch_void != 0u);
         if (progress) progress(n_cells, progress_user);
-        const bool lists_ok = h.n_flagged == 0 && !(pd.two_tier && h.edge_pairs > pd.edge_cap);
+        const bool lists_ok = h.n_flagged == 0 && !untrusted;
         int settled = -1;                  // first sweep that changed nothing
         for (unsigned int i = 0; i < h.sweeps && settled < 0; ++i)
             if (h.sweep_changes[i] == 0) settled = (int)i;
@@ -2139,7 +2176,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
         if (!lists_ok) {
             std::vector<uint8_t> flags_host((size_t)n_cells);
             HIP_TRY(e, hipMemcpy(flags_host.data(), e->flags.p, (size_t)n_cells, hipMemcpyDeviceToHost), "flags");
-            if ((st = redo_flagged_cells(e, cells, 0, n_cells, flags_host.data(), h.edge_pairs > pd.edge_cap, diff_type,
+            if ((st = redo_flagged_cells(e, cells, 0, n_cells, flags_host.data(), untrusted, diff_type,
                                          Ks, K, (int32_t*)e->cand_i.p, (double*)e->cand_s.p, nullptr)))
                 return st;
         }

@@ -852,11 +852,12 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         if constexpr (PRE) {
             // Canary of the pre-tier: a candidate that walked ALL its groups in both forms has two sums of the same terms (the fp16 one
             // without its seam pairs, which can only make it smaller).  An fp16 sum ABOVE the fp32 one by more than the band's worth says
-            // the fp16 form over-estimates here -- what its early exits must never do -- and voids the launch: the discontinuity log is
-            // pushed past its capacity, which sends the whole batch down the fp64-only path (and shows in mm_timing.edge_pairs).
+            // the fp16 form over-estimates here -- what its early exits must never do -- and voids the launch: a sticky bit in the
+            // counter block's void word (an OR: it cannot wrap, however many candidates trip it), which sends the whole batch down
+            // the fp64-only path (and shows in mm_timing.voided_launches).
             if (pre_sum >= 0.0f && !pruned) {
                 const float sum16 = wave_sum_all(pre_sum);
-                if (lane == 0 && sum16 > fmaf(acc, 1.0f + kPreRel, kPreAbs * (float)(groups * 4 * kWave))) atomicAdd(edge_count, edge_cap + 1u);
+                if (lane == 0 && sum16 > fmaf(acc, 1.0f + kPreRel, kPreAbs * (float)(groups * 4 * kWave))) atomicOr(edge_count + kFilterVoidWord, kVoidByCanary);
             }
         }
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
@@ -1733,7 +1734,7 @@ edge_fix_kernel(const float* __restrict__ cells, const float* __restrict__ cell_
 // every term >= 0, can end the walk.  CIEDE2000 pairs on the opposite-hue discontinuity take the fp64 form on the spot (the
 // candidates the bound drops first are the ones of opposite hue).  A walk that completes CLEARLY below the limit -- by 1e-3 of it:
 // ten times the fp32 form's own error on a cell's sum; a bound within rounding of the limit must not void launches -- means the
-// drop was wrong, and the launch is voided like a tripped canary (the discontinuity log pushed past its capacity: the engine
+// drop was wrong, and the launch is voided like a tripped canary (a sticky bit in the counter block's void word: the engine
 // redoes the batch without the filter tiers).  A kernel of its own, after the filter: inside filter_kernel the same check cost
 // every candidate (spills: config D +0.75 % with the audit switched off), here only the audited ones.
 // TYPE = CIEDE2000: the interleaved copies (`cells` = [B][ppad/256][4][256], `lib` likewise per variant; `cells_f0` unused);
@@ -1746,7 +1747,7 @@ template <int TYPE>
 __global__ void __launch_bounds__(kBlock)
 audit_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0, const float* __restrict__ lib,
              const float* __restrict__ scores, int n_cells, int L, int ppad, const float* __restrict__ prune_above,
-             const HueEntry* __restrict__ hue_lut, Variants var, unsigned int* __restrict__ edge_count, unsigned int edge_cap)
+             const HueEntry* __restrict__ hue_lut, Variants var, unsigned int* __restrict__ edge_count)
 {
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     __shared__ int todo_list[kBlock];
@@ -1810,7 +1811,7 @@ audit_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0
                 __syncthreads();
                 const float so_far = (part[round & 1][0] + part[round & 1][1]) + (part[round & 1][2] + part[round & 1][3]);
                 if (so_far > limit) { over = true; break; }                          // (workgroup-uniform: every thread reads the same four)
-                if (base + kBlock / kWave >= groups && threadIdx.x == 0 && so_far <= limit * (1.0f - 1e-3f)) atomicAdd(edge_count, edge_cap + 1u);
+                if (base + kBlock / kWave >= groups && threadIdx.x == 0 && so_far <= limit * (1.0f - 1e-3f)) atomicOr(edge_count + kFilterVoidWord, kVoidByAudit);
             }
             (void)over;
             __syncthreads();        // (the sums' buffers are free again before the next walk writes them)
@@ -1997,21 +1998,21 @@ cell_order_kernel(const uint8_t* __restrict__ cell_full, int n_cells, int shares
 // audit_kernel / audit_euclid_kernel after a filter launch (in.var.audit says how many; a launch of its own so that the engine
 // can clock it apart from the filter).  CIEDE2000: over the interleaved copies only (the default layout)
 hipError_t launch_filter_audit(int type, const FilterInputs& in, const float* scores, int n_cells, int L, int ppad,
-                               const float* prune_above, unsigned int* edge_count, unsigned int edge_cap, hipStream_t stream)
+                               const float* prune_above, unsigned int* edge_count, hipStream_t stream)
 {
     if (prune_above == nullptr || in.var.audit == 0u) return hipSuccess;
     const long long chunks = ((long long)n_cells * L + kBlock - 1) / kBlock;
     const dim3 grid((unsigned)std::min<long long>(chunks, 4096));
     if (type == CIEDE2000) {
         if (in.lib_il == nullptr || in.cells_il == nullptr) return hipSuccess;
-        audit_kernel<CIEDE2000><<<grid, kBlock, 0, stream>>>(in.cells_il, nullptr, in.lib_il, scores, n_cells, L, ppad, prune_above, in.hue_lut, in.var, edge_count, edge_cap);
+        audit_kernel<CIEDE2000><<<grid, kBlock, 0, stream>>>(in.cells_il, nullptr, in.lib_il, scores, n_cells, L, ppad, prune_above, in.hue_lut, in.var, edge_count);
     } else {
         // an eighth of the rate (one in 8192 at the default; `audit` = 1 still means every drop): the Euclidean filter drops 99 % of its
         // candidates on the bound alone, so an audited walk costs it relatively more, and its bound is the triangle inequality with two
         // rounding constants, not a derivation with a page of them
         Variants var = in.var;
         if (var.audit > 1u) var.audit = std::min(var.audit * 8u, 1u << 20);
-        audit_kernel<RGB_EUCLIDEAN><<<grid, kBlock, 0, stream>>>(in.cells, in.cells_f0, in.lib, scores, n_cells, L, ppad, prune_above, in.hue_lut, var, edge_count, edge_cap);
+        audit_kernel<RGB_EUCLIDEAN><<<grid, kBlock, 0, stream>>>(in.cells, in.cells_f0, in.lib, scores, n_cells, L, ppad, prune_above, in.hue_lut, var, edge_count);
     }
     return hipGetLastError();
 }
@@ -2183,7 +2184,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         if (in.lds_pad_bytes > 0 &&
             (code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)in.lds_pad_bytes)) != hipSuccess) return code;
-        kern<<<dim3(persistent_grid(reinterpret_cast<const void*>(kern), blocks, kBlock, in.lds_pad_bytes)), kBlock, in.lds_pad_bytes, stream>>>(
+        // (the grid first: its one-time occupancy query is host work that a clocked launch must not have between its two events)
+        const unsigned grid_n = persistent_grid(reinterpret_cast<const void*>(kern), blocks, kBlock, in.lds_pad_bytes);
+        if (in.clock_begin != nullptr && (code = hipEventRecord(in.clock_begin, stream)) != hipSuccess) return code;
+        kern<<<dim3(grid_n), kBlock, in.lds_pad_bytes, stream>>>(
             pre ? reinterpret_cast<const float*>(in.cells_h) : (il ? nullptr : in.cells), il ? in.cells_il : in.cells_f0, il ? nullptr : in.cell_chroma,
             il ? in.lib_il : in.lib, pre ? reinterpret_cast<const float*>(in.lib_h) : (il ? nullptr : in.lib_chroma), scores, n_cells, L, ppad, cand_per_block,
             item_group, edges, edge_count, edge_cap, prune_above, check_every, in.hue_lut, var, xcd_shares,
@@ -2191,6 +2195,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var, il ? 1 : 0);
+        if (in.clock_end != nullptr && (code = hipGetLastError()) == hipSuccess && (code = hipEventRecord(in.clock_end, stream)) != hipSuccess) return code;
     } else {
         filter_kernel<RGB_EUCLIDEAN, kBlock, false, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN, kBlock, false, false>), blocks, kBlock, 0)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,

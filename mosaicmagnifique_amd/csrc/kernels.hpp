@@ -993,7 +993,8 @@ struct ResultHeader {
     unsigned int edge_pairs;             // discontinuity pairs logged by the filter launch
     unsigned int sweeps;                 // sweeps enqueued
     unsigned int sweep_changes[kFastSweeps];
-    unsigned int pad[2];
+    unsigned int launch_void;            // the filter launch's void word (launch.hpp kFilterVoidWord): non-zero = its scores are not trusted
+    unsigned int pad;
     unsigned long long work[3];          // filter work counters: groups visited, groups of a full visit, bound-dropped
     unsigned long long exact_plain, dense_count, pad64;
     unsigned long long sweep_exact[kFastSweeps];

@@ -72,12 +72,18 @@ struct FilterInputs {
     int32_t* cell_order;        // workspace [B] for Variants::cell_order (null: the cells are taken in their given order)
     const int32_t* seeds;       // [B][n_seeds] candidates launch_prune_limits scored already (their scores are in the
     int n_seeds;                // score rows): filter_kernel skips them.  null / 0: none.  n_seeds <= 256.
+    hipEvent_t clock_begin, clock_end;   // non-null: recorded directly around filter_kernel (+ its seam patch) of the general CIEDE2000 path, after every
+                                         // host-side one-time query of the launch (the engine's pre-tier trial compares two such intervals)
 };
 
 // Words of the counter block launch_filter clears and filter_kernel fills (u32 indices into edge_count):
-// [0] discontinuity pairs logged; [2,3] [4,5] [6,7] u64: pixel groups visited, groups of a full visit,
+// [0] discontinuity pairs logged; [1] the VOID word: sticky bits (atomicOr -- a counter pushed past a capacity could wrap) saying
+// that the launch's scores must not be trusted: kVoidByCanary (the pre-tier's canary), kVoidByAudit (a dropped candidate the audit
+// found below the limit); [2,3] [4,5] [6,7] u64: pixel groups visited, groups of a full visit,
 // candidates dropped by the block bound alone; [32], [64] .. [256] item counters of the persistent workgroups (a cache line each).
 constexpr int kFilterCounterWords = 288;
+constexpr int kFilterVoidWord = 1;
+constexpr unsigned int kVoidByCanary = 1u, kVoidByAudit = 2u;
 
 // Tier-1 filter scores f32 [n_cells][L] (see filter.hip).  Pairs on the discontinuity
 // are logged to `edges` (capacity edge_cap, count in *edge_count, which may exceed
@@ -90,10 +96,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
                          const float* prune_above, hipStream_t stream, int* tile_used = nullptr);
 // The audit of a launch_filter (filter.hip audit_kernel, audit_euclid_kernel): one in in.var.audit of the (cell, candidate) slots
 // that the launch left at +inf is walked again by the fp32 form without the bound; a walk that completes clearly below the
-// cell's limit pushes *edge_count past edge_cap (the caller must then not trust the scores).  A no-op without limits, with
+// cell's limit sets kVoidByAudit in edge_count[kFilterVoidWord] (the caller must then not trust the scores).  A no-op without limits, with
 // audit = 0, and for CIEDE2000 without interleaved copies.
 hipError_t launch_filter_audit(int type, const FilterInputs& in, const float* scores, int n_cells, int L, int ppad,
-                               const float* prune_above, unsigned int* edge_count, unsigned int edge_cap, hipStream_t stream);
+                               const float* prune_above, unsigned int* edge_count, hipStream_t stream);
 
 // stats array k (block_stride floats apart), [img][ppad / 64] over plane positions [64 b, 64 b + 64):
 // masked sum of channel 0, max |channel 0 - 50|, sums of channels 1 and 2, max chroma, hue range.

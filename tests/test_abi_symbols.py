@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared_symbols():
         assert hasattr(lib, name), "missing export %s" % name
     lib.mm_abi_version.restype = ctypes.c_int
-    assert lib.mm_abi_version() == 3
+    assert lib.mm_abi_version() == 4
 
 
 def test_the_collective_is_linked_behind_the_c_abi(built):
@@ -61,7 +61,7 @@ def test_struct_layouts_match_the_header():
     from mosaicmagnifique_amd.grid import CELL_DTYPE
     assert ctypes.sizeof(_lib.MMCell) == 36 == CELL_DTYPE.itemsize
     assert [n for n, _ in _lib.MMCell._fields_] == list(CELL_DTYPE.names)
-    assert ctypes.sizeof(_lib.MMTiming) == 224
+    assert ctypes.sizeof(_lib.MMTiming) == 232
     assert ctypes.sizeof(_lib.MMStageTiming) == 72          # six clocks (f64) + three counters (i64)
 
 

@@ -155,13 +155,11 @@ def test_every_dropped_candidate_audited_at_the_benchmarked_size(engine, name):
     """`audit` = 1: EVERY candidate that leaves the CIEDE2000 filter without a full score -- config D: 2 x 10^7 per launch, dropped
     by the bound's two stages, by the packed-fp16 walk (forced on here) or by the fp32 walk's exit test -- is walked once more by the
     fp32 form without the bound, and one that ended clearly below the limit would void the launch.  None does: no cell goes down
-    the fp64-only path (`dense_cells` 0, the discontinuity log far from its capacity), and the grid is the CPU golden's.  (C: the
+    the fp64-only path (`dense_cells` 0, `voided_launches` 0), and the grid is the CPU golden's.  (C: the
     hexagon's clipped cells; G: cells above 16 groups, stage 0 feeding the candidate loop directly; B and F: the RGB filter's
     own bound and audit_euclid_kernel, 64- and 128-px cells.)"""
     tm, rel, same = whole_grid_against_golden(engine, name, {"audit": 1, "pretier": 1})
-    # (a voided launch pushes the discontinuity log past its capacity, which is 10^6 entries at least; the audit walks themselves
-    # log seam pairs -- the candidates the bound drops first are the ones of opposite hue: config D 1 160 -> 512 020 entries)
-    assert tm["pretier"] == (1 if make_grids.CONFIGS[name][5] == 2 else 0) and tm["dense_cells"] == 0 and tm["edge_pairs"] < 1_000_000, tm
+    assert tm["pretier"] == (1 if make_grids.CONFIGS[name][5] == 2 else 0) and tm["dense_cells"] == 0 and tm["voided_launches"] == 0, tm
     print(json.dumps(dict(config=name, audited="every dropped candidate", visited_groups=tm["visited_groups"], total_groups=tm["total_groups"])))
 
 
