@@ -396,7 +396,10 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * whether it pays depends on the content (synthetic patches: yes; photographs: no); 0 never, 1 always; as with "item_auto" only the TIME of a call
  * depends on the engine's history): CIEDE2000 candidates first walk their pixel groups in
  * a packed-fp16 form (two pixel pairs per lane-instruction, operands half the size) that only takes early-exit decisions, against the limit
- * widened by its own measured band; survivors are scored by the fp32 form as before; "audit" (1024; a power of two, 0 = off): one in N
+ * widened by its own band; survivors are scored by the fp32 form as before; "pretier_band" (0): 0 = that band is the WORST-CASE bound of the
+ * fp16 form -- every rounding of its operation sequence at its worst, tools/filter_error_bound.py, 0.45 + 3.8e-2 dE per pixel pair --, 1 = the
+ * band of round 4, twice the worst OBSERVED pair (0.29 + 8e-3 dE: a third of the worst-case bound, i.e. a statistical guarantee; the audit then
+ * runs at eight times its rate; config D -4 %); "audit" (1024; a power of two, 0 = off): one in N
  * of the CIEDE2000 candidates that leave the filter without a full score -- dropped by the bound, by the pre-tier's walk or by the fp32 walk's
  * exit test -- is walked once more by the fp32 form WITHOUT the bound, and a launch in which such a candidate turns out to lie clearly below
  * the limit is redone without the filter tiers (as when the pre-tier's canary trips); the RGB / CIE76 filter is audited the same way at an

@@ -182,7 +182,7 @@ __device__ __forceinline__ float chroma_of(float a, float b) { return fsqrt(fmaf
 // Every candidate that survives it is scored again by the fp32 form above, which alone feeds the contender selection.
 // A term may therefore be UNDER-estimated freely (terms are >= 0: a lower sum exits later, never wrongly), and that is
 // what happens to everything awkward: pairs near the opposite-hue seam (|cross| < 2^-7 e: the fp16 branch choice may differ
-// from the fp64 one) and anything that came out NaN contribute 0.  What may NOT happen is an over-estimate beyond the band,
+// from the fp64 one), pairs with a chroma below 1 / 16 on either side (squares that underflow) and anything that came out NaN contribute 0.  What may NOT happen is an over-estimate beyond the band,
 // so no intermediate may overflow for inputs inside the validated box (L in [0, 100], chroma <= 150):
 //   operands are prepared (interleave_h_kernel): L / 2 - 25, a / 4, b / 4, C / 4 -- a' <= 57, products <= 4600, e <= 9200;
 //   the 7th power of the mean chroma over 25 is clamped at 4.8^7 (the ratio is 1 - 9e-6 there) and enters as
@@ -297,8 +297,14 @@ __device__ __forceinline__ half2_t ciede2000_h2(half2_t pl, half2_t pa, half2_t 
     const half2_t abs_cross = h2_from(h2_bits(cross) & 0x7fff7fffu);
     const half2_t e = (c1p * c2p + h2_splat(0x1p-13f)) + h2_from(h2_bits(dot) & 0x7fff7fffu);
     // near the seam (obtuse, |cross| < e / 128, i.e. within ~8e-3 rad of opposite hues -- an order above fp16's noise on cross / e)
-    // the pair counts 0: `seam` = 0xffff per half there
-    const unsigned int seam = obtuse & h2_sign_mask(h2_bits(abs_cross - e * h2_splat(1.0f / 128.0f)) & 0x80008000u);
+    // the pair counts 0: `seam` = 0xffff per half there.  And so does a pair with a stored chroma below 2^-6 (C < 1 / 16) on either side:
+    // the squares of a / 4 and b / 4 are subnormal halfs from there down, C' and the hue direction lose their relative accuracy, and a
+    // grey's hue terms beside a saturated colour are small but not zero -- the zone where the worst-case bound of this form
+    // (tools/filter_error_bound.py) exceeded any band worth having.  Non-negative halfs order like their bit patterns: the sign bit of
+    // the 16-bit difference to 0x2400 (a NaN -- an inactive pixel -- lies above it and comes out as 0 further down anyway).
+    const unsigned int tiny = h2_bits(__builtin_bit_cast(half2_t, __builtin_bit_cast(ushort2_t, pc) - ushort2_t{0x2400, 0x2400})) |
+                              h2_bits(__builtin_bit_cast(half2_t, __builtin_bit_cast(ushort2_t, qc) - ushort2_t{0x2400, 0x2400}));
+    const unsigned int seam = h2_sign_mask(((h2_bits(abs_cross - e * h2_splat(1.0f / 128.0f)) & h2_bits(dot)) | tiny) & 0x80008000u);
     const half2_t r = h2_rsq(h2_splat(0.5f) * e);
     const half2_t d_h = h2_sel(obtuse, h2_from(h2_bits(e) | sgn), cross) * r;
     const half2_t c2s = h2_from(h2_bits(c2p) ^ (obtuse & 0x80008000u));

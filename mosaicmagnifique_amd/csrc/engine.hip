@@ -71,6 +71,9 @@ struct mm_engine {
     int audit = 1024;            // mm_set_option("audit", N): one in N (a power of two) of the CIEDE2000 candidates that leave the filter without a full score
                                  // (bound, fp16 walk, fp32 walk) is walked again by the fp32 form without the bound; a wrong drop voids the launch; 0: none
     int pre_band_pct = 100;      // diagnostics ("dbg_pre_band_pct"): the pre-tier's band in per cent of the validated one (negative: drops contenders)
+    int pretier_band = 0;        // mm_set_option("pretier_band", 0 / 1): 0 = the worst-case band (tools/filter_error_bound.py: every rounding of the fp16
+                                 // form at its worst, a tenth of room); 1 = round 4's observed band (twice the worst pair of 1.1e10 swept and climbed
+                                 // pairs: a third of the worst-case bound -- a STATISTICAL guarantee, which is why it is not the default)
     int bound_pct = 100;         // diagnostics ("dbg_bound_pct"): the early exit's lower bound in per cent (above 100: drops contenders)
     int pretier = -1;            // mm_set_option("pretier", 0 / 1): the packed-fp16 pre-tier ahead of the fp32 filter form never / always;
                                  // -1 = measured (PreAuto below) for jobs large enough to gain -- cells above 32 pixel groups (up to
@@ -503,7 +506,8 @@ mm::Variants variants_of(const mm_engine* e)
     v.cell_full = (const uint8_t*)e->cell_full.p;
     v.two_stage = e->two_level ? 1 : 0;     // (bit 1, stage 0, is set per batch once the cells' image statistics exist)
     v.audit = (unsigned int)e->audit;
-    v.pre_band_scale = 0.01f * (float)e->pre_band_pct;
+    v.pre_abs = (e->pretier_band != 0 ? mm::kPreBandAbsObserved : mm::kPreBandAbs) * 0.01f * (float)e->pre_band_pct;
+    v.pre_rel = (e->pretier_band != 0 ? mm::kPreBandRelObserved : mm::kPreBandRel) * 0.01f * (float)e->pre_band_pct;
     v.bound_scale = 0.01f * (float)e->bound_pct;
     return v;
 }
@@ -959,6 +963,8 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         }
         fin.lib_h = pretier ? e->lib_h.p : nullptr;
         fin.cells_h = pretier ? e->cells_h.p : nullptr;
+        // the observed band is a statistical guarantee: where it is in force the audit of the dropped candidates runs at eight times its rate
+        fin.var.audit = pretier && e->pretier_band != 0 && e->audit > 8 ? (unsigned int)(e->audit / 8) : (unsigned int)e->audit;
         if (pretier)
             HIP_TRY(e, mm::launch_interleave_h((const float*)e->cells_il.p, e->cells_h.p, (size_t)b, ppad, e->stream),
                     "Error during half-precision cell kernel");
@@ -2589,6 +2595,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
         return MM_OK;
     }
     if (strcmp(name, "dbg_pre_band_pct") == 0) { e->pre_band_pct = value; return MM_OK; }
+    if (strcmp(name, "pretier_band") == 0) { e->pretier_band = value != 0; e->pre_auto = mm_engine::PreAuto{}; return MM_OK; }
     if (strcmp(name, "dbg_bound_pct") == 0) { e->bound_pct = std::max(0, value); return MM_OK; }
     if (strcmp(name, "pretier") == 0) { e->pretier = value < 0 ? -1 : (value != 0); e->pre_auto = mm_engine::PreAuto{}; return MM_OK; }
     if (strcmp(name, "tiny") == 0) { e->tiny_path = value != 0; return MM_OK; }

@@ -218,29 +218,19 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 #ifndef MM_BIG_CELL_STAGE0
 #define MM_BIG_CELL_STAGE0 1         // cells above 16 groups: stage 0 of the bound ahead of the candidate loop, bound-ordered visits from 17 groups on (0: round 3's form, for A/B builds)
 #endif
-// Error band of the packed-fp16 pre-tier per pixel pair: fp16 form - fp64 form <= kPreAbs + kPreRel * value for operands
-// inside the validated box, with the operands rounded to halfs as interleave_h_kernel stores them (measured by
-// band_sweep_kernel modes 2 / 3 and climbed against by the adversarial maximiser, both held below half of this by
-// tests/test_gpu_filter.py); the pre-tier's accumulation is fp32.
-// History of the number: 0.38 + 8e-3 v was twice the worst over-estimate of 1.1e10 swept pairs (a quarter-grid exploration of the
-// (abs, rel) frontier had under-estimated it: tools/experiments/r4_pre3.sh, profiles/r04_pretier_band_frontier.txt).  The maximiser, once
-// pointed at this form, found what the sweeps' chroma levels step over -- a chroma of 1e-5 .. 1e-3 beside a saturated colour, +1.3 on a pair
-// of 33.7, 1.9 of that band; fixed in ciede2000_h2 by flooring C' with the stored chroma -- and the fix also removed the sweeps' worst pair:
-// share 0.32 of the old band.  This one, 0.29 + 8e-3 v, is twice the worst over-estimate of every search so far: the sweeps' worst pair
-// sits at 0.42 of it (absolute part: small differences), twelve seeds of the maximiser over 400 generations at 0.48 (relative part: saturated
-// colours at opposite corners of the box, dE00 ~ 135, where eleven bits of mantissa show; with 6e-3 v they reached 0.60) --
-// profiles/r04_pretier_maximiser.txt.  Narrower bands buy little once the absolute part is charged as the walk proceeds (config D:
-// 0.26 + 5.5e-3 v is 1.6 % faster than 0.38 + 8e-3 v).
+// Error band of the packed-fp16 pre-tier per pixel pair (launch.hpp kPreBandAbs / kPreBandRel): fp16 form - fp64 form <= abs + rel * value for operands
+// inside the validated box, with the operands rounded to halfs as interleave_h_kernel stores them; the pre-tier's accumulation is fp32.
+// Round 5: the band is no longer sized on OBSERVED errors.  tools/filter_error_bound.py carries, through the form's own sequence of
+// operations, a bound on what the half-precision computation can be off by with EVERY rounding at its worst (u = 2^-11 per packed
+// operation, one ulp per transcendental, subnormal halfs at their absolute step, the hue table's index moved by the direction's
+// error) -- a smooth function of the pair, unlike an observed error, which depends on mantissa bits and let round 4's sweeps step over
+// what the maximiser then found.  Its frontier over thirteen families x 1.5e6 pairs (the form's weak zones, the colours of u8 images):
+// 0.40 + 3.3e-2 v, 0.45 + 3.1e-2 v, 0.50 + 2.9e-2 v; shipped with a tenth of room on either part.  Observed errors sit at a quarter of it
+// (round 4's band, twice the worst observed pair, was 0.29 + 8e-3 v -- kPreBandAbsObserved / kPreBandRelObserved, option "pretier_band" 1:
+// a third of the worst-case bound, i.e. a band that trusts the roundings not to conspire; config D ran 4 % faster on it).
 #ifndef MM_PRE_PREFETCH
 #define MM_PRE_PREFETCH 1            // the pre-tier fetches the next group's operands while it computes this one (0: A/B builds)
 #endif
-#ifndef MM_PRE_ABS
-#define MM_PRE_ABS 0.29f
-#endif
-#ifndef MM_PRE_REL
-#define MM_PRE_REL 8e-3f
-#endif
-constexpr float kPreAbs = MM_PRE_ABS, kPreRel = MM_PRE_REL;
 #ifndef MM_LONG_SPLIT
 #define MM_LONG_SPLIT 0.8f
 #endif
@@ -735,8 +725,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 // true sum of the visited pairs >= (acc16 - abs x pairs visited) / (1 + rel): the exit test compares acc16 + rest with
                 // limit (1 + rel) + abs x (positions visited so far) -- the absolute part grows with the walk instead of being charged
                 // for the whole cell up front
-                const float pre_abs = kPreAbs * var.pre_band_scale;
-                const float limit_rel = limit * fmaf(kPreRel, var.pre_band_scale, 1.0f);
+                const float pre_abs = var.pre_abs;
+                const float limit_rel = limit * (1.0f + var.pre_rel);
                 float acc16 = 0.0f;
                 bool out16 = false;
                 // the operands of the NEXT group are fetched while this one is computed: a group of the fp16 form is ~280 instructions
@@ -857,7 +847,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             // the fp64-only path (and shows in mm_timing.voided_launches).
             if (pre_sum >= 0.0f && !pruned) {
                 const float sum16 = wave_sum_all(pre_sum);
-                if (lane == 0 && sum16 > fmaf(acc, 1.0f + kPreRel, kPreAbs * (float)(groups * 4 * kWave))) atomicOr(edge_count + kFilterVoidWord, kVoidByCanary);
+                // (the band in force; the diagnostics' negative bands -- what the audit is shown to catch -- by their size)
+                if (lane == 0 && sum16 > fmaf(acc, 1.0f + fabsf(var.pre_rel), fabsf(var.pre_abs) * (float)(groups * 4 * kWave))) atomicOr(edge_count + kFilterVoidWord, kVoidByCanary);
             }
         }
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
@@ -1959,7 +1950,7 @@ hipError_t launch_band_sweep(int mode, unsigned long long seed, unsigned long lo
     hipError_t code = hipMemsetAsync(out6, 0, 6 * sizeof(unsigned long long), stream);
     if (code != hipSuccess) return code;
     // modes 2 / 3: the same two sweeps for the packed-fp16 pre-tier's form, against ITS band
-    if ((mode & 2) && !(mode & 4)) { px_abs = kPreAbs; rel = kPreRel; }       // (bit 2: the caller's own band, diagnostics)
+    if ((mode & 2) && !(mode & 4)) { px_abs = kPreBandAbs; rel = kPreBandRel; }       // (bit 2: the caller's own band, diagnostics)
     band_sweep_kernel<<<256 * 16, kBlock, 0, stream>>>(mode, seed, n_pairs, px_abs, rel, hue_lut, out6);
     return hipGetLastError();
 }

@@ -38,7 +38,9 @@ struct Variants {
     unsigned int audit;         // filter_kernel (CIEDE2000): N = 2^k > 0 -- one in N of the candidates that leave without a full score (dropped by the
                                 // bound, by the packed-fp16 pre-tier's walk or by the fp32 walk) is walked once more by the fp32 form without the
                                 // bound, and a launch in which such a candidate turns out to lie clearly below the limit is voided; 0: none
-    float pre_band_scale;       // 1; diagnostics: the pre-tier's band times this (negative: a band that drops true contenders -- what the audit is for)
+    float pre_abs, pre_rel;     // the pre-tier's band per pixel pair, absolute and relative part (kPreBandAbs / kPreBandRel: the worst-case bound of
+                                // tools/filter_error_bound.py; option "pretier_band" 1: round 4's observed band; diagnostics scale both, a negative
+                                // band drops true contenders -- what the audit is for)
     float bound_scale;          // 1; diagnostics: the early exit's lower bound times this (above 1: a bound that drops true contenders)
 };
 
@@ -83,6 +85,8 @@ struct FilterInputs {
 // candidates dropped by the block bound alone; [32], [64] .. [256] item counters of the persistent workgroups (a cache line each).
 constexpr int kFilterCounterWords = 288;
 constexpr int kFilterVoidWord = 1;
+// The packed-fp16 pre-tier's band (filter.hip): worst-case bound with a tenth of room | twice the worst observed pair of round 4.
+constexpr float kPreBandAbs = 0.45f, kPreBandRel = 3.8e-2f, kPreBandAbsObserved = 0.29f, kPreBandRelObserved = 8e-3f;
 constexpr unsigned int kVoidByCanary = 1u, kVoidByAudit = 2u;
 
 // Tier-1 filter scores f32 [n_cells][L] (see filter.hip).  Pairs on the discontinuity

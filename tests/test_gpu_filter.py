@@ -16,8 +16,11 @@ from oracle_ffi import shape_of
 pytestmark = pytest.mark.gpu
 
 LO, HI = np.array([0, -128, -128]), np.array([100, 127, 127])
-# the packed-fp16 pre-tier's band per pixel pair (filter.hip kPreAbs, kPreRel; MM_TEST_PRE_BAND="abs,rel" for variant builds)
-PRE_ABS, PRE_REL = (float(v) for v in os.environ.get("MM_TEST_PRE_BAND", "0.29,8e-3").split(","))
+# the packed-fp16 pre-tier's band per pixel pair (launch.hpp kPreBandAbs, kPreBandRel: the worst-case bound of tools/filter_error_bound.py
+# with a tenth of room; observed errors must stay far below it -- round 4's band, twice the worst observed pair, was 0.29 + 8e-3 v)
+PRE_ABS, PRE_REL = (float(v) for v in os.environ.get("MM_TEST_PRE_BAND", "0.45,3.8e-2").split(","))
+# ... and the share of it an OBSERVED over-estimate may reach (the worst pair of round 4's searches sits at 0.3 of this band)
+PRE_OBSERVED_SHARE = 0.35
 
 
 def lab_sets(rng, n):
@@ -94,27 +97,28 @@ def test_ciede2000_filter_band_structured_sweep(engine):
 
 def test_packed_fp16_pretier_band_structured_sweep(engine):
     """The filter's packed-fp16 pre-tier (colour_diff_fast.hpp ciede2000_h2) takes early-exit decisions only, against the
-    limit widened by ITS band (filter.hip kPreAbs + kPreRel * value per pixel pair).  What must hold is the over-estimate:
+    limit widened by ITS band (launch.hpp kPreBandAbs + kPreBandRel * value per pixel pair).  What must hold is the over-estimate:
     fp16 form - fp64 form <= band on operands rounded to halfs as the engine stores them (an under-estimate only delays an
     exit; pairs near the opposite-hue seam count 0).  The same two structured sweeps that back the fp32 band -- hue x hue x
-    chroma x chroma x lightness, and both sides of the seam -- : the worst over-estimate stays below half of the band, and
+    chroma x chroma x lightness, and both sides of the seam -- : the worst OBSERVED over-estimate stays below a third of the band (which is
+    the worst-case bound of tools/filter_error_bound.py, tests/test_filter_error_bound.py), and
     nothing comes out non-finite inside the box (reported as a share of 1e9)."""
     grid = 512 * 512 * 24 * 24 * 25
     for seed in range(2):
         r = engine.filter_band_sweep(2, grid, seed=seed)
         print("fp16 pre-tier sweep mode 2 seed %d: %s" % (seed, r))
-        assert r["band_share"] <= 0.5, r
-        assert r["measured"] > 3e9 and r["max_value"] > 100
+        assert r["band_share"] <= PRE_OBSERVED_SHARE, r
+        assert r["measured"] > 2.5e9 and r["max_value"] > 100        # (six of the grid's 24 chroma levels lie below 1 / 16: not judged, counted as handed over)
     r = engine.filter_band_sweep(3, 512 * 128 * 24 * 24 * 25, seed=7)
     print("fp16 pre-tier sweep mode 3: %s" % r)
-    assert r["band_share"] <= 0.5, r
-    assert r["handed_over"] > 0 and r["measured"] > 1e8
+    assert r["band_share"] <= PRE_OBSERVED_SHARE, r
+    assert r["handed_over"] > 0 and r["measured"] > 3e7        # (most of this sweep lies inside the seam zone of the fp16 form, or below its chroma floor)
 
 
 def band_share(engine, a, b, fp16=False):
     """|fp32 filter form - fp64 form| as a share of the band the engine trusts (engine.hip filter_band: 1e-3 + 6e-5 * value);
     pairs the filter hands to the fp64 form count as 0.  fp16: the packed-fp16 pre-tier's form against ITS band (filter.hip
-    kPreAbs + kPreRel * value) -- the signed over-estimate, which is what an early exit relies on; seam pairs count as 0."""
+    kPreBandAbs + kPreBandRel * value) -- the signed over-estimate, which is what an early exit relies on; seam pairs count as 0."""
     exact = engine.colour_diff_batch(2, a, b)
     fast = engine.filter_diff_batch(2, a, b).astype(np.float64)
     share = (fast - exact) / (PRE_ABS + PRE_REL * exact) if fp16 else np.abs(fast - exact) / (1e-3 + 6e-5 * exact)
@@ -207,7 +211,8 @@ def test_ciede2000_filter_band_adversarial_maximiser(engine, prepared):
     start, best, a, b, exact = climb(engine, prepared, 17 + prepared)
     print("adversarial maximiser (prepared=%d): band share %.3f -> %.3f; worst pair %s vs %s, dE00 %.6f" % (prepared, start, best, a, b, exact))
     assert best >= start                                           # it climbed (or started at its summit)
-    assert best < 0.5, (a, b, best)
+    # (the fp32 band: half of it; the fp16 band is the worst-case bound itself: an observed error reaches a third of that)
+    assert best < (PRE_OBSERVED_SHARE if prepared == 2 else 0.5), (a, b, best)
 
 
 def test_band_guard_is_silent_on_honest_content_and_loud_on_a_broken_band(oracle, engine):
