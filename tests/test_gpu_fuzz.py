@@ -159,7 +159,8 @@ OPTION_SETS = [
     {"fused_seeds": 0},                             # seeds, their scores and the limit as three launches
     {"prune_min_kpairs": -1, "phase_timing": -1},   # the engine's own defaults: no seeds / early exit and no phase events below a work threshold
     {"prune_min_kpairs": 2000000000},               # never pruned
-    {"pretier": 1},                                 # the packed-fp16 pre-tier ahead of the fp32 filter form (default: large jobs and cells above 32 groups)
+    {"pretier": 1},                                 # the packed-fp16 pre-tier ahead of the fp32 filter form (default: measured on cells above 32 groups)
+    {"pretier": 1, "pretier_band": 1},              # ... on round 4's observed band instead of the worst-case one (the audit eight times as dense)
     {"pretier": 0},
     {"pretier": 1, "tile": 64},
     {"pretier": 1, "audit": 1},                     # ... with EVERY candidate that leaves without a full score walked again without the bound (default: one in 1024)
@@ -194,7 +195,7 @@ def test_tuning_options_do_not_change_the_result(oracle, engine, opts):
     defaults = {"interleave": 1, "xcd_aware": 1, "tile": 0, "xcd_cells": 0, "two_level": 1, "sort_groups": -1,
                 "lds_filter": -1, "seeds": -1, "spec_k": 4, "fused": 1, "fast_path": 1, "item_auto": 1,
                 "fused_seeds": 2048, "prune_min_kpairs": 0, "phase_timing": 1, "stage0": 1, "euclid_stage1": 1, "cell_order": 1,
-                "pretier": -1, "spec_auto": 1, "audit": 1024}
+                "pretier": -1, "pretier_band": 0, "spec_auto": 1, "audit": 1024}
     try:
         for name, value in opts.items():
             engine.set_option(name, value)
