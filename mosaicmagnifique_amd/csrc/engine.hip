@@ -127,7 +127,7 @@ struct mm_engine {
     int xcd_cells = 0;           // mm_set_option("xcd_cells", n): cells per sub-group of an XCD's share (0 = default)
     bool any_clipped = false;        // the cells of the call in flight: does any of them carry a bound short of the whole cell? (check_cells)
     bool long_items_first = true;    // mm_set_option("cell_order", 0 / 1): filter_kernel takes the clipped cells of each XCD's share first
-    int probe_prepared = 0;      // mm_set_option("probe_prepared", 0 / 1 / 2): mm_filter_diff_batch measures the prepared-operand form of the CIEDE2000 filter (1) or the packed-fp16 pre-tier's form (2)
+    int probe_prepared = 0;      // mm_set_option("probe_prepared", 0 / 1 / 2): mm_filter_diff_batch measures the prepared-operand form of the CIEDE2000 filter (1) or the packed-fp16 pre-tier's form (2); 3: mm_colour_diff_batch measures the algebraic fp64 form of the parallel sums
     int check_every = 0;         // mm_set_option("check_every", n): groups between two exit tests of a candidate (0 = by cell size)
     int item_chunk = 0;          // mm_set_option("item_chunk", n): work items per global atomic of the filter's persistent workgroups (0 = by launch size)
     size_t batch_per_cell = 0;   // workspace bytes per cell the batch capacity below was computed for
@@ -2586,7 +2586,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "interleave") == 0) { e->use_interleave = value != 0; return MM_OK; }
     if (strcmp(name, "xcd_aware") == 0) { e->xcd_aware = value != 0; return MM_OK; }
     if (strcmp(name, "cell_order") == 0) { e->long_items_first = value != 0; return MM_OK; }
-    if (strcmp(name, "probe_prepared") == 0) { e->probe_prepared = value == 2 ? 2 : value != 0; return MM_OK; }
+    if (strcmp(name, "probe_prepared") == 0) { e->probe_prepared = value == 2 || value == 3 ? value : value != 0; return MM_OK; }
     if (strcmp(name, "check_every") == 0) { e->check_every = std::min(64, std::max(0, value)); return MM_OK; }
     if (strcmp(name, "item_chunk") == 0) { e->item_chunk = std::max(0, value); return MM_OK; }
     if (strcmp(name, "xcd_cells") == 0) { e->xcd_cells = std::max(0, value); return MM_OK; }
@@ -2646,8 +2646,12 @@ mm_status mm_colour_diff_batch(mm_engine* e, int diff_type, const float* first, 
     if (code == hipSuccess) {
         const int blocks = (int)std::min<size_t>((n + mm::kBlock - 1) / mm::kBlock, 8192);
         by_type(diff_type, [&](auto T) {
-            mm::pair_diff_kernel<decltype(T)::value><<<blocks, mm::kBlock, 0, e->stream>>>(
-                (const float*)a.p, (const float*)b.p, n, (double*)o.p);
+            if (e->probe_prepared == 3)        // diagnostics: the parallel sums' algebraic form, to be measured against the reference form
+                mm::pair_diff_kernel<decltype(T)::value, true><<<blocks, mm::kBlock, 0, e->stream>>>(
+                    (const float*)a.p, (const float*)b.p, n, (double*)o.p);
+            else
+                mm::pair_diff_kernel<decltype(T)::value, false><<<blocks, mm::kBlock, 0, e->stream>>>(
+                    (const float*)a.p, (const float*)b.p, n, (double*)o.p);
             return MM_OK;
         });
         code = hipGetLastError();

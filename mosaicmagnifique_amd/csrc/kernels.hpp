@@ -559,10 +559,10 @@ score_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmask,
             if (m == 0) continue;
             const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
             const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
-            if (m & 0x000000ffu) acc += colour_diff<TYPE>(Px{p0.x, p1.x, p2.x}, Px{q0.x, q1.x, q2.x});
-            if (m & 0x0000ff00u) acc += colour_diff<TYPE>(Px{p0.y, p1.y, p2.y}, Px{q0.y, q1.y, q2.y});
-            if (m & 0x00ff0000u) acc += colour_diff<TYPE>(Px{p0.z, p1.z, p2.z}, Px{q0.z, q1.z, q2.z});
-            if (m & 0xff000000u) acc += colour_diff<TYPE>(Px{p0.w, p1.w, p2.w}, Px{q0.w, q1.w, q2.w});
+            if (m & 0x000000ffu) acc += parallel_term<TYPE>(Px{p0.x, p1.x, p2.x}, Px{q0.x, q1.x, q2.x});
+            if (m & 0x0000ff00u) acc += parallel_term<TYPE>(Px{p0.y, p1.y, p2.y}, Px{q0.y, q1.y, q2.y});
+            if (m & 0x00ff0000u) acc += parallel_term<TYPE>(Px{p0.z, p1.z, p2.z}, Px{q0.z, q1.z, q2.z});
+            if (m & 0xff000000u) acc += parallel_term<TYPE>(Px{p0.w, p1.w, p2.w}, Px{q0.w, q1.w, q2.w});
         }
         acc = wave_sum(acc);
         if (lane == 0) scores[(size_t)cell * L + l] = acc;
@@ -696,7 +696,7 @@ tiny_cells_kernel(const mm_cell* __restrict__ recs, int n_cells, const float* __
             const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v2), k));
             if (l < L) {
                 const float* q = lt + (size_t)k * 3 * L + l;
-                acc += colour_diff<TYPE>(Px{c0, c1, c2}, Px{q[0], q[L], q[2 * (size_t)L]});
+                acc += parallel_term<TYPE>(Px{c0, c1, c2}, Px{q[0], q[L], q[2 * (size_t)L]});
             }
         }
         if (l < L) row_scores[l] = acc;
@@ -880,10 +880,10 @@ rescore_kernel(const float* __restrict__ cells, const uint8_t* __restrict__ cmas
         if (m == 0) continue;
         const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
         const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
-        if (m & 0x000000ffu) acc += colour_diff<TYPE>(Px{p0.x, p1.x, p2.x}, Px{q0.x, q1.x, q2.x});
-        if (m & 0x0000ff00u) acc += colour_diff<TYPE>(Px{p0.y, p1.y, p2.y}, Px{q0.y, q1.y, q2.y});
-        if (m & 0x00ff0000u) acc += colour_diff<TYPE>(Px{p0.z, p1.z, p2.z}, Px{q0.z, q1.z, q2.z});
-        if (m & 0xff000000u) acc += colour_diff<TYPE>(Px{p0.w, p1.w, p2.w}, Px{q0.w, q1.w, q2.w});
+        if (m & 0x000000ffu) acc += parallel_term<TYPE>(Px{p0.x, p1.x, p2.x}, Px{q0.x, q1.x, q2.x});
+        if (m & 0x0000ff00u) acc += parallel_term<TYPE>(Px{p0.y, p1.y, p2.y}, Px{q0.y, q1.y, q2.y});
+        if (m & 0x00ff0000u) acc += parallel_term<TYPE>(Px{p0.z, p1.z, p2.z}, Px{q0.z, q1.z, q2.z});
+        if (m & 0xff000000u) acc += parallel_term<TYPE>(Px{p0.w, p1.w, p2.w}, Px{q0.w, q1.w, q2.w});
     }
     acc = wave_sum(acc);
     if (lane == 0) cont_score[w] = acc;
@@ -1113,10 +1113,10 @@ rank_kernel(const float* __restrict__ fscores, const float* __restrict__ cells, 
                 if (m == 0) continue;
                 const float4 p0 = c0[q], p1 = c1[q], p2 = c2[q];
                 const float4 q0 = b0[q], q1 = b1[q], q2 = b2[q];
-                if (m & 0x000000ffu) acc += colour_diff<TYPE>(Px{p0.x, p1.x, p2.x}, Px{q0.x, q1.x, q2.x});
-                if (m & 0x0000ff00u) acc += colour_diff<TYPE>(Px{p0.y, p1.y, p2.y}, Px{q0.y, q1.y, q2.y});
-                if (m & 0x00ff0000u) acc += colour_diff<TYPE>(Px{p0.z, p1.z, p2.z}, Px{q0.z, q1.z, q2.z});
-                if (m & 0xff000000u) acc += colour_diff<TYPE>(Px{p0.w, p1.w, p2.w}, Px{q0.w, q1.w, q2.w});
+                if (m & 0x000000ffu) acc += parallel_term<TYPE>(Px{p0.x, p1.x, p2.x}, Px{q0.x, q1.x, q2.x});
+                if (m & 0x0000ff00u) acc += parallel_term<TYPE>(Px{p0.y, p1.y, p2.y}, Px{q0.y, q1.y, q2.y});
+                if (m & 0x00ff0000u) acc += parallel_term<TYPE>(Px{p0.z, p1.z, p2.z}, Px{q0.z, q1.z, q2.z});
+                if (m & 0xff000000u) acc += parallel_term<TYPE>(Px{p0.w, p1.w, p2.w}, Px{q0.w, q1.w, q2.w});
             }
             acc = wave_sum(acc);
             if (lane == 0) cs[t] = acc;
@@ -1355,8 +1355,8 @@ __device__ void dense_row(const ResolveArgs& a, const mm_cell& rec, double* row,
                 float src[3];
                 cell_pixel(a.target, a.rows, a.cols, rec.y, rec.x, r, c, a.cell_scale, src);
                 const int k = ip[p];
-                acc += colour_diff<TYPE>(Px{src[0], src[1], src[2]},
-                                         Px{l0[k], l0[a.ppad + k], l0[2 * (size_t)a.ppad + k]});
+                acc += parallel_term<TYPE>(Px{src[0], src[1], src[2]},
+                                            Px{l0[k], l0[a.ppad + k], l0[2 * (size_t)a.ppad + k]});
             }
         }
         acc = wave_sum(acc);
@@ -2182,7 +2182,9 @@ value_range_kernel(const float* __restrict__ hwc, size_t n_pixels, unsigned int*
 // per-pair batch (KATs, differential tests)
 // ---------------------------------------------------------------------------
 
-template <int TYPE>
+// PARALLEL_FORM: what the parallel-order fp64 sums add per pair (colour_diff.hpp parallel_term: the algebraic form of CIEDE2000)
+// instead of the reference form -- how tests measure one against the other (mm_set_option "probe_prepared" 3).
+template <int TYPE, bool PARALLEL_FORM = false>
 __global__ void __launch_bounds__(kBlock)
 pair_diff_kernel(const float* __restrict__ first, const float* __restrict__ second,
                  size_t n, double* __restrict__ out)
@@ -2191,7 +2193,8 @@ pair_diff_kernel(const float* __restrict__ first, const float* __restrict__ seco
          i += (size_t)gridDim.x * kBlock) {
         const float* p = first + 3 * i;
         const float* q = second + 3 * i;
-        out[i] = colour_diff<TYPE>(Px{p[0], p[1], p[2]}, Px{q[0], q[1], q[2]});
+        out[i] = PARALLEL_FORM ? parallel_term<TYPE>(Px{p[0], p[1], p[2]}, Px{q[0], q[1], q[2]})
+                               : colour_diff<TYPE>(Px{p[0], p[1], p[2]}, Px{q[0], q[1], q[2]});
     }
 }
 

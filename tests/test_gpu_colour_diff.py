@@ -91,3 +91,59 @@ def test_empty_batch_and_bad_type(engine):
     with pytest.raises(EngineError) as err:
         engine.colour_diff_batch(3, np.zeros((1, 3)), np.zeros((1, 3)))     # Type::MAX
     assert err.value.status == 2 and "No function for given type" in str(err.value)
+
+
+def test_the_parallel_sums_algebraic_form_agrees_with_the_reference_form(engine, oracle):
+    """colour_diff.hpp ciede2000_algebraic -- what every PARALLEL-order fp64 sum adds per pair since round 5 (no atan2 / cos per hue,
+    about half the instructions) -- against the reference form on the device and against the oracle, over the families where a
+    restated form could go wrong: uniform in the box, near-identical pairs, identical pairs (exactly 0, as the reference), exact
+    greys on one side and on both, tiny chromas, both sides of the opposite-hue seam and of the h_bar = 0 / 360 wrap (pairs within
+    1e-9 of either discontinuity are handed to the reference form by the algebraic one itself), the quarter turn where its arms
+    change, saturated blue, the colours of u8 images.  What the engine needs is a TOTAL good to well below the 1e-9 inside which
+    candidates are re-summed in the reference's order with the reference's arithmetic: 2e-12 absolute per pair is asserted."""
+    rng = np.random.default_rng(2025)
+    n = 1 << 19
+    lo, hi = np.array([0, -128, -128]), np.array([100, 127, 127])
+    two_pi = 2 * np.pi
+
+    def polar(L, c, h):
+        return np.stack([L, c * np.cos(h), c * np.sin(h)], axis=1)
+    L1, L2 = rng.uniform(0, 100, n), rng.uniform(0, 100, n)
+    h1, c1, c2 = rng.uniform(0, two_pi, n), rng.uniform(0, 150, n), rng.uniform(0.5, 150, n)
+    off = rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-12, -0.5, n)
+    uni = rng.uniform(lo, hi, (n, 3))
+    grey = uni.copy(); grey[:, 1:] = 0
+    from mosaicmagnifique_amd import synth
+    u8a, u8b = rng.integers(0, 256, (n, 1, 3), dtype=np.uint8), rng.integers(0, 256, (n, 1, 3), dtype=np.uint8)
+    families = {
+        "uniform": (uni, rng.uniform(lo, hi, (n, 3))),
+        "near-identical": (uni, uni + rng.normal(0, 1, (n, 3)) * 10.0 ** rng.uniform(-6, 0, (n, 1))),
+        "identical": (uni, uni),
+        "grey first": (grey, rng.uniform(lo, hi, (n, 3))),
+        "grey both": (grey, grey[::-1]),
+        "tiny chroma": (polar(L1, 10.0 ** rng.uniform(-9, -1, n), h1), polar(L2, c2, rng.uniform(0, two_pi, n))),
+        "around the seam": (polar(L1, c1, h1), polar(L2, c2, h1 + np.pi + off)),
+        "around the wrap of the mean hue": (polar(L1, c2, off), polar(L2, c2, -off * rng.uniform(0.5, 1.5, n))),
+        "around the quarter turn": (polar(L1, c1, h1), polar(L2, c2, h1 + np.pi / 2 + off)),
+        "saturated blue": (polar(L1, rng.uniform(40, 150, n), np.radians(275) + rng.normal(0, 0.2, n)),
+                           polar(L2, rng.uniform(40, 150, n), np.radians(275) + rng.normal(0, 0.3, n))),
+        "u8 colours": (synth.bgr_u8_to_lab_f32(u8a).reshape(-1, 3), synth.bgr_u8_to_lab_f32(u8b).reshape(-1, 3)),
+    }
+    worst = {}
+    for name, (a, b) in families.items():
+        a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+        ref = engine.colour_diff_batch(2, a, b)
+        engine.set_option("probe_prepared", 3)
+        try:
+            alg = engine.colour_diff_batch(2, a, b)
+        finally:
+            engine.set_option("probe_prepared", 0)
+        assert np.isfinite(alg).all(), name
+        err = np.abs(alg - ref)
+        worst[name] = float(err.max())
+        assert err.max() <= 2e-12, (name, float(err.max()), a[err.argmax()], b[err.argmax()], float(ref[err.argmax()]))
+        if name == "identical":
+            assert (alg == 0).all() and (ref == 0).all()
+        cpu = oracle.colour_diff_batch(2, a[:4096], b[:4096])
+        assert (np.abs(alg[:4096] - cpu) <= 1e-9 * np.maximum(cpu, 1e-3)).all(), name
+    print("algebraic fp64 form, worst |difference| to the reference form per family:", worst)
