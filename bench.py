@@ -326,7 +326,7 @@ def floor_legs(engine, step, n_cells, value):
         out[key] = {"value": n_cells / dt, "unit": "cells/s", "ms_per_step": dt * 1e3, "steps": len(times),
                     "headline_over_floor": value / (n_cells / dt),
                     "what": "early exit off (option prune=0): every pixel of every candidate through the fp32 filter" if option == "prune"
-                            else "fp64 only (option filter=0): the reference-form arithmetic for every pixel pair, no filter tier"}
+                            else "fp64 only (option filter=0): every pixel pair in fp64 (the algebraic form of the parallel sums), no filter tier"}
     return out
 
 

@@ -367,8 +367,9 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
                             mm_progress_cb progress, void *progress_user, volatile int *cancel);
 
 /* Engine options.  "filter" (default 1): two-tier scoring -- an fp32 filter pass over
- * every (cell, candidate), then the fp64 reference-form score of each cell's
- * contenders only; 0 scores everything in fp64.  "prune" (default 1): the filter pass
+ * every (cell, candidate), then the fp64 score of each cell's contenders only (parallel
+ * order; candidates within 1e-9 of each other are re-summed in the reference's order with the
+ * reference's own arithmetic); 0 scores everything in fp64.  "prune" (default 1): the filter pass
  * abandons a candidate once its running sum passes a per-cell upper bound (the device
  * form of the reference's early exit).  "sweep_resolve" (default 1): the repeat
  * penalty as parallel sweeps to the raster-order fix point ("max_sweeps", default 48, before the
@@ -382,7 +383,8 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "sort_groups" (-1 = by cell size): how many of a candidate's pixel groups are visited by descending bound;
  * "check_every" (0 = by cell size): pixel groups between two exit tests of a candidate;
  * "probe_prepared" (0): mm_filter_diff_batch measures the CIEDE2000 filter form with operands prepared as the dominant kernel holds them
- * (1), or the packed-fp16 pre-tier's form on operands rounded to halfs (2; pairs it counts as 0 near the opposite-hue seam read -1);
+ * (1), or the packed-fp16 pre-tier's form on operands rounded to halfs (2; pairs it counts as 0 -- near the opposite-hue seam, a chroma below
+ * 1 / 16 -- read -1); 3: mm_colour_diff_batch returns the algebraic fp64 form of the parallel-order sums instead of the reference form;
  * "lds_filter" (-1 = RGB only): LDS-resident cell tile; "seeds" (-1 = 14 for CIEDE2000, 2 for RGB / CIE76): proxy-chosen seeds beyond the list length;
  * "spec_auto" (1): the length of the speculative short lists ("spec_k", 4) doubles (up to 16) when the engine's PREVIOUS
  * generate over the same library had to deepen more than 2 % of its cells -- content on which neighbouring cells want the same few

@@ -164,7 +164,8 @@ __device__ __forceinline__ double ciede2000_algebraic(const Px& p, const Px& q, 
     const double norm = rsqrt(fma(hx, hx, hy * hy));
     const double ch = hx * norm, sh = hy * norm;               // cos h_bar, sin h_bar
     // within 1e-9 of a discontinuity the reference form decides (see above)
-    *needs_reference = (!grey && !acute && fabs(cross) <= 1e-9 * e) || (ch > 0.0 && fabs(sh) <= 1e-9 && sh != 0.0);
+    // (a grey has no branch to take: h_bar is the other colour's own hue angle, in both forms)
+    *needs_reference = !grey && ((!acute && fabs(cross) <= 1e-9 * e) || (ch > 0.0 && fabs(sh) <= 1e-9));
     const double cos2 = fma(ch, ch, -(sh * sh)), sin2 = 2.0 * (ch * sh);
     const double cos3 = fma(cos2, ch, -(sin2 * sh)), sin3 = fma(sin2, ch, cos2 * sh);
     const double cos4 = fma(cos2, cos2, -(sin2 * sin2)), sin4 = 2.0 * (sin2 * cos2);

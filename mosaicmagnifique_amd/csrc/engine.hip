@@ -96,6 +96,8 @@ struct mm_engine {
     int spec_auto = 1;           // mm_set_option("spec_auto", 0): the list length no longer follows the share of cells the engine's
                                  // previous generate over the same library had to deepen (below)
     int spec_k_learned = 0, spec_lib = 0, spec_size = 0;     // ... what it learned, and for which library (count, cell size)
+    int sweeps_learned = 0, sweeps_lib = 0, sweeps_size = 0; // sweeps the resolve of the previous generate over this library took to settle (its longest
+                                                             // round): sizes the first set of sweeps of the next one (resolve_single_submission)
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
     // mask variants (launch.hpp Variants): library kept as handed over (HWC) and re-planed
     // per distinct mask in that mask's active-pixels-first order whenever either changes
@@ -1349,8 +1351,15 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
     const int blocks = std::max(1, std::min(n, 8192));
     int sweeps = 0;
     if (sequential) {
-        sweeps = std::min(e->max_sweeps, mm::kFastSweeps);
+        // Sweeps per set: eight at first -- config D settles in four --, as many as the engine's previous generate over this library
+        // needed where that was more (photographs: forty per round, i.e. six sets of eight with a host wait each: config P spent
+        // twelve of its fourteen waits here), and a full block's worth when a set is continued.  A sweep enqueued after the grid
+        // has settled returns at once (prev_changes), so a generous set costs a few microseconds of empty launches.
+        const bool learned = e->sweeps_lib == e->n_lib && e->sweeps_size == e->lib_size && e->sweeps_learned > 8;
+        const int want = continuing ? mm::kFastSweeps : (learned ? std::min(mm::kFastSweeps, (e->sweeps_learned + 2 + 7) / 8 * 8) : 8);
+        sweeps = std::min(e->max_sweeps, want);
         for (int i = 0; i < sweeps; ++i) {
+            a.prev_changes = i > 0 ? &hdr->sweep_changes[i - 1] : nullptr;
             a.sweep_changes = &hdr->sweep_changes[i];
             a.exact_count = &hdr->sweep_exact[i];
             a.insufficient_count = speculate ? &hdr->sweep_insufficient[i] : nullptr;
@@ -1373,7 +1382,12 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
     HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     mm::ResultHeader* h = (mm::ResultHeader*)e->pinned;
     h->sweeps = (unsigned int)sweeps;
-    if (sequential && sweeps > 0) h->n_insufficient = h->sweep_insufficient[sweeps - 1];     // the final state's verdicts
+    if (sequential && sweeps > 0) {       // the final state's verdicts: those of the sweep that changed nothing (the ones after it did not run), else the last one's
+        int last = sweeps - 1;
+        for (int i = 0; i < sweeps; ++i)
+            if (h->sweep_changes[i] == 0) { last = i; break; }
+        h->n_insufficient = h->sweep_insufficient[last];
+    }
     h->edge_pairs = h->filter_counters[0];
     h->launch_void = h->filter_counters[mm::kFilterVoidWord];
     memcpy(h->work, h->filter_counters + 2, sizeof h->work);
@@ -2197,6 +2211,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
         if (resolved_ok) {
             if (e->phase_events) e->timing.resolve_ms += elapsed(e->ev[10], e->ev[11]);
             e->timing.resolve_sweeps += sequential ? sweeps_before + settled + 1 : 0;
+            if (sequential) { e->sweeps_learned = sweeps_before + settled + 1; e->sweeps_lib = e->n_lib; e->sweeps_size = e->lib_size; }
             e->timing.exact_rescored += (int64_t)(sequential ? h.sweep_exact[settled] : h.exact_plain);
             e->timing.dense_rows += (int64_t)h.dense_count;
             const char* body = (const char*)e->pinned + sizeof(mm::ResultHeader);
@@ -2250,6 +2265,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
                 if (h.n_marked == 0 && (!sequential || settled >= 0)) {
                     if (e->phase_events) e->timing.resolve_ms += elapsed(e->ev[10], e->ev[11]);
                     e->timing.resolve_sweeps += sequential ? sweeps_before + settled + 1 : 0;
+                    if (sequential) { e->sweeps_learned = sweeps_before + settled + 1; e->sweeps_lib = e->n_lib; e->sweeps_size = e->lib_size; }
                     e->timing.exact_rescored += (int64_t)(sequential ? h.sweep_exact[settled] : h.exact_plain);
                     e->timing.dense_rows += (int64_t)h.dense_count;
                     const char* body = (const char*)e->pinned + sizeof(mm::ResultHeader);

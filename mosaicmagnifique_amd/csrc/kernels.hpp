@@ -984,7 +984,7 @@ rerank_kernel(const int32_t* __restrict__ cont_index, const float* __restrict__ 
 // comes back in the SAME copy as the best-fit grid and the scores that follow it in memory.  All zero (and
 // one sweep without a change) = the result is final; anything else sends the call down the step-by-step
 // path, which recomputes what the header says cannot be trusted.
-constexpr int kFastSweeps = 8;
+constexpr int kFastSweeps = 32;         // sweeps a result block has counters for (a set enqueued at once; the first set of a call is 8 unless the engine learned otherwise)
 struct ResultHeader {
     unsigned int n_flagged;              // cells with a filter flag (overflow, canary, band alarm)
     unsigned int n_band_alarm;           // ... of which band alarms
@@ -1256,6 +1256,7 @@ struct ResolveArgs {
     const double* dense_rows;   // [marked][L]
     // sweep resolve (resolve_wave_kernel mode 2): picks changed by this sweep
     unsigned int* sweep_changes;
+    const unsigned int* prev_changes;   // (may be null) the counter of the sweep enqueued just before this one: 0 = the grid had settled, nothing to do
     unsigned int* insufficient_count;   // (may be null) unverified speculative picks of this launch, counted
 };
 
@@ -1538,6 +1539,9 @@ resolve_wave_kernel(ResolveArgs a, int sequential)
     const bool penalise = sequential && a.repeat_range > 0 && a.repeat_addition != 0;
     const int R = a.repeat_range, ring_rows = R + 1, gw = a.grid_w;
     const int sentinel = a.L;
+    // A set of sweeps is enqueued without asking the host in between: once a sweep has changed nothing the grid is at its fix point
+    // and the rest of the set returns at once (their own counters stay 0, as the block was initialised)
+    if (sweep && a.prev_changes != nullptr && *a.prev_changes == 0u) return;
     if (sweep) sequential = 0;                 // cells are taken independently
     if (penalise && !sweep) {
         for (int i = lane; i < ring_rows * gw; i += kWave) ring[i] = sentinel;

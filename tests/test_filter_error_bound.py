@@ -90,3 +90,16 @@ def test_pairs_the_pretier_does_not_judge_count_zero(pairs):
     assert seam.all() and (need <= 0).all()
     p, q = pairs["contender-like"]
     assert feb.evaluate(p, q, "pretier")[4].mean() < 0.01
+
+
+def test_euclidean_filter_band_holds_the_worst_case_bound():
+    """RGB / CIE76: three differences, a sum of squares, one root -- the bound is a few ulp of the value, a fifth of the 5e-4 the engine trusts
+    (engine.hip filter_band) at the largest value the validated box allows (|channel| <= 256: 887)."""
+    rng = np.random.default_rng(3)
+    p = rng.uniform(-256, 256, (200000, 3)).astype(np.float32).astype(np.float64)
+    q = rng.uniform(-256, 256, (200000, 3)).astype(np.float32).astype(np.float64)
+    p[:1000], q[:1000] = 256.0, -256.0                      # the corner of the box
+    v, e = feb.euclid_bound(p, q)
+    assert np.abs(v - np.sqrt(((p - q) ** 2).sum(-1))).max() < 1e-9
+    print("Euclidean filter form: worst-case bound %.3g at a value of %.1f (band 5e-4)" % (e.max(), v[e.argmax()]))
+    assert e.max() <= 0.5 * 5e-4

@@ -465,6 +465,19 @@ def filter_bound(p, q):
         set_precision("half")
 
 
+def euclid_bound(p, q):
+    """euclidean_fast (RGB / CIE76 filter form): sqrt(fma(d0, d0, fma(d1, d1, d2 d2))), d_i = p_i - q_i in fp32.
+    Returns (value in exact arithmetic, carried error bound); the engine trusts it with 5e-4 absolute per pixel pair."""
+    set_precision("single")
+    try:
+        d = [sub(EV(p[..., i]), EV(q[..., i])) for i in range(3)]
+        m = add(mul(d[0], d[0]), add(mul(d[1], d[1]), mul(d[2], d[2])))
+        v = monotone(m, np.sqrt)
+        return v.v, v.e
+    finally:
+        set_precision("half")
+
+
 # --------------------------------------------------------------------------- input families
 def lab_of_u8(bgr):
     """synth.py's sRGB -> Lab (D65), the conversion the engine's u8 setters specify; float32-valued."""

@@ -11,7 +11,7 @@ mkdir -p $O
 for c in ${CONFIGS:-D C B E8 E A F G H I P}; do
   P=$O/pmc_$c
   mkdir -p $P
-  CMD="python3 bench.py --config $c --steps 1 --warmup 2 --no-cpu"      # (two warm-up steps: a large job measures the fp16 pre-tier over its first two launches; the counted one runs the form it kept)
+  CMD="python3 bench.py --config $c --steps 1 --warmup 3 --no-cpu"      # (three warm-up steps: a job eligible for the fp16 pre-tier spends a warm-up launch and one launch each way on measuring it; the counted one runs the form it kept)
   rocprofv3 --pmc FETCH_SIZE -d $P/fetch -o p --output-format csv -- $CMD > $P/fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -d $P/write -o p --output-format csv -- $CMD > $P/write.log 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE -d $P/sq -o p --output-format csv -- $CMD > $P/bench_sq.json 2> $P/sq.log
