@@ -780,7 +780,7 @@ def main():
     visited_per_launch = visited / max(launches * launches_scale, 1)
     pairs_alg = total_pa * w["L"] / launches_per_step
     ciede = t == 2 and engine_uses_filter
-    pretier_on = ciede and bool(tm.get("pretier"))       # (the engine measures on its first two launches whether the pre-tier pays on this content)
+    pretier_on = ciede and bool(tm.get("pretier"))       # (cells above 32 groups: the engine measures whether the packed-fp16 pre-tier pays on this content)
 
     pmc, pmc_src = pmc_record(w, args.opt, tm.get("filter_tile")) if world == 1 else (None, "PMC records are single-GPU")
     roof = {

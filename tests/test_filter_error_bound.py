@@ -103,3 +103,17 @@ def test_euclidean_filter_band_holds_the_worst_case_bound():
     assert np.abs(v - np.sqrt(((p - q) ** 2).sum(-1))).max() < 1e-9
     print("Euclidean filter form: worst-case bound %.3g at a value of %.1f (band 5e-4)" % (e.max(), v[e.argmax()]))
     assert e.max() <= 0.5 * 5e-4
+
+
+def test_algebraic_fp64_form_of_the_parallel_sums_is_good_to_a_few_1e_12(pairs):
+    """colour_diff.hpp ciede2000_algebraic (what every parallel-order fp64 sum adds per pair since round 5) against CIEDE2000 in long
+    double, every fp64 rounding and every library call (two ulp) at its worst: at most 2e-12 absolute per pair -- a cell's total is then
+    good to 1e-13 relative, four orders inside the 1e-9 within which candidates are re-summed in the reference's order with the
+    reference's own arithmetic (engine.hip kTieBand)."""
+    worst = 0.0
+    for name, (p, q) in pairs.items():
+        true, _, _, need, handed = feb.evaluate(p[:20000], q[:20000], "algebraic")
+        assert np.isfinite(need).all(), name
+        worst = max(worst, float(need.max()))
+        assert need.max() <= 2e-12, (name, float(need.max()))
+    print("algebraic fp64 form: worst-case bound %.3g per pair" % worst)

@@ -39,11 +39,18 @@ HMAX = 65504.0
 def set_precision(kind):
     """'half': the packed-fp16 pre-tier (the defaults above); 'single': the fp32 filter form -- u = 2^-24, v_rsq / v_rcp / v_sqrt_f32
     one ulp, denormals flushed (what lies below 2^-126 counts as an error of its own size, at most 2^-126)."""
-    global U, ULP, ETA, TINY, HMAX
+    global U, ULP, ETA, TINY, HMAX, DT
+    DT = np.float64
     if kind == "half":
         U, ULP, ETA, TINY, HMAX = 2.0 ** -11, 2.0 ** -10, 2.0 ** -25, 2.0 ** -14, 65504.0
-    else:
+    elif kind == "single":
         U, ULP, ETA, TINY, HMAX = 2.0 ** -24, 2.0 ** -23, 2.0 ** -126, 2.0 ** -126, 3.0e38
+    else:       # 'double': the algebraic fp64 form of the parallel sums; the "exact" values are then carried in long double (64-bit mantissa)
+        U, ULP, ETA, TINY, HMAX = 2.0 ** -53, 2.0 ** -52, 0.0, 0.0, 1.0e300
+        DT = np.longdouble
+
+
+DT = np.float64
 N_LUT = 2048
 TINY_CHROMA = 2.0 ** -6   # in the stored units (C / 4): a chroma of 1 / 16
 
@@ -128,8 +135,8 @@ class EV:
     __slots__ = ("v", "e")
 
     def __init__(self, v, e=None):
-        self.v = np.asarray(v, dtype=np.float64)
-        self.e = np.zeros_like(self.v) if e is None else np.asarray(e, dtype=np.float64)
+        self.v = np.asarray(v, dtype=DT)
+        self.e = np.zeros_like(self.v) if e is None else np.asarray(e, dtype=DT)
 
     def mag(self):
         return np.abs(self.v) + self.e
@@ -145,8 +152,8 @@ def rounded(v, e, rel=None):
 
 def const(c):
     """A constant of the source as the half (float) the compiler stores."""
-    h = float(np.float16(c)) if U > 1e-5 else float(np.float32(c))
-    return EV(np.float64(c), abs(h - c))
+    h = float(np.float16(c)) if U > 1e-5 else (float(np.float32(c)) if U > 1e-10 else float(c))
+    return EV(c, abs(h - c))
 
 
 def add(a, b, sign=1.0):
@@ -438,6 +445,156 @@ def filter_form_given_g(one_g, pl, pa, pb, pc, ql, qa, qb, qc, force_obtuse=None
     return v.v, v.e, handed_over, np.abs(dot.v) <= dot.e
 
 
+# --------------------------------------------------------------------------- the algebraic fp64 form (colour_diff.hpp ciede2000_algebraic)
+def ciede2000_ref_ld(p, q):
+    """CIEDE2000 in long double: the yardstick of the fp64 form (float64 itself is what is being measured there)."""
+    ld = np.longdouble
+    p, q = p.astype(ld), q.astype(ld)
+    pi = ld("3.14159265358979323846264338327950288")
+    L1, a1, b1 = p[..., 0], p[..., 1], p[..., 2]
+    L2, a2, b2 = q[..., 0], q[..., 1], q[..., 2]
+    k25 = ld(25) ** 7
+    c1, c2 = np.sqrt(a1 * a1 + b1 * b1), np.sqrt(a2 * a2 + b2 * b2)
+    cb = (c1 + c2) / 2
+    cb7 = cb ** 7
+    g = (1 - np.sqrt(cb7 / (cb7 + k25))) / 2
+    a1p, a2p = (1 + g) * a1, (1 + g) * a2
+    c1p, c2p = np.sqrt(a1p * a1p + b1 * b1), np.sqrt(a2p * a2p + b2 * b2)
+
+    def hue(b, ap):
+        h = np.arctan2(b, ap)
+        h = np.where(h < 0, h + 2 * pi, h)
+        return np.where((b == 0) & (ap == 0), ld(0), h)
+    h1, h2 = hue(b1, a1p), hue(b2, a2p)
+    dl, dc = L2 - L1, c2p - c1p
+    dh = h2 - h1
+    zero = (c1p * c2p) == 0
+    dh = np.where(zero, ld(0), np.where(dh > pi, dh - 2 * pi, np.where(dh < -pi, dh + 2 * pi, dh)))
+    dH = 2 * np.sqrt(c1p * c2p) * np.sin(dh / 2)
+    lb, cbp = (L1 + L2) / 2, (c1p + c2p) / 2
+    hs = h1 + h2
+    hb = np.where(zero, hs, np.where(np.abs(h1 - h2) <= pi, hs / 2, np.where(hs < 2 * pi, (hs + 2 * pi) / 2, (hs - 2 * pi) / 2)))
+    rad = lambda d: ld(d) * pi / 180
+    T = 1 - ld("0.17") * np.cos(hb - rad(30)) + ld("0.24") * np.cos(2 * hb) + ld("0.32") * np.cos(3 * hb + rad(6)) - ld("0.20") * np.cos(4 * hb - rad(63))
+    dth = rad(30) * np.exp(-(((hb - rad(275)) / rad(25)) ** 2))
+    cbp7 = cbp ** 7
+    rc = 2 * np.sqrt(cbp7 / (cbp7 + k25))
+    sl = 1 + ld("0.015") * (lb - 50) ** 2 / np.sqrt(20 + (lb - 50) ** 2)
+    sc = 1 + ld("0.045") * cbp
+    sh = 1 + ld("0.015") * cbp * T
+    rt = -np.sin(2 * dth) * rc
+    tl, tc, th = dl / sl, dc / sc, dH / sh
+    return np.sqrt(np.maximum(tl * tl + tc * tc + th * th + rt * tc * th, 0))
+
+
+def ratio7_double(c_bar):
+    """x rsqrt(x (x + 25^7) + 1e-300), x = c_bar^7: an increasing function of the computed x."""
+    c2 = mul(c_bar, c_bar)
+    x = mul(mul(c2, c2), mul(c2, c_bar))
+    k = DT(25) ** 7
+
+    def f(t):
+        t = np.maximum(t, 0)
+        return t / np.sqrt(t * (t + k) + DT(1e-300))
+    fv = f(x.v)
+    prop = np.maximum(np.abs(f(x.v - x.e) - fv), np.abs(f(x.v + x.e) - fv))
+    return EV(fv, prop + (1.5 * U + ULP + U) * fv)
+
+
+def algebraic_form_given_g(one_g, L1, a1, b1, L2, a2, b2, force_obtuse=None):
+    """ciede2000_algebraic from one_g on.  Every library call is charged two ulp (ocml's documented bounds: sqrt and division are
+    correctly rounded, rsqrt / exp one ulp, atan2 two)."""
+    a1p, a2p = mul(one_g, a1), mul(one_g, a2)
+    c1p = monotone(add(mul(a1p, a1p), mul(b1, b1)), np.sqrt)
+    c2p = monotone(add(mul(a2p, a2p), mul(b2, b2)), np.sqrt)
+    prod = mul(c1p, c2p)
+    dot = add(mul(a1p, a2p), mul(b1, b2))
+    cross = sub(mul(a1p, b2), mul(b1, a2p))
+    grey = ~(prod.v > 0)
+    e = add(prod, absval(dot))
+    handed_over = ~grey & (dot.v < 0) & (np.abs(cross.v) <= 1e-9 * e.v)
+    safe_e = EV(np.where(grey, DT(1), e.v), np.where(grey, DT(0), e.e))
+    r = monotone(scale_pow2(safe_e, 0.5), lambda x: 1 / np.sqrt(x), floor=DT(1e-300))
+    sign_cross = np.where(cross.v < 0, DT(-1), DT(1))
+    obtuse = (dot.v < 0) if force_obtuse is None else np.full(dot.v.shape, bool(force_obtuse))
+    d_acute = mul(cross, r)
+    root = monotone(scale_pow2(safe_e, 2.0), np.sqrt, rel=ULP + U)
+    d_obtuse = EV(sign_cross * root.v, np.where(np.abs(cross.v) <= cross.e, 2 * root.mag(), root.e))
+    d_h = pick(obtuse, d_obtuse, d_acute)
+    d_h = EV(np.where(grey, DT(0), d_h.v), np.where(grey, DT(0), d_h.e))
+    c2s = pick(obtuse, neg(c2p), c2p)
+    wx = add(mul(a2p, c1p), mul(a1p, c2s))
+    wy = add(mul(b2, c1p), mul(b1, c2s))
+    hx = pick(obtuse, EV(sign_cross * wy.v, wy.e), wx)
+    hy = pick(obtuse, EV(-sign_cross * wx.v, wx.e), wy)
+    first_grey = ~(c1p.v > 0)
+    hx = EV(np.where(grey, np.where(first_grey, a2p.v, a1p.v), hx.v), np.where(grey, np.where(first_grey, a2p.e, a1p.e), hx.e))
+    hy = EV(np.where(grey, np.where(first_grey, b2.v, b1.v), hy.v), np.where(grey, np.where(first_grey, b2.e, b1.e), hy.e))
+    both = ~(c1p.v > 0) & ~(c2p.v > 0)
+    hx = EV(np.where(both, DT(1), hx.v), np.where(both, DT(0), hx.e))
+    hy = EV(np.where(both, DT(0), hy.v), np.where(both, DT(0), hy.e))
+    # the mean-hue direction as an angle and its error (the normalisation cancels a common factor of hx, hy exactly)
+    n2 = hx.v * hx.v + hy.v * hy.v
+    room = np.sqrt(n2) - hx.e - hy.e
+    with np.errstate(divide="ignore", invalid="ignore"):
+        d_ang = np.where(room > 0, (np.abs(hy.v) * hx.e + np.abs(hx.v) * hy.e) / (room * room), np.inf) + 4 * U
+    theta = np.arctan2(hy.v, hx.v)
+    ch, sh = np.cos(theta), np.sin(theta)
+    handed_over = handed_over | (~grey & (ch > 0) & (np.abs(sh) <= 1e-9))
+    rad = lambda d: DT(d) * DT(np.pi) / 180
+    t_exact = (1 - DT("0.17") * np.cos(theta - rad(30)) + DT("0.24") * np.cos(2 * theta) + DT("0.32") * np.cos(3 * theta + rad(6))
+               - DT("0.20") * np.cos(4 * theta - rad(63)))
+    t = EV(t_exact, np.minimum(DT("2.41") * d_ang, DT(3)) + 24 * U)       # the multiple-angle identities: ~20 operations on values <= 1
+    h_bar = np.where(theta < 0, theta + 2 * DT(np.pi), theta)
+    z = (h_bar - rad(275)) / rad(25)
+    ez = np.exp(-(z * z))
+    e_z = np.minimum(2 * np.abs(z) * ez / rad(25) * (d_ang + 4 * U * 7), DT(1)) + 4 * U * (1 + z * z) * ez     # atan2 two ulp of <= 2 pi; exp one ulp, its operand's rounding
+    x2 = 2 * rad(30) * ez
+    sn = EV(np.sin(x2), 2 * rad(30) * e_z + 12 * U)          # the Taylor polynomial: 2e-17 truncation, nine fmas
+    cp_bar = scale_pow2(add(c1p, c2p), 0.5)
+    r_t = neg(mul(sn, scale_pow2(ratio7_double(cp_bar), 2.0)))
+    l_off = sub(scale_pow2(add(L1, L2), 0.5), EV(50.0))
+    l2 = mul(l_off, l_off)
+    s_l = add(EV(1.0), mul(mul(const(0.015), l2), monotone(add(EV(20.0), l2), lambda x: 1 / np.sqrt(x), floor=DT(1))))
+    s_c = add(mul(const(0.045), cp_bar), EV(1.0))
+    s_h = add(mul(mul(const(0.015), cp_bar), t), EV(1.0))
+    d_l, d_c = sub(L2, L1), sub(c2p, c1p)
+
+    def quotient(num, den, rel, floor):
+        lo = np.maximum(den.v - den.e, floor)
+        val = num.v / den.v
+        err = num.e / lo + np.abs(num.v) * den.e / (lo * den.v)
+        return EV(val, err + rel * (np.abs(val) + err))
+    # one division for the three terms: the factors that appear on both sides cancel on the device as in exact arithmetic
+    t_l = quotient(d_l, s_l, 6 * U, 1 - 2 * U)
+    t_c = quotient(d_c, s_c, 6 * U, 1 - 2 * U)
+    t_h = quotient(d_h, s_h, 6 * U, 1 - 2 * U)
+    first = (np.abs(2 * t_l.v) * t_l.e + np.abs(2 * t_c.v + r_t.v * t_h.v) * t_c.e + np.abs(2 * t_h.v + r_t.v * t_c.v) * t_h.e +
+             np.abs(t_c.v * t_h.v) * r_t.e)
+    second = (t_l.e ** 2 + t_c.e ** 2 + t_h.e ** 2 + np.abs(r_t.v) * t_c.e * t_h.e +
+              r_t.e * (np.abs(t_c.v) * t_h.e + np.abs(t_h.v) * t_c.e + t_c.e * t_h.e))
+    terms = t_l.v ** 2 + t_c.v ** 2 + t_h.v ** 2 + np.abs(r_t.v * t_c.v * t_h.v)
+    xx_v = np.maximum(t_l.v ** 2 + t_c.v ** 2 + t_h.v ** 2 + r_t.v * t_c.v * t_h.v, 0)
+    xx = EV(xx_v, first + second + 5 * U * (terms + first + second))
+    v = monotone(xx, np.sqrt, rel=U)
+    return v.v, v.e, handed_over, ~grey & (np.abs(dot.v) <= dot.e)
+
+
+def algebraic_bound(p, q):
+    """The algebraic fp64 form on the pair: (value in long double, carried error bound, pairs handed to the reference form)."""
+    set_precision("double")
+    try:
+        L1, a1, b1 = (EV(p[..., i]) for i in range(3))
+        L2, a2, b2 = (EV(q[..., i]) for i in range(3))
+        c1 = monotone(add(mul(a1, a1), mul(b1, b1)), np.sqrt, rel=U)
+        c2 = monotone(add(mul(a2, a2), mul(b2, b2)), np.sqrt, rel=U)
+        one_g = sub(EV(1.5), scale_pow2(ratio7_double(scale_pow2(add(c1, c2), 0.5)), 0.5))
+        v, e, handed, = bound_of(algebraic_form_given_g, one_g, (L1, a1, b1, L2, a2, b2))
+        return v.astype(np.float64), e.astype(np.float64), handed
+    finally:
+        set_precision("half")
+
+
 def bound_of(form, one_g, args):
     """The form at the middle and both ends of one_g's interval, and on either arm where dot's sign is within its error."""
     v0, e0, seam, _ = form(EV(one_g.v), *args)
@@ -538,6 +695,11 @@ def evaluate(p, q, form="pretier"):
     """Per pair: true value, centre - true, the carried bound, the bound on what the band must hold, pairs not judged.
     pretier: the OVER-estimate (v - true) + eps (an under-estimate only delays an exit; a seam pair counts 0);
     filter: |v - true| + eps (the contender selection trusts the band on both sides; seam pairs go to the fp64 form)."""
+    if form == "algebraic":
+        true = ciede2000_ref_ld(p, q)
+        v, e, seam = algebraic_bound(p, q)
+        need = np.where(seam, 0.0, np.abs(v - true.astype(np.float64)) + e)        # (centre and yardstick are long doubles: their difference is the method error)
+        return true.astype(np.float64), v - true.astype(np.float64), e, need, seam
     true = ciede2000_ref(p, q)
     if form == "pretier":
         v, e, seam = pretier_bound(p, q)
@@ -558,12 +720,12 @@ def frontier(true, need, abs_parts):
 
 
 # what the engine ships: filter.hip kPreAbs / kPreRel, engine.hip filter_band (per pixel pair)
-BANDS = {"pretier": (0.45, 3.8e-2), "filter": (1e-3, 6e-5)}
+BANDS = {"pretier": (0.45, 3.8e-2), "filter": (1e-3, 6e-5), "algebraic": (2e-12, 0.0)}
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--form", choices=("pretier", "filter"), default="pretier")
+    ap.add_argument("--form", choices=("pretier", "filter", "algebraic"), default="pretier")
     ap.add_argument("--pairs", type=int, default=400000)
     ap.add_argument("--abs", type=float, default=None)
     ap.add_argument("--rel", type=float, default=None)
@@ -584,7 +746,8 @@ def main():
         all_need.append(need)
     true, need = np.concatenate(all_true), np.concatenate(all_need)
     print("frontier (abs -> smallest rel that holds every pair):")
-    parts = (0.25, 0.3, 0.35, 0.4, 0.45, 0.5, 0.6, 0.8, 1.0) if args.form == "pretier" else (5e-5, 1e-4, 2e-4, 3e-4, 5e-4, 1e-3)
+    parts = {"pretier": (0.25, 0.3, 0.35, 0.4, 0.45, 0.5, 0.6, 0.8, 1.0), "filter": (5e-5, 1e-4, 2e-4, 3e-4, 5e-4, 1e-3),
+             "algebraic": (1e-14, 1e-13, 5e-13, 1e-12)}[args.form]
     for a, r in frontier(true, need, parts):
         print("   %.3g + %.3g v" % (a, r))
 
