@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 passes of tools/profile.sh (all of the SAME command,
-`python3 bench.py --config X --steps 1 --warmup 2 --no-cpu` (warm-up steps first: the item size of a CIEDE2000
+`python3 bench.py --config X --steps 1 --warmup 3 --no-cpu` (warm-up steps first: the item size of a CIEDE2000
 launch can follow the engine's previous launch, so the counted launches are steady-state ones), separate runs as the MI355X guide
 prescribes: --pmc FETCH_SIZE, --pmc WRITE_SIZE, --pmc SQ_*) into the per-launch record of the
 dominant kernel that bench.py prices its roofline with (profiles/pmc_traffic.json).
@@ -74,7 +74,7 @@ def main():
         "WRITE_SIZE_KiB_per_launch": wv / wn,
         "fetch_correction": 2.0,
         "traffic_bytes_per_launch": (2.0 * fv / fn + wv / wn) * 1024.0,
-        "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> -- python3 bench.py --config %s --steps 1 --warmup 2 --no-cpu %s" % (
+        "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_*> -- python3 bench.py --config %s --steps 1 --warmup 3 --no-cpu %s" % (
             config, " ".join("--opt " + o for o in opts)),
     }
     if name in sq:
