@@ -59,9 +59,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("n,k", [(1024, 2), (4097, 42), (5, 3)])
-def test_allgather_of_candidate_lists_world2_gloo(tmp_path, n, k):
-    world = 2
+@pytest.mark.parametrize("world,n,k", [(2, 1024, 2), (2, 4097, 42), (2, 5, 3),
+                                       (8, 4097, 42), (8, 5, 3), (3, 29, 5)])    # (eight ranks: the node the scaling run uses; fewer cells than ranks: empty shards)
+def test_allgather_of_candidate_lists_world2_gloo(tmp_path, world, n, k):
     mp.spawn(_worker, args=(world, _free_port(), n, k, str(tmp_path)), nprocs=world, join=True)
     idx, score = _fake_lists(n, k)
     for rank in range(world):
@@ -188,8 +188,8 @@ def _sharded_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_speculate_verify_deepen_world2_gloo(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3, 8])       # (63 cells: shards of 32 / 31, 21 / 21 / 21, and seven of 8 with a last one of 7)
+def test_sharded_speculate_verify_deepen_world2_gloo(tmp_path, world):
     mp.spawn(_sharded_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
