@@ -137,14 +137,33 @@ __device__ __forceinline__ float4 ld4(const float4* base, unsigned int byte_off)
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// MM_LIB_NT (A/B builds): the library's groups as NON-TEMPORAL loads, on the idea that a visited library group is read once per (cell,
+// candidate) while the cell's groups are read by every candidate of the item, so streaming the library past the L2 should leave the cells in
+// it.  Measured (round 5, tools/experiments/r5_nt.sh): config D +19 %, E's shard +22 %, I +16 %, C +13 %, G -2 % -- the cells of an XCD's
+// sub-group DO share library lines in the L2 and the Infinity Cache, and the hint takes that away.  Off.
+#ifndef MM_LIB_NT
+#define MM_LIB_NT 0
+#endif
+__device__ __forceinline__ float4 ld4_lib(const float4* base, unsigned int byte_off)
+{
+    const float4* at = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+#if MM_LIB_NT
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(at));
+    return float4{v.x, v.y, v.z, v.w};
+#else
+    return *at;
+#endif
+}
+
 template <int TYPE>
 __device__ __forceinline__ LibGroup load_lib_group(const float4* b0, const float4* b1, const float4* b2,
                                                    const float4* bc, int q)
 {
     const unsigned int off = (unsigned int)q * 16u;
     LibGroup g;
-    g.q0 = ld4(b0, off); g.q1 = ld4(b1, off); g.q2 = ld4(b2, off);
-    if constexpr (TYPE == CIEDE2000) g.qc = ld4(bc, off); else g.qc = float4{0.f, 0.f, 0.f, 0.f};
+    g.q0 = ld4_lib(b0, off); g.q1 = ld4_lib(b1, off); g.q2 = ld4_lib(b2, off);
+    if constexpr (TYPE == CIEDE2000) g.qc = ld4_lib(bc, off); else g.qc = float4{0.f, 0.f, 0.f, 0.f};
     return g;
 }
 
@@ -2022,7 +2041,10 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     // (48 x 48 cells: 7 per pass -> 56-candidate items, two passes per wave, instead of 64 = 2.3)
     const int round_of = 4 * (kWave / std::max(groups, 1));
     const int small_tile = round_of > 0 && round_of <= 64 ? 64 / round_of * round_of : 64;
-    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : (small_cells ? small_tile : 32), cell_group = 512;
+    // (cells above 32 groups -- 96 .. 128 px, 150 .. 256 KB interleaved each -- press on the fabric, 0.95 of its peak on config G: what helps them is
+    // FEWER cells in flight per XCD, i.e. 16-candidate items and sub-groups of two or three cells, so that the cells stay in the L2 while the
+    // library streams through it: config G 15.15 -> 14.48 ms per step on one box, 15.31 -> 14.97 on another, tools/experiments/r5_bigcells.sh)
+    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : (small_cells ? small_tile : (groups > 32 ? 16 : 32)), cell_group = 512;
     // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited) -- and not one more: a second workgroup
     // per slot ("so that a finishing workgroup's slot refills at once", rounds 1 and 2) starts when the launch is nearly over, pays
     // its start (hue table, prologue, eight counter probes) and finds nothing; measured at twice the slots against once: the
@@ -2095,9 +2117,12 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     // one share of the cells per XCD (8 on MI355X); small launches keep one share so no XCD idles on an empty one
     const int xcd_shares = (in.xcd_aware && n_cells >= 8 * 64) ? 8 : 1;
     // cells per XCD sub-group: the cells an XCD works on at the same time should sit in its 4 MB L2 beside the candidate tiles --
-    // 64 cells of 64 x 64 (64 KB each, interleaved), 128 of the smaller ones; cells above 16 groups by their size: 2 MB worth of them
-    // (128 x 128 = 256 KB a cell: 8; config G, 1024 such cells x 1000 images: 14.3 ms per launch at 64, 13.4 at 16, 12.7 at 8, 12.5 at 4)
-    const int big_cell_group = std::max(4, (int)((size_t)(2 << 20) / ((size_t)ppad * 16)));
+    // 64 cells of 64 x 64 (64 KB each, interleaved), 128 of the smaller ones; cells of 17 .. 32 groups by their size: 2 MB worth of them
+    // (80 x 80: 20; flat from 2 to 32 cells, round 5); cells above 32 groups 512 KB worth (128 x 128 = 256 KB a cell: 2; config G, 1024 such
+    // cells x 1000 images, per launch: 14.3 ms at 64, 13.4 at 16, 12.7 at 8, 12.5 at 4 in round 4; round 5, with 16-candidate items: 12.1 at 8,
+    // 11.9 at 2 and 4)
+    const int big_cell_group = groups > 32 ? std::max(2, (int)((size_t)(512 << 10) / ((size_t)ppad * 16)))
+                                           : std::max(4, (int)((size_t)(2 << 20) / ((size_t)ppad * 16)));
     const int item_group = xcd_shares > 1 ? (in.xcd_cells > 0 ? in.xcd_cells : (small_cells ? 128 : (groups > 16 ? std::min(64, big_cell_group) : 64))) : cell_group;
     // the exit test after every group wherever the bound reaches (cells up to 64 groups = 128 x 128; config G, 1024 such cells x 1000
     // images: 15.4 ms per launch at every 4th group, 14.4 at every group); larger cells test the plain partial sum 16 times
