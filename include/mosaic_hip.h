@@ -393,10 +393,11 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
  * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
  * dropped in the engine's PREVIOUS CIEDE2000 launch over the same library, so the TIME of a call (never its result)
  * depends on the call history of the engine; 0 pins the size-by-cell default (mm_timing.filter_tile reports what ran).
- * "pretier" (-1 = measured: jobs with something to gain -- cells above 32 pixel groups, i.e. 96 .. 128 px; with "pretier_band" 1 also calls of
- * >= 1e10 pixel pairs -- run a warm-up launch over a (library, cell size, batch, target), then one filter launch without it and one with it, and keep
- * the faster form from there on: whether it pays depends on the content (synthetic patches: yes; photographs: no); 0 never, 1 always; as with
- * "item_auto" only the TIME of a call depends on the engine's history): CIEDE2000 candidates first walk their pixel groups in
+ * "pretier" (-1: off on the default band -- no benchmarked configuration gains there --; with "pretier_band" 1 measured: jobs with something to
+ * gain -- cells above 32 pixel groups, i.e. 96 .. 128 px, or calls of >= 1e10 pixel pairs -- run a warm-up launch over a (library, cell size,
+ * batch, target), then one filter launch without it and one with it, and keep the faster form from there on: whether it pays depends on the content
+ * (synthetic patches: yes; photographs: no); 0 never, 1 always; as with "item_auto" only the TIME of a call depends on the engine's history):
+ * CIEDE2000 candidates first walk their pixel groups in
  * a packed-fp16 form (two pixel pairs per lane-instruction, operands half the size) that only takes early-exit decisions, against the limit
  * widened by its own band; survivors are scored by the fp32 form as before; "pretier_band" (0): 0 = that band is the WORST-CASE bound of the
  * fp16 form -- every rounding of its operation sequence at its worst, tools/filter_error_bound.py, 0.45 + 3.8e-2 dE per pixel pair --, 1 = the

@@ -58,7 +58,7 @@ struct mm_engine {
     DevBuf lib_chroma, cell_chroma, hue_lut, lib_il, cells_il;
     // pretier = -1: WHETHER the pre-tier pays is a property of the content and of its band -- on the synthetic benchmark candidates leave the
     // pixel loop far above the limit and the pre-tier's cheaper arithmetic wins with round 4's observed band (config D -6.3 %), with the
-    // worst-case band of round 5 only on cells above 32 groups (config G -2.3 %; config D +9 %); on photographs the block bound is tight,
+    // worst-case band of round 5 nowhere (config D +9 %, config G +5 %: there -1 means off); on photographs the block bound is tight,
     // many candidates sit within the fp16 band of the limit, walk all their groups in fp16 and then again in fp32 (the photo fixture
     // enlarged to 2752 / 6144 cells: +6 % / +4 %, tools/experiments/r4_photo_scale.py).  So an eligible job MEASURES it: after a warm-up
     // launch over a (library, cell size, batch size, target), one filter launch runs without the pre-tier and one with it, both between
@@ -77,8 +77,8 @@ struct mm_engine {
                                  // pairs: a third of the worst-case bound -- a STATISTICAL guarantee, which is why it is not the default)
     int bound_pct = 100;         // diagnostics ("dbg_bound_pct"): the early exit's lower bound in per cent (above 100: drops contenders)
     int pretier = -1;            // mm_set_option("pretier", 0 / 1): the packed-fp16 pre-tier ahead of the fp32 filter form never / always;
-                                 // -1 = measured (PreAuto above) for jobs with something to gain -- cells above 32 pixel groups (up to
-                                 // 128 x 128, the reference GUI's default) and, with the observed band ("pretier_band" 1), calls of >= 1e10 pixel
+                                 // -1 = off on the worst-case band; with the observed band ("pretier_band" 1) measured (PreAuto above) for jobs
+                                 // with something to gain -- cells above 32 pixel groups (up to 128 x 128, the reference GUI's default) and calls of >= 1e10 pixel
                                  // pairs (config D 45.7 -> 42.8, E's shard 30.1 -> 29.4, 80-px cells 11.7 -> 11.0) --, off for smaller
                                  // ones (config C 3.21 -> 3.36).  Results are identical either way
     DevBuf row_map, spec_recs, deep, insufficient, sweep_counts;
@@ -943,11 +943,13 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         const bool pre_possible = prune && diff_type == MM_CIEDE2000 && e->use_interleave != 0 && fin.use_lds_form == 0;
         bool pretier = pre_possible && e->pretier > 0;
         bool pre_trial = false;
-        // (eligible by size -- small jobs lose to it, config C +5 % -- and not a deepening sub-batch: decided by measurement.  With the
-        // worst-case band only cells above 32 groups have anything to gain -- config G -2.3 %; configs D, E, I lose 5 - 9 % to it
-        // (profiles/r05_pretier_band_ab.txt) -- so only they pay for a trial; the observed band keeps round 4's second clause)
-        if (pre_possible && e->pretier < 0 && row_map_host == nullptr &&
-            (ppad / 256 > 32 || (e->pretier_band != 0 && call_pairs >= 1e10))) {
+        // (eligible by size -- small jobs lose to it, config C +5 % -- and not a deepening sub-batch: decided by measurement.  On the
+        // worst-case band NO benchmarked configuration gains -- configs D, E, I lose 5 - 9 % to it, the 128-px cells of config G gained 2 %
+        // until their item size was retuned and lose 5 % since (profiles/r05_pretier_band_ab.txt, HISTORY.md) -- so a trial would only
+        // cost its two launches: on that band the pre-tier runs where it is asked for ("pretier" 1); the measured rule is the observed
+        // band's, with round 4's eligibility)
+        if (pre_possible && e->pretier < 0 && row_map_host == nullptr && e->pretier_band != 0 &&
+            (ppad / 256 > 32 || call_pairs >= 1e10)) {
             // The state is keyed on the FULL batch of the job (library, cell size, cells per full batch) and only full batches touch it:
             // a job cut into several batches ends on a shorter one, which must neither reset what the full ones measured nor be timed
             // against them -- it runs the form chosen so far (none yet: without the pre-tier).  The two trials are the first two full

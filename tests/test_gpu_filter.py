@@ -611,3 +611,33 @@ def test_values_outside_the_validated_box_run_fp64_only(oracle, engine, t, where
     engine.generate(cells, state.shape[1], state.shape[0], int(t))
     tm = engine.timing()
     assert tm["filter_off_range"] == 0 and tm["rescore_ms"] > 0
+
+
+def test_the_measured_pretier_rule_belongs_to_the_observed_band(oracle, engine):
+    """`pretier` = -1 on the default (worst-case) band: the pre-tier never runs -- no benchmarked configuration gains there.  With
+    `pretier_band` = 1 an eligible job (cells above 32 groups) spends a warm-up launch, then one launch without and one with the
+    pre-tier, and keeps one form; every call returns the same grid and scores (only the TIME of a call depends on the history)."""
+    t = Type.CIEDE2000
+    shape = cases.square_shape(96)                           # 36 groups: eligible by cell size
+    img, lib = cases.inputs(3 * 96, 4 * 96, 96, 150, t)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, img.shape[0], img.shape[1])[0]
+    cells = G.cell_records(group, state, img.shape[0], img.shape[1])
+    engine.set_library(lib); engine.set_masks(shape.masks4()); engine.set_target(img)
+    run = lambda: engine.generate(cells, state.shape[1], state.shape[0], int(t), 1, 300)
+    try:
+        engine.set_option("pretier", -1); engine.set_option("pretier_band", 0)
+        want, want_score = run()
+        assert [engine.timing()["pretier"]] + [run() and engine.timing()["pretier"] for _ in range(3)] == [0, 0, 0, 0]
+        engine.set_option("pretier_band", 1)                  # (resets the trial)
+        seen = []
+        for _ in range(5):
+            best, score = run()
+            seen.append(engine.timing()["pretier"])
+            assert np.array_equal(best, want) and np.array_equal(score, want_score, equal_nan=True)
+            assert engine.timing()["voided_launches"] == 0
+        assert seen[:3] == [0, 0, 1] and seen[3] == seen[4], seen       # warm-up, without, with, then the form it kept
+        ref, _, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t), 1, 300)
+        assert np.array_equal(np.where(want == len(lib), -1, want), ref)
+    finally:
+        engine.set_option("pretier", -1); engine.set_option("pretier_band", 0)
