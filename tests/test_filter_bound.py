@@ -182,3 +182,27 @@ def test_euclid_block_bound_never_exceeds_the_true_sum(oracle, type_id, kind):
     assert (bound <= true * (1 + 1e-12) + 1e-9).all()
     if kind == "patches":
         assert np.median(bound / true) > 0.5
+
+
+def test_block_sums_in_fp32_stay_inside_the_slack_the_bound_grants_them():
+    """`stats_bound` subtracts 1e-2 from |sum_cell - sum_lib| of every channel before it uses it: what the fp32 rounding of the two
+    64-term block sums (filter.hip group_sums_kernel: four values per lane added in turn, then four xor-shuffle stages over the
+    block's sixteen lanes -- seven roundings along any path) and of their difference can hide.  Values at the edge of the validated
+    box (|a|, |b| <= 150): the worst |fp32 sum - exact sum| over 2e5 blocks, twice (two images), plus the difference's own rounding,
+    stays below the slack."""
+    rng = np.random.default_rng(8)
+    n = 200000
+    x = rng.uniform(-150, 150, (n, 16, 4)).astype(np.float32)
+    x[: n // 4] = np.abs(x[: n // 4])                          # same-sign blocks: the largest partial sums
+    x[n // 4: n // 2] = (150.0 - rng.uniform(0, 1e-3, (n // 4, 16, 4))).astype(np.float32)      # everything at the edge
+    lane = x[:, :, 0]
+    for k in range(1, 4):
+        lane = (lane + x[:, :, k]).astype(np.float32)          # s += xs[k], in turn
+    for off in (8, 4, 2, 1):                                   # s += shfl_xor(s, off): every lane ends with the block's sum
+        lane = (lane + lane[:, np.arange(16) ^ off]).astype(np.float32)
+    exact = x.astype(np.float64).sum((1, 2))
+    err = np.abs(lane[:, 0].astype(np.float64) - exact).max()
+    diff_rounding = 2.0 ** -24 * 2 * 64 * 150.0                # |sum_cell - sum_lib| <= 19 200, one rounding
+    print("block sums: worst fp32 error %.3g (x 2 images + %.3g for the difference) against a slack of 1e-2" % (err, diff_rounding))
+    assert 2 * err + diff_rounding <= 1e-2
+    assert err <= 7 * 2.0 ** -24 * 64 * 150.0                  # the first-order bound quoted in DESIGN.md section 2
