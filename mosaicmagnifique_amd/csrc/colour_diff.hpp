@@ -123,7 +123,7 @@ __device__ __forceinline__ double ciede2000(const Px& p, const Px& q)
 __device__ __forceinline__ double ciede2000_algebraic(const Px& p, const Px& q, bool* needs_reference)
 {
     constexpr double kPi = 3.14159265358979323846;
-    constexpr double rad25 = (25.0 * kPi) / 180.0, rad30 = (30.0 * kPi) / 180.0, rad275 = (275.0 * kPi) / 180.0;
+    constexpr double rad30 = (30.0 * kPi) / 180.0, rad275 = (275.0 * kPi) / 180.0;
     constexpr double twentyfive_7 = 6103515625.0;
     // cos / sin of 30, 6 and 63 degrees (T's phase shifts)
     constexpr double cos30 = 0.86602540378443864676, sin30 = 0.5;

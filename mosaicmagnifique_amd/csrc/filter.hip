@@ -244,7 +244,7 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 // operation, one ulp per transcendental, subnormal halfs at their absolute step, the hue table's index moved by the direction's
 // error) -- a smooth function of the pair, unlike an observed error, which depends on mantissa bits and let round 4's sweeps step over
 // what the maximiser then found.  Its frontier over thirteen families x 1.5e6 pairs (the form's weak zones, the colours of u8 images):
-// 0.40 + 3.3e-2 v, 0.45 + 3.1e-2 v, 0.50 + 2.9e-2 v; shipped with a tenth of room on either part.  Observed errors sit at a quarter of it
+// 0.40 + 3.3e-2 v, 0.45 + 3.1e-2 v, 0.50 + 2.9e-2 v; shipped with a tenth of room on either part.  Observed errors sit at a tenth of it
 // (round 4's band, twice the worst observed pair, was 0.29 + 8e-3 v -- kPreBandAbsObserved / kPreBandRelObserved, option "pretier_band" 1:
 // a third of the worst-case bound, i.e. a band that trusts the roundings not to conspire; config D ran 4 % faster on it).
 #ifndef MM_PRE_PREFETCH
@@ -2211,7 +2211,8 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
         if ((code = hipGetLastError()) != hipSuccess) return code;
         edge_fix_kernel<<<1024, kBlock, 0, stream>>>(in.cells, in.cell_chroma, in.lib, in.lib_chroma, scores, L, ppad,
                                                      edges, edge_count, edge_cap, in.hue_lut, in.var, il ? 1 : 0);
-        if (in.clock_end != nullptr && (code = hipGetLastError()) == hipSuccess && (code = hipEventRecord(in.clock_end, stream)) != hipSuccess) return code;
+        if ((code = hipGetLastError()) != hipSuccess) return code;
+        if (in.clock_end != nullptr && (code = hipEventRecord(in.clock_end, stream)) != hipSuccess) return code;
     } else {
         filter_kernel<RGB_EUCLIDEAN, kBlock, false, false><<<dim3(persistent_grid(reinterpret_cast<const void*>(filter_kernel<RGB_EUCLIDEAN, kBlock, false, false>), blocks, kBlock, 0)), kBlock, 0, stream>>>(
             in.cells, in.cells_f0, in.cell_chroma, in.lib, in.lib_chroma, scores, n_cells, L, ppad, cand_per_block,
