@@ -206,3 +206,112 @@ def test_block_sums_in_fp32_stay_inside_the_slack_the_bound_grants_them():
     print("block sums: worst fp32 error %.3g (x 2 images + %.3g for the difference) against a slack of 1e-2" % (err, diff_rounding))
     assert 2 * err + diff_rounding <= 1e-2
     assert err <= 7 * 2.0 ** -24 * 64 * 150.0                  # the first-order bound quoted in DESIGN.md section 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The bound AS THE DEVICE EVALUATES IT (filter.hip stats_bound: fp32, v_rsq / v_rcp / v_sqrt / v_exp / v_sin, block statistics that
+# were themselves summed in fp32) against the same formula in exact arithmetic on exact statistics: with every rounding at its
+# worst (the carried-bound arithmetic of tools/filter_error_bound.py; instruction accuracies as tests/ulp_sweep.hip measured
+# them exhaustively) the device's value must not exceed the exact one -- that is what the formula's cushions (1e-2 of slack per
+# block sum, 0.999 on the eigenvalue's leading term, 1.001 x + 1e-5 on the sine, 0.02 degrees on the arcs, 0.9999 overall) are for.
+# Together with the tests above (exact formula <= true sum) this puts the device's bound below the truth.
+# ---------------------------------------------------------------------------------------------------------------------
+import os  # noqa: E402
+import sys  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def device_bound_upper(cell, lib):
+    """Upper end of what stats_bound can return for one 64-pixel block pair, every fp32 rounding at its worst."""
+    import filter_error_bound as feb
+    from filter_error_bound import EV, add, sub, mul, const, scale_pow2, monotone, absval
+    feb.set_precision("single")
+    try:
+        u = 2.0 ** -24
+
+        def stat_sum(px):                       # fp32 block sum: seven roundings along any path of the reduction
+            return EV(px.sum(-1), 7 * u * np.abs(px).sum(-1))
+        def stat_max(v):                        # a maximum of fp32 values each good to two ulp
+            return EV(v.max(-1), 2 * u * np.abs(v).max(-1) + 1e-30)
+        c_hc, c_hw = hue_arcs(cell)
+        l_hc, l_hw = hue_arcs(lib)              # (the arcs carry + 0.02 degrees already; atan2f and the wraps: 1e-4 degrees)
+        arc = lambda v: EV(v, 1e-4)
+        c_sl, l_sl = stat_sum(cell[..., 0]), stat_sum(lib[..., 0])
+        c_sa, l_sa = stat_sum(cell[..., 1]), stat_sum(lib[..., 1])
+        c_sb, l_sb = stat_sum(cell[..., 2]), stat_sum(lib[..., 2])
+        c_dev, l_dev = stat_max(np.abs(cell[..., 0] - 50)), stat_max(np.abs(lib[..., 0] - 50))
+        c_cm, l_cm = stat_max(np.hypot(cell[..., 1], cell[..., 2])), stat_max(np.hypot(lib[..., 1], lib[..., 2]))
+        x = scale_pow2(add(c_dev, l_dev), 0.5)
+        x2 = mul(x, x)
+        s_l = add(mul(mul(const(0.015), x2), monotone(add(EV(20.0), x2), lambda t: 1 / np.sqrt(t), floor=1.0)), EV(1.0))
+        cbar = scale_pow2(add(c_cm, l_cm), 0.5)
+        g_min = sub(EV(1.5), scale_pow2(feb.ratio7_single(mul(cbar, const(0.04))), 0.5))
+        gc = mul(g_min, cbar)
+        s_c = add(mul(const(0.045), gc), EV(1.0))
+        # the least |h_bar' - 275| any pair can have: wraps, maxima and minima of sums -- 1-Lipschitz in every argument
+        c1, w1, c2, w2 = arc(c_hc), arc(c_hw), arc(l_hc), arc(l_hw)
+        delta = wrap180(c2.v - c1.v)
+        mid = np.abs(wrap180(c1.v + 0.5 * delta))
+        hw = 0.5 * (w1.v + w2.v)
+        d0, d1 = np.maximum(0.0, mid - hw), np.maximum(0.0, (180.0 - mid) - hw)
+        off_v = np.where(np.abs(delta) + w1.v + w2.v >= 180.0, np.minimum(d0, d1), d0)
+        off = EV(off_v, 4e-4 + 8 * u * 360.0)
+        # e_max = exp2(-off^2 log2(e) / 625): decreasing in off (interval ends), v_exp_f32 one ulp (measured 0.78)
+        ex = lambda t: np.exp(-(np.maximum(t, 0.0) / 25.0) ** 2)
+        e_v = ex(off.v)
+        e_max = EV(e_v, np.maximum(np.abs(ex(off.v - off.e) - e_v), np.abs(ex(off.v + off.e) - e_v)) + 4 * u * e_v)
+        # sin(60 deg x e_max) through v_sin_f32 (absolute error 1.8 x 2^-24 measured, 4 charged), then x 1.001 + 1e-5
+        sn = lambda t: np.sin(np.radians(60.0) * np.clip(t, 0.0, 1.0))
+        s_v = sn(e_max.v)
+        sin_2dt = add(mul(EV(s_v, np.maximum(np.abs(sn(e_max.v - e_max.e) - s_v), np.abs(sn(e_max.v + e_max.e) - s_v)) + 4 * u), const(1.001)), const(1e-5))
+        half_rt = mul(feb.ratio7_single(mul(gc, const(0.04))), sin_2dt)
+        slack = EV(1e-2)
+        def pos(a):                             # max(., 0) of an interval: a difference that stays below its slack is exactly 0 on the device
+            lo, hi = np.maximum(a.v - a.e, 0.0), np.maximum(a.v + a.e, 0.0)
+            return EV(0.5 * (lo + hi), 0.5 * (hi - lo))
+        t_l = mul(pos(sub(absval(sub(c_sl, l_sl)), slack)), monotone(s_l, lambda t: 1 / t, floor=1.0))
+        da = mul(pos(sub(absval(sub(c_sa, l_sa)), slack)), g_min)
+        db = pos(sub(absval(sub(c_sb, l_sb)), slack))
+        inv_c = monotone(s_c, lambda t: 1 / t, floor=1.0)
+        inv_h = monotone(add(mul(const(0.015 * 1.5726), gc), EV(1.0)), lambda t: 1 / t, floor=1.0)
+        na, nc = mul(inv_c, inv_c), mul(inv_h, inv_h)
+        nb = mul(mul(half_rt, inv_c), inv_h)
+        half_diff = scale_pow2(sub(na, nc), 0.5)
+        root = monotone(add(mul(half_diff, half_diff), mul(nb, nb)), np.sqrt)
+        lam = pos(sub(mul(const(0.999), scale_pow2(add(na, nc), 0.5)), root))
+        total = add(mul(t_l, t_l), mul(lam, add(mul(da, da), mul(db, db))))
+        out = mul(const(0.9999), monotone(total, np.sqrt))
+        return out.v + out.e
+    finally:
+        feb.set_precision("half")
+
+
+def exact_block_bound(cell, lib):
+    """The same formula in float64 on exact statistics, without any cushion (what the tests above hold below the true sum,
+    up to the 1.0001 they put on R_T)."""
+    dev = 0.5 * (np.abs(cell[..., 0] - 50).max(-1) + np.abs(lib[..., 0] - 50).max(-1))
+    s_l = 1.0 + 0.015 * dev ** 2 / np.sqrt(20.0 + dev ** 2)
+    cbar = 0.5 * (np.hypot(cell[..., 1], cell[..., 2]).max(-1) + np.hypot(lib[..., 1], lib[..., 2]).max(-1))
+    g_min = 1.5 - 0.5 * sqrt_ratio7(cbar)
+    gc = g_min * cbar
+    s_c, s_h = 1.0 + 0.045 * gc, 1.0 + 0.015 * 1.5726 * gc
+    half_rt = sqrt_ratio7(gc) * np.sin(np.radians(60.0) * rotation_bound(cell, lib))
+    a, c, b = 1.0 / s_c ** 2, 1.0 / s_h ** 2, half_rt / (s_c * s_h)
+    lam = np.maximum(0.5 * (a + c) - np.sqrt(0.25 * (a - c) ** 2 + b ** 2), 0.0)
+    d = np.abs(cell.sum(-2) - lib.sum(-2))
+    return np.sqrt((d[..., 0] / s_l) ** 2 + lam * ((g_min * d[..., 1]) ** 2 + d[..., 2] ** 2))
+
+
+@pytest.mark.parametrize("kind", ["uniform", "patches", "close-patches", "blue", "blue-chroma-shift", "hue-pairs", "hue-pairs-wide",
+                                  "mean-at-275", "seam-95", "opposite", "near-grey", "dark-vs-bright"])
+def test_the_bound_as_the_device_evaluates_it_stays_below_the_exact_formula(kind):
+    rng = np.random.default_rng(31)
+    cell, lib = groups(rng, kind, 20000, n=64)                       # one block = 64 positions
+    cell, lib = cell.astype(np.float32).astype(np.float64), lib.astype(np.float32).astype(np.float64)
+    upper, exact = device_bound_upper(cell, lib), exact_block_bound(cell, lib)
+    assert np.isfinite(upper).all()
+    worst = (upper - exact).max()
+    print("%s: device bound (worst roundings) - exact bound: max %.3g, min margin %.3g of the exact bound" %
+          (kind, worst, ((exact - upper) / np.maximum(exact, 1e-9)).min()))
+    assert (upper <= exact + 1e-9).all(), (kind, float(worst))
