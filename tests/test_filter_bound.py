@@ -315,3 +315,22 @@ def test_the_bound_as_the_device_evaluates_it_stays_below_the_exact_formula(kind
     print("%s: device bound (worst roundings) - exact bound: max %.3g, min margin %.3g of the exact bound" %
           (kind, worst, ((exact - upper) / np.maximum(exact, 1e-9)).min()))
     assert (upper <= exact + 1e-9).all(), (kind, float(worst))
+
+
+def test_block_sums_of_the_euclidean_forms_stay_inside_their_slack():
+    """filter_lds_kernel's block bound (RGB / CIE76: the plain triangle inequality, sum ||d|| >= ||sum d||) takes 2e-2 off every
+    |sum_cell - sum_lib| for the same two fp32 block sums, of values up to 256 (the box the Euclidean filter forms are validated on):
+    worst error of the device's summation order, twice, plus the difference's rounding."""
+    rng = np.random.default_rng(9)
+    n = 200000
+    x = rng.uniform(0, 256, (n, 16, 4)).astype(np.float32)
+    x[: n // 2] = (256.0 - rng.uniform(0, 1e-3, (n // 2, 16, 4))).astype(np.float32)
+    lane = x[:, :, 0]
+    for k in range(1, 4):
+        lane = (lane + x[:, :, k]).astype(np.float32)
+    for off in (8, 4, 2, 1):
+        lane = (lane + lane[:, np.arange(16) ^ off]).astype(np.float32)
+    err = np.abs(lane[:, 0].astype(np.float64) - x.astype(np.float64).sum((1, 2))).max()
+    diff_rounding = 2.0 ** -24 * 64 * 256.0
+    print("Euclidean block sums: worst fp32 error %.3g (x 2 images + %.3g) against a slack of 2e-2" % (err, diff_rounding))
+    assert 2 * err + diff_rounding <= 2e-2
