@@ -1,25 +1,34 @@
-"""A-posteriori error bound of the packed-fp16 pre-tier's CIEDE2000 form (csrc/colour_diff_fast.hpp ciede2000_h2).
+"""Worst-case error bounds of the engine's approximate CIEDE2000 forms:
 
-What the pre-tier's band (filter.hip kPreAbs + kPreRel * value) had behind it in round 4 were OBSERVED errors: device sweeps
-and an adversarial maximiser.  An observed error is one realisation of the roundings at one input -- jagged in the input
-bits, which is why the maximiser could find what the sweeps stepped over.  This tool bounds, for a given input pair, EVERY
-realisation: it evaluates the form's own sequence of operations in float64 and carries, beside each intermediate value, a
-bound on how far the half-precision computation can be from it -- the running error analysis of Higham, "Accuracy and
-Stability of Numerical Algorithms", sec. 3.3, with interval endpoints instead of derivatives wherever a function is
-monotone (rsq, rcp, sqrt: no first-order truncation), every rounding charged at its worst (u = 2^-11 per packed operation,
-one ulp = 2^-10 for the three transcendentals, 2^-25 absolute where halfs go subnormal), constants that are no halfs charged
-with their own rounding, a select whose condition the error can flip charged with the distance between its arms.  The result
+    --form filter     the fp32 filter form       (csrc/colour_diff_fast.hpp ciede2000_fast<PREP>; band: engine.hip filter_band)
+    --form pretier    the packed-fp16 pre-tier   (csrc/colour_diff_fast.hpp ciede2000_h2;        band: launch.hpp kPreBandAbs / kPreBandRel)
+    --form algebraic  the fp64 parallel sums     (csrc/colour_diff.hpp ciede2000_algebraic;      against CIEDE2000 in long double)
 
-    over-estimate(x)  <=  m(x) + eps(x),      m = (the form in exact arithmetic) - (CIEDE2000 in float64),   eps = the carried bound
+What the bands had behind them until round 5 were OBSERVED errors: device sweeps and an adversarial maximiser.  An observed error
+is one realisation of the roundings at one input -- jagged in the input's bits, which is how round 4's sweeps stepped over what the
+maximiser then found in the fp16 form.  This tool bounds, for a given input pair, EVERY realisation: it evaluates the form's own
+sequence of operations in float64 (long double for the fp64 form) and carries, beside each intermediate value, a bound on how far
+the device's computation can be from it -- the running error analysis of Higham, "Accuracy and Stability of Numerical
+Algorithms", sec. 3.3, with interval endpoints instead of derivatives wherever a function is monotone (rsq, rcp, sqrt: no
+first-order truncation), every rounding charged at its worst (u = 2^-11 / 2^-24 / 2^-53 per operation, one ulp per transcendental --
+tests/ulp_sweep.hip measures <= 0.92 ulp exhaustively --, subnormal halfs at their absolute step), constants charged with their own
+rounding, the hue table's index moved by the error of the mean-hue direction and priced at the table's steepest step within reach,
+a select whose condition the error can flip evaluated on both arms, and the places where a computed quantity enters numerator and
+denominator alike (1 + G in a1' and a2'; the 7th-power ratio; S_L, S_C, S_H against the single reciprocal; the quadratic form
+dC'^2 + dH'^2 + R_T dC' dH') treated as the device computes them instead of being charged twice.  The result
 
-is a SMOOTH function of the input (no dependence on mantissa bits), so a grid that is dense in the form's weak zones says
-something about the points between its nodes, which a sweep of observed errors does not.  It is still a sampled statement --
-the input space is six-dimensional -- not an interval proof over boxes: DESIGN.md section 2 says so.
+    error(x)  <=  |m(x)| + eps(x),     m = (the form in exact arithmetic) - (CIEDE2000),   eps = the carried bound
 
-    python3 tools/filter_error_bound.py [--pairs N] [--abs A --rel R]
+(for the pre-tier the signed OVER-estimate m + eps: an under-estimate only delays an early exit) is a SMOOTH function of the input
+(no dependence on mantissa bits), so a sample that is dense in the form's weak zones says something about the points between its
+nodes, which a sweep of observed errors does not.  It is still a sampled statement -- the input space is six-dimensional -- not an
+interval proof over boxes: DESIGN.md section 2 says so.
+
+    python3 tools/filter_error_bound.py --form filter|pretier|algebraic [--pairs N] [--abs A --rel R]
 
 prints the worst bound per family as a share of the band, and the smallest (abs, rel) frontier that holds all of them.
-tests/test_filter_error_bound.py holds the shipped band above the bound on a fixed subset (CPU only, seconds).
+tests/test_filter_error_bound.py holds the shipped bands above the bounds on a fixed subset (CPU only, seconds);
+tests/test_filter_bound.py uses the same arithmetic on the block bound of the early exit (stats_bound).
 """
 import argparse
 import math
