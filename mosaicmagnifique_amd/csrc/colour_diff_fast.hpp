@@ -93,11 +93,7 @@ using HueEntry = float2;
 // PREP = true: the operands come from the filter kernel's interleaved copies (filter.hip interleave_kernel), which
 // hold channel 0 as L / 2 - 25 and the chroma as C / 50 -- the mean lightness offset (:138) is then one addition and
 // the mean chroma over 25 (:50-53) needs no multiply; S_L is carried as S_L / 2 against the halved lightness difference.
-// NORT = true: the rotation term R_T tC tH is left out -- for the pixel pairs of a group whose block statistics PROVE it negligible
-// (filter.hip kNoRotationE: every pair's exp(-((h_bar' - 275) / 25)^2) is below 4e-6, i.e. |R_T| <= 8.4e-6 and the value moves by
-// less than 2.1e-6 of itself: a thirtieth of the band's relative part) -- and with it the second table value, one 7th-power ratio
-// and its reciprocal root: ~12 of the form's 86 instructions.
-template <bool PREP = false, bool NORT = false>
+template <bool PREP = false>
 __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, float c1, float c2,
                                                 const HueEntry* __restrict__ lut, bool* needs_exact)
 {
@@ -147,13 +143,10 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     const float fr = __builtin_amdgcn_fractf(x);                // x - floor(x), one instruction
     const HueEntry e0 = lut[idx], e1 = lut[idx + 1];
     const float t = fmaf(fr, e1.x - e0.x, e0.x);
+    const float s2 = fmaf(fr, e1.y - e0.y, e0.y);
 
     const float csum = c1p + c2p;                           // 2 * mean C'
-    float r_t = 0.0f;
-    if constexpr (!NORT) {
-        const float s2 = fmaf(fr, e1.y - e0.y, e0.y);
-        r_t = s2 * sqrt_ratio7_of_sum(csum);                // :136,:145; the table holds -2 sin(2 d_theta)
-    }
+    const float r_t = s2 * sqrt_ratio7_of_sum(csum);            // :136,:145; the table holds -2 sin(2 d_theta)
     const float lb = PREP ? p.c0 + q.c0 : 0.5f * (p.c0 + q.c0) - 50.0f;
     // with u = 20 + lb^2 (one fma): 0.0075 lb^2 = 0.0075 u - 0.15 (one fma; the cancellation near lb = 0 costs 1e-8 of an S_L of 0.5)
     const float u_l = fmaf(lb, lb, 20.0f);
@@ -169,7 +162,7 @@ __device__ __forceinline__ float ciede2000_fast(const PxF& p, const PxF& q, floa
     const float big_d = s_c * s_h;
     const float ta = d_c * s_h;
     const float tb = d_h * s_c;
-    const float num = NORT ? fmaf(ta, ta, tb * tb) : fmaf(ta, fmaf(r_t, tb, ta), tb * tb);        // ta^2 + tb^2 + R_T ta tb
+    const float num = fmaf(ta, fmaf(r_t, tb, ta), tb * tb);        // ta^2 + tb^2 + R_T ta tb
     // (one reciprocal for all three terms -- rcp(S_L S_C S_H), three multiplies more -- measured 0.5 % slower: a quarter-rate
     // instruction costs what three full-rate ones do)
     const float inv_d = frcp(big_d);

@@ -104,12 +104,12 @@ __device__ __forceinline__ float row_suffix_sum(float v)
 // opposite-hue discontinuity (colour_diff_fast.hpp): the filter kernel logs it and
 // edge_fix_kernel later replaces its fp32 term by the fp64 one.  cp, cq = chroma of
 // p and q (read from the precomputed planes), lut = the hue table in LDS.
-template <int TYPE, bool PREP = false, bool NORT = false>
+template <int TYPE, bool PREP = false>
 __device__ __forceinline__ float pair_fast(const PxF& p, const PxF& q, float cp, float cq,
                                            const HueEntry* lut, bool* edge)
 {
     if constexpr (TYPE == CIEDE2000) {
-        return ciede2000_fast<PREP, NORT>(p, q, cp, cq, lut, edge);
+        return ciede2000_fast<PREP>(p, q, cp, cq, lut, edge);
     } else {
         *edge = false;
         return euclidean_fast(p, q);
@@ -144,14 +144,6 @@ __device__ __forceinline__ float4 ld4(const float4* base, unsigned int byte_off)
 #ifndef MM_LIB_NT
 #define MM_LIB_NT 0
 #endif
-// MM_NORT (A/B builds): pixel groups whose block statistics prove the rotation term negligible are evaluated without it
-// (colour_diff_fast.hpp ciede2000_fast<.., NORT>): stats_bound's e_max is an upper bound of exp(-((h_bar' - 275) / 25)^2) over every
-// pixel pair of a block pair; at or below kNoRotationE, |R_T| = R_C sin(2 d_theta) <= 2 sin(60 deg x 4e-6) = 8.4e-6 and leaving
-// R_T tC tH out moves a pair's value by at most |R_T| / 4 of itself.
-#ifndef MM_NORT
-#define MM_NORT 0
-#endif
-constexpr float kNoRotationE = 4e-6f;
 __device__ __forceinline__ float4 ld4_lib(const float4* base, unsigned int byte_off)
 {
     const float4* at = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -181,7 +173,7 @@ __device__ __forceinline__ LibGroup load_lib_group(const float4* b0, const float
 // slack: what the fp32 rounding of the two sums can hide (1e-2 for the 64-term sums of values <= ~128 of a block).
 __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa, float c_sb, float c_cmax, float c_hc, float c_hw,
                                              float l_sl, float l_dev, float l_sa, float l_sb, float l_cmax, float l_hc, float l_hw,
-                                             float slack, float* e_max_out = nullptr)
+                                             float slack)
 {
     // S_L of every pair of the block: |L_bar - 50| <= (max|L_cell - 50| + max|L_lib - 50|) / 2
     // over the block's active pixels, and S_L grows with it (:138-139)
@@ -207,7 +199,6 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
     const float d0 = fmaxf(0.0f, mid - hw), d1 = fmaxf(0.0f, (180.0f - mid) - hw);
     const float off = (fabsf(delta) + w1 + w2 >= 180.0f) ? fminf(d0, d1) : d0;   // least |h_bar' - 275| any pair can have
     const float e_max = fexp2(off * off * (-1.4426950408889634f / 625.0f));
-    if (e_max_out) *e_max_out = e_max;          // (an upper bound of exp(-((h_bar' - 275) / 25)^2) over the block's pairs: MM_NORT)
     // v_sin_f32 takes revolutions: sin(60 deg * E) = sin(2 pi * E / 6); 1.001 + 1e-5 covers its error
     const float sin_2dt = fmaf(__builtin_amdgcn_sinf(e_max * (1.0f / 6.0f)), 1.001f, 1e-5f);
     const float half_rt = sqrt_ratio7(gc) * sin_2dt;                   // >= |R_T| / 2,  R_C = 2 sqrt_ratio7
@@ -327,11 +318,6 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     __shared__ int seed_ids[256];           // the cell's seeds: their scores are in the row already (launch_prune_limits)
     // stage 1 -> stage 2: the bound of every 256-position group of the tile's candidates (<= 64 per tile, <= 16 groups)
     __shared__ float cand_gb[TYPE == CIEDE2000 ? 64 : 1][TYPE == CIEDE2000 ? 16 : 1];
-#if MM_NORT
-    // ... and, per candidate of the tile, the groups whose rotation term is PROVABLY negligible (bit g: every block pair of group g
-    // has e_max <= kNoRotationE): stage 2 evaluates their pixel pairs without it (ciede2000_fast<.., NORT>)
-    __shared__ unsigned short cand_nort[TYPE == CIEDE2000 ? 64 : 1];
-#endif
     // candidates of the tile that passed the bound in stage 1 (<= 64 per tile), in two classes: [0, 1] those whose bound is
     // below kLongSplit of the limit -- the likely contenders, which walk most of their groups -- and [2, 3] the others.
     // Stage 2 hands out the first class first: the waves of an item meet at a barrier, and a long candidate drawn last
@@ -568,9 +554,6 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 for (int t = g; t < n_seeds; t += groups) hit = hit || seed_ids[t] == l;
             const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
             const bool seed = ((hits >> (q * groups)) & ((1ull << groups) - 1ull)) != 0ull;     // (q * groups < 64 where it matters: valid lanes)
-#if MM_NORT
-            float e_grp = valid ? 0.0f : 1.0f;          // the largest exp(-((h_bar' - 275) / 25)^2) any pixel pair of this lane's group can have
-#endif
             if (valid) {
                 // the group's four blocks are four consecutive floats of each statistic
                 const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + 4 * g;
@@ -579,15 +562,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 for (int k = 0; k < 7; ++k) ls[k] = *reinterpret_cast<const float4*>(st + k * bs);
                 auto block = [&](int i, float l0, float l1, float l2, float l3, float l4, float l5, float l6) {
                     const int blk = 4 * g + i;
-#if MM_NORT
-                    float e_blk;
-                    b += cell_st[7][blk] * stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
-                                                       l0, l1, l2, l3, l4, l5, l6, 1e-2f, &e_blk);
-                    e_grp = fmaxf(e_grp, e_blk);
-#else
                     b += cell_st[7][blk] * stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
                                                        l0, l1, l2, l3, l4, l5, l6, 1e-2f);
-#endif
                     __builtin_amdgcn_sched_barrier(0);  // one block at a time: four interleaved evaluations do not fit the registers
                 };
                 block(0, ls[0].x, ls[1].x, ls[2].x, ls[3].x, ls[4].x, ls[5].x, ls[6].x);
@@ -596,12 +572,6 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 block(3, ls[0].w, ls[1].w, ls[2].w, ls[3].w, ls[4].w, ls[5].w, ls[6].w);
                 cand_gb[idx][g] = b;                        // (stage 2 reads the first `groups` entries only)
             }
-#if MM_NORT
-            {
-                const unsigned long long quiet = __builtin_amdgcn_ballot_w64(valid && e_grp <= kNoRotationE);
-                if (valid && g == 0) cand_nort[idx] = (unsigned short)((quiet >> (q * groups)) & ((1ull << groups) - 1ull));
-            }
-#endif
             // sum over the candidate's lanes: a suffix scan that stops at the segment's end; its first lane gets the total
             if (groups == 16) {
                 b = row_suffix_sum(b);                      // a candidate is a 16-lane row: four DPP adds
@@ -821,9 +791,6 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         float acc_edge = 0.0f;     // terms awaiting the fp64 patch
         if (!pruned && groups > 0) {
             // One 256-pixel group of the candidate against the cell; true = candidate dropped.
-#if MM_NORT
-            const unsigned int nort_bits = two_level ? (unsigned int)__builtin_amdgcn_readfirstlane((int)cand_nort[idx]) : 0u;
-#endif
             auto visit = [&](const LibGroup& cur, int j, int step) -> bool {
                 if (step != 0 && step % check_every == 0) {
                     // bound of what is still unvisited: sorted, lane `step` of the scan over the visiting order; else group
@@ -849,21 +816,10 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                 }
                 const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, qc = cur.qc;
                 bool e0, e1, e2, e3;
-                float v0, v1, v2, v3;
-#if MM_NORT
-                if (TYPE == CIEDE2000 && ((nort_bits >> j) & 1u) != 0u) {          // (wave-uniform: a scalar bit of the candidate's mask)
-                    v0 = pair_fast<TYPE, IL, true>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
-                    v1 = pair_fast<TYPE, IL, true>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
-                    v2 = pair_fast<TYPE, IL, true>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
-                    v3 = pair_fast<TYPE, IL, true>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
-                } else
-#endif
-                {
-                    v0 = pair_fast<TYPE, IL>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
-                    v1 = pair_fast<TYPE, IL>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
-                    v2 = pair_fast<TYPE, IL>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
-                    v3 = pair_fast<TYPE, IL>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
-                }
+                const float v0 = pair_fast<TYPE, IL>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
+                const float v1 = pair_fast<TYPE, IL>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
+                const float v2 = pair_fast<TYPE, IL>(PxF{p0.z, p1.z, p2.z}, PxF{q0.z, q1.z, q2.z}, pc.z, qc.z, lut, &e2);
+                const float v3 = pair_fast<TYPE, IL>(PxF{p0.w, p1.w, p2.w}, PxF{q0.w, q1.w, q2.w}, pc.w, qc.w, lut, &e3);
                 if constexpr (TYPE == CIEDE2000) {
                     // discontinuity pairs are rare (~1e-5): one wave-wide test, then the slow branch
                     // not NaN = active; the interleaved cell carries the NaN in channel 1 too, which keeps e0..e3 false by itself
