@@ -17,6 +17,14 @@ from oracle_ffi import shape_of
 pytestmark = pytest.mark.gpu
 
 
+def fuzz_seeds(name, default):
+    """The seeds of one family: `default` of them, or MOSAIC_FUZZ_<NAME> many (the soaks), starting at MOSAIC_FUZZ_BASE
+    (0: the scenarios every run of the suite sees; a soak with another base walks scenarios no run has seen before)."""
+    import os
+    base = int(os.environ.get("MOSAIC_FUZZ_BASE", "0"))
+    return range(base, base + int(os.environ.get("MOSAIC_FUZZ_" + name, str(default))))
+
+
 def random_shape(rng, size):
     kind = rng.integers(3)
     if kind == 0:
@@ -40,7 +48,7 @@ def random_shape(rng, size):
     return s
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MOSAIC_FUZZ_SMALL", "150"))))       # soak: MOSAIC_FUZZ_SMALL=1500
+@pytest.mark.parametrize("seed", fuzz_seeds("SMALL", 150))       # soak: MOSAIC_FUZZ_SMALL=1500
 def test_random_scenario(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     size = int(rng.choice([8, 13, 16, 17, 24, 31, 32, 33, 40, 50, 64, 72]))
@@ -73,7 +81,7 @@ def test_random_scenario(oracle, seed):
     assert (np.abs(score[valid] - want_score[valid]) <= tol * np.abs(want_score[valid]) + 1e-300).all()
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", fuzz_seeds("STEPS", 40))
 def test_random_scenario_with_size_steps(oracle, seed):
     """The same, over size steps (entropy subdivision on a half-busy image, library halved per step,
     cells resized per step) wherever the sizes stay consistent; checked step by step."""
@@ -98,7 +106,7 @@ def test_random_scenario_with_size_steps(oracle, seed):
     run_steps(oracle, shape, img, lib, t, detail, steps, rep)
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MOSAIC_FUZZ_LARGE", "24"))))     # soak: MOSAIC_FUZZ_LARGE=300
+@pytest.mark.parametrize("seed", fuzz_seeds("LARGE", 24))     # soak: MOSAIC_FUZZ_LARGE=300
 def test_random_scenario_large_library(oracle, engine, seed):
     """Scenarios the small ones above cannot reach: hundreds of library images (so most candidates are NOT seeds
     and go through the two stages of the bound, the bound-ordered visits and the early exit), 48 / 56 / 64 px cells with
@@ -220,7 +228,7 @@ def test_tuning_options_do_not_change_the_result(oracle, engine, opts):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MOSAIC_FUZZ_SMOOTH", "16"))))
+@pytest.mark.parametrize("seed", fuzz_seeds("SMOOTH", 16))
 def test_random_scenario_graded_noise(oracle, engine, seed):
     """Between the synthetic library's +-32 of per-channel noise and noise-free gradients: library images = a base colour
     + a linear gradient + noise of a random amplitude (0 .. 24), target = smooth waves + noise (0 .. 12).  The bound then
