@@ -146,10 +146,12 @@ mm_status mm_create(int device, mm_engine **out);
 /* Destroys the engine.  Its DEVICE RESOURCES (stream, events, device buffers, the page-locked result mirror) are
  * parked -- one set per device -- and adopted by the next mm_create on that device, so that a fresh generator per
  * run (MainWindow.cpp:584-607) does not pay the allocations again (mm_stage_timing).  Nothing logical survives:
- * a new engine has no library, masks or target and the default options.  A parked set holds at most
- * MOSAIC_HIP_KEEP_MB (environment; default 256) megabytes of device memory: its largest buffers are released
- * first -- the fixed costs are what parking saves, the large workspaces allocate again in a fraction of a
- * millisecond and would otherwise be kept from everyone else on the device. */
+ * a new engine has no library, masks or target and the default options.  A parked set holds at most 5 % of the
+ * device memory that would be free with the set released (asked at mm_destroy: ~14 GB on an idle MI355X, so a
+ * 4096-cell x 5000-image generator's 2.4 GB of workspaces stay and its successor allocates nothing); the largest
+ * buffers are released first when the set does not fit.  MOSAIC_HIP_KEEP_MB (environment) pins a fixed cap in
+ * megabytes instead.  Measured by the driver in round 5 with a fixed 256 MB cap: 73-76 ms of hipMalloc per fresh
+ * config-D generator -- allocation of multi-GB buffers is NOT sub-millisecond on every box. */
 void mm_destroy(mm_engine *e);
 /* Releases the parked resources of destroyed engines (all devices); returns how many sets were released.
  * MOSAIC_HIP_KEEP=0 in the environment turns the parking off altogether (mm_destroy then frees everything, as the
@@ -366,62 +368,15 @@ mm_status mm_group_generate(mm_group *g, const mm_cell *cells, int n_cells, int 
                             int repeat_range, int repeat_addition, int64_t *best_fit_out, double *best_score_out,
                             mm_progress_cb progress, void *progress_user, volatile int *cancel);
 
-/* Engine options.  "filter" (default 1): two-tier scoring -- an fp32 filter pass over
- * every (cell, candidate), then the fp64 score of each cell's contenders only (parallel
- * order; candidates within 1e-9 of each other are re-summed in the reference's order with the
- * reference's own arithmetic); 0 scores everything in fp64.  "prune" (default 1): the filter pass
- * abandons a candidate once its running sum passes a per-cell upper bound (the device
- * form of the reference's early exit).  "sweep_resolve" (default 1): the repeat
- * penalty as parallel sweeps to the raster-order fix point ("max_sweeps", default 48, before the
- * chain takes over); "wave_resolve" / "row_pipeline" (default 1): the single-wave and the
- * row-pipelined forms of the chain.  "max_batch" (default 0 = sized
- * from free device memory): cap on the cells scored per device batch.  "spec_k" (default 4):
- * length of mm_generate's speculative short lists, 0 = always the full length.
- * Tuning of the filter kernel (measured defaults): "tile" (candidates per work item, 0 = by cell
- * size and by the share of candidates the bound dropped in the engine's last launch over the same library), "xcd_aware" (1) / "xcd_cells" (0 = by cell size): per-XCD item order; "interleave" (1): the [group][plane]
- * image copies with prepared operands; "two_level" (1): the bound's stage 1, several candidates per wave pass;
- * "sort_groups" (-1 = by cell size): how many of a candidate's pixel groups are visited by descending bound;
- * "check_every" (0 = by cell size): pixel groups between two exit tests of a candidate;
- * "probe_prepared" (0): mm_filter_diff_batch measures the CIEDE2000 filter form with operands prepared as the dominant kernel holds them
- * (1), or the packed-fp16 pre-tier's form on operands rounded to halfs (2; pairs it counts as 0 -- near the opposite-hue seam, a chroma below
- * 1 / 16 -- read -1); 3: mm_colour_diff_batch returns the algebraic fp64 form of the parallel-order sums instead of the reference form;
- * "lds_filter" (-1 = RGB only): LDS-resident cell tile; "seeds" (-1 = 14 for CIEDE2000, 2 for RGB / CIE76): proxy-chosen seeds beyond the list length;
- * "spec_auto" (1): the length of the speculative short lists ("spec_k", 4) doubles (up to 16) when the engine's PREVIOUS
- * generate over the same library had to deepen more than 2 % of its cells -- content on which neighbouring cells want the same few
- * images; as with "item_auto" only the TIME of a call depends on the engine's history, never its result; 0 pins "spec_k";
- * "band_guard" (1 = every cell; n: every n-th cell, 0: off): the best candidate the filter band EXCLUDED rides through the fp64 re-score as a sentinel; one that beats a contender is a band failure: the cell is re-done fp64-only and counted (mm_timing.band_alarms);
- * "item_auto" (1): with "tile" 0 the item size of a CIEDE2000 filter launch follows the share of candidates the bound
- * dropped in the engine's PREVIOUS CIEDE2000 launch over the same library, so the TIME of a call (never its result)
- * depends on the call history of the engine; 0 pins the size-by-cell default (mm_timing.filter_tile reports what ran).
- * "pretier" (-1: off on the default band -- no benchmarked configuration gains there --; with "pretier_band" 1 measured: jobs with something to
- * gain -- cells above 32 pixel groups, i.e. 96 .. 128 px, or calls of >= 1e10 pixel pairs -- run a warm-up launch over a (library, cell size,
- * batch, target), then one filter launch without it and one with it, and keep the faster form from there on: whether it pays depends on the content
- * (synthetic patches: yes; photographs: no); 0 never, 1 always; as with "item_auto" only the TIME of a call depends on the engine's history):
- * CIEDE2000 candidates first walk their pixel groups in
- * a packed-fp16 form (two pixel pairs per lane-instruction, operands half the size) that only takes early-exit decisions, against the limit
- * widened by its own band; survivors are scored by the fp32 form as before; "pretier_band" (0): 0 = that band is the WORST-CASE bound of the
- * fp16 form -- every rounding of its operation sequence at its worst, tools/filter_error_bound.py, 0.45 + 3.8e-2 dE per pixel pair --, 1 = the
- * band of round 4, twice the worst OBSERVED pair (0.29 + 8e-3 dE: a third of the worst-case bound, i.e. a statistical guarantee; the audit then
- * runs at eight times its rate; config D -4 %); "audit" (1024; a power of two, 0 = off): one in N
- * of the CIEDE2000 candidates that leave the filter without a full score -- dropped by the bound, by the pre-tier's walk or by the fp32 walk's
- * exit test -- is walked once more by the fp32 form WITHOUT the bound, and a launch in which such a candidate turns out to lie clearly below
- * the limit is redone without the filter tiers (as when the pre-tier's canary trips); the RGB / CIE76 filter is audited the same way at an
- * eighth of the rate (its bound has two rounding constants, and an audited walk costs it relatively more);
- * "stage0" (1): one whole-image bound per candidate ahead of the block bound; "euclid_stage1" (1): the RGB / CIE76 filter
- * judges the block bound one candidate per lane before any wave is spent on a candidate; "item_chunk" (0 = 1): work items a persistent
- * filter workgroup takes per global atomic; "cell_order" (1): the CIEDE2000 filter takes each XCD share's clipped cells (long items) first; "tiny" (1): detail cells of <= 64 pixels take the one-wave-per-cell path;
- * "fused_seeds" (2048): batches of up to n cells pick seeds, score them and set the limit in one launch;
- * "prune_min_kpairs" (-1 = 1e5 for RGB / CIE76, 2e4 for CIEDE2000): below n thousand pixel pairs per call the seeds and the
- * early exit are skipped (they would cost a small job more than they save); "phase_timing" (-1): events between the phases of
- * a call -- the *_ms fields of mm_timing -- 1 always, 0 never, -1 only for calls large enough not to notice their ~35 us.
- * "spin_wait_us" (1000): the host polls the stream for up to n microseconds before it blocks on it (a blocking wait wakes up some
- * 10 us after the last kernel has ended: config A 0.107 -> 0.095 ms per generate, photographs with their 14 waits 5.43 -> 5.25); 0: block at once;
- * "fast_path" (1): mm_generate enqueues a whole generate and reads ONE result block back (one host wait) whenever the
- * cells fit one batch, falling back to the step-by-step path when the block says a host decision was needed; "fused" (1):
- * cell gather + chroma + interleave + block statistics in one launch and contenders + fp64 re-score + re-rank in one.
- * diagnostics only: "band_pct" (100, a deliberately wrong band), "lds_pad_kb", "dbg_pre_band_pct" (100; the pre-tier's band in per cent, negative = drops contenders) and "dbg_bound_pct" (100; the early exit's lower bound in per cent, above 100 = drops contenders): what the audit is for, "dbg_pre_abs_1e4" / "dbg_pre_rel_1e6" (the band
- * mm_debug_filter_band_sweep modes 2 / 3 measure the pre-tier's form against, in units of 1e-4 / 1e-6; 0: the pre-tier's own).  Results are identical whatever the
- * options (tests/test_gpu_fuzz.py::test_tuning_options_do_not_change_the_result). */
+/* Engine options.  Three switches belong to the boundary; every other name is tuning or diagnostics and lives in
+ * mosaic_hip_tuning.h (results are identical whatever the options: tests/test_gpu_fuzz.py).
+ *   "filter"    (default 1)  two-tier scoring: an fp32 filter pass over every (cell, candidate), then the fp64 score of
+ *                            each cell's contenders (near-ties re-summed in the reference's order with its own
+ *                            arithmetic); 0 scores every pixel pair in fp64 -- the escape hatch.
+ *   "prune"     (default 1)  the filter pass abandons a candidate once its running sum passes a per-cell upper bound
+ *                            (the device form of the reference's early exit, CPUPhotomosaicGenerator.cpp:149-161).
+ *   "max_batch" (default 0)  cap on the cells scored per device batch; 0 = sized from free device memory.
+ * Unknown names return MM_INVALID_ARGUMENT. */
 mm_status mm_set_option(mm_engine *e, const char *name, int value);
 
 /* Timings of the last mm_generate / mm_score_cells (+ mm_resolve) on e. */
@@ -438,35 +393,6 @@ mm_status mm_get_stage_timing(const mm_engine *e, mm_stage_timing *out);
 mm_status mm_colour_diff_batch(mm_engine *e, int diff_type,
                                const float *first, const float *second,
                                size_t n, double *out);
-
-/* Diagnostics: the fp32 FILTER form of the same difference (tier 1 of the two-tier
- * scoring).  It never decides a result; this entry exists so that its
- * error against mm_colour_diff_batch can be measured (tests/test_gpu_filter.py). */
-mm_status mm_filter_diff_batch(mm_engine *e, int diff_type,
-                               const float *first, const float *second,
-                               size_t n, float *out);
-
-/* Diagnostics: what backs the error band the engine trusts the fp32 filter with.  A structured
- * sweep generated and reduced on the device -- mode 0: hue x hue x chroma x chroma x lightness
- * (3.8e9 distinct grid points per seed, jittered by `seed`); mode 1: the same chroma / lightness
- * grid on both sides of the opposite-hue discontinuity (hue difference 180 deg +- 1e-7 .. 3e-2 rad).
- * out: max |fp32 - fp64|, max (|err| - 6e-5 v), max |err| / (band px_abs + 6e-5 v) -- the share of
- * the trusted band the worst pair uses, must stay below 1 --, the largest fp64 value met, pairs
- * handed to the fp64 form, pairs measured.  Modes 2 and 3: the same two sweeps for the filter's packed-fp16 pre-tier
- * (operands rounded to halfs as the engine stores them) against ITS band; the share is then the signed OVER-estimate
- * (fp16 - fp64) / band -- an under-estimate only delays an early exit --, "handed over" counts the pairs the form counts as 0
- * near the opposite-hue seam, and a non-finite value off the seam reports a share of 1e9. */
-mm_status mm_debug_filter_band_sweep(mm_engine *e, int mode, uint64_t seed, uint64_t n_pairs, double out[6]);
-
-/* Diagnostics: {pixel groups visited by the filter kernel, groups a full visit takes,
- * candidates dropped outright by the bound} of the last filter launch (always counted; the
- * sums over a generate are in mm_timing). */
-mm_status mm_debug_visit_counters(mm_engine *e, unsigned long long out[3]);
-
-/* Calibration: GB/s a plain coalesced float4 read stream over `bytes` of device memory reaches
- * (best of `repeats` launches); bench.py quotes the roofline fraction against it as well as
- * against the 8 TB/s specification. */
-mm_status mm_debug_stream_read(mm_engine *e, size_t bytes, int repeats, double *gb_per_s);
 
 #ifdef __cplusplus
 }

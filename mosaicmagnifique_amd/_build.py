@@ -24,9 +24,9 @@ UNITS = [("engine.hip", ["-ffp-contract=off"]),
 ROCM_LIB = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
 LINK_FLAGS = ["-L" + ROCM_LIB, "-lrccl", "-Wl,-rpath," + ROCM_LIB, "-lpthread"]
 SOURCES = [os.path.join(CSRC, name) for name, _ in UNITS]
-HEADERS = [os.path.join(CSRC, h) for h in ("kernels.hpp", "colour_diff.hpp", "colour_diff_fast.hpp",
-                                           "launch.hpp")] + \
-          [os.path.join(HERE, "..", "include", "mosaic_hip.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("kernels.hpp", "colour_diff.hpp", "colour_diff_fast.hpp", "colour_diff_fp16.hpp",
+                                           "filter_pretier.hpp", "launch.hpp")] + \
+          [os.path.join(HERE, "..", "include", h) for h in ("mosaic_hip.h", "mosaic_hip_tuning.h")]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra"]
 

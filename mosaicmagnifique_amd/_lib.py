@@ -56,10 +56,11 @@ MM_OK, MM_CANCELLED, MM_INVALID_ARGUMENT, MM_OUT_OF_MEMORY, MM_DEVICE_ERROR, MM_
 STATUS_NAMES = ("MM_OK", "MM_CANCELLED", "MM_INVALID_ARGUMENT", "MM_OUT_OF_MEMORY",
                 "MM_DEVICE_ERROR", "MM_NOT_READY")
 
-# Every symbol include/mosaic_hip.h declares: (restype, argtypes).
+# Every symbol include/mosaic_hip.h and include/mosaic_hip_tuning.h declare: (restype, argtypes).
 _VP = ctypes.c_void_p
 SIGNATURES = {
     "mm_abi_version": (ctypes.c_int, []),
+    "mm_debug_has_pretier": (ctypes.c_int, []),
     "mm_device_count": (ctypes.c_int, [c_int_p]),
     "mm_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_VP)]),
     "mm_destroy": (None, [_VP]),

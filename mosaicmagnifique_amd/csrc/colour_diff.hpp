@@ -116,7 +116,7 @@ __device__ __forceinline__ double ciede2000(const Px& p, const Px& q)
 //   * the mean hue h_bar as a DIRECTION (the bisector construction of ciede2000_fast, identical to the reference's three-branch rule
 //     :107-122), normalised once; T (:124-127) from it by the multiple-angle identities -- no cos;
 //   * only the rotation term's exp(-((h_bar - 275) / 25)^2) needs h_bar as an ANGLE: one atan2, one exp, one sin of an argument <= 60 deg.
-// Per pair it agrees with ciede2000() to a few 1e-15 relative (tests/test_gpu_colour_diff.py: 1e-12 asserted on 1e7 pairs, and the
+// Per pair it agrees with ciede2000() to a few 1e-15 relative (tests/test_gpu_colour_diff.py: 2e-12 asserted on ~5.8e6 pairs, and the
 // worst-case bound of tools/filter_error_bound.py).  The formula has two DISCONTINUITIES, and within rounding of either the two forms may
 // land on different sides: opposite hues (|dh| = 180 deg: the mean hue flips, Sharma 2005) and a mean hue of exactly 0 = 360 deg (the
 // reference does not wrap h_bar - 275).  A pair within 1e-9 of either is handed to ciede2000() itself (*needs_reference).
@@ -204,7 +204,12 @@ __device__ __forceinline__ double ciede2000_algebraic(const Px& p, const Px& q, 
     const double slc = s_l * s_c;
     const double inv_all = 1.0 / (slc * s_h);
     const double t_l = (q.c0 - p.c0) * ((s_c * s_h) * inv_all), t_c = (c2p - c1p) * ((s_l * s_h) * inv_all), t_h = d_h * (slc * inv_all);
-    return sqrt(fmax(fma(t_l, t_l, fma(t_c, fma(r_t, t_h, t_c), t_h * t_h)), 0.0));
+    // (a radicand a rounding took below 0 counts 0; a NON-FINITE one -- NaN or inf in either pixel -- must not: fmax is maxNum and would
+    // turn NaN into a term of 0, where ColourDifference.cpp yields NaN and the candidate never wins.  Such a pair goes to the reference
+    // form, whose own arithmetic then decides what a non-finite input gives)
+    const double s = fma(t_l, t_l, fma(t_c, fma(r_t, t_h, t_c), t_h * t_h));
+    if (!(fabs(s) < __builtin_huge_val())) *needs_reference = true;
+    return sqrt(s < 0.0 ? 0.0 : s);
 }
 
 // What every PARALLEL-order fp64 sum adds per pixel pair: the contenders' re-score (rescore_kernel, rank_kernel), the fp64-only

@@ -668,8 +668,10 @@ void account_score_batch(mm_engine* e, bool two_tier, bool prune, int diff_type,
     e->timing.bound_dropped += (int64_t)work[2];
     if (e->pre_auto.pending >= 0) {             // a pre-tier trial: this launch's time, and the verdict once both forms have one
         mm_engine::PreAuto& a = e->pre_auto;
-        a.ms[a.pending] = elapsed(e->ev[12], e->ev[13]);
-        a.have |= 1 << a.pending;
+        if (!voided) {                          // (a voided launch's time is not a measurement of its form: the trial is taken again)
+            a.ms[a.pending] = elapsed(e->ev[12], e->ev[13]);
+            a.have |= 1 << a.pending;
+        }
         a.pending = -1;
         if (a.have == 3) a.choice = a.ms[1] < 0.98f * a.ms[0] ? 1 : 0;
     }
@@ -791,7 +793,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                 (st = ensure(e, e->cell_chroma, (size_t)bt * ppad * sizeof(float), "Failed to allocate cell chroma planes")) ||
                 (st = ensure(e, e->cells_f0, (size_t)bt * ppad * sizeof(float), "Failed to allocate cell planes")) ||
                 (st = ensure(e, e->cells_il, (size_t)bt * 4 * ppad * sizeof(float), "Failed to allocate interleaved cells")) ||
-                (st = ensure(e, e->cells_h, (size_t)bt * 4 * ppad * sizeof(uint16_t), "Failed to allocate half-precision cells")))
+                (MM_WITH_PRETIER != 0 && (st = ensure(e, e->cells_h, (size_t)bt * 4 * ppad * sizeof(uint16_t), "Failed to allocate half-precision cells"))))
                 return st;
         }
         if (prune) {
@@ -940,7 +942,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                     "Error during cell image-statistics kernel");
         fin.var.two_stage = (e->two_level ? 1 : 0) | (stage0 ? 2 : 0);
         // the packed-fp16 pre-tier reads half copies of the cells and the library (CIEDE2000 with the early exit, interleaved form)
-        const bool pre_possible = prune && diff_type == MM_CIEDE2000 && e->use_interleave != 0 && fin.use_lds_form == 0;
+        const bool pre_possible = MM_WITH_PRETIER != 0 && prune && diff_type == MM_CIEDE2000 && e->use_interleave != 0 && fin.use_lds_form == 0;
         bool pretier = pre_possible && e->pretier > 0;
         bool pre_trial = false;
         // (eligible by size -- small jobs lose to it, config C +5 % -- and not a deepening sub-batch: decided by measurement.  On the
@@ -963,7 +965,9 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
             // warm-up without the pre-tier, then one launch without and one with, both timed)
             if (mine && a.choice >= 0) pretier = a.choice != 0;
             else if (mine && full && !a.warm) { pretier = false; a.warm = true; }
-            else if (mine && full && a.pending < 0) { pretier = (a.have & 1) != 0; a.pending = pretier ? 1 : 0; pre_trial = true; }    // off first, then on
+            // (the trial is PENDING only once its launch has gone out -- below, after launch_filter -- so that an error or a cancel between
+            // here and there cannot leave a pending trial whose two events were never recorded: ADVICE round 5)
+            else if (mine && full && a.pending < 0) { pretier = (a.have & 1) != 0; pre_trial = true; }    // off first, then on
             else pretier = false;
         }
         if (row_map_host == nullptr) e->timing.pretier = pretier ? 1 : 0;
@@ -1011,6 +1015,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
                                      (mm::EdgeEntry*)e->edges.p, counters_dev, edge_cap,
                                      prune ? (const float*)e->limits.p : nullptr, e->stream, &tile_used),
                 "Error during filter colour difference kernel");
+        if (pre_trial) e->pre_auto.pending = pretier ? 1 : 0;
         e->timing.filter_tile = tile_used;
         if (e->phase_events) HIP_TRY(e, hipEventRecord(e->ev[2], e->stream), "event");
         // the audit of what the filter dropped: reads the score rows, may void the launch through the counter block's void word
@@ -1321,7 +1326,7 @@ mm_status begin_single_submission(mm_engine* e, int n, int grid_w, int grid_h, b
 mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n, int grid_w, int grid_h,
                                     int diff_type, int range, int addition, int K, int k_fill, bool speculate,
                                     const int32_t* cand_i_dev, const double* cand_s_dev, bool want_scores,
-                                    const uint8_t* flags_dev, bool counted, bool continuing = false)
+                                    const uint8_t* flags_dev, bool counted, bool continuing = false, int sweeps_done = 0)
 {
     // continuing: the block holds the state after sweeps that had not settled yet (nothing else wrong with it): the header is
     // cleared and another set of sweeps runs from that state -- a fix-point iteration may be resumed anywhere
@@ -1359,7 +1364,9 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
         // has settled returns at once (prev_changes), so a generous set costs a few microseconds of empty launches.
         const bool learned = e->sweeps_lib == e->n_lib && e->sweeps_size == e->lib_size && e->sweeps_learned > 8;
         const int want = continuing ? mm::kFastSweeps : (learned ? std::min(mm::kFastSweeps, (e->sweeps_learned + 2 + 7) / 8 * 8) : 8);
-        sweeps = std::min(e->max_sweeps, want);
+        // (what is left of "max_sweeps" bounds the set, not the option itself: a continued set used to enqueue its full want and the
+        // sets of a call 8 + 32 + 32 = 72 sweeps under the default of 48 -- ADVICE round 5)
+        sweeps = std::max(1, std::min(e->max_sweeps - sweeps_done, want));
         for (int i = 0; i < sweeps; ++i) {
             a.prev_changes = i > 0 ? &hdr->sweep_changes[i - 1] : nullptr;
             a.sweep_changes = &hdr->sweep_changes[i];
@@ -1410,7 +1417,7 @@ mm_status settle_sweeps(mm_engine* e, const mm_cell* recs_dev, int n, int grid_w
     while (*settled < 0 && done < e->max_sweeps) {
         if (e->phase_events) e->timing.resolve_ms += elapsed(e->ev[10], e->ev[11]);      // (the set that did not settle)
         mm_status st = resolve_single_submission(e, recs_dev, n, grid_w, grid_h, diff_type, range, addition, K, k_fill, speculate,
-                                                 cand_i_dev, cand_s_dev, want_scores, nullptr, false, true);
+                                                 cand_i_dev, cand_s_dev, want_scores, nullptr, false, true, done);
         if (st) return st;
         *before = done;
         for (unsigned int i = 0; i < h.sweeps && *settled < 0; ++i)
@@ -1452,15 +1459,23 @@ bool parking_enabled()
     return !(v && v[0] == '0');
 }
 
-// Device bytes a parked set may hold (MOSAIC_HIP_KEEP_MB, default 256).  What parking buys is the fixed cost of a fresh
-// generator -- stream, events, the page-locked mirror, forty small allocations: config A 6 ms -> 0.3 -- not the large
-// workspaces: config D's 2.6 GB take 0.3 ms to allocate again, and left parked they are memory a co-tenant of the device (a
-// second engine budgeting on hipMemGetInfo, PyTorch / RCCL in dist.py) does not get back until mm_trim_cache.
-size_t parked_bytes_cap()
+// Device bytes a parked set may hold.  Default: a BUDGET AGAINST THE DEVICE'S FREE MEMORY -- 5 % of what would be free with the
+// set released (hipMemGetInfo at mm_destroy: free + held), i.e. ~14 GB on an otherwise idle MI355X, so a config-D generator's 2.4 GB
+// of workspaces stay and the next generator allocates nothing, while on a device other tenants have filled the set shrinks with what is
+// left.  MOSAIC_HIP_KEEP_MB in the environment pins a fixed cap instead (0: only stream, events and the pinned mirror are kept).
+// Round 5 shipped a fixed 256 MB on the measurement that config D's workspaces "allocate again in 0.3 ms"; on the driver's box the
+// same hipMallocs took 73-76 ms (BENCH_r05.json first_call: 137 / 122 ms against 56 / 48 with everything parked) -- hipMalloc of a
+// multi-GB buffer is not sub-millisecond on every box, and the reference's pattern (a generator per run, MainWindow.cpp:584-607) pays it
+// every time.  What the cap is for -- memory a co-tenant (a second engine budgeting on hipMemGetInfo, PyTorch / RCCL in dist.py) does
+// not get back until mm_trim_cache -- is bounded by the 5 %.
+constexpr double kParkShareOfFree = 0.05;
+size_t parked_bytes_cap(size_t held)
 {
     const char* v = std::getenv("MOSAIC_HIP_KEEP_MB");
-    const long long mb = v && v[0] ? std::atoll(v) : 256;
-    return (size_t)std::max<long long>(mb, 0) << 20;
+    if (v && v[0]) return (size_t)std::max<long long>(std::atoll(v), 0) << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)256 << 20;
+    return (size_t)(kParkShareOfFree * (double)(free_b + held));
 }
 
 void free_resources(mm_engine* e)
@@ -1495,9 +1510,9 @@ bool park_resources(mm_engine* e)
     keep->device = e->device;
     move_resources(keep, e);
     // the largest buffers are released until the set fits its cap (the two constant tables are a few KB: they stay)
-    const size_t cap = parked_bytes_cap();
     size_t held = 0;
     for (DevBuf mm_engine::* m : kDeviceBuffers) held += (keep->*m).bytes;
+    const size_t cap = parked_bytes_cap(held);
     while (held > cap) {
         DevBuf* largest = nullptr;
         for (DevBuf mm_engine::* m : kDeviceBuffers)
@@ -1544,6 +1559,8 @@ int64_t count_pair_evals(const mm_engine* e, const mm_cell* cells, int n)
 extern "C" {
 
 int mm_abi_version(void) { return MM_ABI_VERSION; }
+
+int mm_debug_has_pretier(void) { return MM_WITH_PRETIER != 0 ? 1 : 0; }
 
 mm_status mm_device_count(int* count)
 {

@@ -14,6 +14,9 @@
 #include "colour_diff.hpp"
 #include "colour_diff_fast.hpp"
 #include "launch.hpp"
+#if MM_WITH_PRETIER
+#include "colour_diff_fp16.hpp"
+#endif
 
 namespace mm {
 
@@ -99,6 +102,10 @@ __device__ __forceinline__ float row_suffix_sum(float v)
                  : "+v"(v));
     return v;
 }
+
+#if MM_WITH_PRETIER
+#include "filter_pretier.hpp"     // pretier_walk, pretier_canary (a fragment of this namespace)
+#endif
 
 // One pair through the fp32 form.  For CIEDE2000 `edge` reports a pair on the
 // opposite-hue discontinuity (colour_diff_fast.hpp): the filter kernel logs it and
@@ -237,19 +244,6 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 #ifndef MM_BIG_CELL_STAGE0
 #define MM_BIG_CELL_STAGE0 1         // cells above 16 groups: stage 0 of the bound ahead of the candidate loop, bound-ordered visits from 17 groups on (0: round 3's form, for A/B builds)
 #endif
-// Error band of the packed-fp16 pre-tier per pixel pair (launch.hpp kPreBandAbs / kPreBandRel): fp16 form - fp64 form <= abs + rel * value for operands
-// inside the validated box, with the operands rounded to halfs as interleave_h_kernel stores them; the pre-tier's accumulation is fp32.
-// Round 5: the band is no longer sized on OBSERVED errors.  tools/filter_error_bound.py carries, through the form's own sequence of
-// operations, a bound on what the half-precision computation can be off by with EVERY rounding at its worst (u = 2^-11 per packed
-// operation, one ulp per transcendental, subnormal halfs at their absolute step, the hue table's index moved by the direction's
-// error) -- a smooth function of the pair, unlike an observed error, which depends on mantissa bits and let round 4's sweeps step over
-// what the maximiser then found.  Its frontier over thirteen families x 1.5e6 pairs (the form's weak zones, the colours of u8 images):
-// 0.40 + 3.3e-2 v, 0.45 + 3.1e-2 v, 0.50 + 2.9e-2 v; shipped with a tenth of room on either part.  Observed errors sit at a tenth of it
-// (round 4's band, twice the worst observed pair, was 0.29 + 8e-3 v -- kPreBandAbsObserved / kPreBandRelObserved, option "pretier_band" 1:
-// a third of the worst-case bound, i.e. a band that trusts the roundings not to conspire; config D ran 4 % faster on it).
-#ifndef MM_PRE_PREFETCH
-#define MM_PRE_PREFETCH 1            // the pre-tier fetches the next group's operands while it computes this one (0: A/B builds)
-#endif
 #ifndef MM_LONG_SPLIT
 #define MM_LONG_SPLIT 0.8f
 #endif
@@ -296,13 +290,7 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // BIG: the instantiation for cells above 16 groups (80 x 80 .. 128 x 128): stage 0 of the bound ahead of the candidate loop and
 // bound-ordered visits from 17 groups on.  A template parameter and not a run-time branch: the extra scalars it keeps alive
 // cost the 64 x 64 instantiation three more spilled SGPRs and config D 0.3 % (measured, tools/experiments/r4_second.sh).
-// PRE: the packed-fp16 pre-tier (colour_diff_fast.hpp ciede2000_h2).  A candidate first walks its groups in the fp16 form,
-// two pixel pairs per lane-instruction, from half copies of the cell and the library (`cells` and `lib_chroma`, which the
-// interleaved fp32 form leaves unused, carry their addresses), with the exit test against the limit widened by the fp16
-// form's own band; only a candidate that survives ALL its groups there is walked again by the fp32 form, whose score is the
-// one the contender selection reads.  Dropped candidates get +inf as before.  Sound because every term is >= 0 and the fp16
-// sum under-estimates by at most its band: "fp16 sum of the visited groups + bound of the others > limit + band" implies the
-// same for the true sum against the limit.
+// PRE: the packed-fp16 pre-tier ahead of the fp32 walk (filter_pretier.hpp; instantiated only with -DMM_WITH_PRETIER=1).
 template <int TYPE, int THREADS, bool CELL_LDS, bool IL, bool BIG = false, bool PRE = false>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(MM_FILTER_WAVES, MM_FILTER_WAVES)))
 filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
@@ -736,57 +724,15 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         }
         int visited = 0;
         float pre_sum = -1.0f;         // PRE: lane-partial fp16-form sum of a candidate that survived the pre-tier (else < 0)
+#if MM_WITH_PRETIER
         if constexpr (PRE) {
-            if (!pruned && groups > 0 && prune_above != nullptr) {
-                // half copies: [image][group][plane][256] halfs -- a group is 2 KB, a plane 512 B, a lane's four positions 8 B
-                const char* const ch = reinterpret_cast<const char*>(cells) + (size_t)cell * 8 * ppad;
-                const char* const lh = reinterpret_cast<const char*>(lib_chroma_base) + ((size_t)v * L + l) * 8 * (size_t)ppad;
-                // true sum of the visited pairs >= (acc16 - abs x pairs visited) / (1 + rel): the exit test compares acc16 + rest with
-                // limit (1 + rel) + abs x (positions visited so far) -- the absolute part grows with the walk instead of being charged
-                // for the whole cell up front
-                const float pre_abs = var.pre_abs;
-                const float limit_rel = limit * (1.0f + var.pre_rel);
-                float acc16 = 0.0f;
-                bool out16 = false;
-                // the operands of the NEXT group are fetched while this one is computed: a group of the fp16 form is ~280 instructions
-                // (the fp32 one ~430) and its sixteen registers of operands leave room for a second set inside the kernel's 96
-                struct HalfGroup { uint2 p0, p1, p2, pc, q0, q1, q2, qc; };
-                auto fetch = [&](int j) {
-                    const unsigned int off = (unsigned int)j * 2048u + (unsigned int)lane * 8u;
-                    HalfGroup g;
-                    g.p0 = *reinterpret_cast<const uint2*>(ch + off); g.p1 = *reinterpret_cast<const uint2*>(ch + off + 512u);
-                    g.p2 = *reinterpret_cast<const uint2*>(ch + off + 1024u); g.pc = *reinterpret_cast<const uint2*>(ch + off + 1536u);
-                    g.q0 = *reinterpret_cast<const uint2*>(lh + off); g.q1 = *reinterpret_cast<const uint2*>(lh + off + 512u);
-                    g.q2 = *reinterpret_cast<const uint2*>(lh + off + 1024u); g.qc = *reinterpret_cast<const uint2*>(lh + off + 1536u);
-                    return g;
-                };
-                HalfGroup cur = fetch((sorted || sorted64) ? __builtin_amdgcn_readlane(order, 0) : 0);
-                for (int step = 0; step < groups; ++step) {
-                    if (step != 0 && step % check_every == 0) {
-                        const float rest_j = use_lb ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rest), by_group ? step : (4 * step) >> lane_shift)) : 0.0f;
-                        if (wave_sum_exceeds(acc16, rest_j, fmaf(pre_abs * (float)(4 * kWave), (float)step, limit_rel))) { out16 = true; break; }
-                    }
-#if MM_PRE_PREFETCH
-                    const int nxt = step + 1 < groups ? step + 1 : step;         // (the last step fetches its own group again: no branch)
-                    const HalfGroup ahead = fetch((sorted || sorted64) ? __builtin_amdgcn_readlane(order, nxt) : nxt);
-#else
-                    if (step != 0) cur = fetch((sorted || sorted64) ? __builtin_amdgcn_readlane(order, step) : step);
-#endif
-                    const half2_t va = ciede2000_h2(h2_from(cur.p0.x), h2_from(cur.p1.x), h2_from(cur.p2.x), h2_from(cur.pc.x),
-                                                    h2_from(cur.q0.x), h2_from(cur.q1.x), h2_from(cur.q2.x), h2_from(cur.qc.x), lut);
-                    const half2_t vb = ciede2000_h2(h2_from(cur.p0.y), h2_from(cur.p1.y), h2_from(cur.p2.y), h2_from(cur.pc.y),
-                                                    h2_from(cur.q0.y), h2_from(cur.q1.y), h2_from(cur.q2.y), h2_from(cur.qc.y), lut);
-                    acc16 += ((float)va.x + (float)va.y) + ((float)vb.x + (float)vb.y);
-                    visited += 1;
-#if MM_PRE_PREFETCH
-                    cur = ahead;
-#endif
-                }
-                if (!out16 && wave_sum_exceeds(acc16, 0.0f, fmaf(pre_abs * (float)(4 * kWave), (float)groups, limit_rel))) out16 = true;
-                if (out16) pruned = true;       // (a survivor goes on to the fp32 form below)
-                else pre_sum = acc16;
-            }
+            if (!pruned && groups > 0 && prune_above != nullptr)
+                pruned = pretier_walk(reinterpret_cast<const char*>(cells) + (size_t)cell * 8 * ppad,
+                                      reinterpret_cast<const char*>(lib_chroma_base) + ((size_t)v * L + l) * 8 * (size_t)ppad,
+                                      lane, groups, check_every, use_lb, rest, by_group, lane_shift, sorted || sorted64, order,
+                                      limit, var.pre_abs, var.pre_rel, lut, visited, pre_sum);
         }
+#endif
         float acc = 0.0f;          // terms with a proven error bound
         float acc_edge = 0.0f;     // terms awaiting the fp64 patch
         if (!pruned && groups > 0) {
@@ -858,18 +804,11 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             n_bound_dropped += (pruned && visited == 0) ? 1u : 0u;
         }
         acc = wave_sum_all(acc + acc_edge);
+#if MM_WITH_PRETIER
         if constexpr (PRE) {
-            // Canary of the pre-tier: a candidate that walked ALL its groups in both forms has two sums of the same terms (the fp16 one
-            // without its seam pairs, which can only make it smaller).  An fp16 sum ABOVE the fp32 one by more than the band's worth says
-            // the fp16 form over-estimates here -- what its early exits must never do -- and voids the launch: a sticky bit in the
-            // counter block's void word (an OR: it cannot wrap, however many candidates trip it), which sends the whole batch down
-            // the fp64-only path (and shows in mm_timing.voided_launches).
-            if (pre_sum >= 0.0f && !pruned) {
-                const float sum16 = wave_sum_all(pre_sum);
-                // (the band in force; the diagnostics' negative bands -- what the audit is shown to catch -- by their size)
-                if (lane == 0 && sum16 > fmaf(acc, 1.0f + fabsf(var.pre_rel), fabsf(var.pre_abs) * (float)(groups * 4 * kWave))) atomicOr(edge_count + kFilterVoidWord, kVoidByCanary);
-            }
+            if (pre_sum >= 0.0f && !pruned) pretier_canary(pre_sum, acc, lane, groups, var.pre_abs, var.pre_rel, edge_count);
         }
+#endif
         if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
     }
     MM_STAMP(5);
@@ -1272,6 +1211,7 @@ interleave_kernel(const float* __restrict__ planar, const float* __restrict__ ch
     }
 }
 
+#if MM_WITH_PRETIER
 // The interleaved copy once more as halfs, for the packed-fp16 pre-tier (colour_diff_fast.hpp ciede2000_h2): the same
 // [image][group][plane][256] order, planes L / 2 - 25, a / 4, b / 4, C / 4, round-to-nearest; a NaN stays a NaN.
 __global__ void __launch_bounds__(kBlock)
@@ -1285,6 +1225,7 @@ interleave_h_kernel(const float4* __restrict__ il, uint2* __restrict__ out, size
         out[t] = uint2{h2_bits(lo), h2_bits(hi)};
     }
 }
+#endif
 
 // Per-image statistics over each 64-position BLOCK of the plane order (four blocks make one of
 // the filter's 256-position groups; the plane order is tile-major, engine.hip prepare_planes, so
@@ -1842,6 +1783,7 @@ pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ seco
         const float* q = second + 3 * i;
         bool edge;
         float v;
+#if MM_WITH_PRETIER
         if (TYPE == CIEDE2000 && (flag_edges & 4) != 0) {   // the packed-fp16 pre-tier's form on operands rounded to halfs as interleave_h_kernel stores them
             auto half_operands = [](const float* c, half2_t& l, half2_t& a, half2_t& b, half2_t& ch) {
                 l = h2_splat(fmaf(0.5f, c[0], -25.0f)); a = h2_splat(kHalfOperandScale * c[1]); b = h2_splat(kHalfOperandScale * c[2]);
@@ -1852,7 +1794,9 @@ pair_fast_kernel(const float* __restrict__ first, const float* __restrict__ seco
             unsigned int seam = 0u;
             v = (float)ciede2000_h2(pl, pa, pb, pch, ql, qa, qb, qch, lut, &seam).x;
             edge = (seam & 0xffffu) != 0u;                  // counted as 0 by the pre-tier
-        } else if (TYPE == CIEDE2000 && (flag_edges & 2) != 0)     // the form the dominant kernel runs: operands prepared as interleave_kernel stores them
+        } else
+#endif
+        if (TYPE == CIEDE2000 && (flag_edges & 2) != 0)     // the form the dominant kernel runs: operands prepared as interleave_kernel stores them
             v = pair_fast<TYPE, true>(PxF{fmaf(0.5f, p[0], -25.0f), p[1], p[2]}, PxF{fmaf(0.5f, q[0], -25.0f), q[1], q[2]},
                                       __fmul_rn(kChromaPrep, chroma_of(p[1], p[2])), __fmul_rn(kChromaPrep, chroma_of(q[1], q[2])), lut, &edge);
         else
@@ -1918,6 +1862,7 @@ band_sweep_kernel(int mode, unsigned long long seed, unsigned long long n_pairs,
         const PxF p{l1, (float)(ch1 * cos(h1)), (float)(ch1 * sin(h1))}, q{l2, (float)(ch2 * cos(h2)), (float)(ch2 * sin(h2))};
         bool edge;
         float fast;
+#if MM_WITH_PRETIER
         if (mode & 2) {
             // the packed-fp16 pre-tier's form on operands rounded to halfs as interleave_h_kernel stores them; pairs it counts as 0
             // (near the seam) are "handed over".  What must hold is the OVER-estimate: fp16 - fp64 <= band (an under-estimate only
@@ -1933,7 +1878,9 @@ band_sweep_kernel(int mode, unsigned long long seed, unsigned long long n_pairs,
             fast = (float)v16.x;
             edge = (seam & 0xffffu) != 0u;
             if (!edge && !(fast == fast && fabsf(fast) < 1e30f)) m_ratio = 1e9;       // NaN / inf outside the seam: must not happen in the box
-        } else {
+        } else
+#endif
+        {
             fast = ciede2000_fast(p, q, chroma_of(p.c1, p.c2), chroma_of(q.c1, q.c2), lut, &edge);
         }
         if (edge) { handed += 1; continue; }
@@ -1966,6 +1913,7 @@ band_sweep_kernel(int mode, unsigned long long seed, unsigned long long n_pairs,
 hipError_t launch_band_sweep(int mode, unsigned long long seed, unsigned long long n_pairs, float px_abs, float rel,
                              const HueEntry* hue_lut, unsigned long long* out6, hipStream_t stream)
 {
+    if ((mode & 2) && !MM_WITH_PRETIER) return hipErrorNotSupported;       // (the fp16 form is not in this build)
     hipError_t code = hipMemsetAsync(out6, 0, 6 * sizeof(unsigned long long), stream);
     if (code != hipSuccess) return code;
     // modes 2 / 3: the same two sweeps for the packed-fp16 pre-tier's form, against ITS band
@@ -2186,10 +2134,14 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     const bool il = in.lib_il && in.cells_il;
     if (type == CIEDE2000) {
         const bool big = groups > 16 && il;
+        auto kern = big ? filter_kernel<CIEDE2000, kBlock, false, true, true>
+                        : (il ? filter_kernel<CIEDE2000, kBlock, false, true> : filter_kernel<CIEDE2000, kBlock, false, false>);
+#if MM_WITH_PRETIER
         const bool pre = il && in.lib_h != nullptr && in.cells_h != nullptr && prune_above != nullptr;
-        auto kern = pre ? (big ? filter_kernel<CIEDE2000, kBlock, false, true, true, true> : filter_kernel<CIEDE2000, kBlock, false, true, false, true>)
-                        : big ? filter_kernel<CIEDE2000, kBlock, false, true, true>
-                              : (il ? filter_kernel<CIEDE2000, kBlock, false, true> : filter_kernel<CIEDE2000, kBlock, false, false>);
+        if (pre) kern = big ? filter_kernel<CIEDE2000, kBlock, false, true, true, true> : filter_kernel<CIEDE2000, kBlock, false, true, false, true>;
+#else
+        constexpr bool pre = false;
+#endif
         Variants var = in.var;
         var.cell_order = nullptr;
         if (in.cell_order != nullptr && xcd_shares > 1 && prune_above != nullptr && var.cell_full != nullptr) {
@@ -2234,11 +2186,16 @@ hipError_t launch_interleave(const float* planar, const float* chroma, const flo
 
 hipError_t launch_interleave_h(const float* il, void* out_halfs, size_t n_images, int ppad, hipStream_t stream)
 {
+#if MM_WITH_PRETIER
     const size_t n_vec = n_images * (size_t)ppad;                  // 4 planes x ppad floats = ppad float4
     const unsigned blocks = (unsigned)std::min<size_t>((n_vec + kBlock - 1) / kBlock, 65536);
     if (blocks == 0) return hipSuccess;
     interleave_h_kernel<<<blocks, kBlock, 0, stream>>>(reinterpret_cast<const float4*>(il), reinterpret_cast<uint2*>(out_halfs), n_vec);
     return hipGetLastError();
+#else
+    (void)il; (void)out_halfs; (void)n_images; (void)ppad; (void)stream;
+    return hipErrorNotSupported;
+#endif
 }
 
 hipError_t launch_group_sums(const float* planar, const uint8_t* mask, size_t mask_stride, float* stats,
@@ -2321,6 +2278,7 @@ hipError_t launch_prune_limits(int type, const FilterInputs& in, const float* li
 hipError_t launch_pair_fast(int type, const float* first, const float* second, size_t n,
                             float* out, int flag_edges, const HueEntry* hue_lut, hipStream_t stream)
 {
+    if ((flag_edges & 4) && !MM_WITH_PRETIER) return hipErrorNotSupported;  // (the fp16 form is not in this build)
     const int blocks = (int)((n + kBlock - 1) / kBlock < 8192 ? (n + kBlock - 1) / kBlock : 8192);
     if (type == CIEDE2000)
         pair_fast_kernel<CIEDE2000><<<blocks, kBlock, 0, stream>>>(first, second, n, out, flag_edges, hue_lut);

@@ -19,7 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/mosaic_hip.h"
+#include "../../include/mosaic_hip_tuning.h"   // (includes mosaic_hip.h)
 #include "colour_diff.hpp"
 #include "colour_diff_fast.hpp"
 #include "launch.hpp"

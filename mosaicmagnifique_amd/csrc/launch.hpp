@@ -6,6 +6,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// The packed-fp16 pre-tier of the CIEDE2000 filter (colour_diff_fp16.hpp, filter_pretier.hpp): 0 = not compiled in (the default
+// build: no PRE instantiations of filter_kernel, no half copies, the options "pretier" / "pretier_band" accepted and ignored,
+// mm_debug_has_pretier() == 0); 1 = round 5's code (tools/build_variant.sh NAME -DMM_WITH_PRETIER=1 with MM_ENGINE_FLAGS the same).
+#ifndef MM_WITH_PRETIER
+#define MM_WITH_PRETIER 0
+#endif
+
 namespace mm {
 
 // A pixel pair the fp32 CIEDE2000 form must not judge (opposite-hue discontinuity).

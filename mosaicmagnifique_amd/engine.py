@@ -31,6 +31,11 @@ def device_count():
     return n.value
 
 
+def has_pretier():
+    """mm_debug_has_pretier: 1 if the library was built with the packed-fp16 pre-tier (-DMM_WITH_PRETIER=1; default: not)."""
+    return bool(_lib.load().mm_debug_has_pretier())
+
+
 def trim_cache():
     """mm_trim_cache: release the device resources destroyed engines left parked; returns the number of sets released."""
     return _lib.load().mm_trim_cache()

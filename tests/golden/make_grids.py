@@ -57,6 +57,8 @@ CONFIGS = {
     "H": (800, 1000, 25, "square", 214, 2, 0, 0),
     "I": (4000, 4000, 80, "square", 1000, 2, 0, 0),
     "P": (1363, 2048, 64, "square", 1024, 2, 4, 500),
+    # ... and at config D's scale (PD: tests/golden/photo_pd_*.jpg, make_photo_fixture_pd.py): 4096 cells, 5000 tiles, repeat range 4
+    "PD": (4096, 4096, 64, "square", 5000, 2, 4, 500),
     # reduced shapes (seconds): used by the CPU suite to hold this script's two modes to each other
     "d": (512, 512, 32, "square", 60, 2, 4, 500),
 }
@@ -71,10 +73,14 @@ def scenario(name):
     from mosaicmagnifique_amd import GridUtility as G
     rows, cols, size, shape_name, L, t, rng, add = CONFIGS[name]
     shape = cases.hexagon_shape() if shape_name == "hexagon" else cases.square_shape(size)
-    if name == "P":
-        import make_photo_fixture
+    if name in ("P", "PD"):
         from mosaicmagnifique_amd import synth
-        img_u8, lib_u8 = make_photo_fixture.load()
+        if name == "P":
+            import make_photo_fixture
+            img_u8, lib_u8 = make_photo_fixture.load()
+        else:
+            import make_photo_fixture_pd
+            img_u8, lib_u8 = make_photo_fixture_pd.load()
         img, lib = synth.preprocess(img_u8, t), synth.preprocess(lib_u8, t)
     else:
         img, lib = cases._inputs(rows, cols, size, L, t, lattice=64)

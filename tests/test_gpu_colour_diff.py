@@ -147,3 +147,30 @@ def test_the_parallel_sums_algebraic_form_agrees_with_the_reference_form(engine,
         cpu = oracle.colour_diff_batch(2, a[:4096], b[:4096])
         assert (np.abs(alg[:4096] - cpu) <= 1e-9 * np.maximum(cpu, 1e-3)).all(), name
     print("algebraic fp64 form, worst |difference| to the reference form per family:", worst)
+
+
+def test_non_finite_pixels_keep_their_nan_through_the_parallel_sums_form(engine, oracle):
+    """the algebraic form ended in sqrt(fmax(s, 0)) -- fmax is maxNum, so a NaN radicand became a term of 0 where
+    ColourDifference.cpp:42-158 (and the oracle) yield NaN and the candidate can never win.  A pair whose radicand is not finite now
+    goes to the reference form: NaN / inf in any channel of either pixel gives what the reference form gives, NaN pattern included."""
+    rng = np.random.default_rng(7)
+    n = 4096
+    a = rng.uniform([0, -100, -100], [100, 100, 100], (n, 3)).astype(np.float32)
+    b = rng.uniform([0, -100, -100], [100, 100, 100], (n, 3)).astype(np.float32)
+    bad = np.array([np.nan, np.inf, -np.inf], dtype=np.float32)
+    for i in range(n):                                   # every (side, channel, kind) combination many times over, plus both sides at once
+        side, ch, kind = i % 2, (i // 2) % 3, (i // 6) % 3
+        (a if side == 0 else b)[i, ch] = bad[kind]
+        if i % 17 == 0:
+            (b if side == 0 else a)[i, (ch + 1) % 3] = bad[(kind + 1) % 3]
+    ref = engine.colour_diff_batch(2, a, b)
+    engine.set_option("probe_prepared", 3)
+    try:
+        alg = engine.colour_diff_batch(2, a, b)
+    finally:
+        engine.set_option("probe_prepared", 0)
+    assert np.array_equal(np.isnan(alg), np.isnan(ref))
+    assert np.array_equal(alg, ref, equal_nan=True)
+    assert np.isnan(alg).sum() > n // 2                  # (an inf lightness against a finite one can give inf: whatever the reference form says)
+    cpu = oracle.colour_diff_batch(2, a, b)
+    assert np.array_equal(np.isnan(alg), np.isnan(cpu))

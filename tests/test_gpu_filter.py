@@ -95,6 +95,20 @@ def test_ciede2000_filter_band_structured_sweep(engine):
     assert r["handed_over"] > 0 and r["measured"] > 5e8    # both: pairs inside the hand-over zone and just outside it
 
 
+def _has_pretier():
+    try:
+        from mosaicmagnifique_amd.engine import has_pretier
+        return has_pretier()
+    except Exception:                     # (library not built yet at collection time: only the pre-tier's own tests depend on this)
+        return False
+
+
+# the packed-fp16 pre-tier is compiled in only with -DMM_WITH_PRETIER=1 (round 6: out of the default build -- on its certified band it
+# loses on every benchmarked configuration); its tests run against such a build (MOSAIC_HIP_LIB=gpurun_out/pretier.so)
+needs_pretier = pytest.mark.skipif(not _has_pretier(), reason="libmosaic_hip.so was built without the packed-fp16 pre-tier (MM_WITH_PRETIER=0)")
+
+
+@needs_pretier
 def test_packed_fp16_pretier_band_structured_sweep(engine):
     """The filter's packed-fp16 pre-tier (colour_diff_fast.hpp ciede2000_h2) takes early-exit decisions only, against the
     limit widened by ITS band (launch.hpp kPreBandAbs + kPreBandRel * value per pixel pair).  What must hold is the over-estimate:
@@ -195,7 +209,7 @@ def climb(engine, prepared, seed, generations=80, n=1 << 17):
         engine.set_option("probe_prepared", 0)
 
 
-@pytest.mark.parametrize("prepared", [0, 1, 2])
+@pytest.mark.parametrize("prepared", [0, 1, pytest.param(2, marks=needs_pretier)])
 def test_ciede2000_filter_band_adversarial_maximiser(engine, prepared):
     """Random and structured sweeps find the TYPICAL worst error; this one climbs: 2^17 pairs of f32 Lab colours -- seeded
     on the families where the fp32 form is weakest (near-grey with either operand, saturated blue where R_T peaks, both
@@ -344,7 +358,7 @@ def test_discontinuity_log_overflow_falls_back_to_fp64(oracle, engine):
     assert tm["edge_pairs"] > 1_000_000 and tm["dense_cells"] == 9
 
 
-@pytest.mark.parametrize("broken", ["fp16 band", "bound", "euclid bound"])
+@pytest.mark.parametrize("broken", [pytest.param("fp16 band", marks=needs_pretier), "bound", "euclid bound"])
 def test_audit_voids_a_launch_that_dropped_a_contender(engine, broken):
     """A candidate that leaves the CIEDE2000 filter without a full score -- dropped by the bound's stages 0 / 1, by the
     packed-fp16 pre-tier's walk or by the fp32 walk's exit test -- is seen by neither the pre-tier's canary (survivors only) nor
@@ -603,9 +617,12 @@ def test_values_outside_the_validated_box_run_fp64_only(oracle, engine, t, where
     best, score = engine.generate(cells, state.shape[1], state.shape[0], int(t))
     tm = engine.timing()
     assert tm["filter_off_range"] == 1 and tm["rescore_ms"] == 0 and tm["seed_ms"] == 0
-    if finite:
-        want, _, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t))
-        assert np.array_equal(np.where(best == len(lib), -1, best), want)
+    # (the non-finite case too since round 6: a NaN term stays NaN in the parallel sums' form, as in ColourDifference.cpp -- the cell
+    # holding the pixel gets no fit from any candidate, the oracle's -1 / the engine's sentinel)
+    want, _, _ = oracle.generate_best_fits(shape_of(shape), img, lib, shape.masks4(), int(t))
+    assert np.array_equal(np.where(best == len(lib), -1, best), want)
+    if not finite:
+        assert (want == -1).sum() > (state < 0).sum()
     img2, lib2 = cases.inputs(128, 160, 32, 120, t)
     engine.set_library(lib2); engine.set_target(img2)
     engine.generate(cells, state.shape[1], state.shape[0], int(t))
@@ -613,6 +630,7 @@ def test_values_outside_the_validated_box_run_fp64_only(oracle, engine, t, where
     assert tm["filter_off_range"] == 0 and tm["rescore_ms"] > 0
 
 
+@needs_pretier
 def test_the_measured_pretier_rule_belongs_to_the_observed_band(oracle, engine):
     """`pretier` = -1 on the default (worst-case) band: the pre-tier never runs -- no benchmarked configuration gains there.  With
     `pretier_band` = 1 an eligible job (cells above 32 groups) spends a warm-up launch, then one launch without and one with the
