@@ -51,6 +51,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction x 128 flop
 VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2.0
+FORM_VALU_PER_PAIR = 86.0      # VALU instructions of ciede2000_fast per pixel pair in the ISA of filter_kernel (344 per four pairs)
 
 CONFIGS = {
     # name: (rows, cols, cell, shape, L, diff type, repeat range, addition, cells of the 1-thread CPU sample)
@@ -74,6 +75,9 @@ CONFIGS = {
     # config D's parameters on PHOTOGRAPHIC content (tests/golden/make_photo_fixture.py: one of the reference's SampleImages as the
     # target, 1024 tiles of 64 x 64 cut from the other four as the library): what the early-exit bound does off the synthetic patches
     "P": (1363, 2048, 64, "square", 1024, 2, 4, 500, 16),
+    # ... and at config D's own scale (tests/golden/make_photo_fixture_pd.py): one photograph as a 4096 x 4096 target, 5000 tiles of 64 x 64 cut
+    # from the other four at two zoom levels, CIEDE2000, repeat range 4 (+500) -- config D's job shape on the content the tool is for
+    "PD": (4096, 4096, 64, "square", 5000, 2, 4, 500, 8),
     "D500": (4096, 4096, 64, "square", 500, 2, 4, 500, 8),
     "D3800": (4096, 4096, 64, "square", 3800, 2, 4, 500, 8),     # ... and one whose interleaved copy (249 MB) just fits the 256 MB Infinity Cache
     # reduced shapes of D and E for the rank rehearsals of tests/test_gpu_bench_ranks.py (not bench lines)
@@ -99,7 +103,7 @@ def result_digest(best, score):
     return h.hexdigest()
 
 
-def build_workload(name, world, scaling="weak", mcs=None, mil=None, bands=0):
+def build_workload(name, world, scaling="weak", mcs=None, mil=None, bands=0, host_preprocess=False):
     import cases
     from mosaicmagnifique_amd import GridUtility as G
     from mosaicmagnifique_amd import synth
@@ -119,10 +123,14 @@ def build_workload(name, world, scaling="weak", mcs=None, mil=None, bands=0):
         if library.getImageSize() != size:
             lib_u8 = np.stack([imageutil.resize_area_u8(im, size, size) for im in lib_u8])
         L = len(lib_u8)
-    elif name == "P":
+    elif name in ("P", "PD"):
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-        import make_photo_fixture
-        photo_u8, lib_u8 = make_photo_fixture.load()
+        if name == "P":
+            import make_photo_fixture
+            photo_u8, lib_u8 = make_photo_fixture.load()
+        else:
+            import make_photo_fixture_pd
+            photo_u8, lib_u8 = make_photo_fixture_pd.load()
         assert photo_u8.shape == (rows, cols, 3) and lib_u8.shape == (L, size, size, 3)
     else:
         lib_u8 = synth.library_u8(L, size)
@@ -133,11 +141,13 @@ def build_workload(name, world, scaling="weak", mcs=None, mil=None, bands=0):
         n_shard = -(-len(cells1) // 8)
         cells1 = cells1[:n_shard]
         band_rows_px = min(rows, (int(cells1["y"].max()) // size + 2) * size)
-    img_u8 = photo_u8 if name == "P" else synth.target_u8(band_rows_px, cols, lattice=64)
-    big = band_rows_px * cols > 4096 * 4096   # convert on the device (mm_set_*_u8) instead of ~1 min of numpy per rank
+    img_u8 = photo_u8 if name in ("P", "PD") else synth.target_u8(band_rows_px, cols, lattice=64)
+    # convert on the device (mm_set_*_u8) instead of ~1 min of numpy per rank -- unless the caller wants the arrays the committed CPU
+    # golden was computed on (numpy's float64 Lab conversion; the device's differs from it in the last place of single f32 values)
+    big = band_rows_px * cols > 4096 * 4096 and not host_preprocess
     w = dict(name=name, shape=shape, shape_name=shape_name, t=t, rep=(rng, add), L=L, size=size,
              rows=band_rows_px, cols=cols, cpu_cells=cpu_cells, state_single=state1,
-             device_preprocess=big, img_u8=img_u8, lib_u8=lib_u8, scaling=scaling)
+             device_preprocess=big, img_u8=img_u8, lib_u8=lib_u8, scaling=scaling, custom_inputs=bool(mcs or mil))
     if not big:
         w["img"] = synth.preprocess(img_u8, t)
         w["lib"] = synth.preprocess(lib_u8, t)
@@ -257,16 +267,19 @@ def parity_sample(w, my_cells):
         min(64, len(inner)), min(16, len(clipped)))
 
 
-def golden_parity(w, img, lib, best, score):
+def golden_parity(w, img, lib, best, score, bands=1, only_cells=None):
     """The WHOLE grid against the committed CPU golden of the configuration (tests/golden/grid_<config>.npz, the oracle's run over
     every cell: tests/golden/make_grids.py) -- when the arrays the engine holds are the ones the golden was computed on
-    (sha256 of both).  None if there is no golden for this workload."""
+    (sha256 of both; arrays converted on the device are read back and hashed like any others).  None if there is no golden for
+    this workload.  One GPU and N strong-scaled shards end with the golden's own grid; of N weak-scaled bands (the configuration's
+    image repeated down the mosaic) band 0 IS the golden's job -- the window of calculateRepeats looks up and left only
+    (CPUPhotomosaicGenerator.cpp:185-225), so nothing below reaches it -- and without a repeat penalty every band is."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     try:
         import make_grids
     except ImportError:
         return None
-    if w["name"] not in make_grids.CONFIGS or w["name"] == "d" or w.get("device_preprocess") or len(w["cells"]) != len(w["cells_single"]):
+    if w["name"] not in make_grids.CONFIGS or w["name"] == "d" or w.get("custom_inputs"):
         return None
     got = make_grids.load(w["name"])
     if got is None:
@@ -274,14 +287,37 @@ def golden_parity(w, img, lib, best, score):
     want, want_score, meta = got
     if make_grids.sha(img) != meta["img_sha256"] or make_grids.sha(lib) != meta["lib_sha256"]:
         return {"cells": 0, "indices_equal": None, "note": "the golden was computed on other arrays (numpy rounds differently on this host?): not compared"}
-    mine = np.where(best < w["L"], best, -1)
+    gh1 = w["state_single"].shape[0]
+    band_rows = gh1 - 2                        # GridUtility.PAD_GRID
+    n_bands = bands if len(w["cells"]) != len(w["cells_single"]) else 1
+    compared = n_bands if w["rep"][0] == 0 else 1
+    equal, differing, worst, cells = True, 0, 0.0, 0
     valid = want >= 0
-    rel = np.abs(score[valid] - want_score[valid]) / np.maximum(np.abs(want_score[valid]), 1e-300)
-    rel = rel[want_score[valid] != 0]
-    return {"cells": int(valid.sum()), "indices_equal": bool(np.array_equal(mine, want)), "cells_differing": int((mine != want).sum()),
-            "max_rel_score_err": float(rel.max()) if len(rel) else 0.0,
-            "golden": "tests/golden/grid_%s.npz (oracle/oracle.c over the whole grid, %s mode, %.0f s on %d host threads)" % (
-                w["name"], meta["mode"], meta["seconds"], meta["threads"])}
+    if only_cells is not None:                 # a shard of the grid (config E8): the golden's entries of exactly these cells
+        valid = np.zeros_like(valid)
+        valid[only_cells["grid_y"], only_cells["grid_x"]] = True
+        n_bands = 2                            # (compare the valid cells only: the rest of the grid was not computed)
+        compared = 1
+    for b in range(compared):
+        mine = np.where(best < w["L"], best, -1)[b * band_rows:b * band_rows + gh1]
+        sc = score[b * band_rows:b * band_rows + gh1]
+        if b > 0 or n_bands > 1:               # the two padding rows at a band seam belong to the neighbouring band: valid cells only
+            same = np.array_equal(mine[valid], want[valid])
+        else:
+            same = np.array_equal(mine, want)
+        equal = equal and same
+        differing += int((mine[valid] != want[valid]).sum())
+        rel = np.abs(sc[valid] - want_score[valid]) / np.maximum(np.abs(want_score[valid]), 1e-300)
+        rel = rel[want_score[valid] != 0]
+        worst = max(worst, float(rel.max()) if len(rel) else 0.0)
+        cells += int(valid.sum())
+    out = {"cells": cells, "indices_equal": bool(equal), "cells_differing": differing, "max_rel_score_err": worst,
+           "golden": "tests/golden/grid_%s.npz (oracle/oracle.c over the whole grid, %s mode, %.0f s on %d host threads)" % (
+               w["name"], meta["mode"], meta["seconds"], meta["threads"])}
+    if n_bands > 1 and only_cells is None:
+        out["bands_compared"] = ("all %d (no repeat penalty: every band is the golden's job)" % n_bands) if compared == n_bands else \
+            "band 0 of %d (the repeat window looks up and left only; later bands: parity_on_cpu_sample)" % n_bands
+    return out
 
 
 def cpu_parity_rows(w, img, lib, best, recs):
@@ -327,6 +363,74 @@ def floor_legs(engine, step, n_cells, value):
                     "headline_over_floor": value / (n_cells / dt),
                     "what": "early exit off (option prune=0): every pixel of every candidate through the fp32 filter" if option == "prune"
                             else "fp64 only (option filter=0): every pixel pair in fp64 (the algebraic form of the parallel sums), no filter tier"}
+    return out
+
+
+def config_legs(device, opts, names, steps=4):
+    """The other BASELINE configurations (and photographs at config D's scale) in the SAME run, the way the reference's harness sweeps
+    its configurations in one process (Benchmark/Benchmark_Generator.h:125-183): per configuration a fresh engine, staging, one warm-up
+    step, `steps` timed steps (wall clock between two device synchronisations), the dominant kernel's launch time from HIP events on
+    the engine's stream, and the WHOLE grid of the last step against the committed CPU golden.  "E8" is config E's first
+    ceil(29 241 / 8) cells -- one rank's shard of BASELINE config 5 -- on the engine that holds config E."""
+    import torch
+    from mosaicmagnifique_amd.engine import Engine
+    from mosaicmagnifique_amd.grid import CELL_DTYPE
+    out = {}
+    todo = [n for n in names if n != "E8"]
+    for name in todo:
+        t_all = time.perf_counter()
+        w = build_workload(name, 1, host_preprocess=True)      # (the golden's own input arrays: config E costs ~10 s of numpy)
+        e = Engine(device)
+        try:
+            for item in opts:
+                k, v = item.split("=")
+                e.set_option(k, int(v))
+            stage(e, w)
+            runs = [(name, np.ascontiguousarray(w["cells"], dtype=CELL_DTYPE))]
+            if name == "E" and "E8" in names:
+                runs.append(("E8", runs[0][1][:-(-len(runs[0][1]) // 8)]))
+            img = lib = None
+            for label, cells in runs:
+                gw, gh = w["grid_w"], w["grid_h"]
+                arrays = (np.empty((gh, gw), dtype=np.int64), np.empty((gh, gw), dtype=np.float64))
+                run = lambda: e.generate(cells, gw, gh, w["t"], *w["rep"], out=arrays)
+                run()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    best, score = run()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+                tm = e.timing()
+                kernel_ms = tm["score_ms"] / max(tm["score_launches"], 1)
+                if kernel_ms == 0.0:                # a small job runs without phase events: one more step with them on
+                    e.set_option("phase_timing", 1)
+                    run()
+                    tp = e.timing()
+                    kernel_ms = tp["score_ms"] / max(tp["score_launches"], 1)
+                    e.set_option("phase_timing", -1)
+                if img is None:
+                    img, lib = host_arrays(e, w)
+                gold = golden_parity(w, img, lib, best, score, only_cells=cells if label == "E8" else None)
+                alg_bytes, total_pa = algorithmic_bytes(w, cells)
+                out[label] = {
+                    "workload": "%dx%d target, %dx%d %s cells, %d images, %s, repeat %d (+%d)%s" % (
+                        w["cols"], w["rows"], w["size"], w["size"], w["shape_name"], w["L"], TYPE_NAMES[w["t"]], w["rep"][0], w["rep"][1],
+                        ", first 1/8 of the cells (one rank's shard of BASELINE config 5)" if label == "E8" else ""),
+                    "cells": int(len(cells)), "cells_per_s": len(cells) / dt, "ms_per_step": dt * 1e3, "steps": steps,
+                    "kernel_ms": kernel_ms, "kernel": "filter_kernel" if w["t"] == 2 else "filter_lds_kernel",
+                    "visited_fraction_of_groups": tm["visited_groups"] / tm["total_groups"] if tm["total_groups"] else None,
+                    "host_syncs": tm["host_syncs"], "resolve_sweeps": tm["resolve_sweeps"], "deepened_cells": tm["deepened_cells"],
+                    "section_8d_algorithmic_gbs": alg_bytes / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else None,
+                    "parity_on_golden": ({k: gold[k] for k in ("cells", "indices_equal", "cells_differing", "max_rel_score_err") if k in gold}
+                                         if gold else None),
+                    "band_alarms": tm["band_alarms"], "voided_launches": tm["voided_launches"],
+                    "spec_rounds": tm["spec_rounds"], "filter_tile": tm["filter_tile"],
+                }
+            for label, _ in runs:
+                out[label]["wall_s_incl_staging_and_golden"] = round(time.perf_counter() - t_all, 1)
+        finally:
+            e.close()
     return out
 
 
@@ -604,6 +708,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity legs (and the floors / first-call legs: "
                                                          "nothing but the timed steps reaches the device, as the PMC passes want it)")
     ap.add_argument("--no-floors", action="store_true", help="skip the floor legs (early exit off; fp64 only) and the first-call leg")
+    ap.add_argument("--configs", default=None, metavar="B,C,...",
+                    help="further configurations run after the headline in the same process, each against its whole-grid CPU golden "
+                         "(default with the default config D on one GPU: B,C,E,E8,G,PD -- every BASELINE configuration, the GUI's default "
+                         "cell size, and photographs at config D's scale; 'none' skips them)")
     ap.add_argument("--mcs", default=None, help="cell shape from a MosaicMagnifique .mcs file (resized to the config's cell size)")
     ap.add_argument("--mil", default=None, help="library from a MosaicMagnifique .mil file (resized to the config's cell size)")
     ap.add_argument("--stage", choices=("build", "preprocess"), default=None,
@@ -758,6 +866,18 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
 
+    per_rank_score_ms, ranks_seen, backend = None, None, None
+    if use_dist:
+        # what the communicator itself reports (a launcher that started fewer ranks than --gpus says shows here), and every
+        # rank's own scoring time per step (the all-gather absorbs their spread as waiting)
+        ranks_seen, backend = dist.get_world_size(), dist.get_backend()
+        mine_ms = torch.tensor([sharded.phase_ms["score"] / max(args.steps, 1)], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        every = [torch.zeros_like(mine_ms) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(every, mine_ms)
+        else:
+            every = [mine_ms]
+        per_rank_score_ms = [round(float(v.item()), 4) for v in every]
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -836,6 +956,34 @@ def main():
             roof["achieved"] = None
             roof["frac"] = None
             roof["note"] = "no PMC record for this build/config: VALU rate not priced (run tools/profile.sh)"
+        # WORK-NORMALISED fractions -- they rise when the kernel spends less on the same evaluated work, unlike `frac` (issue-rate
+        # use, which falls when instructions are removed): (1) the pixel pairs actually evaluated x the filter form's own VALU
+        # instructions (86 per pair-lane: 344 per four pairs in the ISA of the pixel loop, colour_diff_fast.hpp) against the issue
+        # peak -- everything else the kernel issues (the bound's stages, preludes, exit tests, addresses) is overhead this fraction
+        # does not credit; (2) the bytes of the library and cell groups it visited against the read-stream ceiling measured on
+        # this box (filled in below).  SURVEY 8(d)'s own fraction -- algorithmic bytes / kernel time / 8 TB/s -- is stated beside
+        # them: above 1 because the kernel provably does not do the work that byte model counts (the reference's own early exit,
+        # CPUPhotomosaicGenerator.cpp:149-161, in its device form).
+        if visited_per_launch and per_launch_s > 0:
+            pairs_s = visited_per_launch * 256 / per_launch_s
+            roof["work_normalised"] = {
+                "executed_pair_evals_per_s": pairs_s,
+                "form_valu_insts_per_pair": FORM_VALU_PER_PAIR,
+                "useful_issue_frac": pairs_s / 64.0 * FORM_VALU_PER_PAIR / VALU_PEAK_WAVE_INSTS,
+                "visited_bytes_per_launch": visited_per_launch * 4096.0,
+                "visited_gbs": visited_per_launch * 4096.0 / per_launch_s / 1e9,
+                "note": "useful_issue_frac = executed pair-evals / 64 lanes x 86 VALU instructions of the filter form / (1024 SIMDs x 2.4 GHz / 2); "
+                        "visited bytes = visited groups x 4 KB of the library image's interleaved planes (the cell's 4 KB per visit come from the XCD's L2: "
+                        "the PMC record's fabric traffic equals the library bytes alone); "
+                        "visited_stream_frac = visited_gbs / the read-stream rate measured in this run",
+            }
+        roof["section_8d_frac"] = {
+            "value": alg_per_launch / per_launch_s / 1e9 / HBM_PEAK_GBS if per_launch_s > 0 else None,
+            "why_above_1": "algorithmic bytes (every pixel of every candidate once per cell) / kernel time / 8 TB/s; the kernel drops %.0f %% of the "
+                           "candidates on a bound before any pixel is read and visits %.1f %% of the pixel groups -- the device form of the reference's "
+                           "own early exit -- so this is an effective rate, not a roofline fraction; floor_unpruned (every pair evaluated) is the "
+                           "comparable figure" % (100.0 * dropped / max(launches * launches_scale, 1) / max(len(my_cells) * w["L"], 1),
+                                                  100.0 * visited / groups_all if groups_all else 0.0)}
     else:
         # RGB-Euclid / fp64-only: memory-side view, from measured traffic only
         roof["bound"] = "hbm"
@@ -861,7 +1009,7 @@ def main():
         # large CIEDE2000 jobs a packed-f16 pre-tier takes the filter's early-exit decisions: engine option "pretier")
         "dtype": ("f16 pre-tier + f32 filter + f64 arbiter" if pretier_on else "f32 filter + f64 arbiter") if engine_uses_filter else "f64",
         "data": "synthetic (REHEARSAL: all ranks on one GPU over gloo, timings void)" if rehearsal else
-                "photographs (derived fixture of the reference's SampleImages, tests/golden/photo_*.png)" if w["name"] == "P" else
+                "photographs (derived fixture of the reference's SampleImages, tests/golden/photo_*)" if w["name"] in ("P", "PD") else
                 "synthetic" if not (args.mcs or args.mil) else "synthetic target; %s" % ", ".join(
             os.path.basename(p) for p in (args.mcs, args.mil) if p),
         "config": {
@@ -883,7 +1031,10 @@ def main():
         "last_step_device_ms": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
     }
     if dist_phase_ms is not None:
+        dist_phase_ms["score_per_rank"] = per_rank_score_ms
         out["dist_phase_ms"] = dist_phase_ms
+        out["rccl_ranks_seen"] = ranks_seen
+        out["collective_backend"] = "%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "rehearsal: gloo")
     if world == 1 and sharded is None and not (args.no_cpu or args.no_floors):
         out.update(floor_legs(engine, step, n_cells, value))
         out["first_call"] = first_call_leg(w, local_rank, args.opt)
@@ -891,6 +1042,37 @@ def main():
     if world == 1:
         # what a plain coalesced read stream reaches on this device (4 GiB, past the Infinity Cache)
         out["roofline"]["hbm_stream_read_measured_gbs"] = engine.stream_read_gbs(4 << 30, 5)
+        wn = out["roofline"].get("work_normalised")
+        if wn:
+            wn["visited_stream_frac"] = wn["visited_gbs"] / out["roofline"]["hbm_stream_read_measured_gbs"]
+    if world > 1 and not args.no_cpu:
+        # An N-rank line checks ITSELF (the reference's standard is cell-by-cell equality, test/tst_CUDAGenerator.h:163-212): the
+        # gathered grid against the committed CPU golden -- strong shards: the whole grid; weak bands: band 0 (every band without a
+        # repeat penalty) -- and, with a repeat penalty, two full grid rows INSIDE the last band evaluated by the CPU oracle as the
+        # raster loop reaches them given the engine's earlier picks (the rows above them included: the window crosses no seam there,
+        # and a band's rows equal the oracle's given the rows above by induction over the raster order).
+        img, lib = host_arrays(engine, w)
+        gold = golden_parity(w, img, lib, best, score, bands)
+        if gold is not None:
+            out["parity_on_golden"] = gold
+        if scaling == "weak" and bands > 1 and rep[0] > 0:
+            gh1 = w["state_single"].shape[0]
+            band_rows = gh1 - 2
+            b = bands - 1
+            rows = np.unique(w["cells_single"]["grid_y"])
+            first = int(np.random.default_rng(0xC0FFEE + w["L"] + b).integers(min(rep[0] + 1, len(rows) - 2), max(len(rows) - 2, rep[0] + 2)))
+            first = min(first, len(rows) - 2)
+            par = w["cells_single"][(w["cells_single"]["grid_y"] == rows[first]) | (w["cells_single"]["grid_y"] == rows[first + 1])][:256]
+            band_view = dict(w, state_single=w["state_single"])
+            sub_best = best[b * band_rows:b * band_rows + gh1]
+            pos, picks, pscores, cores, dt_all = cpu_parity_rows(band_view, img, lib, sub_best, par)
+            got = sub_best[pos[:, 0], pos[:, 1]]
+            prel = np.abs(pscores - score[b * band_rows:b * band_rows + gh1][pos[:, 0], pos[:, 1]]) / np.maximum(pscores, 1e-300)
+            out["parity_on_cpu_sample"] = {
+                "indices_equal": bool(np.array_equal(picks, got)), "max_rel_score_err": float(prel.max()), "cells": int(len(par)),
+                "sample": "two full grid rows (%d, %d) inside band %d of %d, each cell evaluated by the oracle as the reference's raster "
+                          "loop reaches it given the engine's picks above and left of it (%d host threads, %.1f s)" % (
+                              int(rows[first]), int(rows[first + 1]), b, bands, cores, dt_all)}
     if world == 1 and not args.no_cpu:
         img, lib = host_arrays(engine, w)
         grid, cscore, done, dt = cpu_baseline(w, img, lib)
@@ -905,10 +1087,10 @@ def main():
         }
         out["speedup_vs_cpu"] = value / (done / dt)
         # the whole grid against the committed CPU golden, where there is one for this workload
-        gold = golden_parity(w, img, lib, best, score)
+        gold = golden_parity(w, img, lib, best, score, bands)
         if gold is not None:
             out["parity_on_golden"] = gold
-            w["golden_ok"] = bool(gold.get("indices_equal"))
+            w["golden_ok"] = bool(gold.get("indices_equal")) and bands == 1
         # parity where the repeat window is exercised + the all-cores rate: two full grid rows
         par_recs, par_text = parity_sample(w, my_cells)
         n_par = len(par_recs)
@@ -928,6 +1110,12 @@ def main():
                       "(oracle/oracle.c, early exit on, %.1f s)" % (n_par, dt_all),
         }
         out["speedup_vs_cpu_all_cores"] = value / (n_par / dt_all)
+    if world == 1 and sharded is None and not args.no_cpu:
+        names = args.configs if args.configs is not None else ("B,C,E,E8,G,PD" if args.config == "D" and bands == 1 and not (args.mcs or args.mil) else "none")
+        names = [n for n in names.split(",") if n and n != "none"]
+        if names:
+            engine.close()                       # (its workspaces are parked for the legs' engines)
+            out["configs"] = config_legs(local_rank, args.opt, names)
     emit(json.dumps(out))
     if use_dist:
         os.dup2(2, 1)

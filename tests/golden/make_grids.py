@@ -59,6 +59,10 @@ CONFIGS = {
     "P": (1363, 2048, 64, "square", 1024, 2, 4, 500),
     # ... and at config D's scale (PD: tests/golden/photo_pd_*.jpg, make_photo_fixture_pd.py): 4096 cells, 5000 tiles, repeat range 4
     "PD": (4096, 4096, 64, "square", 5000, 2, 4, 500),
+    # the reduced shapes of D and E that bench.py's rank rehearsals run (tests/test_gpu_bench_ranks.py): an N-rank line checks itself
+    # against these (band 0 of the weak-scaled Ds, the whole grid of the strong-scaled Es)
+    "Ds": (1024, 1024, 64, "square", 400, 2, 4, 500),
+    "Es": (1000, 1000, 48, "square", 500, 2, 0, 0),
     # reduced shapes (seconds): used by the CPU suite to hold this script's two modes to each other
     "d": (512, 512, 32, "square", 60, 2, 4, 500),
 }

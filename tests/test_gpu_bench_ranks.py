@@ -51,6 +51,8 @@ def test_two_ranks_weak_bands_of_config_b():
     single = run_single("--config", "B", "--bands", "2")          # the same 2-band mosaic on one GPU
     out = run_ranks(2, "--config", "B")       # weak bands need square cells: B (config D is the same path, 25 s)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 2
+    gold = out["parity_on_golden"]            # no repeat penalty: BOTH bands are the golden's job
+    assert gold["indices_equal"] is True and gold["cells"] == 2 * 1024 and "all 2" in gold["bands_compared"]
     assert out["config"]["cells"] == single["config"]["cells"] == 2 * 1024          # one band per rank
     assert "REHEARSAL" in out["data"] and out["value"] > 0
     assert out["last_step_device_ms"]["band_alarms"] == 0
@@ -78,6 +80,13 @@ def test_weak_bands_with_the_repeat_penalty_and_forced_deepening(n):
     assert out["n_gpus"] == n and out["scaling"] == "weak"
     assert out["config"]["cells"] == single["config"]["cells"] == n * 256
     assert out["result_digest"] == single["result_digest"]
+    # the N-rank line checks ITSELF (round 6): band 0 against the committed CPU golden of the reduced config D, and two full grid rows
+    # inside the LAST band evaluated by the CPU oracle as the raster loop reaches them (the window of calculateRepeats in play)
+    gold = out["parity_on_golden"]
+    assert gold["indices_equal"] is True and gold["cells"] == 256 and gold["max_rel_score_err"] < 1e-9 and "band 0" in gold["bands_compared"]
+    par = out["parity_on_cpu_sample"]
+    assert par["indices_equal"] is True and par["cells"] == 32 and par["max_rel_score_err"] < 1e-9
+    assert out["rccl_ranks_seen"] == n and len(out["dist_phase_ms"]["score_per_rank"]) == n
 
 
 @pytest.mark.gpu
@@ -89,6 +98,11 @@ def test_strong_shards_of_the_reduced_config_e(n):
     out = run_ranks(n, "--config", "Es")           # E-shaped configs default to strong scaling
     assert out["config"]["cells"] == single["config"]["cells"] == 441
     assert out["result_digest"] == single["result_digest"]
+    # ... and against the committed CPU golden of the whole grid, inside the N-rank job itself (tests/golden/grid_Es.npz)
+    gold = out["parity_on_golden"]
+    assert gold["indices_equal"] is True and gold["cells"] == 441 and gold["cells_differing"] == 0 and gold["max_rel_score_err"] < 1e-9
+    assert out["rccl_ranks_seen"] == n and "gloo" in out["collective_backend"]
+    assert len(out["dist_phase_ms"]["score_per_rank"]) == n and all(v > 0 for v in out["dist_phase_ms"]["score_per_rank"])
 
 
 @pytest.mark.gpu
