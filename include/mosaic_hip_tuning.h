@@ -23,8 +23,10 @@ extern "C" {
  * -- the repeat-penalty resolve ------------------------------------------------------------------------------------
  *   sweep_resolve      1     the raster-order dependency as parallel sweeps to its fix point
  *   max_sweeps         48    sweeps in total before the sequential chain takes over
+ *   front_resolve      1     where a first set of sweeps does not settle (photographs): the exact wavefront in ONE launch, built for latency,
+ *                            and at once on the next generate over the same library; 0 = further sets of sweeps, then round 1's row pipeline
  *   wave_resolve       1     the chain's single-wave form (0: workgroup per cell)
- *   row_pipeline       1     the chain's row-pipelined form where the grid fits LDS
+ *   row_pipeline       1     the wavefront forms where the grid fits LDS (0: the single-wave chain)
  *   spec_k             4     length of mm_generate's speculative short lists; 0 = always mm_candidates_per_cell
  *   spec_auto          1     lists twice as long (<= 16) after a generate over the same library deepened > 2 % of its cells
  * -- submission ------------------------------------------------------------------------------------------------------

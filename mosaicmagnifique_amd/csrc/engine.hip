@@ -106,6 +106,9 @@ struct mm_engine {
     bool planes_dirty = true;
     int n_var = 0, var_of_mask[4] = {0, 0, 0, 0}, var_groups[4] = {0, 0, 0, 0};
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
+    int use_front_resolve = 1;   // mm_set_option("front_resolve", 0): resolve_rows_kernel as the wavefront form, and further sets of sweeps instead of it
+    bool front_learned = false;  // the sweeps of a generate over (sweeps_lib, sweeps_size) did not settle in their first set: the front form at once
+    bool last_front = false;     // the last resolve_single_submission ran the front form (its "sweep" count says nothing about the sweeps' depth)
     int use_sweep_resolve = 1;   // mm_set_option("sweep_resolve", 0): raster-order chain instead of parallel sweeps
     int max_sweeps = 48;         // mm_set_option("max_sweeps", n): sweeps before falling back to the chain
     int use_lds_filter = -1;     // mm_set_option("lds_filter", 0/1); -1 = auto (Euclid only: it is the L2-bound one)
@@ -1107,6 +1110,41 @@ mm::ResolveArgs resolve_args_of(const mm_engine* e, const mm_cell* recs_dev, int
     return a;
 }
 
+// The wavefront forms of the raster-order dependency (kernels.hpp resolve_front_kernel / resolve_rows_kernel): ONE workgroup, the
+// whole padded grid of picks in LDS.  Bytes of dynamic LDS they need, or 0 when the grid does not fit.
+size_t wavefront_lds_bytes(int grid_w, int grid_h, bool front)
+{
+    // (the front form stages a row's totals and flags per wave: + kFrontWaves x grid_w x 9 bytes, rounded up)
+    const size_t b = (((size_t)grid_w * grid_h + grid_h + 2) & ~(size_t)1) * sizeof(int) +
+                     (size_t)(front ? mm::kFrontWaves : mm::kRowWaves) * mm::kRowExactChunk * sizeof(double) +
+                     (front ? (size_t)mm::kFrontWaves * ((size_t)grid_w * 9 + 8) : 0);
+    return b <= 158 * 1024 ? b : 0;
+}
+
+// Enqueues row index + wavefront kernel; `stuck` (device, zeroed by the caller or here) is raised if a wait timed out.
+mm_status launch_wavefront(mm_engine* e, const mm::ResolveArgs& a, const mm_cell* recs_dev, int n, int grid_h, int diff_type,
+                           bool front, size_t lds_bytes, int* stuck_dev)
+{
+    mm_status st;
+    if ((st = ensure(e, e->row_index, ((size_t)2 * grid_h + 1) * sizeof(int), "Failed to allocate row index"))) return st;
+    int* row_first = (int*)e->row_index.p;
+    int* row_count = row_first + grid_h;
+    int* stuck = stuck_dev ? stuck_dev : row_count + grid_h;
+    HIP_TRY(e, hipMemsetAsync(row_first, 0, ((size_t)2 * grid_h + 1) * sizeof(int), e->stream), "Failed to clear row index");
+    mm::row_index_kernel<<<std::min((n + mm::kBlock - 1) / mm::kBlock, 256), mm::kBlock, 0, e->stream>>>(recs_dev, n, row_first, row_count);
+    HIP_TRY(e, hipGetLastError(), "Error during row index kernel");
+    st = by_type(diff_type, [&](auto T) {
+        auto kern = front ? mm::resolve_front_kernel<decltype(T)::value> : mm::resolve_rows_kernel<decltype(T)::value>;
+        hipError_t code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (code != hipSuccess) return hip_fail(e, code, "Failed to raise the LDS limit", __FILE__, __LINE__);
+        kern<<<1, (front ? mm::kFrontWaves : mm::kRowWaves) * mm::kWave, lds_bytes, e->stream>>>(a, row_first, row_count, stuck);
+        return MM_OK;
+    });
+    if (st) return st;
+    HIP_TRY(e, hipGetLastError(), "Error during calculate repeats / find lowest kernel");
+    return MM_OK;
+}
+
 // deep_dev (may be null = every list is full): 1 where the list holds the full K; the
 // others are speculative lists of k_fill entries whose pick is verified on the device;
 // insufficient_dev receives the verdict per cell.
@@ -1172,7 +1210,10 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
         // e.g. a flat target) the grid is reset and the sequential forms below take over.
         bool swept = false;
         if (sequential && e->use_sweep_resolve != 0) {
-            const int max_sweeps = e->max_sweeps, batch = 6;
+            // (with the front form behind them the sweeps get two sets: content they do not settle in twelve passes is the front form's)
+            const bool front_ready = e->use_front_resolve != 0 && wavefront_lds_bytes(grid_w, grid_h, true) != 0;
+            const bool skip_sweeps = front_ready && e->front_learned && e->sweeps_lib == e->n_lib && e->sweeps_size == e->lib_size;
+            const int max_sweeps = skip_sweeps ? 0 : (front_ready ? std::min(e->max_sweeps, 12) : e->max_sweeps), batch = 6;
             // per sweep: [max_sweeps] exact re-sum counters (u64), then [max_sweeps] change counters (u32)
             const size_t counts_bytes = (size_t)max_sweeps * (sizeof(unsigned long long) + sizeof(unsigned int));
             if ((st = ensure(e, e->sweep_counts, counts_bytes, "Failed to allocate sweep counters"))) return st;
@@ -1214,34 +1255,17 @@ mm_status resolve_device(mm_engine* e, const mm_cell* recs_dev, int n, int grid_
             }
         }
         // whole grid + progress counters + per-wave exact buffers in LDS?
-        const size_t rows_lds = (((size_t)grid_w * grid_h + grid_h + 2) & ~(size_t)1) * sizeof(int) +
-                                (size_t)mm::kRowWaves * mm::kRowExactChunk * sizeof(double);
+        const bool front = e->use_front_resolve != 0;
+        const size_t rows_lds = wavefront_lds_bytes(grid_w, grid_h, front);
         if (swept) {
             // final state reached by the sweeps
-        } else if (sequential && e->use_row_pipeline != 0 && rows_lds <= 158 * 1024) {
-            if ((st = ensure(e, e->row_index, ((size_t)2 * grid_h + 1) * sizeof(int), "Failed to allocate row index")))
-                return st;
-            int* row_first = (int*)e->row_index.p;
-            int* row_count = row_first + grid_h;
-            int* stuck = row_count + grid_h;
-            HIP_TRY(e, hipMemsetAsync(row_first, 0, ((size_t)2 * grid_h + 1) * sizeof(int), e->stream), "Failed to clear row index");
-            mm::row_index_kernel<<<std::min((n + mm::kBlock - 1) / mm::kBlock, 256), mm::kBlock, 0, e->stream>>>(
-                recs_dev, n, row_first, row_count);
-            HIP_TRY(e, hipGetLastError(), "Error during row index kernel");
-            st = by_type(diff_type, [&](auto T) {
-                auto kern = mm::resolve_rows_kernel<decltype(T)::value>;
-                hipError_t code = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds);
-                if (code != hipSuccess) return hip_fail(e, code, "Failed to raise the LDS limit", __FILE__, __LINE__);
-                kern<<<1, mm::kRowWaves * mm::kWave, rows_lds, e->stream>>>(a, row_first, row_count, stuck);
-                return MM_OK;
-            });
-            if (st) return st;
-            HIP_TRY(e, hipGetLastError(), "Error during calculate repeats / find lowest kernel");
+        } else if (sequential && e->use_row_pipeline != 0 && rows_lds != 0) {
+            if (e->use_sweep_resolve != 0 && front) { e->front_learned = true; e->sweeps_learned = 0; e->sweeps_lib = e->n_lib; e->sweeps_size = e->lib_size; }
+            if ((st = launch_wavefront(e, a, recs_dev, n, grid_h, diff_type, front, rows_lds, nullptr))) return st;
             int stuck_host = 0;
-            HIP_TRY(e, hipMemcpyAsync(&stuck_host, stuck, sizeof(int), hipMemcpyDeviceToHost, e->stream), "stuck flag");
+            HIP_TRY(e, hipMemcpyAsync(&stuck_host, (int*)e->row_index.p + 2 * grid_h, sizeof(int), hipMemcpyDeviceToHost, e->stream), "stuck flag");
             HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
-            if (stuck_host) { set_err(e, "row-pipelined resolve made no progress (internal error)"); return MM_DEVICE_ERROR; }
+            if (stuck_host) { set_err(e, "wavefront resolve made no progress (internal error)"); return MM_DEVICE_ERROR; }
         } else {
             const int blocks = sequential ? 1 : std::max(1, std::min(n, 8192));
             by_type(diff_type, [&](auto T) {
@@ -1357,11 +1381,24 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
     const int sequential = (range > 0 && addition != 0) ? 1 : 0;
     const int blocks = std::max(1, std::min(n, 8192));
     int sweeps = 0;
-    if (sequential) {
-        // Sweeps per set: eight at first -- config D settles in four --, as many as the engine's previous generate over this library
-        // needed where that was more (photographs: forty per round, i.e. six sets of eight with a host wait each: config P spent
-        // twelve of its fourteen waits here), and a full block's worth when a set is continued.  A sweep enqueued after the grid
-        // has settled returns at once (prev_changes), so a generous set costs a few microseconds of empty launches.
+    // The front form (kernels.hpp resolve_front_kernel: the exact wavefront in ONE launch, ~0.1 us per cell of its critical path) where the
+    // sweeps do not settle in their first set: a continued block goes to it instead of further sets (photographs at config D's scale
+    // had not settled after 240 sweeps), and once that has happened over a (library, cell size) the next generate starts with it.
+    const size_t front_lds = wavefront_lds_bytes(grid_w, grid_h, true);
+    const bool front = sequential && e->use_front_resolve != 0 && front_lds != 0 &&
+                       (continuing || (e->front_learned && e->sweeps_lib == e->n_lib && e->sweeps_size == e->lib_size));
+    e->last_front = front;
+    if (front) {
+        if (continuing) { e->front_learned = true; e->sweeps_learned = 0; e->sweeps_lib = e->n_lib; e->sweeps_size = e->lib_size; }
+        a.sweep_changes = nullptr;
+        a.prev_changes = nullptr;
+        a.exact_count = &hdr->sweep_exact[0];
+        a.insufficient_count = speculate ? &hdr->sweep_insufficient[0] : nullptr;
+        // (the header was cleared: sweep_changes[0] stays 0 = "this pass left the grid at its fix point", which is what one exact pass does;
+        // the kernel's stuck flag is the header's spare word)
+        if ((st = launch_wavefront(e, a, recs_dev, n, grid_h, diff_type, true, front_lds, (int*)&hdr->pad))) return st;
+        sweeps = 1;
+    } else if (sequential) {
         const bool learned = e->sweeps_lib == e->n_lib && e->sweeps_size == e->lib_size && e->sweeps_learned > 8;
         const int want = continuing ? mm::kFastSweeps : (learned ? std::min(mm::kFastSweeps, (e->sweeps_learned + 2 + 7) / 8 * 8) : 8);
         // (what is left of "max_sweeps" bounds the set, not the option itself: a continued set used to enqueue its full want and the
@@ -1391,6 +1428,7 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
     HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
     mm::ResultHeader* h = (mm::ResultHeader*)e->pinned;
     h->sweeps = (unsigned int)sweeps;
+    if (front && h->pad != 0u) { set_err(e, "wavefront resolve made no progress (internal error)"); return MM_DEVICE_ERROR; }
     if (sequential && sweeps > 0) {       // the final state's verdicts: those of the sweep that changed nothing (the ones after it did not run), else the last one's
         int last = sweeps - 1;
         for (int i = 0; i < sweeps; ++i)
@@ -2230,7 +2268,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
         if (resolved_ok) {
             if (e->phase_events) e->timing.resolve_ms += elapsed(e->ev[10], e->ev[11]);
             e->timing.resolve_sweeps += sequential ? sweeps_before + settled + 1 : 0;
-            if (sequential) { e->sweeps_learned = sweeps_before + settled + 1; e->sweeps_lib = e->n_lib; e->sweeps_size = e->lib_size; }
+            if (sequential && !e->last_front) { if (e->sweeps_lib != e->n_lib || e->sweeps_size != e->lib_size) e->front_learned = false; e->sweeps_learned = sweeps_before + settled + 1; e->sweeps_lib = e->n_lib; e->sweeps_size = e->lib_size; }
             e->timing.exact_rescored += (int64_t)(sequential ? h.sweep_exact[settled] : h.exact_plain);
             e->timing.dense_rows += (int64_t)h.dense_count;
             const char* body = (const char*)e->pinned + sizeof(mm::ResultHeader);
@@ -2284,7 +2322,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
                 if (h.n_marked == 0 && (!sequential || settled >= 0)) {
                     if (e->phase_events) e->timing.resolve_ms += elapsed(e->ev[10], e->ev[11]);
                     e->timing.resolve_sweeps += sequential ? sweeps_before + settled + 1 : 0;
-                    if (sequential) { e->sweeps_learned = sweeps_before + settled + 1; e->sweeps_lib = e->n_lib; e->sweeps_size = e->lib_size; }
+                    if (sequential && !e->last_front) { if (e->sweeps_lib != e->n_lib || e->sweeps_size != e->lib_size) e->front_learned = false; e->sweeps_learned = sweeps_before + settled + 1; e->sweeps_lib = e->n_lib; e->sweeps_size = e->lib_size; }
                     e->timing.exact_rescored += (int64_t)(sequential ? h.sweep_exact[settled] : h.exact_plain);
                     e->timing.dense_rows += (int64_t)h.dense_count;
                     const char* body = (const char*)e->pinned + sizeof(mm::ResultHeader);
@@ -2607,6 +2645,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "prune") == 0) { e->use_prune = value != 0; return MM_OK; }
     if (strcmp(name, "wave_resolve") == 0) { e->use_wave_resolve = value != 0; return MM_OK; }
     if (strcmp(name, "row_pipeline") == 0) { e->use_row_pipeline = value != 0; return MM_OK; }
+    if (strcmp(name, "front_resolve") == 0) { e->use_front_resolve = value != 0; e->front_learned = false; return MM_OK; }
     if (strcmp(name, "sweep_resolve") == 0) { e->use_sweep_resolve = value != 0; return MM_OK; }
     if (strcmp(name, "max_sweeps") == 0) { if (value < 1 || value > 4096) return MM_INVALID_ARGUMENT; e->max_sweeps = value; return MM_OK; }
     if (strcmp(name, "lds_filter") == 0) { e->use_lds_filter = value < 0 ? -1 : (value != 0); return MM_OK; }

@@ -61,6 +61,41 @@ __device__ __forceinline__ ScoreIdx wave_min(ScoreIdx v)
     return v;
 }
 
+// wave_min without the LDS crossbar: the partner's (score, index) through DPP row rotations (four steps leave every lane of a 16-lane
+// row with the row's minimum), then the four rows' minima through v_readlane.  Same lexicographic order, same result in every lane.
+// ds_bpermute costs a wave that has the SIMD to itself (the wavefront resolve) ~100 cycles of LDS latency per step, 18 of them.
+template <int CTRL>
+__device__ __forceinline__ void lexmin_dpp_step(double& s, int& i)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, s);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_mov_dpp((int)(unsigned int)b, CTRL, 0xf, 0xf, false);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_mov_dpp((int)(unsigned int)(b >> 32), CTRL, 0xf, 0xf, false);
+    const int oi = __builtin_amdgcn_mov_dpp(i, CTRL, 0xf, 0xf, false);
+    const double os = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    if (lex_less(os, oi, s, i)) { s = os; i = oi; }
+}
+
+__device__ __forceinline__ ScoreIdx wave_min_dpp(ScoreIdx v)
+{
+    lexmin_dpp_step<0x128>(v.s, v.i);       // row_ror:8
+    lexmin_dpp_step<0x124>(v.s, v.i);       // row_ror:4
+    lexmin_dpp_step<0x122>(v.s, v.i);       // row_ror:2
+    lexmin_dpp_step<0x121>(v.s, v.i);       // row_ror:1
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v.s);
+    ScoreIdx r{v.s, v.i};
+    bool first = true;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, 16 * row);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), 16 * row);
+        const int oi = __builtin_amdgcn_readlane(v.i, 16 * row);
+        const double os = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        if (first || lex_less(os, oi, r.s, r.i)) { r.s = os; r.i = oi; }
+        first = false;
+    }
+    return r;
+}
+
 // Block-wide lexicographic min; every thread gets the result.  `sh` = 4 slots.
 __device__ __forceinline__ ScoreIdx block_min(ScoreIdx v, ScoreIdx* sh)
 {
@@ -1936,6 +1971,289 @@ resolve_rows_kernel(ResolveArgs a, const int* __restrict__ row_first, const int*
             rec = nrec;
             my_ci = nci;
             my_cs = ncs;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// resolve, FRONT form: the same wavefront, built for latency (round 6)
+// ---------------------------------------------------------------------------
+//
+// The sweeps (resolve_wave_kernel mode 2) settle config D's synthetic content in four passes; on photographs neighbouring cells
+// want the same few images, a change travels one cell per sweep along the raster order, and the grid of bench.py --config PD had
+// not settled after 240 sweeps (4.3 ms of 18-us launches, then the fallback to resolve_rows_kernel: 2.4 ms -- twice per generate).
+// The wavefront itself is exact in ONE pass; what made resolve_rows_kernel slow is its critical path: per cell two dependent
+// global loads after the wait (row_slot, deep), a workgroup-scope release fence that drains the cell's GLOBAL result stores
+// (a store's round trip, 1 - 2 us) before the row's progress may move, 128-cycle sleeps in the poll, and eight rows in flight.
+// Here: everything that does not depend on the neighbours is loaded a cell ahead, the pick is published through LDS alone -- LDS operations of a wave complete in order, so `lgrid` then
+// `progress` needs a wait on the LDS counter only -- and the global stores of a cell's results trail behind, off the path.
+// Same per-cell arithmetic and tie handling as the other forms (a copy of resolve_rows_kernel's evaluation), same arguments.
+// Eight waves, as resolve_rows_kernel: the cell loop with the fp64 reference form of the near-tie re-sum inlined wants ~200 VGPRs, and a
+// 16-wave workgroup (128 per lane) spilled 60 of them into the loop (868 bytes of scratch per lane on the critical path of every cell).
+constexpr int kFrontWaves = 8;
+
+template <int TYPE>
+__global__ void __launch_bounds__(kFrontWaves * kWave)
+resolve_front_kernel(ResolveArgs a, const int* __restrict__ row_first, const int* __restrict__ row_count,
+                     int* __restrict__ stuck)
+{
+    extern __shared__ int lds[];
+    const int gw = a.grid_w, gh = a.grid_h;
+    int* lgrid = lds;                                  // [gh][gw] chosen index, sentinel L
+    int* progress = lds + (size_t)gw * gh;             // [gh]
+    double* exact_buf = reinterpret_cast<double*>(lds + (((size_t)gw * gh + gh + 2) & ~(size_t)1));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* wbuf = exact_buf + (size_t)wave * kRowExactChunk;
+    // a row's results wait in LDS until the row is done: a global store inside the cell loop is waited for at the loop's next
+    // vmcnt(0) (CDNA counts stores in vmcnt, and the prefetch of the next cell's list ends in one) -- a store's round trip per cell
+    double* row_score = exact_buf + (size_t)kFrontWaves * kRowExactChunk + (size_t)wave * gw;     // [gw] totals of this wave's row
+    unsigned char* row_flag = reinterpret_cast<unsigned char*>(exact_buf + (size_t)kFrontWaves * (kRowExactChunk + gw)) + (size_t)wave * gw;
+    const int R = a.repeat_range, sentinel = a.L;
+
+    for (int i = threadIdx.x; i < gw * gh; i += blockDim.x) lgrid[i] = sentinel;
+    for (int y = threadIdx.x; y < gh; y += blockDim.x) progress[y] = row_count[y] == 0 ? gw : 0;
+    __syncthreads();                                   // the only workgroup barrier
+
+    // FAST PATH (the common shape: the window's <= R (2R + 1) + R neighbours fit one wave -- R <= 5 -- and so does the list):
+    // lane t owns one neighbour slot for the whole kernel -- (dq, dr) = its offset from the cell, doff the same as a distance in the LDS
+    // grid -- so a cell's neighbour fetch is an add, three range tests and ONE ds_read (no division by the clipped window's width);
+    // the penalty is counted per CANDIDATE when the list is shorter than the window (ballot + popcount + a select per candidate:
+    // 16 candidates against 40 neighbours); the arg-min runs on DPP rotations instead of 18 ds_bpermute.  Anything else -- a dense
+    // row, a near-tie that needs the reference-order re-sum -- takes the general code below, which recomputes the cell from scratch.
+    const int W = 2 * R + 1, n_slots = R * W + R;
+    const bool fast_shape = n_slots <= kWave && a.K <= kWave && R > 0;
+    int dq = 0, dr = 0;
+    bool slot_used = false;
+    if (fast_shape && lane < n_slots) {
+        slot_used = true;
+        if (lane < R * W) { const int q = lane / W; dq = q - R; dr = lane - q * W - R; }
+        else { dq = 0; dr = lane - R * W - R; }
+    }
+    const int doff = dq * gw + dr;
+
+    for (int py = wave; py < gh; py += kFrontWaves) {
+        const int n_row = row_count[py];
+        if (n_row == 0) continue;
+        const int c_first = row_first[py];
+        mm_cell rec = a.recs[c_first];
+        int my_ci = lane < a.K ? a.cand_index[(size_t)c_first * a.K + lane] : -1;
+        double my_cs = lane < a.K ? a.cand_score[(size_t)c_first * a.K + lane] : kInf;
+        int my_slot = a.row_slot ? a.row_slot[c_first] : -1;
+        int my_deep = a.deep ? (int)a.deep[c_first] : 1;
+
+        for (int i = 0; i < n_row; ++i) {
+            const int c = c_first + i;
+            mm_cell nrec = rec;
+            int nci = -1, nslot = -1, ndeep = 1;
+            double ncs = kInf;
+            if (i + 1 < n_row) {                       // everything of the row's next cell that does not depend on a neighbour
+                nrec = a.recs[c + 1];
+                if (lane < a.K) { nci = a.cand_index[(size_t)(c + 1) * a.K + lane]; ncs = a.cand_score[(size_t)(c + 1) * a.K + lane]; }
+                if (a.row_slot) nslot = a.row_slot[c + 1];
+                if (a.deep) ndeep = (int)a.deep[c + 1];
+            }
+            const int px = rec.grid_x;
+            // cells between the row's previous valid cell and this one are not in the grid: final too
+            if (lane == 0 && i > 0) __atomic_store_n(&progress[py], px, __ATOMIC_RELAXED);
+            const int sy = min(max(py - R, 0), gh);
+            const int sx = min(max(px - R, 0), gw);
+            const int ex = min(max(px + R, 0), gw - 1);
+            const int wrow = ex - sx + 1;
+            const int n_above = (py - sy) * wrow;
+            const int nn = n_above + (px - sx);
+
+            // Wait until every row of the window has cleared columns <= ex (each row is checked: with ragged rows -- offset cell shapes --
+            // "row y-1 is past ex" does not imply the rows above it are).  ONE LDS read per poll: lane r reads the progress word of window
+            // row r.  Bounded: a timeout raises `stuck` and opens every row's progress, so every wave runs out and the kernel drains (the
+            // host then reports the error; the grid of such a launch is not used).
+            {
+                const int n_rows_above = py - sy;
+                int spins = 0;
+                for (;;) {
+                    int pr = 0x7fffffff;
+                    for (int r0 = lane; r0 < n_rows_above; r0 += kWave) pr = min(pr, __atomic_load_n(&progress[sy + r0], __ATOMIC_RELAXED));
+                    if (__ballot(pr < ex + 1) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 24)) {
+                        for (int y = lane; y < gh; y += kWave) __atomic_store_n(&progress[y], 0x7ffffffe, __ATOMIC_RELAXED);
+                        if (lane == 0) atomicExch(stuck, 1);
+                        break;
+                    }
+                }
+            }
+            // (LDS only: the picks this cell reads were written before the progress words it has just seen, by in-order LDS writes)
+            asm volatile("" ::: "memory");
+
+            const int slot = my_slot;
+            const bool dense = slot >= 0;
+            const bool is_deep = my_deep != 0;
+            const int K = dense ? a.L : (is_deep ? a.K : min(a.K, a.k_fill));
+            const double* row = dense ? a.dense_rows + (size_t)slot * a.L : nullptr;
+
+            long long chosen = a.L;                 // sentinel: "Failed to find a best fit" (CPUPhotomosaicGenerator.cpp:173-177)
+            double chosen_total = kInf;
+            int c0 = -1;
+            double s0 = kInf;
+            bool done = false;
+            if (fast_shape && !dense) {
+                const int cand = lane < K ? ((!is_deep && my_ci <= -2) ? -(my_ci + 2) : my_ci) : -1;
+                const double sb = lane < K ? my_cs : kInf;
+                const int ry = py + dq, rx = px + dr;
+                int nbv = sentinel;
+                if (slot_used && ry >= 0 && rx >= 0 && rx < gw) nbv = __atomic_load_n(&lgrid[py * gw + px + doff], __ATOMIC_RELAXED);
+                int cnt = 0;
+                if (K <= n_slots) {
+                    for (int k = 0; k < K; ++k) {   // per candidate: how many neighbours hold it
+                        const int ck = __builtin_amdgcn_readlane(cand, k);
+                        const int hits = __popcll(__ballot(nbv == ck));
+                        cnt = lane == k ? hits : cnt;
+                    }
+                } else {
+                    for (int t = 0; t < n_slots; ++t) cnt += (__builtin_amdgcn_readlane(nbv, t) == cand) ? 1 : 0;
+                }
+                const int rep = cnt * a.repeat_addition;
+                const double total = (double)rep + sb;
+                ScoreIdx best{kInf, 0x7fffffff};
+                if (cand >= 0) { best.s = total; best.i = cand; }
+                best = wave_min_dpp(best);
+                c0 = cand; s0 = sb;
+                if (best.i == 0x7fffffff) {
+                    done = true;                    // no candidate at all: the sentinel, total +inf (as the general code leaves it)
+                } else {
+                    const double thr = best.s + fabs(best.s) * a.tie_band;
+                    const int near = __popcll(__ballot(cand >= 0 && total <= thr));
+                    const int nonzero = __popcll(__ballot(cand >= 0 && total <= thr && sb != 0.0));
+                    if (!(near > 1 && nonzero > 0)) { chosen = best.i; chosen_total = best.s; done = true; }
+                }
+            }
+            if (!done) {
+
+            auto eval = [&](int base, int& cand, double& total, int& rep_out, double& base_out) {
+                const int k = base + lane;
+                double s;
+                if (dense) { cand = k < K ? k : -1; s = k < K ? row[k] : kInf; }
+                else if (base == 0) { cand = k < K ? my_ci : -1; s = k < K ? my_cs : kInf; }
+                else { cand = k < K ? a.cand_index[(size_t)c * a.K + k] : -1; s = k < K ? a.cand_score[(size_t)c * a.K + k] : kInf; }
+                if (!is_deep && cand <= -2) cand = -(cand + 2);     // a mark on a speculative list is just an entry
+                int rep = 0;
+                for (int t0 = 0; t0 < nn; t0 += kWave) {
+                    const int t = t0 + lane;
+                    int nbv = sentinel;
+                    if (t < nn) {
+                        int ry, rx;
+                        if (t < n_above) { const int q = t / wrow; ry = sy + q; rx = sx + (t - q * wrow); }
+                        else { ry = py; rx = sx + (t - n_above); }
+                        nbv = __atomic_load_n(&lgrid[ry * gw + rx], __ATOMIC_RELAXED);
+                    }
+                    // (lanes past the window hold the sentinel, which no candidate equals: whole octets, no tail test)
+                    const int cnt = min(kWave, nn - t0);
+                    for (int j = 0; j < cnt; j += 8) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) rep += (__builtin_amdgcn_readlane(nbv, j + u) == cand) ? 1 : 0;
+                    }
+                }
+                rep *= a.repeat_addition;
+                rep_out = rep;
+                base_out = s;
+                total = (double)rep + s;
+            };
+
+            ScoreIdx best{kInf, 0x7fffffff};
+            int r0 = 0;
+            double t0v = kInf;
+            for (int base = 0; base < K; base += kWave) {
+                int cand, rep; double total, sb;
+                eval(base, cand, total, rep, sb);
+                if (base == 0) { c0 = cand; t0v = total; r0 = rep; s0 = sb; }
+                if (cand >= 0 && lex_less(total, cand, best.s, best.i)) { best.s = total; best.i = cand; }
+            }
+            best = wave_min(best);
+
+            chosen = a.L;
+            chosen_total = best.s;
+            if (best.i != 0x7fffffff) {
+                chosen = best.i;
+                const double thr = best.s + fabs(best.s) * a.tie_band;
+                int near = 0, nonzero = 0;
+                for (int base = 0; base < K; base += kWave) {
+                    int cand, rep; double total, sb;
+                    if (base == 0) { cand = c0; total = t0v; sb = s0; } else eval(base, cand, total, rep, sb);
+                    near += __popcll(__ballot(cand >= 0 && total <= thr));
+                    nonzero += __popcll(__ballot(cand >= 0 && total <= thr && sb != 0.0));
+                }
+                if (near > 1 && nonzero > 0) {         // re-sum every contender in the reference's order, ascending index, strict <
+                    double ex_best = kInf;
+                    int ex_idx = -1, prev = -1;
+                    for (;;) {
+                        int key_i = 0x7fffffff, key_rep = 0, key_zero = 0;
+                        for (int base = 0; base < K; base += kWave) {
+                            int cand, rep; double total, sb;
+                            if (base == 0) { cand = c0; total = t0v; rep = r0; sb = s0; } else eval(base, cand, total, rep, sb);
+                            if (cand > prev && total <= thr && cand < key_i) { key_i = cand; key_rep = rep; key_zero = sb == 0.0; }
+                        }
+                        const ScoreIdx win = wave_min(ScoreIdx{(double)key_i, key_i});
+                        if (win.i == 0x7fffffff) break;
+                        const unsigned long long who = __ballot(key_i == win.i);
+                        const int src = __ffsll((long long)who) - 1;
+                        const int win_rep = __shfl(key_rep, src, kWave);
+                        const bool win_zero = __shfl(key_zero, src, kWave) != 0;
+                        const double ex = win_zero ? (double)win_rep : exact_total_wave<TYPE>(a, rec, win.i, win_rep, wbuf);
+                        if (lane == 0 && !win_zero) atomicAdd(a.exact_count, 1ull);
+                        if (ex < ex_best) { ex_best = ex; ex_idx = win.i; }
+                        prev = win.i;
+                    }
+                    if (ex_idx >= 0) { chosen = ex_idx; chosen_total = ex_best; }
+                }
+            }
+            }   // general path
+
+            // publish the pick: LDS only, in order (the grid entry, then the row's progress)
+            if (lane == 0) {
+                const size_t pos = (size_t)py * gw + px;
+                __atomic_store_n(&lgrid[pos], (int)chosen, __ATOMIC_RELAXED);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // (up to and including this cell; the gap to the row's next valid cell -- ragged rows -- is added when that cell's turn
+                // comes, so that nothing here needs the NEXT record yet: asking for nrec.grid_x at this point made the compiler wait for
+                // the prefetch right after issuing it, a global load's latency on every cell's path)
+                __atomic_store_n(&progress[py], (i + 1 < n_row) ? px + 1 : gw, __ATOMIC_RELAXED);
+            }
+            // ... and the cell's results into the row's LDS staging, off the critical path
+            bool insuff = false;
+            if (a.insufficient && !is_deep) {
+                const int nvalid = __popcll(__ballot(c0 >= 0));
+                double b_last = -kInf;
+                if (nvalid > 0) {                   // (a uniform lane number: two v_readlane, no LDS crossbar)
+                    const unsigned long long bits = __builtin_bit_cast(unsigned long long, s0);
+                    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, nvalid - 1);
+                    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(bits >> 32), nvalid - 1);
+                    b_last = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+                }
+                insuff = !(chosen != a.L && chosen_total + fabs(chosen_total) * a.tie_band < b_last);
+            }
+            if (lane == 0) {
+                row_score[i] = chosen_total;
+                row_flag[i] = insuff ? 1 : 0;
+            }
+            asm volatile("" ::: "memory");             // (our own next read of lgrid[py][px] comes after its write in program order)
+
+            rec = nrec;
+            my_ci = nci;
+            my_cs = ncs;
+            my_slot = nslot;
+            my_deep = ndeep;
+        }
+        // the row's results to global memory, all lanes (cells of a row are consecutive records)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        unsigned int n_insuff = 0;
+        for (int i = lane; i < n_row; i += kWave) {
+            const size_t pos = (size_t)py * gw + a.recs[c_first + i].grid_x;
+            a.grid[pos] = (long long)__atomic_load_n(&lgrid[pos], __ATOMIC_RELAXED);
+            a.best_score[pos] = row_score[i];
+            if (a.insufficient) { a.insufficient[c_first + i] = row_flag[i]; n_insuff += row_flag[i]; }
+        }
+        if (a.insufficient_count) {
+            for (int off = 32; off > 0; off >>= 1) n_insuff += __shfl_xor(n_insuff, off, kWave);
+            if (lane == 0 && n_insuff != 0u) atomicAdd(a.insufficient_count, n_insuff);
         }
     }
 }

@@ -26,9 +26,11 @@ SHAPES = {
 REL_TOL = {0: 1e-12, 1: 1e-12, 2: 1e-4}
 
 
-# (wave_resolve, row_pipeline, sweep_resolve): the parallel sweeps (default), the row-pipelined
-# chain, the single-wave chain, the workgroup-per-cell chain
-RESOLVE_MODES = {"sweep": (1, 1, 1), "rows": (1, 1, 0), "wave": (1, 0, 0), "workgroup": (0, 0, 0)}
+# (wave_resolve, row_pipeline, sweep_resolve, front_resolve): the parallel sweeps (default; content they do not settle goes on to the
+# front form), the wavefront in its latency-built front form (round 6) and in round 1's row-pipelined form, the single-wave chain,
+# the workgroup-per-cell chain
+RESOLVE_MODES = {"sweep": (1, 1, 1, 1), "rows": (1, 1, 0, 1), "rows_r1": (1, 1, 0, 0), "sweep_r5": (1, 1, 1, 0), "wave": (1, 0, 0, 1),
+                 "workgroup": (0, 0, 0, 1)}
 
 
 def generate(shape, img, lib, t, rep=(0, 0), device=0, use_filter=1, wave_resolve="sweep", options=()):
@@ -38,6 +40,7 @@ def generate(shape, img, lib, t, rep=(0, 0), device=0, use_filter=1, wave_resolv
     gen.m_engine.set_option("wave_resolve", RESOLVE_MODES[wave_resolve][0])
     gen.m_engine.set_option("row_pipeline", RESOLVE_MODES[wave_resolve][1])
     gen.m_engine.set_option("sweep_resolve", RESOLVE_MODES[wave_resolve][2])
+    gen.m_engine.set_option("front_resolve", RESOLVE_MODES[wave_resolve][3])
     for name, value in options:
         gen.m_engine.set_option(name, value)
     gen.setMainImage(img)
@@ -105,7 +108,8 @@ def test_sweep_resolve_reaches_the_raster_order_result(oracle, t):
     shape = cases.square_shape(size)
     img, lib = cases.inputs(12 * size, 14 * size, size, 90, t, lattice=64 * size)   # one lattice cell: smooth, near-flat
     sweeps = {}
-    for name, options in (("free", (("max_sweeps", 512),)), ("starved", (("max_sweeps", 2),)), ("off", (("sweep_resolve", 0),))):
+    for name, options in (("free", (("max_sweeps", 512),)), ("starved", (("max_sweeps", 2),)), ("off", (("sweep_resolve", 0),)),
+                          ("free", (("max_sweeps", 512), ("front_resolve", 0)))):
         for rep in ((3, 250), (4, 100000), (2, -40)):
             gen = compare(oracle, shape, img, lib, t, rep=rep, options=options)
             sweeps[name, rep] = gen.timing()["resolve_sweeps"]
