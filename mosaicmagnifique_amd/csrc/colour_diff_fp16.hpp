@@ -41,7 +41,7 @@ __device__ __forceinline__ half2_t h2_from(unsigned int v) { return __builtin_bi
 // that register -- the compiler inserts it for its own code, inline asm is not hazard-checked: the s_nop 0.  Found the hard way: without
 // it the structured sweep returned inf and config G's golden failed.  And the SDWA instruction's PRESERVE is itself a read of the register
 // the e32 instruction has just written: issued back to back it kept a stale low half in a third of the cases
-// (tools/experiments/r4_sdwa_test.hip) -- a wait state between the two as well.)
+// (tools/experiments/archive/r4_sdwa_test.hip) -- a wait state between the two as well.)
 #ifndef MM_PRE_ONE_RCP
 #define MM_PRE_ONE_RCP 1             // ciede2000_h2: one reciprocal for t_L, t_C and t_H (0: two, as the fp32 form has them)
 #endif

@@ -60,7 +60,7 @@ struct mm_engine {
     // pixel loop far above the limit and the pre-tier's cheaper arithmetic wins with round 4's observed band (config D -6.3 %), with the
     // worst-case band of round 5 nowhere (config D +9 %, config G +5 %: there -1 means off); on photographs the block bound is tight,
     // many candidates sit within the fp16 band of the limit, walk all their groups in fp16 and then again in fp32 (the photo fixture
-    // enlarged to 2752 / 6144 cells: +6 % / +4 %, tools/experiments/r4_photo_scale.py).  So an eligible job MEASURES it: after a warm-up
+    // enlarged to 2752 / 6144 cells: +6 % / +4 %, tools/experiments/archive/r4_photo_scale.py).  So an eligible job MEASURES it: after a warm-up
     // launch over a (library, cell size, batch size, target), one filter launch runs without the pre-tier and one with it, both between
     // two events, and the faster form is kept from there on.  As with the item size and the list length only the TIME of a call
     // depends on the engine's history, never its result.
@@ -731,7 +731,7 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
     // 0.042 to 0.129 ms, so the Euclidean forms take two)
     // (and a SMALL CIEDE2000 call -- the reference harness's line, config H: 1280 cells of 25 x 25 against 214 images -- is made of
     // its fixed costs: 2 extra seeds instead of 14 take the seed phase from 0.109 to 0.041 ms and the step from 0.576 to 0.520 ms,
-    // while config C, 27 times the work, runs the same within 1 % from 6 to 14; tools/experiments/r4_third.sh)
+    // while config C, 27 times the work, runs the same within 1 % from 6 to 14; tools/experiments/archive/r4_third.sh)
     const bool small_call = (double)std::min(n, 32768) * L * P < 1e9;
     const int extra_seeds = e->extra_seeds >= 0 ? e->extra_seeds : (diff_type == MM_CIEDE2000 ? (small_call ? 2 : 14) : 2);
     const int M = std::min(L, std::min(256, round_up(K + extra_seeds, 4)));

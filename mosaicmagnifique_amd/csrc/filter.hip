@@ -146,7 +146,7 @@ __device__ __forceinline__ float4 ld4(const float4* base, unsigned int byte_off)
 
 // MM_LIB_NT (A/B builds): the library's groups as NON-TEMPORAL loads, on the idea that a visited library group is read once per (cell,
 // candidate) while the cell's groups are read by every candidate of the item, so streaming the library past the L2 should leave the cells in
-// it.  Measured (round 5, tools/experiments/r5_nt.sh): config D +19 %, E's shard +22 %, I +16 %, C +13 %, G -2 % -- the cells of an XCD's
+// it.  Measured (round 5, tools/experiments/archive/r5_nt.sh): config D +19 %, E's shard +22 %, I +16 %, C +13 %, G -2 % -- the cells of an XCD's
 // sub-group DO share library lines in the L2 and the Infinity Cache, and the hint takes that away.  Off.
 #ifndef MM_LIB_NT
 #define MM_LIB_NT 0
@@ -163,15 +163,25 @@ __device__ __forceinline__ float4 ld4_lib(const float4* base, unsigned int byte_
 #endif
 }
 
-template <int TYPE>
+// NO_QC: the library's chroma plane is not fetched (filter_kernel<.., BIG>: a quarter of a visit's library bytes on cells whose launches
+// press on the fabric); the caller recomputes it from a and b with the instructions that filled the plane (prep_chroma4), bit for bit.
+template <int TYPE, bool NO_QC = false>
 __device__ __forceinline__ LibGroup load_lib_group(const float4* b0, const float4* b1, const float4* b2,
                                                    const float4* bc, int q)
 {
     const unsigned int off = (unsigned int)q * 16u;
     LibGroup g;
     g.q0 = ld4_lib(b0, off); g.q1 = ld4_lib(b1, off); g.q2 = ld4_lib(b2, off);
-    if constexpr (TYPE == CIEDE2000) g.qc = ld4_lib(bc, off); else g.qc = float4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (TYPE == CIEDE2000 && !NO_QC) g.qc = ld4_lib(bc, off); else g.qc = float4{0.f, 0.f, 0.f, 0.f};
     return g;
+}
+
+// The interleaved copy's chroma plane of four pixels from their a and b: chroma_planes_kernel's chroma_of, then interleave_kernel's
+// __fmul_rn by kChromaPrep (a product the compiler may not contract into a later sum) -- the stored values, bit for bit.
+__device__ __forceinline__ float4 prep_chroma4(const float4& a, const float4& b)
+{
+    return float4{__fmul_rn(kChromaPrep, chroma_of(a.x, b.x)), __fmul_rn(kChromaPrep, chroma_of(a.y, b.y)),
+                  __fmul_rn(kChromaPrep, chroma_of(a.z, b.z)), __fmul_rn(kChromaPrep, chroma_of(a.w, b.w))};
 }
 
 // Lower bound of  sum over a block's pixel pairs of dE00  from the seven statistics of the cell's block (c_*) and the
@@ -241,6 +251,9 @@ __device__ __forceinline__ float stats_bound(float c_sl, float c_dev, float c_sa
 #ifndef MM_STAT_BLOCKS
 #define MM_STAT_BLOCKS (4 * kWave)   // blocks of a cell whose statistics filter_kernel keeps in LDS (experiments: 64 = cells up to 64 x 64 only)
 #endif
+#ifndef MM_BIG_RECOMPUTE_QC
+#define MM_BIG_RECOMPUTE_QC 1
+#endif
 #ifndef MM_BIG_CELL_STAGE0
 #define MM_BIG_CELL_STAGE0 1         // cells above 16 groups: stage 0 of the bound ahead of the candidate loop, bound-ordered visits from 17 groups on (0: round 3's form, for A/B builds)
 #endif
@@ -289,7 +302,7 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // address everything, and the groups a candidate visits before its early exit are one contiguous prefix.
 // BIG: the instantiation for cells above 16 groups (80 x 80 .. 128 x 128): stage 0 of the bound ahead of the candidate loop and
 // bound-ordered visits from 17 groups on.  A template parameter and not a run-time branch: the extra scalars it keeps alive
-// cost the 64 x 64 instantiation three more spilled SGPRs and config D 0.3 % (measured, tools/experiments/r4_second.sh).
+// cost the 64 x 64 instantiation three more spilled SGPRs and config D 0.3 % (measured, tools/experiments/archive/r4_second.sh).
 // PRE: the packed-fp16 pre-tier ahead of the fp32 walk (filter_pretier.hpp; instantiated only with -DMM_WITH_PRETIER=1).
 template <int TYPE, int THREADS, bool CELL_LDS, bool IL, bool BIG = false, bool PRE = false>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(MM_FILTER_WAVES, MM_FILTER_WAVES)))
@@ -302,6 +315,10 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
               const HueEntry* __restrict__ hue_lut, Variants var, int xcd_shares,
               const int32_t* __restrict__ seeds, int n_seeds, int sort_groups, int item_chunk)
 {
+    // BIG cells (17 .. 64 groups: 80 .. 128 px) press on the fabric (config G 0.80 .. 0.95 of the 8 TB/s peak at a VALU rate of 0.40): their
+    // library visits leave the stored chroma plane where it is and recompute it (two fmas, a v_sqrt and a multiply per pixel for a
+    // quarter of the bytes).  -DMM_BIG_RECOMPUTE_QC=0: round 5's loads (A/B builds).
+    constexpr bool kNoQc = BIG && IL && !CELL_LDS && TYPE == CIEDE2000 && MM_BIG_RECOMPUTE_QC != 0;
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
     __shared__ int seed_ids[256];           // the cell's seeds: their scores are in the row already (launch_prune_limits)
     // stage 1 -> stage 2: the bound of every 256-position group of the tile's candidates (<= 64 per tile, <= 16 groups)
@@ -336,7 +353,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     __shared__ int chunk_left, chunk_share;
     if (threadIdx.x == 0) chunk_left = 0;
 #ifdef MM_FILTER_STAMPS
-    // Instrumented build (tools/experiments/r3_stamps.sh): where a wave's cycles go inside an item, summed over the launch
+    // Instrumented build (tools/experiments/archive/r3_stamps.sh): where a wave's cycles go inside an item, summed over the launch
     // into words 24..31 of the counters (units of 1024 cycles): 0 waiting for the workgroup's slowest wave, 1 item fetch
     // (the global atomic), 2 statistics / seeds into LDS, 3 stage 0, 4 stage 1, 5 stage 2; 6 the longest workgroup lifetime, 7 the sum of the lifetimes / 16
     __shared__ unsigned int stamp_acc[8];
@@ -760,7 +777,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     p0 = ld4(c0, off); p1 = ld4(c1, off); p2 = ld4(c2, off);
                     if constexpr (TYPE == CIEDE2000) pc = ld4(cc, off);
                 }
-                const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, qc = cur.qc;
+                const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, qc = kNoQc ? prep_chroma4(cur.q1, cur.q2) : cur.qc;
                 bool e0, e1, e2, e3;
                 const float v0 = pair_fast<TYPE, IL>(PxF{p0.x, p1.x, p2.x}, PxF{q0.x, q1.x, q2.x}, pc.x, qc.x, lut, &e0);
                 const float v1 = pair_fast<TYPE, IL>(PxF{p0.y, p1.y, p2.y}, PxF{q0.y, q1.y, q2.y}, pc.y, qc.y, lut, &e1);
@@ -794,7 +811,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             // kernel at 4 waves (155 VGPRs wanted, 128 allowed, spills).
             for (int step = 0; step < groups; ++step) {
                 const int j = (sorted || sorted64) ? __builtin_amdgcn_readlane(order, step) : step;
-                const LibGroup g = load_lib_group<TYPE>(b0, b1, b2, bc, IL ? lane + 4 * kWave * j : lane + kWave * j);
+                const LibGroup g = load_lib_group<TYPE, kNoQc>(b0, b1, b2, bc, IL ? lane + 4 * kWave * j : lane + kWave * j);
                 if (visit(g, j, step)) { pruned = true; break; }
             }
         }
@@ -1991,7 +2008,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     const int small_tile = round_of > 0 && round_of <= 64 ? 64 / round_of * round_of : 64;
     // (cells above 32 groups -- 96 .. 128 px, 150 .. 256 KB interleaved each -- press on the fabric, 0.95 of its peak on config G: what helps them is
     // FEWER cells in flight per XCD, i.e. 16-candidate items and sub-groups of two or three cells, so that the cells stay in the L2 while the
-    // library streams through it: config G 15.15 -> 14.48 ms per step on one box, 15.31 -> 14.97 on another, tools/experiments/r5_bigcells.sh)
+    // library streams through it: config G 15.15 -> 14.48 ms per step on one box, 15.31 -> 14.97 on another, tools/experiments/archive/r5_bigcells.sh)
     const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : (small_cells ? small_tile : (groups > 32 ? 16 : 32)), cell_group = 512;
     // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited) -- and not one more: a second workgroup
     // per slot ("so that a finishing workgroup's slot refills at once", rounds 1 and 2) starts when the launch is nearly over, pays

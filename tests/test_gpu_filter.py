@@ -221,7 +221,7 @@ def test_ciede2000_filter_band_adversarial_maximiser(engine, prepared):
     band, maximising the OVER-estimate fp16 - fp64 (what an early exit relies on), with the families of half precision
     (tiny_chroma_sets) in the population and multiplicative moves of the chroma.  (Its first run found a violation the
     sweeps' chroma levels step over -- fixed in ciede2000_h2, profiles/r04_pretier_maximiser.txt; more seeds and
-    generations: tools/experiments/r4_maximiser_long.py.)"""
+    generations: tools/experiments/archive/r4_maximiser_long.py.)"""
     start, best, a, b, exact = climb(engine, prepared, 17 + prepared)
     print("adversarial maximiser (prepared=%d): band share %.3f -> %.3f; worst pair %s vs %s, dE00 %.6f" % (prepared, start, best, a, b, exact))
     assert best >= start                                           # it climbed (or started at its summit)
