@@ -1006,8 +1006,10 @@ mm_status score_cells_device(mm_engine* e, const mm_cell* cells_host, const mm_c
         // the TIME of a call therefore depends on the engine's previous CIEDE2000 call over the same library
         // (mm_set_option("item_auto", 0) turns the feedback off; mm_timing.filter_tile reports what was used).
         fin.tile_candidates = e->tile_candidates;
+        // (cells above 32 groups keep their measured 16-candidate items: the 64-candidate rule was measured on 64-px cells, and such
+        // cells' launches are bound by the fabric, where FEWER cells and candidates in flight is what helps -- ADVICE round 5)
         if (e->tile_candidates == 0 && e->item_auto != 0 && prune && diff_type == MM_CIEDE2000 && e->drop_rate >= 0.9 &&
-            e->drop_rate_lib == L && e->drop_rate_size == size)
+            e->drop_rate_lib == L && e->drop_rate_size == size && ppad / 256 <= 32)
             fin.tile_candidates = 64;
         int tile_used = 0;
         // (a trial's two events are recorded by launch_filter itself, directly around the kernel: after the one-time occupancy query

@@ -2009,7 +2009,7 @@ hipError_t launch_filter(int type, const FilterInputs& in, float* scores, int n_
     // (cells above 32 groups -- 96 .. 128 px, 150 .. 256 KB interleaved each -- press on the fabric, 0.95 of its peak on config G: what helps them is
     // FEWER cells in flight per XCD, i.e. 16-candidate items and sub-groups of two or three cells, so that the cells stay in the L2 while the
     // library streams through it: config G 15.15 -> 14.48 ms per step on one box, 15.31 -> 14.97 on another, tools/experiments/archive/r5_bigcells.sh)
-    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : (small_cells ? small_tile : (groups > 32 ? 16 : 32)), cell_group = 512;
+    const int cand_per_block = in.tile_candidates > 0 ? in.tile_candidates : (small_cells ? small_tile : (groups > 32 && type == CIEDE2000 ? 16 : 32)), cell_group = 512;      // (16: measured on CIEDE2000 only)
     // persistent workgroups of filter_kernel: what the device holds at once (LDS-limited) -- and not one more: a second workgroup
     // per slot ("so that a finishing workgroup's slot refills at once", rounds 1 and 2) starts when the launch is nearly over, pays
     // its start (hue table, prologue, eight counter probes) and finds nothing; measured at twice the slots against once: the

@@ -103,17 +103,16 @@ class ShardedBestFit:
     def _same_on_all_ranks(self, todo, device):
         """Every rank must derive the SAME set of unverified cells (identical inputs, identical
         deterministic resolve) or the next all-gather would pair up different rounds and hang:
-        one tiny all-reduce (count and a checksum, MIN and MAX) turns a divergence into an error."""
+        one tiny all-reduce (count and two checksums, as v and -v under MAX) turns a divergence into an error."""
         import torch
         import torch.distributed as dist
         if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
             return
         digest = [float(len(todo)), float(int(todo.sum()) % 1000003), float(int((todo * todo % 7919).sum()) % 1000003)]
-        lo = torch.tensor(digest, dtype=torch.float64, device=device)
-        hi = lo.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
-        if not torch.equal(lo, hi):
+        # ONE collective: the maximum of (v, -v) over the ranks is (max v, -min v); all ranks agree iff the two halves cancel
+        both = torch.tensor(digest + [-v for v in digest], dtype=torch.float64, device=device)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(both[:3], -both[3:]):
             raise RuntimeError("ranks disagree on the cells to deepen (rank %d: %d cells): inputs or engines differ"
                                % (self.rank, len(todo)))
 
