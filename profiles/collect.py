@@ -18,10 +18,11 @@ def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", tag)
     shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(HERE, "pmc_traffic.json"))
-    for name, dst in (("kt/d_kernel_stats.csv", "_configD_kernel_stats.csv"), ("filter_resource_usage.txt", "_filter_resource_usage.txt")):
+    for name, dst in (("kt/d_kernel_stats.csv", "_configD_kernel_stats.csv"), ("kt_PD/d_kernel_stats.csv", "_configPD_kernel_stats.csv"),
+                      ("filter_resource_usage.txt", "_filter_resource_usage.txt")):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(HERE, tag + dst))
-    for c in ("D", "C", "B", "E8", "E", "A", "F", "G", "H", "I", "P"):
+    for c in ("D", "C", "B", "E8", "E", "A", "F", "G", "H", "I", "P", "PD"):
         if not os.path.isdir(os.path.join(src, "pmc_" + c)):
             continue
         for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"), ("SQ", "sq")):

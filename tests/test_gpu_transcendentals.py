@@ -31,14 +31,14 @@ def test_transcendental_instructions_are_as_accurate_as_the_bounds_assume(tmp_pa
 
 
 def test_sdwa_joined_half_transcendentals_equal_the_builtins(tmp_path):
-    """colour_diff_fast.hpp h2_rsq / h2_rcp / h2_sqrt join the two halves of a packed transcendental with the SDWA destination select
+    """colour_diff_fp16.hpp h2_rsq / h2_rcp / h2_sqrt (the packed-fp16 form of the optional pre-tier) join the two halves of a packed transcendental with the SDWA destination select
     (inline asm: the compiler's hazard recognizer does not look inside, so the block carries its own wait states before, between and
     after the two instructions).  tools/experiments/archive/r4_sdwa_test.hip runs them beside the builtins over 65 536 operand pairs, alone
     and chained into the arithmetic the pre-tier's form puts around them: every result must be the builtin's, bit for bit."""
     exe = str(tmp_path / "sdwa_test")
     hipcc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "mosaicmagnifique_amd", "csrc"),
-                    "-o", exe, os.path.join(ROOT, "tools", "experiments", "r4_sdwa_test.hip")], check=True)
+                    "-o", exe, os.path.join(ROOT, "tools", "experiments", "archive", "r4_sdwa_test.hip")], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout
     print(out)
     assert "mismatches rsq 0 rcp 0 sqrt 0 chained 0 of 65536" in out, out

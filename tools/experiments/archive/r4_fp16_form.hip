@@ -17,7 +17,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "colour_diff_fast.hpp"
+#include "colour_diff_fp16.hpp"
 
 typedef _Float16 h1;
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));

@@ -1,6 +1,6 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "colour_diff_fast.hpp"
+#include "colour_diff_fp16.hpp"
 using namespace mm;
 __global__ void k(const unsigned int* in, unsigned int* out, int n)
 {
