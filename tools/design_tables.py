@@ -14,6 +14,7 @@ NAMES = {
     "H": "H: the reference harness's CIEDE2000 line at its detail size -- 1280 cells of 25², 214 images",
     "I": "I: 4000², 80² cells (25 pixel groups), 1000 images, CIEDE2000",
     "P": "P: config D's parameters on PHOTOGRAPHS -- 2048 × 1363 target, 704 cells of 64², 1024 tiles",
+    "PD": "**PD: config D's job on PHOTOGRAPHS -- 4096² target, 4096 cells of 64², 5000 tiles, CIEDE2000, repeat 4 (+500)**",
 }
 
 
@@ -26,7 +27,7 @@ def main():
     tag = sys.argv[1]
     print("| configuration | cells/s | ms per step | dominant kernel, ms per launch | groups visited | `roofline.frac` | fabric traffic per launch, ÷ 8 TB/s |")
     print("|---|---|---|---|---|---|---|")
-    for name in ("A", "B", "C", "D", "E8", "E_1gpu", "D_dist1", "F", "G", "H", "I", "P"):
+    for name in ("A", "B", "C", "D", "E8", "E_1gpu", "D_dist1", "F", "G", "H", "I", "P", "PD"):
         d = load(tag, name)
         if not d:
             continue
@@ -43,7 +44,7 @@ def main():
     print()
     print("| configuration | headline ms | early exit off (`prune` 0) | fp64 only (`filter` 0) | headline ÷ floors | CPU oracle, 1 thread (cells/s) | all cores | first call: fresh engine / after a destroyed one (ms) |")
     print("|---|---|---|---|---|---|---|---|")
-    for name in ("A", "B", "C", "D", "E8", "F", "G", "H", "I", "P"):
+    for name in ("A", "B", "C", "D", "E8", "F", "G", "H", "I", "P", "PD"):
         d = load(tag, name)
         if not d or "floor_unpruned" not in d:
             continue
