@@ -94,6 +94,25 @@ def main():
                     kc = np.clip(np.ceil(a * share).astype(np.int64) + c0, 4, kmax)
                     print("    top %d a %.1f c0 %d Kmax %2d -> mean k %5.2f, at Kmax %5.1f %%, deepened %5.2f %%" % (
                         top, a, c0, kmax, kc.mean(), 100.0 * (kc == kmax).mean(), 100.0 * (kc < need).mean()))
+    # ... and the same from the PROXY alone (the library images closest in mean colour, before anything is scored): what a host could
+    # know before the first scoring pass, to split the cells into a short-list and a long-list batch
+    print("  two classes from the proxy order: class LONG (lists of 16) iff >= thr window neighbours share one of their `top` closest-mean images; else lists of `short`")
+    for top in (1, 2, 3, 4):
+        mine = [set(seeds[c, :top].tolist()) for c in range(n)]
+        share = np.zeros(n, dtype=np.int64)
+        for c in range(n):
+            x, y = int(cells["grid_x"][c]), int(cells["grid_y"][c])
+            nb = []
+            for yy in range(max(y - rng, 0), y):
+                nb += cell_at[yy, max(x - rng, 0):min(x + rng, gw - 1) + 1].tolist()
+            nb += cell_at[y, max(x - rng, 0):x].tolist()
+            share[c] = sum(1 for m in nb if m >= 0 and mine[m] & mine[c])
+        print("    top %d (proxy): correlation with need %.3f" % (top, float(np.corrcoef(share, need)[0, 1])))
+        for short in (4, 6):
+            for thr in (1, 2, 3, 5):
+                kc = np.where(share >= thr, 16, short)
+                print("    top %d short %d thr %d -> LONG class %5.1f %% of the cells, mean k %5.2f, deepened %5.2f %%" % (
+                    top, short, thr, 100.0 * (kc == 16).mean(), kc.mean(), 100.0 * (kc < need).mean()))
     e.close()
 
 
