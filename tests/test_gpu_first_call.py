@@ -83,3 +83,51 @@ def test_two_live_engines_do_not_share_resources_and_trim_releases_the_parked_se
     c = Engine(0)
     assert c.stage_timing()["reused_engine"] == 0
     c.close()
+
+
+def test_a_second_generator_of_a_benchmark_sized_job_allocates_nothing_under_the_default_budget(oracle):
+    """Round 5 capped a parked set at 256 MB and the driver's box then paid 73-76 ms of hipMalloc per fresh config-D generator
+    (BENCH_r05.json).  The cap is a budget now -- 5 % of the device memory that would be free with the set released -- so the
+    workspaces of a job well above 256 MB (here 0.55 GB: 2048 x 2048 target, 1500 images of 64 x 64, CIEDE2000, repeat range 4)
+    stay parked and the next generator makes NO device allocation; MOSAIC_HIP_KEEP_MB pins a fixed cap instead (64 MB: the large
+    buffers are released at mm_destroy and allocated again)."""
+    import os
+    from mosaicmagnifique_amd import synth
+    shape = cases.square_shape(64)
+    rows = cols = 2048
+    n_lib, t, rep = 1500, Type.CIEDE2000, (4, 500)
+    lib_u8, img_u8 = synth.library_u8(n_lib, 64), synth.target_u8(rows, cols, lattice=64)
+    group = cases.group_of(shape)
+    state = G.getGridState(group, rows, cols)[0]
+    cells = G.cell_records(group, state, rows, cols)
+
+    def fresh():
+        e = Engine(0)
+        e.set_library_u8(lib_u8, int(t))
+        e.set_target_u8(img_u8, int(t))
+        e.set_masks(shape.masks4())
+        best, _ = e.generate(cells, state.shape[1], state.shape[0], int(t), *rep)
+        clocks = e.stage_timing()
+        e.close()
+        return best, clocks
+
+    trim_cache()
+    saved = os.environ.pop("MOSAIC_HIP_KEEP_MB", None)
+    try:
+        first, c1 = fresh()
+        assert c1["reused_engine"] == 0 and c1["allocated_bytes"] > (400 << 20), c1      # far above round 5's fixed cap
+        second, c2 = fresh()
+        assert c2["reused_engine"] == 1 and c2["allocations"] == 0 and c2["alloc_ms"] == 0.0, c2
+        assert np.array_equal(first, second)
+        os.environ["MOSAIC_HIP_KEEP_MB"] = "64"       # (read at mm_destroy)
+        third, c3 = fresh()                           # adopts the full set the second one parked; parks at most 64 MB itself
+        assert c3["allocations"] == 0
+        fourth, c4 = fresh()
+        assert c4["reused_engine"] == 1 and c4["allocations"] > 0 and c4["allocated_bytes"] > (300 << 20), c4
+        assert np.array_equal(first, fourth)
+    finally:
+        if saved is None:
+            os.environ.pop("MOSAIC_HIP_KEEP_MB", None)
+        else:
+            os.environ["MOSAIC_HIP_KEEP_MB"] = saved
+        trim_cache()
