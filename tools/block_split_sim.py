@@ -1,6 +1,22 @@
-import os, sys
+"""Offline simulation (numpy + the oracle): WHICH part of a finer block of the early-exit bound buys its gain.
+
+tools/block_size_sim.py (round 5) found that 16-position blocks instead of 64 would walk 13 % fewer pixel groups on config D.  A finer
+block changes two things at once: the SUMS of the triangle inequality (sum L, sum a, sum b over fewer positions: less cancellation) and the
+CONSTANTS of the metric (S_L, S_C, lambda, g_min, the hue arcs: maxima over fewer pixels are tighter).  The sums are cheap to refine
+(three subtractions and a root per sub-block), the constants are one stats_bound -- ~90 instructions, ten transcendental -- per block
+pair.  This tool evaluates the bound with the two block sizes chosen separately ("c64/s16" = constants per 64 positions, sums per 16)
+on a few cells x 600 candidates of config D, true fp64 group sums from the oracle, the kernel's visiting order.
+Result (DESIGN.md section 4 "The finer block"): the sums buy nothing, the constants everything.
+Not a test: a design tool (python tools/block_split_sim.py)."""
+import os
+import sys
+
 import numpy as np
-sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import oracle_ffi
 from test_filter_bound import rotation_bound, sqrt_ratio7
 from bound_sim import walk_order
