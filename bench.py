@@ -394,7 +394,8 @@ def config_legs(device, opts, names, steps=4):
                 gw, gh = w["grid_w"], w["grid_h"]
                 arrays = (np.empty((gh, gw), dtype=np.int64), np.empty((gh, gw), dtype=np.float64))
                 run = lambda: e.generate(cells, gw, gh, w["t"], *w["rep"], out=arrays)
-                run()
+                for _ in range(5 if w["rep"][0] > 0 else 1):      # (with a repeat penalty the engine tries up to three list lengths over its first generates, the base one twice)
+                    run()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(steps):

@@ -29,6 +29,8 @@ extern "C" {
  *   row_pipeline       1     the wavefront forms where the grid fits LDS (0: the single-wave chain)
  *   spec_k             4     length of mm_generate's speculative short lists; 0 = always mm_candidates_per_cell
  *   spec_auto          1     lists twice as long (<= 16) after a generate over the same library deepened > 2 % of its cells
+ *   deepen_mid         16    a cell whose short list did not verify its pick is first extended to n entries (>= twice the short length),
+ *                            to the full counting length only if that did not verify either; 0 = straight to the full length
  * -- submission ------------------------------------------------------------------------------------------------------
  *   fast_path          1     a whole generate as ONE submission and one result block (one host wait)
  *   fused              1     gather + chroma + interleave + block statistics in one launch; contenders + re-score + re-rank in one

@@ -96,6 +96,11 @@ struct mm_engine {
     int spec_auto = 1;           // mm_set_option("spec_auto", 0): the list length no longer follows the share of cells the engine's
                                  // previous generate over the same library had to deepen (below)
     int spec_k_learned = 0, spec_lib = 0, spec_size = 0;     // ... what it learned, and for which library (count, cell size)
+    int spec_cells = 0;          // ... and cell count: the lengths are compared by the TIME of whole generates over the same job
+    float spec_ms[3] = {0.f, 0.f, 0.f};     // fastest generate seen at the base length, twice and four times it (0: not tried)
+    int spec_base_runs = 0;      // generates timed at the base length (the first one over a library runs cold: it gets a second, warm one before the verdict)
+    int deepen_mid = 16;         // mm_set_option("deepen_mid", n): a cell whose short list could not verify its pick is first extended to n entries
+                                 // (at least twice the short length) and only then to the full counting length; 0: straight to the full length
     int sweeps_learned = 0, sweeps_lib = 0, sweeps_size = 0; // sweeps the resolve of the previous generate over this library took to settle (its longest
                                                              // round): sizes the first set of sweeps of the next one (resolve_single_submission)
     DevBuf lib_bgr, owner, mosaic;   int n_lib_bgr = 0, lib_bgr_size = 0;
@@ -2203,13 +2208,47 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     // what the engine's PREVIOUS generate over the same library saw: more than 2 % of the cells deepened doubles it (up to 16).
     // As with the filter's item size, only the TIME of a call depends on the history, never its result ("spec_auto" 0 pins it).
     int spec_k = e->spec_k;
-    if (e->spec_auto != 0 && spec_k > 0 && e->spec_lib == e->n_lib && e->spec_size == e->lib_size) spec_k = std::max(spec_k, e->spec_k_learned);
+    if (e->spec_auto != 0 && spec_k > 0 && e->spec_lib == e->n_lib && e->spec_size == e->lib_size && e->spec_cells == n_cells && e->spec_k_learned > 0)
+        spec_k = e->spec_k_learned;
     const int Ks = std::max(1, mm_speculative_candidates(e->n_lib, repeat_range, repeat_addition, spec_k));
     const bool speculate = Ks < K && n_cells > 0;
+    // Deepening BY NEED (round 6): on photographs a cell needs 3.8 list entries on average, a tenth of the cells more than 8, none more than 16
+    // (tools/list_length_sim.py on config PD) -- and the counting bound's full length is 42 at repeat range 4.  A cell whose short list did
+    // not verify is therefore extended to a MIDDLE length first (its filter pass runs against the limit of the Kmid-th seed instead of the
+    // 42nd: a fraction of the walks), and to the full length only if that did not verify either.  Rows are K wide and padded with empty
+    // entries behind what is filled, so the resolve reads every non-deep cell as a list of <= Kmid entries whatever its level.
+    const int Kmid = (speculate && e->deepen_mid > 0 && std::max(e->deepen_mid, 2 * Ks) < K) ? std::max(e->deepen_mid, 2 * Ks) : K;
+    const int Kfill = Kmid < K ? Kmid : Ks;        // what the resolve takes as the length of a non-deep list
+    // The short lists' length by MEASUREMENT (round 6; until then: "more than 2 % of the cells deepened doubles it").  Longer lists cost every
+    // cell's filter limit and fp64 re-score; shorter ones cost deepening rounds, each a resolve and a few host waits.  Which is cheaper
+    // depends on the job: photographs at config D's scale run 17.9 ms per generate at 4 entries with deepening by need against 21.3 at
+    // 16 entries without a second round; the 704 cells of config P 4.8 against 4.0.  So: a generate that had to deepen more than 2 % of its
+    // cells lets the NEXT generate over the same job (library, cell size, cell count) try twice the length, once per length up to four
+    // times the base; every generate records its own total time under its length, and once the lengths due for a try have been tried the
+    // fastest one is kept.  As everywhere else here, only the TIME of a call depends on the engine's history, never its result.
     auto learn_list_length = [&]() {
-        if (!speculate || e->spec_auto == 0) return;
-        if (e->spec_lib != e->n_lib || e->spec_size != e->lib_size) { e->spec_lib = e->n_lib; e->spec_size = e->lib_size; e->spec_k_learned = 0; }
-        if ((double)e->timing.deepened_cells > 0.02 * n_cells) e->spec_k_learned = std::min(16, 2 * Ks);
+        if (!speculate || e->spec_auto == 0 || e->spec_k <= 0) return;
+        if (e->spec_lib != e->n_lib || e->spec_size != e->lib_size || e->spec_cells != n_cells) {
+            e->spec_lib = e->n_lib; e->spec_size = e->lib_size; e->spec_cells = n_cells; e->spec_k_learned = 0;
+            e->spec_ms[0] = e->spec_ms[1] = e->spec_ms[2] = 0.f;
+            e->spec_base_runs = 0;
+        }
+        const int base = e->spec_k;
+        const int li = spec_k >= 4 * base ? 2 : (spec_k >= 2 * base ? 1 : 0);
+        const float ms = (float)e->timing.total_ms;
+        if (ms > 0.f) e->spec_ms[li] = e->spec_ms[li] > 0.f ? std::min(e->spec_ms[li], ms) : ms;
+        if (li == 0) e->spec_base_runs += 1;
+        const bool many_deepened = (double)e->timing.deepened_cells > 0.02 * n_cells;
+        if (many_deepened && li < 2 && (base << (li + 1)) <= 16 && e->spec_ms[li + 1] == 0.f) {
+            e->spec_k_learned = base << (li + 1);          // the next length gets its try
+        } else if (e->spec_ms[1] > 0.f && e->spec_base_runs < 2) {
+            e->spec_k_learned = 0;                          // the base length once more, warm: its first generate was the library's first
+        } else {
+            int best = -1;
+            for (int i = 0; i < 3; ++i)
+                if (e->spec_ms[i] > 0.f && (best < 0 || e->spec_ms[i] < e->spec_ms[best])) best = i;
+            e->spec_k_learned = best > 0 ? base << best : 0;
+        }
     };
     const size_t cells_total = (size_t)grid_w * grid_h;
     HIP_TRY(e, hipEventRecord(e->ev[6], e->stream), "event");
@@ -2243,7 +2282,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
         const mm_engine::Pending pd = e->pend;
         e->pend.active = false;
         st = resolve_single_submission(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition,
-                                       K, Ks, speculate, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr,
+                                       K, Kfill, speculate, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr,
                                        pd.two_tier ? (const uint8_t*)e->flags.p : nullptr, pd.counted);
         if (st) return st;
         const mm::ResultHeader& h = *(const mm::ResultHeader*)e->pinned;
@@ -2256,7 +2295,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
             if (h.sweep_changes[i] == 0) settled = (int)i;
         int sweeps_before = 0;
         if (lists_ok && h.n_marked == 0 && sequential && settled < 0 &&
-            (st = settle_sweeps(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, K, Ks, speculate,
+            (st = settle_sweeps(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, K, Kfill, speculate,
                                 (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr, &settled, &sweeps_before)))
             return st;
         const bool resolved_ok = lists_ok && h.n_marked == 0 && (!sequential || settled >= 0);
@@ -2282,6 +2321,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
                 e->timing.total_ms = elapsed(e->ev[6], e->ev[7]);
                 e->timing.pair_evals = count_pair_evals(e, cells, n_cells);
                 e->timing.host_syncs = e->syncs;
+                learn_list_length();
                 return MM_OK;
             }
             have_verdicts = true;          // only the unverified cells are left: straight to the deepening step
@@ -2290,8 +2330,10 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
 
     std::vector<mm_cell> sub_cells;
     std::vector<int> sub_rows;
+    std::vector<uint8_t> level;            // 0: the cell's list is the short one, 1: it was extended to the middle length
     if (speculate) {
         deep.assign((size_t)n_cells, 0);
+        level.assign((size_t)n_cells, 0);
         insufficient.assign((size_t)n_cells, 0);
         if ((st = ensure(e, e->deep, (size_t)n_cells, "Failed to allocate list flags")) ||
             (st = ensure(e, e->insufficient, (size_t)n_cells, "Failed to allocate list flags")))
@@ -2310,7 +2352,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
                 if (speculate)      // (after the block's initialisation, which clears the flag arrays, in stream order)
                     HIP_TRY(e, hipMemcpyAsync(e->deep.p, deep.data(), (size_t)n_cells, hipMemcpyHostToDevice, e->stream), "Failed to copy list flags");
                 st = resolve_single_submission(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition,
-                                               K, Ks, speculate, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr,
+                                               K, Kfill, speculate, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr,
                                                nullptr, false);
                 if (st) return st;
                 const mm::ResultHeader& h = *(const mm::ResultHeader*)e->pinned;
@@ -2318,7 +2360,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
                 for (unsigned int i = 0; i < h.sweeps && settled < 0; ++i)
                     if (h.sweep_changes[i] == 0) settled = (int)i;
                 if (h.n_marked == 0 && sequential && settled < 0 &&
-                    (st = settle_sweeps(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, K, Ks, speculate,
+                    (st = settle_sweeps(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition, K, Kfill, speculate,
                                         (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr, &settled, &sweeps_before)))
                     return st;
                 if (h.n_marked == 0 && (!sequential || settled >= 0)) {
@@ -2341,29 +2383,44 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
                 st = resolve_device(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range,
                                     repeat_addition, K, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p,
                                     best_fit_out, best_score_out,
-                                    speculate ? (const uint8_t*)e->deep.p : nullptr, speculate ? (uint8_t*)e->insufficient.p : nullptr, Ks);
+                                    speculate ? (const uint8_t*)e->deep.p : nullptr, speculate ? (uint8_t*)e->insufficient.p : nullptr, Kfill);
                 if (st) return st;
             }
         }
         e->timing.spec_rounds = round + 1;
         if (!speculate) break;
         HIP_TRY(e, hipMemcpy(insufficient.data(), e->insufficient.p, (size_t)n_cells, hipMemcpyDeviceToHost), "Error copying list flags to host");
-        sub_cells.clear();
-        sub_rows.clear();
-        for (int c = 0; c < n_cells; ++c)
-            if (insufficient[(size_t)c] && !deep[(size_t)c]) { sub_cells.push_back(cells[c]); sub_rows.push_back(c); deep[(size_t)c] = 1; }
-        if (sub_cells.empty()) break;
-        if (cancel && *cancel) return MM_CANCELLED;
-        const int ns = (int)sub_cells.size();
-        if ((st = ensure(e, e->spec_recs, (size_t)ns * sizeof(mm_cell), "Failed to allocate cell records"))) return st;
-        HIP_TRY(e, hipMemcpyAsync(e->spec_recs.p, sub_cells.data(), (size_t)ns * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
-                "Failed to copy cell records to device");
-        // (a handful of cells is latency either way: sending them down the fp64-only path instead -- three launches for six -- was
-        // measured no faster, config P 5.5 -> 5.6 ms: one cell's 1024 fp64 rows are 64 workgroups of a kernel laid out for thousands)
-        st = score_cells_device(e, sub_cells.data(), (const mm_cell*)e->spec_recs.p, ns, diff_type, K, K,
-                                (int32_t*)e->cand_i.p, (double*)e->cand_s.p, sub_rows.data(), nullptr, nullptr, cancel);
-        if (st) return st;
-        e->timing.deepened_cells += ns;
+        // unverified cells: those still on their short list go to the middle length, those already there to the full one
+        bool any = false;
+        const std::vector<uint8_t> level_before = level;    // (a cell extended to the middle length in this round is not also sent on to the full one)
+        for (int target = 0; target < 2; ++target) {       // 0: short -> middle (only if there is a middle length), 1: -> full
+            if (target == 0 && Kmid >= K) continue;
+            sub_cells.clear();
+            sub_rows.clear();
+            for (int c = 0; c < n_cells; ++c) {
+                if (!insufficient[(size_t)c] || deep[(size_t)c]) continue;
+                const bool at_mid = level_before[(size_t)c] != 0;
+                if (target == 0 ? !at_mid : (at_mid || Kmid >= K)) {
+                    sub_cells.push_back(cells[c]);
+                    sub_rows.push_back(c);
+                    if (target == 0) level[(size_t)c] = 1; else deep[(size_t)c] = 1;
+                }
+            }
+            if (sub_cells.empty()) continue;
+            any = true;
+            if (cancel && *cancel) return MM_CANCELLED;
+            const int ns = (int)sub_cells.size();
+            if ((st = ensure(e, e->spec_recs, (size_t)ns * sizeof(mm_cell), "Failed to allocate cell records"))) return st;
+            HIP_TRY(e, hipMemcpyAsync(e->spec_recs.p, sub_cells.data(), (size_t)ns * sizeof(mm_cell), hipMemcpyHostToDevice, e->stream),
+                    "Failed to copy cell records to device");
+            // (a handful of cells is latency either way: sending them down the fp64-only path instead -- three launches for six -- was
+            // measured no faster, config P 5.5 -> 5.6 ms: one cell's 1024 fp64 rows are 64 workgroups of a kernel laid out for thousands)
+            st = score_cells_device(e, sub_cells.data(), (const mm_cell*)e->spec_recs.p, ns, diff_type, target == 0 ? Kmid : K, K,
+                                    (int32_t*)e->cand_i.p, (double*)e->cand_s.p, sub_rows.data(), nullptr, nullptr, cancel);
+            if (st) return st;
+            e->timing.deepened_cells += ns;
+        }
+        if (!any) break;
     }
     HIP_TRY(e, hipEventRecord(e->ev[7], e->stream), "event");
     HIP_TRY(e, sync_stream(e), "Failed to synchronise stream");
@@ -2651,8 +2708,9 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "sweep_resolve") == 0) { e->use_sweep_resolve = value != 0; return MM_OK; }
     if (strcmp(name, "max_sweeps") == 0) { if (value < 1 || value > 4096) return MM_INVALID_ARGUMENT; e->max_sweeps = value; return MM_OK; }
     if (strcmp(name, "lds_filter") == 0) { e->use_lds_filter = value < 0 ? -1 : (value != 0); return MM_OK; }
-    if (strcmp(name, "spec_k") == 0) { e->spec_k = std::max(0, value); e->spec_k_learned = 0; return MM_OK; }
-    if (strcmp(name, "spec_auto") == 0) { e->spec_auto = value != 0; e->spec_k_learned = 0; return MM_OK; }
+    if (strcmp(name, "spec_k") == 0) { e->spec_k = std::max(0, value); e->spec_k_learned = 0; e->spec_cells = 0; return MM_OK; }
+    if (strcmp(name, "spec_auto") == 0) { e->spec_auto = value != 0; e->spec_k_learned = 0; e->spec_cells = 0; return MM_OK; }
+    if (strcmp(name, "deepen_mid") == 0) { e->deepen_mid = std::max(0, value); return MM_OK; }
     if (strcmp(name, "seeds") == 0) { e->extra_seeds = std::max(-1, value); return MM_OK; }
     if (strcmp(name, "lds_pad_kb") == 0) { e->lds_pad_kb = std::min(120, std::max(0, value)); return MM_OK; }
     if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }

@@ -2102,8 +2102,11 @@ resolve_front_kernel(ResolveArgs a, const int* __restrict__ row_first, const int
                 int nbv = sentinel;
                 if (slot_used && ry >= 0 && rx >= 0 && rx < gw) nbv = __atomic_load_n(&lgrid[py * gw + px + doff], __ATOMIC_RELAXED);
                 int cnt = 0;
-                if (K <= n_slots) {
-                    for (int k = 0; k < K; ++k) {   // per candidate: how many neighbours hold it
+                // (a list is filled from its front and padded with empty entries behind: only the filled ones are looked up -- a short list in
+                // a row read at the middle length of the deepening costs its own length, not the row's)
+                const int n_listed = __popcll(__ballot(cand >= 0));
+                if (n_listed <= n_slots) {
+                    for (int k = 0; k < n_listed; ++k) {   // per candidate: how many neighbours hold it
                         const int ck = __builtin_amdgcn_readlane(cand, k);
                         const int hits = __popcll(__ballot(nbv == ck));
                         cnt = lane == k ? hits : cnt;

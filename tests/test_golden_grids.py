@@ -195,6 +195,27 @@ def test_sharded_group_whole_grid_equals_the_cpu_golden(name, members):
 
 
 @pytest.mark.gpu
+def test_photographs_at_config_d_scale_equal_the_cpu_golden_through_the_list_length_trials(engine):
+    """Config PD (round 6): one of the reference's SampleImages as a 4096 x 4096 target, 5000 tiles of 64 x 64 cut from the other four,
+    CIEDE2000, repeat range 4 (+500) -- config D's job on the content the tool is for; 4096 cells against the oracle's whole-grid golden
+    (1001 s of CPU).  Neighbouring cells want the same few images here: the sweeps do not settle (the front form of the wavefront
+    resolves), short lists do not verify (deepening by need: 4 -> 16 -> 42 entries), and over its first generates the engine TRIES list
+    lengths of 4, 8 and 16 and keeps the fastest.  Every one of six consecutive generates must give the golden's grid."""
+    from mosaicmagnifique_amd.engine import Engine
+    e = Engine(0)                                   # a fresh engine: the trials start from nothing
+    try:
+        seen = []
+        for call in range(6):
+            tm, rel, same = whole_grid_against_golden(e, "PD")
+            seen.append((tm["spec_rounds"], tm["deepened_cells"], tm["resolve_sweeps"], tm["host_syncs"], round(tm["total_ms"], 2)))
+            assert tm["band_alarms"] == 0 and tm["voided_launches"] == 0 and tm["dense_cells"] == 0
+        print(json.dumps(dict(config="PD", max_rel_score_err=rel, inputs_identical=same, rounds_deepened_sweeps_syncs_ms=seen)))
+        assert seen[0][1] > 0.02 * 4096             # the first generate, on lists of 4, had to deepen (that is what starts the trials)
+    finally:
+        e.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["A", "F", "G", "H", "I", "P"])
 def test_further_bench_configurations_whole_grid_equals_the_cpu_golden(engine, name):
     """bench.py's other configurations, every cell: the reference's CPU-runnable case (A), the GUI's default 128-px cells as
