@@ -28,7 +28,8 @@ extern "C" {
  *   wave_resolve       1     the chain's single-wave form (0: workgroup per cell)
  *   row_pipeline       1     the wavefront forms where the grid fits LDS (0: the single-wave chain)
  *   spec_k             4     length of mm_generate's speculative short lists; 0 = always mm_candidates_per_cell
- *   spec_auto          1     lists twice as long (<= 16) after a generate over the same library deepened > 2 % of its cells
+ *   spec_auto          1     the short lists' length by measurement: a generate that deepened > 2 % of its cells lets the next ones over the same job try
+ *                            twice and four times the length (<= 16); the length whose whole generate was fastest is kept; 0 pins spec_k
  *   deepen_mid         16    a cell whose short list did not verify its pick is first extended to n entries (>= twice the short length),
  *                            to the full counting length only if that did not verify either; 0 = straight to the full length
  * -- submission ------------------------------------------------------------------------------------------------------

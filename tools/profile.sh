@@ -4,7 +4,7 @@
 # kernel trace of the default command, and the bench lines of every configuration.
 # usage (on the box): bash tools/profile.sh r02_v13        -> gpurun_out/r02_v13/
 set -x
-V=${1:-r06_v60}
+V=${1:-r06_v61}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$V
 mkdir -p $O
@@ -21,8 +21,8 @@ cp profiles/pmc_traffic.json $O/pmc_traffic.json
 [ "$ONLY" = pmc ] && exit 0
 rocprofv3 --kernel-trace --stats -d $O/kt -o d --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $O/kt.log 2>&1
 python3 bench.py --steps 20 --warmup 5 > $O/bench_D.json 2> $O/bench_D.err      # (the driver's own command: the line carries every BASELINE configuration)
-for c in A B C E8 F G H I P PD; do python3 bench.py --config $c --steps 5 --warmup 2 > $O/bench_$c.json 2>/dev/null; done
-rocprofv3 --kernel-trace --stats -d $O/kt_PD -o d --output-format csv -- python3 bench.py --config PD --steps 3 --warmup 3 --no-cpu > $O/kt_PD.log 2>&1
+for c in A B C E8 F G H I P PD; do python3 bench.py --config $c --steps 5 --warmup 6 > $O/bench_$c.json 2>/dev/null; done      # (six warm-up steps: with a repeat penalty the engine tries list lengths over its first four generates)
+rocprofv3 --kernel-trace --stats -d $O/kt_PD -o d --output-format csv -- python3 bench.py --config PD --steps 3 --warmup 6 --no-cpu > $O/kt_PD.log 2>&1
 python3 bench.py --config E --steps 2 --warmup 1 --no-cpu > $O/bench_E_1gpu.json 2>/dev/null
 MOSAIC_BENCH_FORCE_DIST=1 python3 bench.py --steps 5 --warmup 2 --no-cpu > $O/bench_D_dist1.json 2> $O/bench_D_dist1.err
 python3 bench.py --steps 5 --warmup 2 --no-cpu --opt lds_filter=1 --opt tile=128 > $O/bench_D_lds_tile.json 2>/dev/null
