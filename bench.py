@@ -88,11 +88,17 @@ TYPE_NAMES = {0: "RGB-Euclidean", 1: "CIE76", 2: "CIEDE2000"}
 
 
 def kernel_source_hash():
-    """sha256 (first 16 hex digits) over the engine's kernel sources: ties a PMC record to the code it measured."""
+    """sha256 (first 16 hex digits) over the engine's kernel sources: ties a PMC record to the CODE it measured -- comments and
+    white space are taken out first (a record stays valid through an edit that changes no token of the code)."""
+    import re
     from mosaicmagnifique_amd import _build
     h = hashlib.sha256()
     for path in sorted(_build.SOURCES + [p for p in _build.HEADERS if os.sep + "csrc" + os.sep in p]):
-        h.update(open(path, "rb").read())
+        text = open(path, "r", encoding="utf-8", errors="replace").read()
+        # (string literals of these sources hold neither "//" nor "/*" except in asm templates, which hold none either)
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update(" ".join(text.split()).encode("utf-8"))
     return h.hexdigest()[:16]
 
 

@@ -93,8 +93,8 @@ struct mm_engine {
     DevBuf area_tab;             // [detail + 1] first | [entries] src | [entries] alpha (kernels.hpp CellResize)
     int area_entries = 0;
     int spec_k = 4;              // mm_set_option("spec_k", n): entries of the speculative short lists (0 = off)
-    int spec_auto = 1;           // mm_set_option("spec_auto", 0): the list length no longer follows the share of cells the engine's
-                                 // previous generate over the same library had to deepen (below)
+    int spec_auto = 1;           // mm_set_option("spec_auto", 0): the list length no longer follows what the engine's previous generates over the
+                                 // same job measured (mm_generate learn_list_length)
     int spec_k_learned = 0, spec_lib = 0, spec_size = 0;     // ... what it learned, and for which library (count, cell size)
     int spec_cells = 0;          // ... and cell count: the lengths are compared by the TIME of whole generates over the same job
     float spec_ms[3] = {0.f, 0.f, 0.f};     // fastest generate seen at the base length, twice and four times it (0: not tried)
@@ -2203,10 +2203,9 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
 
     const int K = std::max(1, mm_candidates_per_cell(e->n_lib, repeat_range, repeat_addition));
     // Short lists of 4 verify every pick of the synthetic benchmark in one round; on content where neighbouring cells want the
-    // same few images (photographs: bench.py --config P deepens a fifth of its cells over four rounds at 4 entries, 7.5 ms per
-    // step; at 12 entries five cells in two rounds, 5.3 ms) longer lists are cheaper than the rounds.  So the length follows
-    // what the engine's PREVIOUS generate over the same library saw: more than 2 % of the cells deepened doubles it (up to 16).
-    // As with the filter's item size, only the TIME of a call depends on the history, never its result ("spec_auto" 0 pins it).
+    // same few images (photographs) a share of the cells has to be deepened, and whether longer lists or more rounds are cheaper
+    // depends on the job: the length follows what the engine's previous generates over the same job MEASURED (learn_list_length
+    // below).  As with the filter's item size, only the TIME of a call depends on the history, never its result ("spec_auto" 0 pins it).
     int spec_k = e->spec_k;
     if (e->spec_auto != 0 && spec_k > 0 && e->spec_lib == e->n_lib && e->spec_size == e->lib_size && e->spec_cells == n_cells && e->spec_k_learned > 0)
         spec_k = e->spec_k_learned;
