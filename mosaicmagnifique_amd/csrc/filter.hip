@@ -304,6 +304,50 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // bound-ordered visits from 17 groups on.  A template parameter and not a run-time branch: the extra scalars it keeps alive
 // cost the 64 x 64 instantiation three more spilled SGPRs and config D 0.3 % (measured, tools/experiments/archive/r4_second.sh).
 // PRE: the packed-fp16 pre-tier ahead of the fp32 walk (filter_pretier.hpp; instantiated only with -DMM_WITH_PRETIER=1).
+// How filter_kernel reads its arguments.  A persistent kernel with 27 arguments -- sixteen of them pointers, a `Variants` struct among them --
+// keeps them all in SGPRs across its item loop, and the dominant instantiation then spilled 122 SGPRs into VGPR lanes and 4 VGPRs into
+// scratch (20 bytes per lane): ~150 v_readlane reloads per item and ~27 per candidate.  The kernarg segment is memory the scalar unit reads
+// through its own cache, so the arguments are read THERE at the point of use, through a pointer the compiler cannot see through (an empty
+// asm: without it the loads are hoisted to the kernel's entry and the values held again): MM_KERNARG_RELOAD 2 (default) = every argument
+// but check_every (the pixel loop's), 1 = the `Variants` struct only, 0 = round 5's form.  Dominant instantiation (-Rpass-analysis):
+//   0: 122 spilled SGPRs, 4 spilled VGPRs, 20 B scratch, 95 VGPRs;  1: 63 / 0 / 20 / 95;  2: 14 / 0 / 0 / 91.
+// Same box, two runs each (round 6): config D 43.19 -> 42.71 (1) / 42.66 ms per step (2), E's shard 29.22 -> 28.63 / 28.73, C 2.96 -> 2.93 /
+// 2.94, G 14.08 -> 14.00 / 13.98; result digests equal.  FilterKernArgs mirrors the kernel's parameter list: the kernarg segment lays
+// the explicit arguments out in order at their natural alignment, as a C struct -- whoever changes one changes the other (a mismatch
+// garbles every argument: no test of the suite survives it).
+#ifndef MM_KERNARG_RELOAD
+#define MM_KERNARG_RELOAD 2
+#endif
+#if MM_KERNARG_RELOAD
+struct FilterKernArgs {        // the kernel's explicit arguments as the kernarg segment lays them out (in order, naturally aligned)
+    const float *cells, *cells_f0, *cell_chroma, *lib, *lib_chroma; float* scores;
+    int n_cells, L, ppad, cand_per_block, cell_group;
+    EdgeEntry* edges; unsigned int* edge_count; unsigned int edge_cap; const float* prune_above; int check_every;
+    const HueEntry* hue_lut; Variants var; int xcd_shares; const int32_t* seeds; int n_seeds, sort_groups, item_chunk;
+};
+typedef const Variants __attribute__((address_space(4))) KernargVariants;
+__device__ __forceinline__ KernargVariants* kernarg_variants()
+{
+    const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (KernargVariants*)(p + offsetof(FilterKernArgs, var));
+}
+__device__ __forceinline__ const FilterKernArgs __attribute__((address_space(4)))* kernarg_all()
+{
+    const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const FilterKernArgs __attribute__((address_space(4)))*)p;
+}
+#define MM_VAR (*kernarg_variants())
+#else
+#define MM_VAR var
+#endif
+#if MM_KERNARG_RELOAD >= 2
+#define KA(name) (kernarg_all()->name)
+#else
+#define KA(name) name
+#endif
+
 template <int TYPE, int THREADS, bool CELL_LDS, bool IL, bool BIG = false, bool PRE = false>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(MM_FILTER_WAVES, MM_FILTER_WAVES)))
 filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f0,
@@ -320,7 +364,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // quarter of the bytes).  -DMM_BIG_RECOMPUTE_QC=0: round 5's loads (A/B builds).
     constexpr bool kNoQc = BIG && IL && !CELL_LDS && TYPE == CIEDE2000 && MM_BIG_RECOMPUTE_QC != 0;
     __shared__ HueEntry lut[TYPE == CIEDE2000 ? kHueLutEntries : 1];
-    __shared__ int seed_ids[256];           // the cell's seeds: their scores are in the row already (launch_prune_limits)
+    __shared__ int seed_ids[256];           // the cell's KA(seeds): their KA(scores) are in the row already (launch_prune_limits)
     // stage 1 -> stage 2: the bound of every 256-position group of the tile's candidates (<= 64 per tile, <= 16 groups)
     __shared__ float cand_gb[TYPE == CIEDE2000 ? 64 : 1][TYPE == CIEDE2000 ? 16 : 1];
     // candidates of the tile that passed the bound in stage 1 (<= 64 per tile), in two classes: [0, 1] those whose bound is
@@ -328,7 +372,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // Stage 2 hands out the first class first: the waves of an item meet at a barrier, and a long candidate drawn last
     // keeps the other three waiting for it
     __shared__ unsigned int alive_mask[4];
-    // stage 0 -> stage 1: the tile's candidates that passed the whole-image bound (and are no seeds), compacted
+    // stage 0 -> stage 1: the tile's candidates that passed the whole-image bound (and are no KA(seeds)), compacted
     __shared__ unsigned char surv_idx[TYPE == CIEDE2000 ? 64 : 1];
     __shared__ int n_surv;
     __shared__ float cell_ist[TYPE == CIEDE2000 ? 7 : 1];
@@ -338,16 +382,16 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // block statistics of the cell (early-exit bound), up to 4 blocks per lane
     // (row 7: 1 where the block's mask pixels are all active in this cell, else 0 -- a clipped cell's bound counts only such blocks)
     __shared__ __attribute__((aligned(16))) float cell_st[TYPE == CIEDE2000 ? 8 : 1][TYPE == CIEDE2000 ? (CELL_LDS ? kWave : MM_STAT_BLOCKS) : 1];
-    extern __shared__ float4 cell_tile[];   // CELL_LDS: [3][ppad / 4] -- channel 0 (NaN = inactive), a, b
-    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, hue_lut);
-    const int n_tiles = (L + cand_per_block - 1) / cand_per_block;
-    const float* const lib_base = lib;
-    const float* const lib_chroma_base = lib_chroma;
-    unsigned int* const item_counter = edge_count + kItemCounters;
-    const int my_share = xcd_shares > 1 ? xcc_id() % xcd_shares : 0;
+    extern __shared__ float4 cell_tile[];   // CELL_LDS: [3][KA(ppad) / 4] -- channel 0 (NaN = inactive), a, b
+    if constexpr (TYPE == CIEDE2000) load_hue_lut(lut, KA(hue_lut));
+    const int n_tiles = (KA(L) + KA(cand_per_block) - 1) / KA(cand_per_block);
+    const float* const lib_base = KA(lib);
+    const float* const lib_chroma_base = KA(lib_chroma);
+    unsigned int* const item_counter = KA(edge_count) + kItemCounters;
+    const int my_share = KA(xcd_shares) > 1 ? xcc_id() % KA(xcd_shares) : 0;
     int first_live = 0;                     // thread 0: shares before my_share + first_live (cyclically) are exhausted
-    // thread 0: items are taken `item_chunk` at a time -- one global atomic (a ~2 us round trip the whole workgroup sits
-    // out) per chunk instead of per item; consecutive item numbers are neighbouring cells on the same candidate tile
+    // thread 0: items are taken `KA(item_chunk)` at a time -- one global atomic (a ~2 us round trip the whole workgroup sits
+    // out) per chunk instead of per item; consecutive item numbers are neighbouring KA(cells) on the same candidate tile
     // (kept in LDS, not in registers of thread 0: the kernel sits exactly at its 96-VGPR budget)
     __shared__ unsigned int chunk_next;
     __shared__ int chunk_left, chunk_share;
@@ -355,7 +399,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
 #ifdef MM_FILTER_STAMPS
     // Instrumented build (tools/experiments/archive/r3_stamps.sh): where a wave's cycles go inside an item, summed over the launch
     // into words 24..31 of the counters (units of 1024 cycles): 0 waiting for the workgroup's slowest wave, 1 item fetch
-    // (the global atomic), 2 statistics / seeds into LDS, 3 stage 0, 4 stage 1, 5 stage 2; 6 the longest workgroup lifetime, 7 the sum of the lifetimes / 16
+    // (the global atomic), 2 statistics / KA(seeds) into LDS, 3 stage 0, 4 stage 1, 5 stage 2; 6 the longest workgroup lifetime, 7 the sum of the lifetimes / 16
     __shared__ unsigned int stamp_acc[8];
     if (threadIdx.x < 8) stamp_acc[threadIdx.x] = 0u;
     unsigned long long stamp_t = __builtin_readcyclecounter();
@@ -380,15 +424,15 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         if (chunk_left > 0) {
             share = chunk_share; item = chunk_next; chunk_next = item + 1u; chunk_left = chunk_left - 1;
         } else {
-            for (int k = first_live; k < xcd_shares; ++k) {
-                const int sh = (my_share + k) % xcd_shares;
-                const long long lo = (long long)n_cells * sh / xcd_shares, hi = (long long)n_cells * (sh + 1) / xcd_shares;
+            for (int k = first_live; k < KA(xcd_shares); ++k) {
+                const int sh = (my_share + k) % KA(xcd_shares);
+                const long long lo = (long long)KA(n_cells) * sh / KA(xcd_shares), hi = (long long)KA(n_cells) * (sh + 1) / KA(xcd_shares);
                 const long long total = (hi - lo) * n_tiles;
-                const unsigned int it = atomicAdd(item_counter + sh * kItemCounterStride, (unsigned int)item_chunk);
+                const unsigned int it = atomicAdd(item_counter + sh * kItemCounterStride, (unsigned int)KA(item_chunk));
                 if ((long long)it < total) {
                     share = sh; item = it;
                     chunk_share = sh; chunk_next = it + 1u;
-                    chunk_left = (int)min((long long)item_chunk, total - (long long)it) - 1;
+                    chunk_left = (int)min((long long)KA(item_chunk), total - (long long)it) - 1;
                     break;
                 }
                 first_live = k + 1;             // that share is exhausted for good
@@ -404,32 +448,32 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     const int share = __builtin_amdgcn_readfirstlane(item_share);
     if (share < 0) break;
     const long long bid = (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)next_item);
-    const int share_lo = (int)((long long)n_cells * share / xcd_shares);
-    const int share_cells = (int)((long long)n_cells * (share + 1) / xcd_shares) - share_lo;
-    const long long per_group = (long long)cell_group * n_tiles;
+    const int share_lo = (int)((long long)KA(n_cells) * share / KA(xcd_shares));
+    const int share_cells = (int)((long long)KA(n_cells) * (share + 1) / KA(xcd_shares)) - share_lo;
+    const long long per_group = (long long)KA(cell_group) * n_tiles;
     const int group = (int)(bid / per_group);
     const long long rem = bid - (long long)group * per_group;
-    const int cells_here = min(cell_group, share_cells - group * cell_group);
+    const int cells_here = min(KA(cell_group), share_cells - group * KA(cell_group));
     const int tile = (int)(rem / cells_here);
-    const int cell_at = share_lo + group * cell_group + (int)(rem - (long long)tile * cells_here);
-    if (tile >= n_tiles || cell_at >= n_cells) continue;
-    // (long items first: launch_filter's order of the share's cells; a scalar load, the cell number stays in an SGPR)
-    const int cell = var.cell_order ? __builtin_amdgcn_readfirstlane(var.cell_order[cell_at]) : cell_at;
+    const int cell_at = share_lo + group * KA(cell_group) + (int)(rem - (long long)tile * cells_here);
+    if (tile >= n_tiles || cell_at >= KA(n_cells)) continue;
+    // (long items first: launch_filter's order of the share's KA(cells); a scalar load, the cell number stays in an SGPR)
+    const int cell = MM_VAR.cell_order ? __builtin_amdgcn_readfirstlane(MM_VAR.cell_order[cell_at]) : cell_at;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int v = var.cell_var[cell];
-    const int groups = var.groups[v];                    // only the variant's active pixels
-    lib = lib_base + (size_t)v * (IL ? var.chroma_stride * 4 : var.lib_stride);
-    lib_chroma = IL ? nullptr : lib_chroma_base + (size_t)v * var.chroma_stride;
+    const int v = MM_VAR.cell_var[cell];
+    const int groups = MM_VAR.groups[v];                    // only the variant's active pixels
+    lib = lib_base + (size_t)v * (IL ? MM_VAR.chroma_stride * 4 : MM_VAR.lib_stride);
+    lib_chroma = IL ? nullptr : lib_chroma_base + (size_t)v * MM_VAR.chroma_stride;
     // channel 0 from the plane that holds NaN at inactive pixels: their terms come out as
     // max(NaN, 0) = 0 (colour_diff_fast.hpp), so there is no mask to load or test here
-    // IL: cells_f0 is the interleaved copy [cell][group][4][256]; planes of a group 64 float4 apart
-    const float4* c0 = reinterpret_cast<const float4*>(cells_f0 + (size_t)cell * (IL ? 4 : 1) * ppad);
-    const float4* c1 = IL ? c0 + kWave : reinterpret_cast<const float4*>(cells + (size_t)cell * 3 * ppad) + ppad / 4;
-    const float4* c2 = IL ? c0 + 2 * kWave : c1 + ppad / 4;
-    const float4* cc = IL ? c0 + 3 * kWave : reinterpret_cast<const float4*>(cell_chroma + (size_t)cell * ppad);
-    const int pq = ppad / 4;
-    for (int t = threadIdx.x; t < n_seeds; t += THREADS) seed_ids[t] = seeds[(size_t)cell * n_seeds + t];
+    // IL: KA(cells_f0) is the interleaved copy [cell][group][4][256]; planes of a group 64 float4 apart
+    const float4* c0 = reinterpret_cast<const float4*>(KA(cells_f0) + (size_t)cell * (IL ? 4 : 1) * KA(ppad));
+    const float4* c1 = IL ? c0 + kWave : reinterpret_cast<const float4*>(KA(cells) + (size_t)cell * 3 * KA(ppad)) + KA(ppad) / 4;
+    const float4* c2 = IL ? c0 + 2 * kWave : c1 + KA(ppad) / 4;
+    const float4* cc = IL ? c0 + 3 * kWave : reinterpret_cast<const float4*>(KA(cell_chroma) + (size_t)cell * KA(ppad));
+    const int pq = KA(ppad) / 4;
+    for (int t = threadIdx.x; t < KA(n_seeds); t += THREADS) seed_ids[t] = KA(seeds)[(size_t)cell * KA(n_seeds) + t];
     if constexpr (CELL_LDS) {                             // stage the cell (active groups only); the barrier below covers it
         const int nq = groups * kWave;
         for (int q = threadIdx.x; q < nq; q += THREADS) {
@@ -468,25 +512,25 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // inside the bound of a clipped one -- its other blocks contribute 0, which every sum of non-negative terms exceeds.
     // Terms of pairs flagged for the fp64 patch (hue discontinuity) are summed apart and
     // never enter the exit test: only terms with a proven error bound may prune.
-    const float limit = prune_above ? prune_above[cell] : __builtin_huge_valf();
+    const float limit = KA(prune_above) ? KA(prune_above)[cell] : __builtin_huge_valf();
     bool use_lb = false;
     if constexpr (TYPE == CIEDE2000) {
-        use_lb = prune_above != nullptr && var.cell_full[cell] != 0 && groups <= (CELL_LDS ? kWave / 4 : kWave);     // workgroup-uniform
+        use_lb = KA(prune_above) != nullptr && MM_VAR.cell_full[cell] != 0 && groups <= (CELL_LDS ? kWave / 4 : kWave);     // workgroup-uniform
         if (use_lb) {
             // the cell's seven numbers per block (group_sums_kernel) wait in LDS: read per candidate, no registers held
-            const bool clipped = var.cell_full[cell] == 2;
+            const bool clipped = MM_VAR.cell_full[cell] == 2;
             for (int t = threadIdx.x; t < 4 * groups; t += THREADS) {
                 for (int k = 0; k < 7; ++k)
-                    cell_st[k][t] = var.cell_stats[(size_t)k * var.cell_stats_stride + (size_t)cell * var.n_blocks + t];
+                    cell_st[k][t] = MM_VAR.cell_stats[(size_t)k * MM_VAR.cell_stats_stride + (size_t)cell * MM_VAR.n_blocks + t];
                 // (statistic 7, the factor of every block's bound, carries the diagnostics' scale of the bound: 1)
-                cell_st[7][t] = var.bound_scale * (clipped ? var.cell_stats[(size_t)7 * var.cell_stats_stride + (size_t)cell * var.n_blocks + t] : 1.0f);
+                cell_st[7][t] = MM_VAR.bound_scale * (clipped ? MM_VAR.cell_stats[(size_t)7 * MM_VAR.cell_stats_stride + (size_t)cell * MM_VAR.n_blocks + t] : 1.0f);
             }
         }
     }
     // blocks per lane in the bound's prelude: 1, 2 or 4 (a power of two, so groups start on lane boundaries)
     const int lane_shift = groups <= 16 ? 0 : (groups <= 32 ? 1 : 2), per_lane = 1 << lane_shift;
-    const int l_base = tile * cand_per_block;
-    const int n_here = min(cand_per_block, L - l_base);
+    const int l_base = tile * KA(cand_per_block);
+    const int n_here = min(KA(cand_per_block), KA(L) - l_base);
     // Two stages.  The bound of a candidate takes one stats_bound per 64-position block (~75 instructions, ten of them
     // transcendental) and half of the candidates end there, so it is computed where all 64 lanes work on it.  Stage 1:
     // sixteen lanes hold a candidate, lane g its group g = four blocks, so one pass of the wave judges FOUR candidates;
@@ -494,23 +538,23 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     // mask of the survivors.  Stage 2: the waves pull survivors from the mask; a survivor's prelude is then a read of its
     // group bounds, the visiting order and a scan -- ~60 instructions instead of ~300 -- before the pixel loop.
     bool two_level = false;
-    if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && groups > 0 && cand_per_block <= 64 && (var.two_stage & 1) != 0;
+    if constexpr (TYPE == CIEDE2000) two_level = use_lb && lane_shift == 0 && groups > 0 && KA(cand_per_block) <= 64 && (MM_VAR.two_stage & 1) != 0;
     if (two_level && threadIdx.x < 4) alive_mask[threadIdx.x] = 0u;
     // Stage 0: ONE bound per candidate from the statistics of the two WHOLE images (the triangle inequality holds for any
     // partition of the pixels, the one-block partition included).  Weaker than the block bound, but 1 / 64 of its cost, and it
     // drops a third of config D's candidates (more on smoother content) before stage 1 spends 64 block evaluations on them.
-    // Unclipped cells only (the image statistics are over the whole mask).
+    // Unclipped KA(cells) only (the image statistics are over the whole mask).
     bool stage0 = false;
     if constexpr (TYPE == CIEDE2000) {
-        // (cells above 16 groups have no stage 1 -- a lane of the prelude holds two or four blocks there -- but stage 0 is the same
+        // (KA(cells) above 16 groups have no stage 1 -- a lane of the prelude holds two or four blocks there -- but stage 0 is the same
         // one pass of wave 0 whatever the cell size: the survivors' compacted list then feeds the candidate loop directly)
-        stage0 = use_lb && groups > 0 && cand_per_block <= 64 && (var.two_stage & 2) != 0 && var.cell_full[cell] == 1 &&
+        stage0 = use_lb && groups > 0 && KA(cand_per_block) <= 64 && (MM_VAR.two_stage & 2) != 0 && MM_VAR.cell_full[cell] == 1 &&
                  (two_level || (BIG && MM_BIG_CELL_STAGE0 != 0 && lane_shift > 0));
-        // (the image-level statistics sit in slot ppad / 64 of each image's block statistics: no arguments of their own)
+        // (the image-level statistics sit in slot KA(ppad) / 64 of each image's block statistics: no arguments of their own)
         if (stage0 && threadIdx.x < 7)
-            cell_ist[threadIdx.x] = var.cell_stats[(size_t)threadIdx.x * var.cell_stats_stride + (size_t)cell * var.n_blocks + ppad / 64];
+            cell_ist[threadIdx.x] = MM_VAR.cell_stats[(size_t)threadIdx.x * MM_VAR.cell_stats_stride + (size_t)cell * MM_VAR.n_blocks + KA(ppad) / 64];
     }
-    if (use_lb || CELL_LDS || n_seeds > 0) __syncthreads();   // workgroup-uniform
+    if (use_lb || CELL_LDS || KA(n_seeds) > 0) __syncthreads();   // workgroup-uniform
     MM_STAMP(2);
     if constexpr (TYPE == CIEDE2000) if (stage0) {
         if (wave == 0) {
@@ -518,18 +562,18 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             const bool valid = lane < n_here;
             bool seed = false;
             if (valid)
-                for (int t = 0; t < n_seeds; ++t) seed = seed || seed_ids[t] == l;
+                for (int t = 0; t < KA(n_seeds); ++t) seed = seed || seed_ids[t] == l;
             bool keep = valid && !seed;
             if (keep) {
-                const float* is = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + ppad / 64;
-                const size_t ss = var.lib_stats_stride;
+                const float* is = MM_VAR.lib_stats + ((size_t)v * KA(L) + l) * MM_VAR.n_blocks + KA(ppad) / 64;
+                const size_t ss = MM_VAR.lib_stats_stride;
                 // slack 1: the fp32 rounding of a 4096-term sum of values <= 128 kept in fp64 until its one rounding (0.03),
                 // plus what the 64 block sums behind it carry (64 x 1e-2)
                 const float b0 = stats_bound(cell_ist[0], cell_ist[1], cell_ist[2], cell_ist[3], cell_ist[4], cell_ist[5], cell_ist[6],
                                              is[0], is[ss], is[2 * ss], is[3 * ss], is[4 * ss], is[5 * ss], is[6 * ss], 1.0f);
                 n_groups_all += (unsigned int)groups;
-                if (b0 * var.bound_scale > limit) {
-                    scores[(size_t)cell * L + l] = __builtin_huge_valf();
+                if (b0 * MM_VAR.bound_scale > limit) {
+                    KA(scores)[(size_t)cell * KA(L) + l] = __builtin_huge_valf();
                     n_bound_dropped += 1;
                     keep = false;
                 }
@@ -553,16 +597,16 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             const int l = l_base + idx;
             float b = 0.0f;
             // scored already as a seed: not a survivor.  The candidate's lanes share the seed list out; one ballot gathers the hits
-            // (stage 0 has taken the seeds out already)
+            // (stage 0 has taken the KA(seeds) out already)
             bool hit = false;
             if (valid && !stage0)
-                for (int t = g; t < n_seeds; t += groups) hit = hit || seed_ids[t] == l;
+                for (int t = g; t < KA(n_seeds); t += groups) hit = hit || seed_ids[t] == l;
             const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
             const bool seed = ((hits >> (q * groups)) & ((1ull << groups) - 1ull)) != 0ull;     // (q * groups < 64 where it matters: valid lanes)
             if (valid) {
                 // the group's four blocks are four consecutive floats of each statistic
-                const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + 4 * g;
-                const size_t bs = var.lib_stats_stride;
+                const float* st = MM_VAR.lib_stats + ((size_t)v * KA(L) + l) * MM_VAR.n_blocks + 4 * g;
+                const size_t bs = MM_VAR.lib_stats_stride;
                 float4 ls[7];
                 for (int k = 0; k < 7; ++k) ls[k] = *reinterpret_cast<const float4*>(st + k * bs);
                 auto block = [&](int i, float l0, float l1, float l2, float l3, float l4, float l5, float l6) {
@@ -588,7 +632,7 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             }
             if (g == 0 && valid && !seed) {
                 if (b > limit) {
-                    scores[(size_t)cell * L + l] = __builtin_huge_valf();
+                    KA(scores)[(size_t)cell * KA(L) + l] = __builtin_huge_valf();
                     n_bound_dropped += 1;       // (per lane; summed over the wave's lanes at the end)
                 } else {
                     atomicOr(&alive_mask[(b < kLongSplit * limit ? 0 : 2) + (idx >> 5)], 1u << (idx & 31));
@@ -618,37 +662,37 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             const bool mine = ((survivors >> lane) & 1ull) != 0 && __builtin_popcountll(survivors & ((1ull << lane) - 1ull)) == nth;
             idx = __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine));
         } else if (BIG && stage0) {
-            idx = __builtin_amdgcn_readfirstlane((int)surv_idx[turn]);     // stage 0's compacted list (seeds are not on it)
+            idx = __builtin_amdgcn_readfirstlane((int)surv_idx[turn]);     // stage 0's compacted list (KA(seeds) are not on it)
         }
         const int l = l_base + idx;
         if (!two_level) {   // the next candidate of this tile not yet taken by any wave
             int nxt = 0;
             if (lane == 0) nxt = atomicAdd(&next_candidate, 1);
             turn = __builtin_amdgcn_readfirstlane(nxt);      // scalar: library addresses stay in SGPRs
-            if (n_seeds > 0 && !(BIG && stage0)) {
+            if (KA(n_seeds) > 0 && !(BIG && stage0)) {
                 // scored already as a seed (seed_score_kernel left its score in the row): nothing to do
                 bool hit = false;
-                for (int t = lane; t < n_seeds; t += kWave) hit = hit || seed_ids[t] == l;
+                for (int t = lane; t < KA(n_seeds); t += kWave) hit = hit || seed_ids[t] == l;
                 if (__builtin_amdgcn_ballot_w64(hit) != 0) continue;
             }
         }
-        const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * (IL ? 4 : 3) * ppad);
-        const float4* b1 = IL ? b0 + kWave : b0 + ppad / 4;
-        const float4* b2 = IL ? b0 + 2 * kWave : b1 + ppad / 4;
-        const float4* bc = IL ? b0 + 3 * kWave : reinterpret_cast<const float4*>(lib_chroma + (size_t)l * ppad);
+        const float4* b0 = reinterpret_cast<const float4*>(lib + (size_t)l * (IL ? 4 : 3) * KA(ppad));
+        const float4* b1 = IL ? b0 + kWave : b0 + KA(ppad) / 4;
+        const float4* b2 = IL ? b0 + 2 * kWave : b1 + KA(ppad) / 4;
+        const float4* bc = IL ? b0 + 3 * kWave : reinterpret_cast<const float4*>(lib_chroma + (size_t)l * KA(ppad));
         bool pruned = false;
         float rest = 0.0f;                 // lane k: bound of the groups not yet visited at step k (see rest_at)
         int order = lane;                  // lane k: the group visited k-th
-        const bool sorted = TYPE == CIEDE2000 && use_lb && lane_shift == 0 && sort_groups != 0;
-        // cells of 33 .. 64 groups (up to 128 x 128): a lane of the prelude holds exactly one group (four blocks), so the
+        const bool sorted = TYPE == CIEDE2000 && use_lb && lane_shift == 0 && KA(sort_groups) != 0;
+        // KA(cells) of 33 .. 64 groups (up to 128 x 128): a lane of the prelude holds exactly one group (four blocks), so the
         // same descending-bound visiting order comes from ranking the 64 lanes against each other
-        // ... and cells of 17 .. 32 groups (72 .. 90 px), whose lanes hold HALF a group each: the halves are added up into lanes
+        // ... and KA(cells) of 17 .. 32 groups (72 .. 90 px), whose lanes hold HALF a group each: the halves are added up into lanes
         // 0 .. 31 first (two ds_bpermute), then ranked the same way
-        const bool sorted64 = TYPE == CIEDE2000 && use_lb && lane_shift >= (BIG && MM_BIG_CELL_STAGE0 != 0 ? 1 : 2) && sort_groups != 0 && !two_level;
+        const bool sorted64 = TYPE == CIEDE2000 && use_lb && lane_shift >= (BIG && MM_BIG_CELL_STAGE0 != 0 ? 1 : 2) && KA(sort_groups) != 0 && !two_level;
         const bool by_group = sorted || two_level || sorted64;      // lane k of `rest`: visiting step k (else: block k)
         if constexpr (TYPE == CIEDE2000) {
             if (use_lb) {
-                // Lane k takes blocks k*m .. k*m+m-1 (m = blocks per lane: 1 up to 64 x 64 cells, so a lane
+                // Lane k takes blocks k*m .. k*m+m-1 (m = blocks per lane: 1 up to 64 x 64 KA(cells), so a lane
                 // is a quarter of a group; 4 at 128 x 128: a lane is a group).  After stage 1 the group bounds wait in LDS.
                 const int n_blk = 4 * groups;
                 float d = 0.0f;
@@ -658,8 +702,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     for (int i = 0; i < per_lane; ++i) {
                         const int blk = lane * per_lane + i;
                         if (blk >= n_blk) break;
-                        const float* st = var.lib_stats + ((size_t)v * L + l) * var.n_blocks + blk;
-                        const size_t bs = var.lib_stats_stride;
+                        const float* st = MM_VAR.lib_stats + ((size_t)v * KA(L) + l) * MM_VAR.n_blocks + blk;
+                        const size_t bs = MM_VAR.lib_stats_stride;
                         d += cell_st[7][blk] * stats_bound(cell_st[0][blk], cell_st[1][blk], cell_st[2][blk], cell_st[3][blk], cell_st[4][blk], cell_st[5][blk], cell_st[6][blk],
                                                            st[0], st[bs], st[2 * bs], st[3 * bs], st[4 * bs], st[5 * bs], st[6 * bs], 1e-2f);
                     }
@@ -695,12 +739,12 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     before += __builtin_amdgcn_ds_bpermute(pull + 48, key) > key;
                     before += __builtin_amdgcn_mov_dpp(before, 0xB1, 0xf, 0xf, false);
                     before += __builtin_amdgcn_mov_dpp(before, 0x4E, 0xf, 0xf, false);     // rank of group j (groups past the last have the smallest keys)
-                    // Only the `sort_groups` largest bounds are visited out of order; the other groups follow in plane order
+                    // Only the `KA(sort_groups)` largest bounds are visited out of order; the other groups follow in plane order
                     // (position = groups of lower number that are not among the largest), which keeps most of a candidate's
                     // reads a contiguous run -- the L2 hit rate falls when every candidate walks its own permutation.
-                    const unsigned long long tail_lanes = __builtin_amdgcn_ballot_w64(t == 0 && before >= sort_groups);
+                    const unsigned long long tail_lanes = __builtin_amdgcn_ballot_w64(t == 0 && before >= KA(sort_groups));
                     const int below = __builtin_popcountll(tail_lanes & ((1ull << lane) - 1ull));
-                    const int pos = before < sort_groups ? before : sort_groups + below;
+                    const int pos = before < KA(sort_groups) ? before : KA(sort_groups) + below;
                     // scatter (group number, bound) to the lane of their place; every lane pushes somewhere unique
                     const int dest = t != 0 ? 16 + 3 * j + t - 1 : pos;
                     order = __builtin_amdgcn_ds_permute(dest * 4, j);
@@ -719,10 +763,10 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                     int before = 0;
 #pragma nounroll
                     for (int j = 0; j < kWave; ++j) before += __builtin_amdgcn_readlane(key, j) > key;
-                    // as above: only the `sort_groups` largest bounds are visited out of order, the rest in plane order
-                    const unsigned long long tail_lanes = __builtin_amdgcn_ballot_w64(before >= sort_groups);
+                    // as above: only the `KA(sort_groups)` largest bounds are visited out of order, the rest in plane order
+                    const unsigned long long tail_lanes = __builtin_amdgcn_ballot_w64(before >= KA(sort_groups));
                     const int below = __builtin_popcountll(tail_lanes & ((1ull << lane) - 1ull));
-                    const int pos = before < sort_groups ? before : sort_groups + below;
+                    const int pos = before < KA(sort_groups) ? before : KA(sort_groups) + below;
                     order = __builtin_amdgcn_ds_permute(pos * 4, lane);
                     d = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(pos * 4, __builtin_bit_cast(int, d)));
                 }
@@ -743,11 +787,11 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         float pre_sum = -1.0f;         // PRE: lane-partial fp16-form sum of a candidate that survived the pre-tier (else < 0)
 #if MM_WITH_PRETIER
         if constexpr (PRE) {
-            if (!pruned && groups > 0 && prune_above != nullptr)
-                pruned = pretier_walk(reinterpret_cast<const char*>(cells) + (size_t)cell * 8 * ppad,
-                                      reinterpret_cast<const char*>(lib_chroma_base) + ((size_t)v * L + l) * 8 * (size_t)ppad,
+            if (!pruned && groups > 0 && KA(prune_above) != nullptr)
+                pruned = pretier_walk(reinterpret_cast<const char*>(KA(cells)) + (size_t)cell * 8 * KA(ppad),
+                                      reinterpret_cast<const char*>(lib_chroma_base) + ((size_t)v * KA(L) + l) * 8 * (size_t)KA(ppad),
                                       lane, groups, check_every, use_lb, rest, by_group, lane_shift, sorted || sorted64, order,
-                                      limit, var.pre_abs, var.pre_rel, lut, visited, pre_sum);
+                                      limit, MM_VAR.pre_abs, MM_VAR.pre_rel, lut, visited, pre_sum);
         }
 #endif
         float acc = 0.0f;          // terms with a proven error bound
@@ -795,8 +839,8 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
                         const bool ea[4] = {e0 && a0, e1 && a1, e2 && a2, e3 && a3};
                         for (int k = 0; k < 4; ++k)
                             if (ea[k]) {
-                                const unsigned int slot = atomicAdd(edge_count, 1u);
-                                if (slot < edge_cap) edges[slot] = EdgeEntry{cell, l, 4 * q + k};
+                                const unsigned int slot = atomicAdd(KA(edge_count), 1u);
+                                if (slot < KA(edge_cap)) KA(edges)[slot] = EdgeEntry{cell, l, 4 * q + k};
                             }
                     } else {
                         acc += (v0 + v1) + (v2 + v3);
@@ -823,10 +867,10 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
         acc = wave_sum_all(acc + acc_edge);
 #if MM_WITH_PRETIER
         if constexpr (PRE) {
-            if (pre_sum >= 0.0f && !pruned) pretier_canary(pre_sum, acc, lane, groups, var.pre_abs, var.pre_rel, edge_count);
+            if (pre_sum >= 0.0f && !pruned) pretier_canary(pre_sum, acc, lane, groups, MM_VAR.pre_abs, MM_VAR.pre_rel, KA(edge_count));
         }
 #endif
-        if (lane == 0) scores[(size_t)cell * L + l] = pruned ? __builtin_huge_valf() : acc;
+        if (lane == 0) KA(scores)[(size_t)cell * KA(L) + l] = pruned ? __builtin_huge_valf() : acc;
     }
     MM_STAMP(5);
 #ifdef MM_FILTER_STAMPS
@@ -835,11 +879,11 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
     }   // next item
 #ifdef MM_FILTER_STAMPS
     __syncthreads();
-    if (threadIdx.x < 6) atomicAdd(edge_count + 24 + threadIdx.x, stamp_acc[threadIdx.x] >> 6);
+    if (threadIdx.x < 6) atomicAdd(KA(edge_count) + 24 + threadIdx.x, stamp_acc[threadIdx.x] >> 6);
     if (threadIdx.x == 0 && stamp_items > 0) {      // 6: the longest workgroup lifetime, 7: the sum of the lifetimes (workgroups that took an item)
         const unsigned int life = (unsigned int)((__builtin_readcyclecounter() - stamp_begin) >> 10);
-        atomicMax(edge_count + 30, life);
-        atomicAdd(edge_count + 31, life >> 4);
+        atomicMax(KA(edge_count) + 30, life);
+        atomicAdd(KA(edge_count) + 31, life >> 4);
     }
 #endif
     {   // one set of atomics per wave and launch
@@ -849,13 +893,16 @@ filter_kernel(const float* __restrict__ cells, const float* __restrict__ cells_f
             n_bound_dropped += __shfl_xor(n_bound_dropped, off, kWave);
         }
         if ((threadIdx.x & 63) == 0) {
-            unsigned long long* c = reinterpret_cast<unsigned long long*>(edge_count + kCounterBase);
+            unsigned long long* c = reinterpret_cast<unsigned long long*>(KA(edge_count) + kCounterBase);
             atomicAdd(c, (unsigned long long)n_visited);
             atomicAdd(c + 1, (unsigned long long)n_groups_all);
             atomicAdd(c + 2, (unsigned long long)n_bound_dropped);
         }
     }
 }
+
+#undef MM_VAR
+#undef KA
 
 // LDS-resident form of filter_kernel: a 1024-thread workgroup (16 waves) stages ONE cell
 // -- its three colour planes, chroma plane and mask, only the groups holding active
