@@ -314,7 +314,10 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // Same box, two runs each (round 6): config D 43.19 -> 42.71 (1) / 42.66 ms per step (2), E's shard 29.22 -> 28.63 / 28.73, C 2.96 -> 2.93 /
 // 2.94, G 14.08 -> 14.00 / 13.98; result digests equal.  FilterKernArgs mirrors the kernel's parameter list: the kernarg segment lays
 // the explicit arguments out in order at their natural alignment, as a C struct -- whoever changes one changes the other (a mismatch
-// garbles every argument: no test of the suite survives it).
+// garbles every argument: no test of the suite survives it).  The same treatment makes LATENCY-bound code slower -- a scalar load's ~50 cycles
+// where a spill's v_readlane took 4: filter_lds_kernel<RGB> (stage 1: a candidate per lane, waiting on its own loads) 119 -> 16 spilled SGPRs
+// and config B's kernel 0.102 -> 0.121 ms, F +3.5 %; resolve_front_kernel (one wave alone on its SIMD) 122 -> 83 and config PD's resolve
+// 2.67 -> 3.15 ms: both left as they were.
 #ifndef MM_KERNARG_RELOAD
 #define MM_KERNARG_RELOAD 2
 #endif
