@@ -30,6 +30,7 @@ extern "C" {
  *   spec_k             4     length of mm_generate's speculative short lists; 0 = always mm_candidates_per_cell
  *   spec_auto          1     the short lists' length by measurement: a generate that deepened > 2 % of its cells lets the next ones over the same job try
  *                            twice and four times the length (<= 16); the length whose whole generate was fastest is kept; 0 pins spec_k
+ *   warm_rounds        1     the resolve after a round that extended only a few lists starts its sweeps from the previous round's grid; 0 = from a cleared one
  *   deepen_mid         16    a cell whose short list did not verify its pick is first extended to n entries (>= twice the short length),
  *                            to the full counting length only if that did not verify either; 0 = straight to the full length
  * -- submission ------------------------------------------------------------------------------------------------------

@@ -99,6 +99,7 @@ struct mm_engine {
     int spec_cells = 0;          // ... and cell count: the lengths are compared by the TIME of whole generates over the same job
     float spec_ms[3] = {0.f, 0.f, 0.f};     // fastest generate seen at the base length, twice and four times it (0: not tried)
     int spec_base_runs = 0;      // generates timed at the base length (the first one over a library runs cold: it gets a second, warm one before the verdict)
+    int warm_rounds = 1;         // mm_set_option("warm_rounds", 0): a later round's resolve starts from a cleared grid (and goes to the front form at once where that was learned)
     int deepen_mid = 16;         // mm_set_option("deepen_mid", n): a cell whose short list could not verify its pick is first extended to n entries
                                  // (at least twice the short length) and only then to the full counting length; 0: straight to the full length
     int sweeps_learned = 0, sweeps_lib = 0, sweeps_size = 0; // sweeps the resolve of the previous generate over this library took to settle (its longest
@@ -113,6 +114,8 @@ struct mm_engine {
     int use_row_pipeline = 1;    // mm_set_option("row_pipeline", 0): single serial chain
     int use_front_resolve = 1;   // mm_set_option("front_resolve", 0): resolve_rows_kernel as the wavefront form, and further sets of sweeps instead of it
     bool front_learned = false;  // the sweeps of a generate over (sweeps_lib, sweeps_size) did not settle in their first set: the front form at once
+    bool result_grid_valid = false;   // the device result block holds the final grid of the last single-submission resolve (a later round of the
+                                 // same generate may start its sweeps from it)
     bool last_front = false;     // the last resolve_single_submission ran the front form (its "sweep" count says nothing about the sweeps' depth)
     int use_sweep_resolve = 1;   // mm_set_option("sweep_resolve", 0): raster-order chain instead of parallel sweeps
     int max_sweeps = 48;         // mm_set_option("max_sweeps", n): sweeps before falling back to the chain
@@ -1323,8 +1326,10 @@ mm_status ensure_pinned(mm_engine* e, size_t bytes)
 
 // Single submission, part 1 (before any scoring): the result block -- header, grid, scores -- allocated and
 // initialised on the device; the filter kernels count straight into the header from here on.
-mm_status begin_single_submission(mm_engine* e, int n, int grid_w, int grid_h, bool speculate)
+mm_status begin_single_submission(mm_engine* e, int n, int grid_w, int grid_h, bool speculate, bool keep_grid = false)
 {
+    // keep_grid: a later round of the same generate -- the block's grid is the fix point of the PREVIOUS lists and stays as the sweeps'
+    // starting state (header and flags are cleared as ever)
     const size_t cells_total = (size_t)grid_w * grid_h;
     const size_t block_bytes = sizeof(mm::ResultHeader) + cells_total * (sizeof(long long) + sizeof(double));
     mm_status st;
@@ -1341,7 +1346,7 @@ mm_status begin_single_submission(mm_engine* e, int n, int grid_w, int grid_h, b
     const size_t work = std::max(cells_total, speculate ? (size_t)n : 0);
     const unsigned fill_blocks = (unsigned)std::min<size_t>((work + mm::kBlock - 1) / mm::kBlock, 1024);
     mm::result_init_kernel<<<std::max(fill_blocks, 1u), mm::kBlock, 0, e->stream>>>(
-        hdr, grid_dev, best_dev, cells_total, (long long)e->n_lib,
+        hdr, grid_dev, best_dev, keep_grid ? (size_t)0 : cells_total, (long long)e->n_lib,
         speculate ? (uint8_t*)e->deep.p : nullptr, speculate ? (uint8_t*)e->insufficient.p : nullptr, speculate ? n : 0);
     HIP_TRY(e, hipGetLastError(), "Error during result initialisation kernel");
     e->fast_hdr = hdr;
@@ -1357,8 +1362,11 @@ mm_status begin_single_submission(mm_engine* e, int n, int grid_w, int grid_h, b
 mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n, int grid_w, int grid_h,
                                     int diff_type, int range, int addition, int K, int k_fill, bool speculate,
                                     const int32_t* cand_i_dev, const double* cand_s_dev, bool want_scores,
-                                    const uint8_t* flags_dev, bool counted, bool continuing = false, int sweeps_done = 0)
+                                    const uint8_t* flags_dev, bool counted, bool continuing = false, int sweeps_done = 0, bool warm = false)
 {
+    // warm: the block's grid is the previous round's fix point (begin_single_submission keep_grid): after a round of deepening only the
+    // extended cells and what they displace change, so the sweeps -- hopeless from a cold grid on such content -- get a first set from
+    // there before the front form is asked (a sweep that changes nothing proves the unique fix point whatever the start)
     // continuing: the block holds the state after sweeps that had not settled yet (nothing else wrong with it): the header is
     // cleared and another set of sweeps runs from that state -- a fix-point iteration may be resumed anywhere
     const size_t cells_total = (size_t)grid_w * grid_h;
@@ -1393,7 +1401,8 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
     // had not settled after 240 sweeps), and once that has happened over a (library, cell size) the next generate starts with it.
     const size_t front_lds = wavefront_lds_bytes(grid_w, grid_h, true);
     const bool front = sequential && e->use_front_resolve != 0 && front_lds != 0 &&
-                       (continuing || (e->front_learned && e->sweeps_lib == e->n_lib && e->sweeps_size == e->lib_size));
+                       (continuing || (!warm && e->front_learned && e->sweeps_lib == e->n_lib && e->sweeps_size == e->lib_size));
+    e->result_grid_valid = false;
     e->last_front = front;
     if (front) {
         if (continuing) { e->front_learned = true; e->sweeps_learned = 0; e->sweeps_lib = e->n_lib; e->sweeps_size = e->lib_size; }
@@ -1441,6 +1450,7 @@ mm_status resolve_single_submission(mm_engine* e, const mm_cell* recs_dev, int n
         for (int i = 0; i < sweeps; ++i)
             if (h->sweep_changes[i] == 0) { last = i; break; }
         h->n_insufficient = h->sweep_insufficient[last];
+        e->result_grid_valid = h->sweep_changes[last] == 0u;     // (the front form leaves its one counter at 0)
     }
     h->edge_pairs = h->filter_counters[0];
     h->launch_void = h->filter_counters[mm::kFilterVoidWord];
@@ -2200,6 +2210,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     HIP_TRY(e, select_device(e), "Failed to select device");
     e->timing = mm_timing{};
     e->syncs = 0;
+    e->result_grid_valid = false;
 
     const int K = std::max(1, mm_candidates_per_cell(e->n_lib, repeat_range, repeat_addition));
     // Short lists of 4 verify every pick of the synthetic benchmark in one round; on content where neighbouring cells want the
@@ -2330,6 +2341,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
     std::vector<mm_cell> sub_cells;
     std::vector<int> sub_rows;
     std::vector<uint8_t> level;            // 0: the cell's list is the short one, 1: it was extended to the middle length
+    int extended_since_resolve = 0;        // cells whose lists were extended since the last resolve
     if (speculate) {
         deep.assign((size_t)n_cells, 0);
         level.assign((size_t)n_cells, 0);
@@ -2347,12 +2359,16 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
             // block cannot vouch for (an overflow mark, sweeps that did not settle) falls through to the step-by-step form.
             bool resolved = false;
             if (want_fast) {
-                if ((st = begin_single_submission(e, n_cells, grid_w, grid_h, speculate))) return st;
+                // (warm: the previous round of THIS generate left its fix point in the block, and only a few cells were extended since -- what
+                // they displace stays local and the sweeps settle in a handful of passes: config P's round after one extended cell 0.56 -> 0.32 ms;
+                // after the 1176 cells of config PD's first round eight sweeps do not settle and only delay the front form: 2.67 -> 2.94 ms)
+                const bool warm = sequential && e->result_grid_valid && e->warm_rounds != 0 && extended_since_resolve <= std::max(8, n_cells / 256);
+                if ((st = begin_single_submission(e, n_cells, grid_w, grid_h, speculate, warm))) return st;
                 if (speculate)      // (after the block's initialisation, which clears the flag arrays, in stream order)
                     HIP_TRY(e, hipMemcpyAsync(e->deep.p, deep.data(), (size_t)n_cells, hipMemcpyHostToDevice, e->stream), "Failed to copy list flags");
                 st = resolve_single_submission(e, (const mm_cell*)e->recs.p, n_cells, grid_w, grid_h, diff_type, repeat_range, repeat_addition,
                                                K, Kfill, speculate, (const int32_t*)e->cand_i.p, (const double*)e->cand_s.p, best_score_out != nullptr,
-                                               nullptr, false);
+                                               nullptr, false, false, 0, warm);
                 if (st) return st;
                 const mm::ResultHeader& h = *(const mm::ResultHeader*)e->pinned;
                 int settled = -1, sweeps_before = 0;
@@ -2387,6 +2403,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
             }
         }
         e->timing.spec_rounds = round + 1;
+        extended_since_resolve = 0;
         if (!speculate) break;
         HIP_TRY(e, hipMemcpy(insufficient.data(), e->insufficient.p, (size_t)n_cells, hipMemcpyDeviceToHost), "Error copying list flags to host");
         // unverified cells: those still on their short list go to the middle length, those already there to the full one
@@ -2418,6 +2435,7 @@ mm_status mm_generate(mm_engine* e, const mm_cell* cells, int n_cells, int grid_
                                     (int32_t*)e->cand_i.p, (double*)e->cand_s.p, sub_rows.data(), nullptr, nullptr, cancel);
             if (st) return st;
             e->timing.deepened_cells += ns;
+            extended_since_resolve += ns;
         }
         if (!any) break;
     }
@@ -2710,6 +2728,7 @@ mm_status mm_set_option(mm_engine* e, const char* name, int value)
     if (strcmp(name, "spec_k") == 0) { e->spec_k = std::max(0, value); e->spec_k_learned = 0; e->spec_cells = 0; return MM_OK; }
     if (strcmp(name, "spec_auto") == 0) { e->spec_auto = value != 0; e->spec_k_learned = 0; e->spec_cells = 0; return MM_OK; }
     if (strcmp(name, "deepen_mid") == 0) { e->deepen_mid = std::max(0, value); return MM_OK; }
+    if (strcmp(name, "warm_rounds") == 0) { e->warm_rounds = value != 0; return MM_OK; }
     if (strcmp(name, "seeds") == 0) { e->extra_seeds = std::max(-1, value); return MM_OK; }
     if (strcmp(name, "lds_pad_kb") == 0) { e->lds_pad_kb = std::min(120, std::max(0, value)); return MM_OK; }
     if (strcmp(name, "tile") == 0) { e->tile_candidates = std::max(0, value); return MM_OK; }

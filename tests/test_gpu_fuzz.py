@@ -161,6 +161,7 @@ OPTION_SETS = [
     {"sweep_resolve": 0},                           # the front form from the start (step-by-step path)
     {"spec_k": 2},                                  # short speculative lists: cells get deepened (from the result block's verdicts)
     {"spec_k": 2, "deepen_mid": 0},                 # ... straight to the full counting length, as before round 6
+    {"spec_k": 2, "warm_rounds": 0},                # ... every round's resolve from a cleared grid (default: a later round's sweeps start from the previous round's fix point)
     {"spec_k": 2, "deepen_mid": 5},                 # ... through a middle length of 5 entries first (three levels: 2 -> 5 -> full)
     {"spec_auto": 0, "spec_k": 1, "deepen_mid": 3, "fast_path": 0},
     {"fused": 0},                                   # separate gather / chroma / interleave / statistics and contenders / re-score / re-rank launches
@@ -208,7 +209,7 @@ def test_tuning_options_do_not_change_the_result(oracle, engine, opts):
     defaults = {"interleave": 1, "xcd_aware": 1, "tile": 0, "xcd_cells": 0, "two_level": 1, "sort_groups": -1,
                 "lds_filter": -1, "seeds": -1, "spec_k": 4, "fused": 1, "fast_path": 1, "item_auto": 1,
                 "fused_seeds": 2048, "prune_min_kpairs": 0, "phase_timing": 1, "stage0": 1, "euclid_stage1": 1, "cell_order": 1,
-                "pretier": -1, "pretier_band": 0, "spec_auto": 1, "audit": 1024, "front_resolve": 1, "sweep_resolve": 1, "deepen_mid": 16}
+                "pretier": -1, "pretier_band": 0, "spec_auto": 1, "audit": 1024, "front_resolve": 1, "sweep_resolve": 1, "deepen_mid": 16, "warm_rounds": 1}
     try:
         for name, value in opts.items():
             engine.set_option(name, value)
